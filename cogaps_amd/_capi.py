@@ -1,0 +1,318 @@
+"""ctypes view of include/cogaps_hip.h.
+
+`load()` returns the product library (libcogaps_hip.so, HIP/gfx950).  It fails loudly when the
+library has not been built: there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcogaps_hip.so")
+
+INTERRUPT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+
+class CogapsParamsC(C.Structure):
+    _fields_ = [
+        ("seed", C.c_uint32), ("nPatterns", C.c_uint32), ("nIterations", C.c_uint32),
+        ("maxThreads", C.c_uint32), ("outputFrequency", C.c_uint32),
+        ("checkpointInterval", C.c_uint32), ("snapshotFrequency", C.c_uint32),
+        ("alphaA", C.c_float), ("alphaP", C.c_float),
+        ("maxGibbsMassA", C.c_float), ("maxGibbsMassP", C.c_float),
+        ("transposeData", C.c_int32), ("printMessages", C.c_int32),
+        ("subsetData", C.c_int32), ("subsetGenes", C.c_int32),
+        ("dataIndicesSubset", C.POINTER(C.c_uint32)), ("nSubset", C.c_uint32),
+        ("useSparseOptimization", C.c_int32), ("takePumpSamples", C.c_int32),
+        ("asynchronousUpdates", C.c_int32),
+        ("whichMatrixFixed", C.c_char), ("fixedPatterns", C.POINTER(C.c_float)),
+        ("fixedRows", C.c_uint32), ("workerID", C.c_uint32), ("runningDistributed", C.c_int32),
+        ("device", C.c_int32), ("interrupt", INTERRUPT_FN), ("interruptArg", C.c_void_p),
+    ]
+
+
+class CogapsResultC(C.Structure):
+    _fields_ = [
+        ("nGenes", C.c_uint32), ("nSamples", C.c_uint32), ("nPatterns", C.c_uint32),
+        ("Amean", C.POINTER(C.c_float)), ("Asd", C.POINTER(C.c_float)),
+        ("Pmean", C.POINTER(C.c_float)), ("Psd", C.POINTER(C.c_float)),
+        ("nHistory", C.c_uint32), ("chisqHistory", C.POINTER(C.c_float)),
+        ("atomHistoryA", C.POINTER(C.c_uint32)), ("atomHistoryP", C.POINTER(C.c_uint32)),
+        ("totalUpdates", C.c_uint64), ("seed", C.c_uint32), ("totalRunningTime", C.c_uint32),
+        ("meanChiSq", C.c_float), ("averageQueueLengthA", C.c_float), ("averageQueueLengthP", C.c_float),
+        ("samplerSeconds", C.c_double),
+    ]
+
+
+class CogapsPerfC(C.Structure):
+    _fields_ = [
+        ("evalBytes", C.c_uint64), ("evalLaunches", C.c_uint64), ("genLaunches", C.c_uint64),
+        ("batches", C.c_uint64), ("proposalsQueued", C.c_uint64),
+        ("evalMs", C.c_double), ("genMs", C.c_double), ("syncMs", C.c_double),
+    ]
+
+
+TRACE_DTYPE = np.dtype([
+    ("pos", "<u8"), ("rng_state", "<u8"), ("atom1", "<u4"), ("atom2", "<u4"),
+    ("r1", "<u4"), ("c1", "<u4"), ("r2", "<u4"), ("c2", "<u4"), ("type", "<u4"), ("batch", "<u4"),
+])
+
+# every symbol include/cogaps_hip.h declares
+EXPORTS = [
+    "cogaps_default_params", "cogaps_run", "cogaps_result_free", "cogaps_last_error",
+    "cogaps_build_report", "cogaps_checkpoints_enabled", "cogaps_compiled_with_openmp",
+    "cogaps_session_create", "cogaps_session_destroy", "cogaps_session_set_annealing",
+    "cogaps_session_draw_steps", "cogaps_session_update", "cogaps_session_sync",
+    "cogaps_session_iterate", "cogaps_session_run_iterations", "cogaps_session_natoms",
+    "cogaps_session_chisq", "cogaps_session_get_matrix", "cogaps_session_get_ap",
+    "cogaps_session_get_atoms", "cogaps_session_dims", "cogaps_session_avg_queue",
+    "cogaps_session_finish", "cogaps_session_set_timing", "cogaps_session_perf",
+    "cogaps_reduction_width",
+]
+
+
+def bind(L):
+    """Attach prototypes to an opened library implementing include/cogaps_hip.h."""
+    fp, u32p, vp = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_void_p
+    L.cogaps_default_params.argtypes = [C.POINTER(CogapsParamsC)]
+    L.cogaps_default_params.restype = None
+    L.cogaps_run.argtypes = [fp, C.c_uint32, C.c_uint32, C.POINTER(CogapsParamsC), fp, C.POINTER(CogapsResultC)]
+    L.cogaps_result_free.argtypes = [C.POINTER(CogapsResultC)]
+    L.cogaps_result_free.restype = None
+    L.cogaps_last_error.restype = C.c_char_p
+    L.cogaps_build_report.restype = C.c_char_p
+    L.cogaps_session_create.restype = vp
+    L.cogaps_session_create.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(CogapsParamsC), vp, C.c_int]
+    L.cogaps_session_destroy.argtypes = [vp]
+    L.cogaps_session_destroy.restype = None
+    L.cogaps_session_set_annealing.argtypes = [vp, C.c_float]
+    L.cogaps_session_draw_steps.argtypes = [vp, u32p, u32p]
+    L.cogaps_session_update.argtypes = [vp, C.c_char, C.c_uint32, vp, C.c_uint32, u32p, u32p, u32p, C.c_uint32, u32p]
+    L.cogaps_session_sync.argtypes = [vp, C.c_char]
+    L.cogaps_session_iterate.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int]
+    L.cogaps_session_run_iterations.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+    L.cogaps_session_natoms.argtypes = [vp, C.c_char, u32p]
+    L.cogaps_session_chisq.argtypes = [vp, C.c_char, fp]
+    L.cogaps_session_get_matrix.argtypes = [vp, C.c_char, fp]
+    L.cogaps_session_get_ap.argtypes = [vp, C.c_char, fp]
+    L.cogaps_session_get_atoms.argtypes = [vp, C.c_char, C.POINTER(C.c_uint64), fp, u32p, u32p]
+    L.cogaps_session_dims.argtypes = [vp, C.c_char, u32p, u32p, u32p]
+    L.cogaps_session_avg_queue.argtypes = [vp, C.c_char, fp]
+    L.cogaps_session_finish.argtypes = [vp, C.POINTER(CogapsResultC)]
+    L.cogaps_session_set_timing.argtypes = [vp, C.c_int]
+    L.cogaps_session_perf.argtypes = [vp, C.POINTER(CogapsPerfC)]
+    L.cogaps_reduction_width.restype = C.c_uint32
+    L.cogaps_reduction_width.argtypes = [C.c_uint32]
+    return L
+
+
+_lib = None
+
+
+def load():
+    """The HIP library, or RuntimeError.  No fallback of any kind."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "cogaps_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        _lib = bind(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def make_params(L, nPatterns=3, nIterations=1000, seed=0, outputFrequency=500, nThreads=1,
+                alphaA=0.01, alphaP=0.01, maxGibbsMassA=100.0, maxGibbsMassP=100.0,
+                transposeData=False, subsetIndices=None, subsetDim=0, whichMatrixFixed="N",
+                fixedPatterns=None, sparseOptimization=False, asynchronousUpdates=True,
+                messages=False, workerID=1, device=-1, takePumpSamples=False,
+                checkpointInterval=0, nSnapshots=0):
+    p = CogapsParamsC()
+    L.cogaps_default_params(C.byref(p))
+    p.nPatterns, p.nIterations, p.seed = int(nPatterns), int(nIterations), int(seed)
+    p.outputFrequency, p.maxThreads = int(outputFrequency), int(nThreads)
+    p.alphaA, p.alphaP = float(alphaA), float(alphaP)
+    p.maxGibbsMassA, p.maxGibbsMassP = float(maxGibbsMassA), float(maxGibbsMassP)
+    p.transposeData = int(bool(transposeData))
+    p.printMessages = int(bool(messages)) if workerID == 1 else 0       # Cogaps.cpp:85
+    p.useSparseOptimization = int(bool(sparseOptimization))
+    p.asynchronousUpdates = int(bool(asynchronousUpdates))
+    p.takePumpSamples = int(bool(takePumpSamples))
+    p.checkpointInterval = int(checkpointInterval)
+    p.workerID = int(workerID)
+    p.device = int(device)
+    keep = []
+    if subsetIndices is not None and subsetDim > 0:
+        idx = np.ascontiguousarray(subsetIndices, dtype=np.uint32)
+        keep.append(idx)
+        p.subsetData = 1
+        p.subsetGenes = 1 if subsetDim == 1 else 0
+        p.dataIndicesSubset = idx.ctypes.data_as(C.POINTER(C.c_uint32))
+        p.nSubset = idx.size
+        p.runningDistributed = 1
+    p.whichMatrixFixed = str(whichMatrixFixed).encode()[:1]
+    if fixedPatterns is not None and whichMatrixFixed != "N":
+        fx = np.ascontiguousarray(fixedPatterns, dtype=np.float32)
+        keep.append(fx)
+        p.fixedPatterns = _fp(fx)
+        p.fixedRows = fx.shape[0]
+    p._keep = keep
+    return p
+
+
+def result_to_dict(L, r):
+    g, s, k, h = r.nGenes, r.nSamples, r.nPatterns, r.nHistory
+    out = {
+        "Amean": np.ctypeslib.as_array(r.Amean, shape=(g, k)).copy(),
+        "Asd": np.ctypeslib.as_array(r.Asd, shape=(g, k)).copy(),
+        "Pmean": np.ctypeslib.as_array(r.Pmean, shape=(s, k)).copy(),
+        "Psd": np.ctypeslib.as_array(r.Psd, shape=(s, k)).copy(),
+        "chisq": np.ctypeslib.as_array(r.chisqHistory, shape=(max(h, 1),))[:h].copy(),
+        "atomsA": np.ctypeslib.as_array(r.atomHistoryA, shape=(max(h, 1),))[:h].copy(),
+        "atomsP": np.ctypeslib.as_array(r.atomHistoryP, shape=(max(h, 1),))[:h].copy(),
+        "totalUpdates": int(r.totalUpdates), "meanChiSq": float(r.meanChiSq), "seed": int(r.seed),
+        "averageQueueLengthA": float(r.averageQueueLengthA),
+        "averageQueueLengthP": float(r.averageQueueLengthP),
+        "totalRunningTime": int(r.totalRunningTime), "samplerSeconds": float(r.samplerSeconds),
+    }
+    L.cogaps_result_free(C.byref(r))
+    return out
+
+
+class Session:
+    """One sampler run, one step at a time (cogaps_session_* of include/cogaps_hip.h)."""
+
+    def __init__(self, data, unc=None, lib=None, **kw):
+        self.L = lib if lib is not None else load()
+        self.d = np.ascontiguousarray(data, dtype=np.float32)
+        self.u = None if unc is None else np.ascontiguousarray(unc, dtype=np.float32)
+        self.p = make_params(self.L, **kw)
+        self.h = self.L.cogaps_session_create(self.d.ctypes.data, self.d.shape[0], self.d.shape[1], C.byref(self.p),
+                                              None if self.u is None else self.u.ctypes.data, 0)
+        if not self.h:
+            raise RuntimeError("cogaps_session_create: " + self.L.cogaps_last_error().decode())
+
+    def _ck(self, rc):
+        if rc:
+            raise RuntimeError(self.L.cogaps_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.cogaps_session_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_annealing(self, t):
+        self._ck(self.L.cogaps_session_set_annealing(self.h, t))
+
+    def draw_steps(self):
+        a, b = C.c_uint32(), C.c_uint32()
+        self._ck(self.L.cogaps_session_draw_steps(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def update(self, which, nsteps, trace_cap=0):
+        if not trace_cap:
+            self._ck(self.L.cogaps_session_update(self.h, which.encode(), nsteps, None, 0, None, None, None, 0, None))
+            return None
+        rec = np.zeros(trace_cap, dtype=TRACE_DTYPE)
+        bn = np.zeros(trace_cap, dtype=np.uint32)
+        bq = np.zeros(trace_cap, dtype=np.uint32)
+        nt, nb = C.c_uint32(), C.c_uint32()
+        u32p = C.POINTER(C.c_uint32)
+        self._ck(self.L.cogaps_session_update(self.h, which.encode(), nsteps, rec.ctypes.data, trace_cap, C.byref(nt),
+                                              bn.ctypes.data_as(u32p), bq.ctypes.data_as(u32p), trace_cap, C.byref(nb)))
+        assert nt.value <= trace_cap and nb.value <= trace_cap, "trace overflow"
+        return {"rec": rec[:nt.value], "nproc": bn[:nb.value], "qlen": bq[:nb.value]}
+
+    def sync(self, which):
+        self._ck(self.L.cogaps_session_sync(self.h, which.encode()))
+
+    def iterate(self, nA, nP, sampling=False):
+        self._ck(self.L.cogaps_session_iterate(self.h, nA, nP, int(sampling)))
+
+    def run_iterations(self, phase, first, n):
+        upd = C.c_uint64(0)
+        self._ck(self.L.cogaps_session_run_iterations(self.h, phase, first, n, C.byref(upd)))
+        return upd.value
+
+    def natoms(self, which):
+        n = C.c_uint32()
+        self._ck(self.L.cogaps_session_natoms(self.h, which.encode(), C.byref(n)))
+        return n.value
+
+    def chisq(self, which):
+        c = C.c_float()
+        self._ck(self.L.cogaps_session_chisq(self.h, which.encode(), C.byref(c)))
+        return c.value
+
+    def dims(self, which):
+        m, n, k = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._ck(self.L.cogaps_session_dims(self.h, which.encode(), C.byref(m), C.byref(n), C.byref(k)))
+        return m.value, n.value, k.value
+
+    def matrix(self, which):
+        m, n, k = self.dims(which)
+        out = np.zeros((m, k), dtype=np.float32)
+        self._ck(self.L.cogaps_session_get_matrix(self.h, which.encode(), _fp(out)))
+        return out
+
+    def ap(self, which):
+        m, n, k = self.dims(which)
+        out = np.zeros((m, n), dtype=np.float32)
+        self._ck(self.L.cogaps_session_get_ap(self.h, which.encode(), _fp(out)))
+        return out
+
+    def atoms(self, which, n=None):
+        # size query: the library reports the current count through natoms after an update;
+        # before any update it is 0
+        cap = self.dims(which)[0] * self.dims(which)[2] + (1 << 17)
+        pos = np.zeros(cap, dtype=np.uint64)
+        mass = np.zeros(cap, dtype=np.float32)
+        left = np.zeros(cap, dtype=np.uint32)
+        right = np.zeros(cap, dtype=np.uint32)
+        u32p = C.POINTER(C.c_uint32)
+        self._ck(self.L.cogaps_session_get_atoms(self.h, which.encode(), pos.ctypes.data_as(C.POINTER(C.c_uint64)), _fp(mass),
+                                                 left.ctypes.data_as(u32p), right.ctypes.data_as(u32p)))
+        n = self.natoms(which) if n is None else n
+        return {"pos": pos[:n].copy(), "mass": mass[:n].copy(), "left": left[:n].copy(), "right": right[:n].copy()}
+
+    def avg_queue(self, which):
+        a = C.c_float()
+        self._ck(self.L.cogaps_session_avg_queue(self.h, which.encode(), C.byref(a)))
+        return a.value
+
+    def set_timing(self, on):
+        self._ck(self.L.cogaps_session_set_timing(self.h, int(on)))
+
+    def perf(self):
+        p = CogapsPerfC()
+        self._ck(self.L.cogaps_session_perf(self.h, C.byref(p)))
+        return {f[0]: getattr(p, f[0]) for f in CogapsPerfC._fields_}
+
+    def finish(self):
+        r = CogapsResultC()
+        self._ck(self.L.cogaps_session_finish(self.h, C.byref(r)))
+        return result_to_dict(self.L, r)
+
+
+def run(data, unc=None, lib=None, **kw):
+    """cogaps_run: one full equilibration + sampling run."""
+    L = lib if lib is not None else load()
+    d = np.ascontiguousarray(data, dtype=np.float32)
+    u = None if unc is None else np.ascontiguousarray(unc, dtype=np.float32)
+    p = make_params(L, **kw)
+    r = CogapsResultC()
+    rc = L.cogaps_run(_fp(d), d.shape[0], d.shape[1], C.byref(p), None if u is None else _fp(u), C.byref(r))
+    if rc:
+        raise RuntimeError("cogaps_run: " + L.cogaps_last_error().decode())
+    return result_to_dict(L, r)

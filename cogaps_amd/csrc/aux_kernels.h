@@ -1,0 +1,122 @@
+// aux_kernels.h -- the remaining DenseNormalModel / GapsStatistics pieces around the sampler loop:
+// sync (AP transpose), extraInitialization, chiSq partials, running statistics, meanChiSq partials.
+#pragma once
+#include "gaps_state.h"
+#include "eval_kernel.h"
+
+// DenseNormalModel::sync (DenseNormalModel.cpp:20-36): dst.AP(j,i) = src.AP(i,j).
+// src is [srcM][srcNpad] (vector r contiguous), dst is [dstM = srcN][dstNpad], dstN = srcM.
+// 64x64 tiles through LDS (+1 padding), coalesced on both sides.
+#define TR_TILE 64
+CG_DEVICE void transpose_body(const float *src, float *dst, uint32_t srcM, uint32_t srcN, uint32_t srcNpad, uint32_t dstNpad, uint32_t tilesX)
+{
+    CG_SHARED float tile[TR_TILE][TR_TILE + 1];
+    const uint32_t t = cg_tid();                 // 256 threads: 64 columns x 4 rows per pass
+    const uint32_t bx = cg_bid() % tilesX, by = cg_bid() / tilesX;
+    const uint32_t tx = t & 63u, ty = t >> 6;
+    for (uint32_t k = ty; k < TR_TILE; k += 4) {
+        const uint32_t r = by * TR_TILE + k, c = bx * TR_TILE + tx;   // src row r (vector), element c
+        tile[k][tx] = (r < srcM && c < srcN) ? src[(size_t)r * srcNpad + c] : 0.f;
+    }
+    cg_sync();
+    for (uint32_t k = ty; k < TR_TILE; k += 4) {
+        const uint32_t r = bx * TR_TILE + k, c = by * TR_TILE + tx;   // dst row r = src element index, element c = src row
+        if (r < srcN && c < srcM) dst[(size_t)r * dstNpad + c] = tile[tx][k];
+    }
+}
+CG_KERNEL void transpose_kernel(const float *src, float *dst, uint32_t srcM, uint32_t srcN, uint32_t srcNpad, uint32_t dstNpad, uint32_t tilesX)
+{
+    transpose_body(src, dst, srcM, srcN, srcNpad, dstNpad, tilesX);
+}
+
+// DenseNormalModel::extraInitialization (DenseNormalModel.cpp:38-54): AP(i,j) = sum_k other(i,k)*mat(j,k), k ascending
+CG_KERNEL void init_ap_kernel(SamplerDev S)
+{
+    const uint32_t i = cg_bid() * cg_bdim() + cg_tid();   // element within the vector
+    if (i >= S.N) return;
+    for (uint32_t j = 0; j < S.M; ++j) {
+        float acc = 0.f;
+        for (uint32_t k = 0; k < S.K; ++k) acc = acc + S.other[(size_t)k * S.Npad + i] * S.mat[(size_t)k * S.Mpad + j];
+        S.AP[(size_t)j * S.Npad + i] = acc;
+    }
+}
+
+// number of entries > 0 per column of mat (canUseGibbs counters), one workgroup per column
+CG_KERNEL void count_pos_kernel(SamplerDev S)
+{
+    CG_SHARED uint32_t cnt;
+    const uint32_t k = cg_bid(), t = cg_tid();
+    if (t == 0) cnt = 0;
+    cg_sync();
+    uint32_t c = 0;
+    for (uint32_t r = t; r < S.M; r += cg_bdim()) c += (S.mat[(size_t)k * S.Mpad + r] > 0.f) ? 1u : 0u;
+    if (c) cg_atomic_add_u32(&cnt, c);
+    cg_sync();
+    if (t == 0) S.colPos[k] = cnt;
+}
+
+// DenseNormalModel::chiSq (DenseNormalModel.cpp:56-68): per-vector partials in the (W, float4) lane order;
+// the host adds the M partials sequentially.  One workgroup of redW lanes per vector.
+// chiSq needs the un-squared uncertainty to reproduce ((D-AP)/S)^2 bit for bit: Sraw is [M][Npad]
+CG_KERNEL void chisq_rows_kernel_s(SamplerDev S, const float *Sraw, float *partial)
+{
+    CG_SHARED float lds[32];
+    const uint32_t row = cg_bid(), t = cg_tid(), W = cg_bdim(), nq = S.Npad >> 2;
+    const float *D = S.D + (size_t)row * S.Npad, *SR = Sraw + (size_t)row * S.Npad, *AP = S.AP + (size_t)row * S.Npad;
+    EvalAcc a; a.s = 0.f; a.m = 0.f;
+    for (uint32_t j = t; j < nq; j += W) {
+        const cg_f4 d = ld4(D, j), s = ld4(SR, j), p = ld4(AP, j);
+        { float q = (d.x - p.x) / s.x; a.s = a.s + q * q; }
+        { float q = (d.y - p.y) / s.y; a.s = a.s + q * q; }
+        { float q = (d.z - p.z) / s.z; a.s = a.s + q * q; }
+        { float q = (d.w - p.w) / s.w; a.s = a.s + q * q; }
+    }
+    a = eval_block_reduce(a, lds);
+    if (t == 0) partial[row] = a.s;
+}
+
+// GapsStatistics::update / updateA / updateP (GapsStatistics.h:130-185), one workgroup per pattern.
+// sums are column-major like `mat`: [K][Mpad].  mode: 0 = both (norm = max P column), 1 = A only
+// (norm 1), 2 = P only (norm 1).
+CG_KERNEL void stats_kernel(SamplerDev A, SamplerDev P, float *Asum, float *Asq, float *Psum, float *Psq, uint32_t mode)
+{
+    CG_SHARED float red[256];
+    const uint32_t k = cg_bid(), t = cg_tid(), B = cg_bdim();
+    const float *pc = P.mat + (size_t)k * P.Mpad, *ac = A.mat + (size_t)k * A.Mpad;
+    float norm = 1.f;
+    if (mode == 0) {
+        float mx = 0.f;                                   // gaps::max(Vector): starts at 0 (VectorMath.cpp:43-51)
+        for (uint32_t i = t; i < P.M; i += B) { const float v = pc[i]; mx = (v > mx) ? v : mx; }
+        red[t] = mx; cg_sync();
+        for (uint32_t off = B >> 1; off > 0; off >>= 1) { if (t < off) { const float o = red[t + off]; if (o > red[t]) red[t] = o; } cg_sync(); }
+        norm = red[0];
+        norm = (norm == 0.f) ? 1.f : norm;
+    }
+    if (mode != 1) for (uint32_t i = t; i < P.M; i += B) { const float q = pc[i] / norm; Psum[(size_t)k * P.Mpad + i] += q; Psq[(size_t)k * P.Mpad + i] += q * q; }
+    if (mode != 2) for (uint32_t i = t; i < A.M; i += B) { const float q = ac[i] * norm; Asum[(size_t)k * A.Mpad + i] += q; Asq[(size_t)k * A.Mpad + i] += q * q; }
+}
+
+// GapsStatistics::meanChiSq (GapsStatistics.cpp:63-86) per-vector partials over the P sampler's data
+// (vector j = sample j, elements i = genes), lane order as chiSq.  Asum: [K][A.Mpad], Psum: [K][P.Mpad].
+CG_KERNEL void mean_chisq_rows_kernel(SamplerDev P, const float *Sraw, const float *Asum, const float *Psum, uint32_t AMpad, float n2, float *partial)
+{
+    CG_SHARED float lds[32];
+    const uint32_t j = cg_bid(), t = cg_tid(), W = cg_bdim(), nq = P.Npad >> 2;
+    const float *D = P.D + (size_t)j * P.Npad, *SR = Sraw + (size_t)j * P.Npad;
+    EvalAcc a; a.s = 0.f; a.m = 0.f;
+    for (uint32_t c = t; c < nq; c += W) {
+        const cg_f4 d = ld4(D, c), s = ld4(SR, c);
+        float dd[4] = {d.x, d.y, d.z, d.w}, ss[4] = {s.x, s.y, s.z, s.w};
+        for (uint32_t e = 0; e < 4; ++e) {
+            const uint32_t i = 4 * c + e;
+            if (i < P.N) {
+                float m = 0.f;
+                for (uint32_t k = 0; k < P.K; ++k) m = m + Asum[(size_t)k * AMpad + i] * Psum[(size_t)k * P.Mpad + j];
+                m = m / n2;
+                a.s = a.s + ((dd[e] - m) * (dd[e] - m)) / (ss[e] * ss[e]);
+            }
+        }
+    }
+    a = eval_block_reduce(a, lds);
+    if (t == 0) partial[j] = a.s;
+}

@@ -1,0 +1,644 @@
+// cogaps_hip.cpp -- host side of libcogaps_hip.so: the runner around the HIP kernels and the C ABI
+// of include/cogaps_hip.h.  Restates runCoGAPSAlgorithm / runOnePhase / updateSampler
+// (reference src/GapsRunner.cpp:382-499, :272-327, :201-222), GapsStatistics (GapsStatistics.h/.cpp)
+// and the DenseNormalModel constructor (gibbs_sampler/DenseNormalModel.h:66-88) with every matrix,
+// the atomic domains and the proposal queues resident in HBM.  The host only draws the per-iteration
+// Poisson step counts (GapsRunner.cpp:294-295), streams the Xoroshiro seed sequence the proposal
+// generator consumes (math/Random.cpp:221-248) and enqueues kernels.
+#include "../../include/cogaps_hip.h"
+#include "rt.h"
+#include "gaps_state.h"
+#include "gen_kernel.h"
+#include "eval_kernel.h"
+#include "aux_kernels.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <time.h>
+#include <algorithm>
+#include <vector>
+
+#ifndef GEN_WIN
+#define GEN_WIN 256
+#endif
+
+static thread_local std::string g_last_error;
+static int fail(const std::string &m) { g_last_error = m; return 1; }
+
+// ------------------------------------------------------------------------------------------------
+// host RNG pieces: Xoroshiro128+ seeder (Random.cpp:221-248) and the runner's PCG (GapsRunner.cpp:437)
+// ------------------------------------------------------------------------------------------------
+struct HostSeeder {
+    uint64_t s0, s1;
+    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    uint64_t next()
+    {
+        const uint64_t a = s0; uint64_t b = s1; const uint64_t r = a + b;
+        b ^= a; s0 = rotl(a, 24) ^ b ^ (b << 16); s1 = rotl(b, 37);
+        return r;
+    }
+    void init(uint64_t seed) { s0 = seed | 1; s1 = seed | 1; for (int i = 0; i < 5000; ++i) next(); }
+};
+
+// Random.cpp:125-170 (host double math, as in the reference; gaps::lgamma = libm lgamma here)
+static int host_poisson(uint64_t &st, double lambda)
+{
+    auto unifd = [&]() { return (double)pcg_u32(st) / 4294967295.0; };
+    if (lambda <= 5.0) {
+        int x = 0; double p = unifd(); const double cutoff = exp(-lambda);
+        while (p >= cutoff) { p *= unifd(); ++x; }
+        return x;
+    }
+    const double c = 0.767 - 3.36 / lambda;
+    const double beta = 3.1415926535897932384626433832795 / sqrt(3.0 * lambda);
+    const double alpha = beta * lambda;
+    const double k = log(c) - lambda - log(beta);
+    for (;;) {
+        const double u = unifd();
+        const double x = (alpha - log((1.0 - u) / u)) / beta;
+        const double n = floor(x + 0.5);
+        if (n < 0.0) continue;
+        const double v = unifd();
+        const double y = alpha - beta * x;
+        const double w = 1.0 + exp(y);
+        const double lhs = y + log(v / (w * w));
+        const double rhs = k + n * log(lambda) - lgamma(n + 1);
+        if (lhs <= rhs) return (int)n;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// lookup tables (Random.cpp:269-295 over Math.cpp:43-81): float argument, double-precision normal /
+// gamma(2,1) cdf and quantile, rounded to float.  Boost.Math in the reference; libm + Newton here.
+// ------------------------------------------------------------------------------------------------
+static double lut_erfc_inv(double y)
+{
+    if (y == 1.0) return 0.0;
+    double lo = -6.0, hi = 6.0;
+    for (int i = 0; i < 60; ++i) { const double mid = 0.5 * (lo + hi); if (erfc(mid) > y) lo = mid; else hi = mid; }
+    double x = 0.5 * (lo + hi);
+    for (int i = 0; i < 4; ++i) {
+        const double f = erfc(x) - y, fp = -2.0 / sqrt(3.1415926535897932384626433832795) * exp(-x * x), fpp = -2.0 * x * fp;
+        const double dx = f / fp;
+        x -= dx / (1.0 - 0.5 * dx * fpp / fp);
+    }
+    return x;
+}
+static double lut_gamma2_cdf(double x)
+{
+    if (x < 0.5) { double sum = 0.0, xk = x * x, fact = 2.0; for (int k = 2; k < 40; ++k) { const double t = xk * (double)(k - 1) / fact; sum += (k & 1) ? -t : t; xk *= x; fact *= (double)(k + 1); } return sum; }
+    return 1.0 - exp(-x) * (1.0 + x);
+}
+static double lut_gamma2_quantile(double p)
+{
+    double lo = 0.0, hi = 60.0;
+    for (int i = 0; i < 80; ++i) { const double mid = 0.5 * (lo + hi); if (lut_gamma2_cdf(mid) < p) lo = mid; else hi = mid; }
+    double x = 0.5 * (lo + hi);
+    for (int i = 0; i < 3; ++i) { const double f = lut_gamma2_cdf(x) - p, fp = x * exp(-x); if (fp > 0) x -= f / fp; }
+    return x;
+}
+static void build_luts(std::vector<float> &e, std::vector<float> &ei, std::vector<float> &qg)
+{
+    e.resize(GAPS_ERF_N); ei.resize(GAPS_ERFINV_N); qg.resize(GAPS_QGAMMA_N);
+    auto pnorm = [](float p) { return (float)(0.5 * erfc(-(double)p / 1.41421356237309504880)); };
+    auto qnorm = [](float q) { double r = lut_erfc_inv(2.0 * (double)q); r = -r; r *= 1.41421356237309504880; return (float)(r + 0.0); };
+    auto qgam = [](float q) { if (q < 0.000001f) return 0.f; return (float)lut_gamma2_quantile((double)q); };
+    for (unsigned i = 0; i < GAPS_ERF_N; ++i) { const float x = (float)i / 1000.f; e[i] = 2.f * pnorm(x * GAPS_SQRT2F) - 1.f; }
+    for (unsigned i = 0; i < GAPS_ERFINV_N - 1; ++i) { const float x = (float)i / (float)(GAPS_ERFINV_N - 1); ei[i] = qnorm((1.f + x) / 2.f) / GAPS_SQRT2F; }
+    ei[GAPS_ERFINV_N - 1] = qnorm(1.9998f / 2.f) / GAPS_SQRT2F;
+    qg[0] = 0.f;
+    for (unsigned i = 1; i < GAPS_QGAMMA_N - 1; ++i) { const float x = (float)i / (float)(GAPS_QGAMMA_N - 1); qg[i] = qgam(x); }
+    qg[GAPS_QGAMMA_N - 1] = qgam(0.9998f);
+}
+
+extern "C" uint32_t cogaps_reduction_width(uint32_t N)
+{
+    uint32_t need = (N + 31u) / 32u, w = 64;
+    while (w < need && w < 1024u) w <<= 1;
+    return w;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct HostSampler {
+    SamplerDev d;                 // device pointers + constants (passed by value to the kernels)
+    float *Sraw = nullptr;        // un-squared uncertainty [M][Npad] (chiSq)
+    uint64_t *seeds = nullptr; size_t seedCap = 0;
+    uint64_t *hSeeds = nullptr; size_t hSeedCap = 0;
+    float *partial = nullptr;     // [M] chi2 partials
+    uint32_t nAtoms = 0;          // host copy after the last update
+    float avgQueue = 0.f;
+    size_t traceCap = 0;
+    char name = 'A';
+    // perf accounting
+    uint64_t evalLaunches = 0, genLaunches = 0, batches = 0;
+    double evalMs = 0, genMs = 0; uint64_t evalTimed = 0, genTimed = 0;
+};
+
+struct cogaps_session {
+    cogaps_params p;
+    std::vector<uint32_t> subset; std::vector<float> fixed;
+    uint32_t nGenes = 0, nSamples = 0, K = 0;
+    HostSampler A, P;
+    HostSeeder seeder; uint64_t runnerRng = 0;
+    rt_stream_t stream;
+    float *dErf = nullptr, *dErfinv = nullptr, *dQgamma = nullptr; uint64_t *dLcgMul = nullptr, *dLcgInc = nullptr;
+    float *Asum = nullptr, *Asq = nullptr, *Psum = nullptr, *Psq = nullptr;
+    unsigned statUpdates = 0;
+    std::vector<float> chisqHist; std::vector<uint32_t> atomHistA, atomHistP;
+    uint64_t totalUpdates = 0; double samplerSeconds = 0; double syncMs = 0;
+    bool timing = false; rt_event_pair ev; bool evInit = false;
+    GenScalars *hGs = nullptr;    // pinned staging
+};
+
+static double now_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
+template <class T> static T *dalloc(size_t n) { return (T *)rt_malloc(n * sizeof(T)); }
+
+static void free_sampler(HostSampler &h)
+{
+    SamplerDev &d = h.d;
+    rt_free((void *)d.D); rt_free((void *)d.S2); rt_free(d.AP); rt_free(d.mat); rt_free(d.colPos);
+    rt_free(d.atoms); rt_free(d.vec); rt_free(d.freeHandles); rt_free(d.binHead);
+    rt_free(d.bits0); rt_free(d.bits1); rt_free(d.bits2); rt_free(d.eraseList); rt_free(d.queue);
+    rt_free(d.rowRound); rt_free(d.rowBatch); rt_free(d.atomRound); rt_free(d.atomBatch); rt_free(d.batchMoves);
+    rt_free(d.gs); rt_free(d.trace); rt_free(d.traceBatchNproc); rt_free(d.traceBatchQlen);
+    rt_free(h.Sraw); rt_free(h.seeds); rt_free_host(h.hSeeds); rt_free(h.partial);
+}
+
+// Matrix(mat, genesInCols, subsetGenes, indices) (data_structures/Matrix.cpp:30-69) laid out as
+// [vector j][element i] + the DenseNormalModel constructor (DenseNormalModel.h:66-88)
+static void build_sampler(cogaps_session *s, HostSampler &h, char name, const float *data, uint32_t nrow, uint32_t ncol, const float *unc,
+                          bool genesInCols, bool subsetGenes, float alpha, float maxGibbsMass)
+{
+    const cogaps_params &p = s->p;
+    const bool subsetData = p.subsetData && !s->subset.empty();
+    const uint32_t *indices = s->subset.data(); const uint32_t nIdx = (uint32_t)s->subset.size();
+    const uint32_t nG = (subsetData && subsetGenes) ? nIdx : (genesInCols ? ncol : nrow);
+    const uint32_t nS = (subsetData && !subsetGenes) ? nIdx : (genesInCols ? nrow : ncol);
+    SamplerDev &d = h.d; memset(&d, 0, sizeof(d)); h.name = name;
+    d.N = nG; d.M = nS; d.K = p.nPatterns;
+    d.Npad = (d.N + 3u) & ~3u; d.Mpad = (d.M + 3u) & ~3u;
+    d.redW = cogaps_reduction_width(d.N);
+    const size_t tot = (size_t)d.M * d.Npad;
+    std::vector<float> D(tot, 0.f), S2(tot, 1.f), SR(tot, 1.f);
+    float sum = 0.f; unsigned nnz = 0;
+    for (uint32_t j = 0; j < nS; ++j)
+        for (uint32_t i = 0; i < nG; ++i) {
+            const uint32_t dataRow = (subsetData && (subsetGenes != genesInCols)) ? indices[genesInCols ? j : i] - 1 : (genesInCols ? j : i);
+            const uint32_t dataCol = (subsetData && (subsetGenes == genesInCols)) ? indices[genesInCols ? i : j] - 1 : (genesInCols ? i : j);
+            const float v = data[(size_t)dataRow * ncol + dataCol];
+            const size_t o = (size_t)j * d.Npad + i;
+            D[o] = v;
+            const float sd = unc ? unc[(size_t)dataRow * ncol + dataCol] : gm_max(v * 0.1f, 0.1f);   // gaps::pmax, MatrixMath.cpp:74-84
+            SR[o] = sd; S2[o] = sd * sd;
+            sum += v; if (v > 0.f) ++nnz;                                    // gaps::nonZeroMean, MatrixMath.cpp:39-55
+        }
+    const float meanD = sum / (float)nnz;
+    d.alpha = alpha;
+    d.lambda = alpha * sqrtf((float)(uint64_t)d.K / meanD);
+    d.maxGibbsMass = maxGibbsMass / d.lambda;
+    d.annealTemp = 1.f;
+    float *dD = dalloc<float>(tot), *dS2 = dalloc<float>(tot); h.Sraw = dalloc<float>(tot);
+    rt_h2d(dD, D.data(), tot * 4, s->stream); rt_h2d(dS2, S2.data(), tot * 4, s->stream); rt_h2d(h.Sraw, SR.data(), tot * 4, s->stream);
+    rt_sync(s->stream);
+    d.D = dD; d.S2 = dS2;
+    d.AP = dalloc<float>(tot);
+    d.mat = dalloc<float>((size_t)d.K * d.Mpad);
+    d.colPos = dalloc<uint32_t>(d.K);
+    d.luts.erf = s->dErf; d.luts.erfinv = s->dErfinv; d.luts.qgamma = s->dQgamma;
+    // atomic domain
+    const uint64_t nBins = (uint64_t)d.M * d.K;
+    d.atomCap = (uint32_t)std::min<uint64_t>(nBins + 65536ull, 0x7FFFFFF0ull);
+    d.atoms = dalloc<AtomRec>(d.atomCap); d.vec = dalloc<uint32_t>(d.atomCap); d.freeHandles = dalloc<uint32_t>(d.atomCap);
+    d.binHead = dalloc<uint32_t>(nBins); rt_memset(d.binHead, 0xFF, nBins * 4, s->stream);
+    d.nWords0 = (uint32_t)((nBins + 63) / 64); d.nWords1 = (d.nWords0 + 63) / 64; d.nWords2 = (d.nWords1 + 63) / 64;
+    d.bits0 = dalloc<unsigned long long>(d.nWords0); d.bits1 = dalloc<unsigned long long>(d.nWords1); d.bits2 = dalloc<unsigned long long>(d.nWords2);
+    d.queueCap = d.M + 8; d.eraseCap = d.queueCap;
+    d.eraseList = dalloc<uint32_t>(d.eraseCap); d.queue = dalloc<PropRec>(d.queueCap);
+    d.rowRound = dalloc<unsigned long long>(d.M); d.rowBatch = dalloc<unsigned long long>(d.M);
+    d.atomRound = dalloc<unsigned long long>(d.atomCap); d.atomBatch = dalloc<unsigned long long>(d.atomCap);
+    d.batchMoves = dalloc<uint64_t>(2 * (size_t)d.queueCap);
+    d.lcgMul = s->dLcgMul; d.lcgInc = s->dLcgInc;
+    d.binLength = 0xFFFFFFFFFFFFFFFFull / nBins;               // ProposalQueue.cpp:27
+    d.domainLenU = d.binLength * nBins;                         // ConcurrentAtomicDomain.cpp:16-18
+    d.domainLenD = (double)d.domainLenU;                        // ProposalQueue.cpp:30
+    d.numBins = (double)nBins; d.alphaD = (double)alpha;
+    d.rboundNone = gm_u64_from_double_x86(d.domainLenD);
+    d.gs = dalloc<GenScalars>(1);
+    GenScalars g; memset(&g, 0, sizeof(g));
+    g.front = CG_NONE;
+    g.qrng = pcg_from_seed(s->seeder.next());                   // ProposalQueue::mRng(randState), ProposalQueue.cpp:24
+    rt_h2d(d.gs, &g, sizeof(g), s->stream); rt_sync(s->stream);
+    h.partial = dalloc<float>(d.M);
+}
+
+static void read_gs(cogaps_session *s, HostSampler &h)
+{
+    rt_d2h(s->hGs, h.d.gs, sizeof(GenScalars), s->stream);
+    rt_sync(s->stream);
+}
+
+static void grow_atoms(cogaps_session *s, HostSampler &h, uint32_t need)
+{
+    SamplerDev &d = h.d;
+    if (need <= d.atomCap) return;
+    uint32_t cap = d.atomCap;
+    while (cap < need) cap = (uint32_t)std::min<uint64_t>((uint64_t)cap * 2, 0x7FFFFFF0ull);
+    auto regrow = [&](auto *&ptr, size_t elt) {
+        void *n = rt_malloc((size_t)cap * elt);
+        rt_d2d(n, ptr, (size_t)d.atomCap * elt, s->stream); rt_sync(s->stream);
+        rt_free(ptr); ptr = (decltype(ptr))n;
+    };
+    regrow(d.atoms, sizeof(AtomRec)); regrow(d.vec, 4); regrow(d.freeHandles, 4);
+    regrow(d.atomRound, 8); regrow(d.atomBatch, 8);
+    d.atomCap = cap;
+}
+
+static void launch_gen(cogaps_session *s, HostSampler &h)
+{
+    const bool timed = s->timing && (h.genLaunches % 8 == 0);
+    if (timed) rt_event_start(s->ev, s->stream);
+    RT_LAUNCH(gen_kernel<GEN_WIN>, 1, GEN_WIN, s->stream, h.d);
+    if (timed) { rt_event_stop(s->ev, s->stream); h.genMs += rt_event_ms(s->ev); h.genTimed++; }
+    h.genLaunches++;
+}
+static void launch_eval(cogaps_session *s, HostSampler &h)
+{
+    const uint32_t grid = std::min<uint32_t>(h.d.queueCap, h.d.redW >= 512 ? 256u : 512u);
+    const bool timed = s->timing && (h.evalLaunches % 8 == 0);
+    if (timed) rt_event_start(s->ev, s->stream);
+    RT_LAUNCH(eval_kernel, grid, h.d.redW, s->stream, h.d);
+    if (timed) { rt_event_stop(s->ev, s->stream); h.evalMs += rt_event_ms(s->ev); h.evalTimed++; }
+    h.evalLaunches++;
+}
+
+// AsynchronousGibbsSampler::update (AsynchronousGibbsSampler.h:88-122): batches of generate + evaluate
+// until nSteps proposals have been processed.  The number of batches is data dependent, so (generate,
+// evaluate) pairs are enqueued in chunks and the generator's progress word is read back per chunk;
+// pairs enqueued past the end are no-ops (the generator flushes the last erase cache and reports
+// qlen = 0).
+static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool trace, uint32_t traceCap)
+{
+    SamplerDev &d = h.d;
+    read_gs(s, h);
+    GenScalars g = *s->hGs;
+    grow_atoms(s, h, g.nAtoms + nSteps + 1024u);
+    // seed stream for this update: exactly nSteps seeder outputs are consumed (ProposalQueue.cpp:12-15;
+    // a failed attempt rolls the seeder back, Random.cpp:244-248)
+    if (h.seedCap < (size_t)nSteps + 1) { rt_free(h.seeds); h.seedCap = (size_t)nSteps * 5 / 4 + 1024; h.seeds = dalloc<uint64_t>(h.seedCap); }
+    if (h.hSeedCap < (size_t)nSteps + 1) { rt_free_host(h.hSeeds); h.hSeedCap = (size_t)nSteps * 5 / 4 + 1024; h.hSeeds = (uint64_t *)rt_malloc_host(h.hSeedCap * 8); }
+    for (uint32_t i = 0; i < nSteps; ++i) h.hSeeds[i] = s->seeder.next();
+    rt_h2d(h.seeds, h.hSeeds, (size_t)nSteps * 8, s->stream);
+    d.seeds = h.seeds;
+    if (trace) {
+        if (h.traceCap < traceCap) {
+            rt_free(d.trace); rt_free(d.traceBatchNproc); rt_free(d.traceBatchQlen);
+            d.trace = dalloc<PropRec>(traceCap); d.traceBatchNproc = dalloc<uint32_t>(traceCap); d.traceBatchQlen = dalloc<uint32_t>(traceCap);
+            h.traceCap = traceCap;
+        }
+    }
+    g.nSteps = nSteps; g.nDone = 0; g.nBatches = 0; g.updateFlushed = 0; g.qlen = 0;
+    g.traceOn = trace ? 1u : 0u; g.traceCount = 0; g.traceCap = trace ? traceCap : 0; g.traceBatchCount = 0;
+    *s->hGs = g;
+    rt_h2d(d.gs, s->hGs, sizeof(GenScalars), s->stream);
+    rt_sync(s->stream);
+    if (nSteps == 0) return 0;
+    float avgq = g.avgQueue > 1.f ? g.avgQueue : 1.f;
+    for (;;) {
+        const uint32_t remaining = nSteps - s->hGs->nDone;
+        uint32_t chunk = (uint32_t)((double)remaining / avgq * 1.1) + 4u;
+        if (chunk > 4096u) chunk = 4096u;
+        for (uint32_t b = 0; b < chunk; ++b) { launch_gen(s, h); launch_eval(s, h); }
+        read_gs(s, h);
+        if (s->hGs->error) return fail(std::string("device error code ") + std::to_string(s->hGs->error) + " in sampler " + h.name);
+        if (s->hGs->updateFlushed) break;
+        if (s->hGs->nBatches > 0) avgq = std::max(1.f, (float)s->hGs->nDone / (float)s->hGs->nBatches);
+    }
+    h.nAtoms = s->hGs->nAtoms; h.avgQueue = s->hGs->avgQueue; h.batches += s->hGs->nBatches;
+    return 0;
+}
+
+static void do_sync(cogaps_session *s, HostSampler &dst, HostSampler &src)
+{
+    const uint32_t tilesX = (src.d.N + TR_TILE - 1) / TR_TILE, tilesY = (src.d.M + TR_TILE - 1) / TR_TILE;
+    RT_LAUNCH(transpose_kernel, tilesX * tilesY, 256, s->stream, (const float *)src.d.AP, dst.d.AP, src.d.M, src.d.N, src.d.Npad, dst.d.Npad, tilesX);
+}
+
+static float chisq_of(cogaps_session *s, HostSampler &h)
+{
+    RT_LAUNCH(chisq_rows_kernel_s, h.d.M, h.d.redW, s->stream, h.d, (const float *)h.Sraw, h.partial);
+    std::vector<float> part(h.d.M);
+    rt_d2h(part.data(), h.partial, (size_t)h.d.M * 4, s->stream); rt_sync(s->stream);
+    float c = 0.f;
+    for (uint32_t j = 0; j < h.d.M; ++j) c += part[j];
+    return c;
+}
+
+extern "C" {
+
+void cogaps_default_params(cogaps_params *p)
+{
+    memset(p, 0, sizeof(*p));
+    p->nPatterns = 3; p->nIterations = 1000; p->maxThreads = 1; p->outputFrequency = 500;   // GapsParameters.h:79-111
+    p->alphaA = 0.01f; p->alphaP = 0.01f; p->maxGibbsMassA = 100.f; p->maxGibbsMassP = 100.f;
+    p->printMessages = 0; p->asynchronousUpdates = 1; p->whichMatrixFixed = 'N'; p->workerID = 1; p->device = -1;
+}
+const char *cogaps_last_error(void) { return g_last_error.c_str(); }
+const char *cogaps_build_report(void)
+{
+#if defined(COGAPS_EMUL)
+    return "cogaps-amd TEST-ONLY emulator build (not a product library)";
+#else
+    return "cogaps-amd 0.1 | HIP gfx950 (MI355X) | asynchronous Gibbs sampler, dense normal model | checkpoints: no";
+#endif
+}
+int cogaps_checkpoints_enabled(void) { return 0; }
+int cogaps_compiled_with_openmp(void) { return 0; }
+
+cogaps_session *cogaps_session_create(const float *data, uint32_t nrow, uint32_t ncol, const cogaps_params *params, const float *unc, int data_on_device)
+{
+    cogaps_session *s = nullptr;
+    try {
+        const cogaps_params &p = *params;
+        if (p.useSparseOptimization) { fail("useSparseOptimization (SparseNormalModel) is not available in this build"); return nullptr; }
+        if (!p.asynchronousUpdates) { fail("asynchronousUpdates=FALSE (SingleThreadedGibbsSampler) is not part of this library"); return nullptr; }
+        if (p.nPatterns == 0 || nrow == 0 || ncol == 0) { fail("empty problem"); return nullptr; }
+        if (p.whichMatrixFixed != 'N' && p.whichMatrixFixed != 'A' && p.whichMatrixFixed != 'P') { fail("whichMatrixFixed must be 'N', 'A' or 'P'"); return nullptr; }
+        rt_set_device(p.device);
+        s = new cogaps_session();
+        s->p = p;
+        if (p.subsetData && p.dataIndicesSubset) s->subset.assign(p.dataIndicesSubset, p.dataIndicesSubset + p.nSubset);
+        s->stream = rt_stream_create();
+        std::vector<float> hostData, hostUnc;
+        if (data_on_device) {          // device-resident input: stage through the host once, outside any timed region
+            hostData.resize((size_t)nrow * ncol); rt_d2h(hostData.data(), data, hostData.size() * 4, s->stream);
+            if (unc) { hostUnc.resize((size_t)nrow * ncol); rt_d2h(hostUnc.data(), unc, hostUnc.size() * 4, s->stream); }
+            rt_sync(s->stream); data = hostData.data(); if (unc) unc = hostUnc.data();
+        }
+        s->hGs = (GenScalars *)rt_malloc_host(sizeof(GenScalars));
+        // GapsRandomState(seed): seeder + lookup tables (Cogaps.cpp:158, Random.cpp:264-267)
+        s->seeder.init(p.seed);
+        std::vector<float> e, ei, qg; build_luts(e, ei, qg);
+        s->dErf = dalloc<float>(e.size()); s->dErfinv = dalloc<float>(ei.size()); s->dQgamma = dalloc<float>(qg.size());
+        rt_h2d(s->dErf, e.data(), e.size() * 4, s->stream); rt_h2d(s->dErfinv, ei.data(), ei.size() * 4, s->stream); rt_h2d(s->dQgamma, qg.data(), qg.size() * 4, s->stream);
+        std::vector<uint64_t> lm(2 * GEN_WIN + 2), li(2 * GEN_WIN + 2);
+        for (uint32_t k = 0; k < lm.size(); ++k) pcg_jump_coeffs(k, lm[k], li[k]);
+        s->dLcgMul = dalloc<uint64_t>(lm.size()); s->dLcgInc = dalloc<uint64_t>(li.size());
+        rt_h2d(s->dLcgMul, lm.data(), lm.size() * 8, s->stream); rt_h2d(s->dLcgInc, li.data(), li.size() * 8, s->stream);
+        rt_sync(s->stream);
+        // samplers: A on the transposed data with the subset flag flipped (GapsRunner.cpp:402-406);
+        // seed order: A queue, P queue, runner (AsynchronousGibbsSampler.h:68, GapsRunner.cpp:437)
+        build_sampler(s, s->A, 'A', data, nrow, ncol, unc, !p.transposeData, !p.subsetGenes, p.alphaA, p.maxGibbsMassA);
+        build_sampler(s, s->P, 'P', data, nrow, ncol, unc, p.transposeData != 0, p.subsetGenes != 0, p.alphaP, p.maxGibbsMassP);
+        s->nGenes = s->A.d.M; s->nSamples = s->P.d.M; s->K = p.nPatterns;
+        if (s->A.d.N != s->P.d.M || s->P.d.N != s->A.d.M) throw std::runtime_error("internal: sampler dimensions do not mirror");
+        s->A.d.other = s->P.d.mat; s->A.d.otherColPos = s->P.d.colPos;
+        s->P.d.other = s->A.d.mat; s->P.d.otherColPos = s->A.d.colPos;
+        // processFixedMatrix (GapsRunner.cpp:329-350)
+        if (p.whichMatrixFixed != 'N') {
+            HostSampler &f = (p.whichMatrixFixed == 'A') ? s->A : s->P;
+            if (!p.fixedPatterns || p.fixedRows != f.d.M) throw std::runtime_error("fixedPatterns must have one row per row of the fixed matrix");
+            std::vector<float> m((size_t)f.d.K * f.d.Mpad, 0.f);
+            for (uint32_t r = 0; r < f.d.M; ++r) for (uint32_t k = 0; k < f.d.K; ++k) m[(size_t)k * f.d.Mpad + r] = p.fixedPatterns[(size_t)r * f.d.K + k];
+            rt_h2d(f.d.mat, m.data(), m.size() * 4, s->stream); rt_sync(s->stream);
+            RT_LAUNCH(count_pos_kernel, f.d.K, 256, s->stream, f.d);
+        }
+        s->Asum = dalloc<float>((size_t)s->K * s->A.d.Mpad); s->Asq = dalloc<float>((size_t)s->K * s->A.d.Mpad);
+        s->Psum = dalloc<float>((size_t)s->K * s->P.d.Mpad); s->Psq = dalloc<float>((size_t)s->K * s->P.d.Mpad);
+        s->runnerRng = pcg_from_seed(s->seeder.next());
+        // ASampler.sync(PSampler); PSampler.sync(ASampler); extraInitialization x2 (GapsRunner.cpp:444-447)
+        RT_LAUNCH(init_ap_kernel, (s->A.d.N + 255) / 256, 256, s->stream, s->A.d);
+        RT_LAUNCH(init_ap_kernel, (s->P.d.N + 255) / 256, 256, s->stream, s->P.d);
+        rt_sync(s->stream);
+        return s;
+    } catch (const std::exception &e) {
+        fail(e.what());
+        if (s) cogaps_session_destroy(s);
+        return nullptr;
+    }
+}
+
+void cogaps_session_destroy(cogaps_session *s)
+{
+    if (!s) return;
+    free_sampler(s->A); free_sampler(s->P);
+    rt_free(s->dErf); rt_free(s->dErfinv); rt_free(s->dQgamma); rt_free(s->dLcgMul); rt_free(s->dLcgInc);
+    rt_free(s->Asum); rt_free(s->Asq); rt_free(s->Psum); rt_free(s->Psq);
+    rt_free_host(s->hGs);
+    if (s->evInit) rt_event_destroy(s->ev);
+    rt_stream_destroy(s->stream);
+    delete s;
+}
+
+#define SESSION_TRY try {
+#define SESSION_END } catch (const std::exception &e) { return fail(e.what()); } return 0;
+
+static HostSampler &pick(cogaps_session *s, char w) { return w == 'A' ? s->A : s->P; }
+
+int cogaps_session_set_annealing(cogaps_session *s, float temp) { s->A.d.annealTemp = temp; s->P.d.annealTemp = temp; return 0; }
+
+int cogaps_session_draw_steps(cogaps_session *s, uint32_t *nA, uint32_t *nP)
+{
+    const unsigned a = std::max(s->A.nAtoms, 10u), b = std::max(s->P.nAtoms, 10u);
+    *nA = (uint32_t)host_poisson(s->runnerRng, (double)a);
+    *nP = (uint32_t)host_poisson(s->runnerRng, (double)b);
+    return 0;
+}
+
+int cogaps_session_update(cogaps_session *s, char which, uint32_t nSteps, cogaps_trace_rec *trace, uint32_t traceCap, uint32_t *nTrace,
+                          uint32_t *batchNproc, uint32_t *batchQlen, uint32_t batchCap, uint32_t *nBatches)
+{
+    SESSION_TRY
+    HostSampler &h = pick(s, which);
+    const bool tr = trace != nullptr && traceCap > 0;
+    const uint32_t cap = tr ? std::max(traceCap, batchCap) : 0;
+    if (run_update(s, h, nSteps, tr, cap)) return 1;
+    if (tr) {
+        const uint32_t n = std::min(s->hGs->traceCount, cap), nb = std::min(s->hGs->traceBatchCount, cap);
+        std::vector<PropRec> rec(n);
+        if (n) rt_d2h(rec.data(), h.d.trace, (size_t)n * sizeof(PropRec), s->stream);
+        std::vector<uint32_t> bn(nb), bq(nb);
+        if (nb) { rt_d2h(bn.data(), h.d.traceBatchNproc, (size_t)nb * 4, s->stream); rt_d2h(bq.data(), h.d.traceBatchQlen, (size_t)nb * 4, s->stream); }
+        rt_sync(s->stream);
+        for (uint32_t i = 0; i < n && i < traceCap; ++i) {
+            cogaps_trace_rec &o = trace[i]; const PropRec &r = rec[i];
+            o.pos = r.pos; o.rng_state = r.rng; o.atom1 = r.i1; o.atom2 = r.i2; o.r1 = r.r1; o.c1 = r.c1; o.r2 = r.r2; o.c2 = r.c2; o.type = r.type; o.batch = r.pad[0];
+        }
+        for (uint32_t i = 0; i < nb && i < batchCap; ++i) { if (batchNproc) batchNproc[i] = bn[i]; if (batchQlen) batchQlen[i] = bq[i]; }
+        if (nTrace) *nTrace = s->hGs->traceCount;
+        if (nBatches) *nBatches = s->hGs->traceBatchCount;
+    }
+    SESSION_END
+}
+
+int cogaps_session_sync(cogaps_session *s, char which)
+{
+    SESSION_TRY
+    if (which == 'A') do_sync(s, s->A, s->P); else do_sync(s, s->P, s->A);
+    SESSION_END
+}
+
+// updateSampler (GapsRunner.cpp:201-222) + GapsStatistics::update* (GapsRunner.cpp:299-312)
+int cogaps_session_iterate(cogaps_session *s, uint32_t nA, uint32_t nP, int sampling)
+{
+    SESSION_TRY
+    const char f = s->p.whichMatrixFixed;
+    if (f != 'A') { if (run_update(s, s->A, nA, false, 0)) return 1; if (f != 'P') do_sync(s, s->P, s->A); }
+    if (f != 'P') { if (run_update(s, s->P, nP, false, 0)) return 1; if (f != 'A') do_sync(s, s->A, s->P); }
+    s->totalUpdates += (uint64_t)nA + nP;
+    if (sampling) {
+        const uint32_t mode = (f == 'N') ? 0u : (f == 'P' ? 1u : 2u);   // P fixed -> updateA ; A fixed -> updateP
+        RT_LAUNCH(stats_kernel, s->K, 256, s->stream, s->A.d, s->P.d, s->Asum, s->Asq, s->Psum, s->Psq, mode);
+        s->statUpdates++;
+    }
+    SESSION_END
+}
+
+// runOnePhase (GapsRunner.cpp:272-327) for iterations [firstIter, firstIter+n)
+int cogaps_session_run_iterations(cogaps_session *s, int phase, uint32_t firstIter, uint32_t n, uint64_t *updates)
+{
+    SESSION_TRY
+    const double t0 = now_s();
+    for (uint32_t it = firstIter; it < firstIter + n; ++it) {
+        if (s->p.interrupt && s->p.interrupt(s->p.interruptArg)) return fail("interrupted");
+        if (phase == 1) {
+            const float temp = (float)(2 * it) / (float)s->p.nIterations;
+            cogaps_session_set_annealing(s, gm_min(1.f, temp));
+        }
+        uint32_t nA, nP; cogaps_session_draw_steps(s, &nA, &nP);
+        if (cogaps_session_iterate(s, nA, nP, phase == 2)) return 1;
+        if (updates) *updates += (uint64_t)nA + nP;
+        if (s->p.outputFrequency > 0 && ((it + 1) % s->p.outputFrequency) == 0) {        // displayStatus, :162-199
+            const float cs = (s->p.whichMatrixFixed == 'P') ? chisq_of(s, s->A) : chisq_of(s, s->P);
+            s->chisqHist.push_back(cs); s->atomHistA.push_back(s->A.nAtoms); s->atomHistP.push_back(s->P.nAtoms);
+            if (s->p.printMessages) { printf("%u of %u, Atoms: %u(A), %u(P), ChiSq: %.0f\n", it + 1, s->p.nIterations, s->A.nAtoms, s->P.nAtoms, cs); fflush(stdout); }
+        }
+    }
+    rt_sync(s->stream);
+    s->samplerSeconds += now_s() - t0;
+    SESSION_END
+}
+
+int cogaps_session_natoms(cogaps_session *s, char which, uint32_t *n) { *n = pick(s, which).nAtoms; return 0; }
+int cogaps_session_chisq(cogaps_session *s, char which, float *c) { SESSION_TRY *c = chisq_of(s, pick(s, which)); SESSION_END }
+int cogaps_session_dims(cogaps_session *s, char which, uint32_t *M, uint32_t *N, uint32_t *K) { HostSampler &h = pick(s, which); *M = h.d.M; *N = h.d.N; *K = h.d.K; return 0; }
+int cogaps_session_avg_queue(cogaps_session *s, char which, float *a) { *a = pick(s, which).avgQueue; return 0; }
+
+int cogaps_session_get_matrix(cogaps_session *s, char which, float *out)
+{
+    SESSION_TRY
+    HostSampler &h = pick(s, which);
+    std::vector<float> m((size_t)h.d.K * h.d.Mpad);
+    rt_d2h(m.data(), h.d.mat, m.size() * 4, s->stream); rt_sync(s->stream);
+    for (uint32_t r = 0; r < h.d.M; ++r) for (uint32_t k = 0; k < h.d.K; ++k) out[(size_t)r * h.d.K + k] = m[(size_t)k * h.d.Mpad + r];
+    SESSION_END
+}
+int cogaps_session_get_ap(cogaps_session *s, char which, float *out)
+{
+    SESSION_TRY
+    HostSampler &h = pick(s, which);
+    std::vector<float> m((size_t)h.d.M * h.d.Npad);
+    rt_d2h(m.data(), h.d.AP, m.size() * 4, s->stream); rt_sync(s->stream);
+    for (uint32_t r = 0; r < h.d.M; ++r) memcpy(out + (size_t)r * h.d.N, m.data() + (size_t)r * h.d.Npad, (size_t)h.d.N * 4);
+    SESSION_END
+}
+int cogaps_session_get_atoms(cogaps_session *s, char which, uint64_t *pos, float *mass, uint32_t *left, uint32_t *right)
+{
+    SESSION_TRY
+    HostSampler &h = pick(s, which);
+    read_gs(s, h);
+    const uint32_t n = s->hGs->nAtoms;
+    std::vector<uint32_t> vec(n); std::vector<AtomRec> atoms(h.d.atomCap);
+    if (n) rt_d2h(vec.data(), h.d.vec, (size_t)n * 4, s->stream);
+    rt_d2h(atoms.data(), h.d.atoms, (size_t)h.d.atomCap * sizeof(AtomRec), s->stream); rt_sync(s->stream);
+    for (uint32_t i = 0; i < n; ++i) {
+        const AtomRec &a = atoms[vec[i]];
+        if (pos) pos[i] = a.pos;
+        if (mass) mass[i] = a.mass;
+        if (left) left[i] = a.left != CG_NONE ? atoms[a.left].idx : CG_NONE;
+        if (right) right[i] = a.right != CG_NONE ? atoms[a.right].idx : CG_NONE;
+    }
+    SESSION_END
+}
+
+int cogaps_session_finish(cogaps_session *s, cogaps_result *out)
+{
+    SESSION_TRY
+    memset(out, 0, sizeof(*out));
+    out->nGenes = s->nGenes; out->nSamples = s->nSamples; out->nPatterns = s->K;
+    const uint32_t K = s->K;
+    auto fetch = [&](float *dptr, size_t n) { std::vector<float> v(n); rt_d2h(v.data(), dptr, n * 4, s->stream); rt_sync(s->stream); return v; };
+    std::vector<float> As = fetch(s->Asum, (size_t)K * s->A.d.Mpad), Aq = fetch(s->Asq, (size_t)K * s->A.d.Mpad);
+    std::vector<float> Ps = fetch(s->Psum, (size_t)K * s->P.d.Mpad), Pq = fetch(s->Psq, (size_t)K * s->P.d.Mpad);
+    const float n = (float)s->statUpdates;
+    auto fill = [&](uint32_t rows, uint32_t Mpad, const std::vector<float> &sum, const std::vector<float> &sq, float *&mean, float *&sd) {
+        mean = (float *)malloc((size_t)rows * K * 4 + 4); sd = (float *)malloc((size_t)rows * K * 4 + 4);
+        for (uint32_t i = 0; i < rows; ++i) for (uint32_t k = 0; k < K; ++k) {       // GapsStatistics.cpp:13-59
+            const float a = sum[(size_t)k * Mpad + i], q = sq[(size_t)k * Mpad + i];
+            mean[(size_t)i * K + k] = a / n;
+            const float meanTerm = (a * a) / n, numer = gm_max(0.f, q - meanTerm);
+            sd[(size_t)i * K + k] = sqrtf(numer / (n - 1.f));
+        }
+    };
+    fill(s->nGenes, s->A.d.Mpad, As, Aq, out->Amean, out->Asd);
+    fill(s->nSamples, s->P.d.Mpad, Ps, Pq, out->Pmean, out->Psd);
+    out->nHistory = (uint32_t)s->chisqHist.size();
+    out->chisqHistory = (float *)malloc(out->nHistory * 4 + 4); out->atomHistoryA = (uint32_t *)malloc(out->nHistory * 4 + 4); out->atomHistoryP = (uint32_t *)malloc(out->nHistory * 4 + 4);
+    memcpy(out->chisqHistory, s->chisqHist.data(), out->nHistory * 4); memcpy(out->atomHistoryA, s->atomHistA.data(), out->nHistory * 4); memcpy(out->atomHistoryP, s->atomHistP.data(), out->nHistory * 4);
+    out->totalUpdates = s->totalUpdates; out->seed = s->p.seed;
+    out->averageQueueLengthA = s->A.avgQueue; out->averageQueueLengthP = s->P.avgQueue;
+    out->samplerSeconds = s->samplerSeconds; out->totalRunningTime = (uint32_t)s->samplerSeconds;
+    out->meanChiSq = 0.f;                                                             // GapsRunner.cpp:478-484
+    if (s->p.whichMatrixFixed == 'N' && s->statUpdates > 0) {
+        const float n2 = (float)s->statUpdates * (float)s->statUpdates;
+        RT_LAUNCH(mean_chisq_rows_kernel, s->P.d.M, s->P.d.redW, s->stream, s->P.d, (const float *)s->P.Sraw, (const float *)s->Asum, (const float *)s->Psum, s->A.d.Mpad, n2, s->P.partial);
+        std::vector<float> part(s->P.d.M);
+        rt_d2h(part.data(), s->P.partial, (size_t)s->P.d.M * 4, s->stream); rt_sync(s->stream);
+        float c = 0.f; for (uint32_t j = 0; j < s->P.d.M; ++j) c += part[j];
+        out->meanChiSq = c;
+    }
+    SESSION_END
+}
+
+int cogaps_session_set_timing(cogaps_session *s, int on)
+{
+    SESSION_TRY
+    if (on && !s->evInit) { rt_event_create(s->ev); s->evInit = true; }
+    s->timing = on != 0;
+    SESSION_END
+}
+int cogaps_session_perf(cogaps_session *s, cogaps_perf *out)
+{
+    SESSION_TRY
+    memset(out, 0, sizeof(*out));
+    for (HostSampler *h : {&s->A, &s->P}) {
+        read_gs(s, *h);
+        out->evalBytes += s->hGs->evalBytes; out->proposalsQueued += s->hGs->evalProps;
+        out->evalLaunches += h->evalLaunches; out->genLaunches += h->genLaunches; out->batches += h->batches;
+        // sampled event timing (every 8th launch) scaled to all launches
+        if (h->evalTimed) out->evalMs += h->evalMs * (double)h->evalLaunches / (double)h->evalTimed;
+        if (h->genTimed) out->genMs += h->genMs * (double)h->genLaunches / (double)h->genTimed;
+    }
+    out->syncMs = s->syncMs;
+    SESSION_END
+}
+
+int cogaps_run(const float *data, uint32_t nrow, uint32_t ncol, const cogaps_params *params, const float *unc, cogaps_result *out)
+{
+    cogaps_session *s = cogaps_session_create(data, nrow, ncol, params, unc, 0);
+    if (!s) return 1;
+    int rc = cogaps_session_run_iterations(s, 1, 0, params->nIterations, nullptr);
+    if (!rc) rc = cogaps_session_run_iterations(s, 2, 0, params->nIterations, nullptr);
+    if (!rc) rc = cogaps_session_finish(s, out);
+    cogaps_session_destroy(s);
+    return rc;
+}
+
+void cogaps_result_free(cogaps_result *r)
+{
+    if (!r) return;
+    free(r->Amean); free(r->Asd); free(r->Pmean); free(r->Psd); free(r->chisqHistory); free(r->atomHistoryA); free(r->atomHistoryP);
+    memset(r, 0, sizeof(*r));
+}
+
+} // extern "C"

@@ -1,0 +1,106 @@
+// gaps_state.h -- HBM-resident state of one Gibbs sampler (the A or the P instance) as the kernels
+// see it.  One `SamplerDev` mirrors AsynchronousGibbsSampler<DenseNormalModel> =
+// DenseNormalModel matrices + ConcurrentAtomicDomain + ProposalQueue
+// (reference: gibbs_sampler/AsynchronousGibbsSampler.h:32-84, DenseNormalModel.h:56-64,
+//  atomic/ConcurrentAtomicDomain.h:43-47, atomic/ProposalQueue.h:55-73).
+#pragma once
+#include "platform.h"
+#include "gaps_math.h"
+
+// One atom.  Addressed by HANDLE (stable for the atom's life, like the reference's heap pointer);
+// `vec` (index -> handle) restates the unsorted mAtoms vector used for uniform random picks
+// (ConcurrentAtomicDomain.cpp:32-44) and `idx` is the back pointer (ConcurrentAtom::mIndex).
+struct alignas(32) AtomRec {
+    uint64_t pos;
+    uint32_t left, right;   // neighbour handles in position order, CG_NONE at the ends
+    float mass;
+    uint32_t idx;
+    uint32_t pad0, pad1;
+};
+
+// One queued proposal (ProposalQueue.h:15-28).  64 bytes.
+struct alignas(16) PropRec {
+    uint64_t pos;        // move destination
+    uint64_t rng;        // PCG state after the populate-phase draws
+    uint32_t h1, h2;     // atom handles
+    uint32_t i1, i2;     // their indices in `vec` at populate time (trace / parity only)
+    uint32_t r1, c1, r2, c2;
+    uint32_t type;       // 'B','D','M','E'
+    uint32_t pad[3];
+};
+
+// Mutable scalars of the proposal generator, one cache line region in HBM.
+struct GenScalars {
+    uint64_t qrng;            // ProposalQueue::mRng state
+    uint64_t batchEpoch;      // stamps for the conflict tables
+    uint64_t roundEpoch;
+    uint32_t nAtoms;          // domain size (mAtoms.size())
+    uint32_t front;           // handle of the lowest-position atom (ConcurrentAtomicDomain::front)
+    uint32_t freeCount;       // free-handle stack depth
+    uint32_t handleHi;        // bump allocator high-water mark
+    uint32_t nSteps, nDone;   // update(nSteps) progress
+    uint32_t qlen;            // queue size of the current batch
+    uint32_t batchNproc;      // mNumProcessed of the current batch
+    uint32_t eraseCount;      // erase cache fill
+    uint32_t useCached;       // mUseCachedRng
+    float u1, u2;             // mU1, mU2
+    float avgQueue, nQueueSamples;   // AsynchronousGibbsSampler::mAvgQueueLength / mNumQueueSamples
+    uint32_t nBatches;        // batches generated in this update
+    uint32_t error;           // sticky error code (capacity overflow ...)
+    uint32_t traceOn, traceCount, traceCap, traceBatchCount;
+    uint32_t updateFlushed;   // set by the generator once nDone == nSteps and the last erase cache is flushed
+    uint32_t pad0;
+    unsigned long long evalBytes;   // algorithmic HBM bytes of the evaluation kernel (roofline numerator)
+    unsigned long long evalProps;   // proposals evaluated
+    uint32_t pad[2];
+};
+
+enum GapsError { GAPS_OK = 0, GAPS_ERR_ATOM_CAP = 1, GAPS_ERR_QUEUE_CAP = 2, GAPS_ERR_ERASE_CAP = 3, GAPS_ERR_SPIN = 4 };
+
+struct SamplerDev {
+    // ---- dimensions -------------------------------------------------------------------------
+    uint32_t M;        // rows of this sampler's factor matrix (genes for A, samples for P)
+    uint32_t N;        // length of every data vector (samples for A, genes for P)
+    uint32_t K;        // nPatterns
+    uint32_t Npad;     // row stride of D/S2/AP (N rounded up to a multiple of 4; pad: D=0,S2=1,AP=0)
+    uint32_t Mpad;     // column stride of `mat` (== the other sampler's Npad)
+    uint32_t redW;     // reduction lanes (= evaluation workgroup size), power of two, 64..1024
+    // ---- DenseNormalModel ----------------------------------------------------------------------
+    const float *D;    // [M][Npad]
+    const float *S2;   // [M][Npad]  S*S precomputed (v/(S*S) is evaluated as v/S2: same rounding)
+    float *AP;         // [M][Npad]
+    float *mat;        // column-major [K][Mpad]: mMatrix(r,k) = mat[k*Mpad + r]
+    const float *other;// the other sampler's mat: [K][Npad]
+    uint32_t *colPos;  // [K] number of entries > 0 in each column of `mat`
+    const uint32_t *otherColPos; // the other sampler's colPos (canUseGibbs, DenseNormalModel.cpp:100-108)
+    float lambda, maxGibbsMass, annealTemp, alpha;
+    GapsLuts luts;
+    // ---- ConcurrentAtomicDomain ---------------------------------------------------------------
+    AtomRec *atoms;    // [atomCap] by handle
+    uint32_t *vec;     // [atomCap] index -> handle
+    uint32_t *freeHandles; // [atomCap] stack
+    uint32_t atomCap;
+    uint32_t *binHead; // [M*K] lowest-position atom of each bin or CG_NONE
+    unsigned long long *bits0, *bits1, *bits2;  // occupancy bitmap: exact level 0, monotone hints above
+    uint32_t nWords0, nWords1, nWords2;
+    uint32_t *eraseList; // [eraseCap] handles (mEraseCache)
+    uint32_t eraseCap;
+    // ---- ProposalQueue -------------------------------------------------------------------------
+    PropRec *queue;    // [queueCap]
+    uint32_t queueCap;
+    const uint64_t *seeds;  // seeder outputs for this update(): candidate k of the update uses seeds[k]
+    unsigned long long *rowRound, *rowBatch;   // [M]   conflict stamps (FixedHashSetU32 mUsedMatrixIndices)
+    unsigned long long *atomRound, *atomBatch; // [atomCap] (SmallHashSetU64 mUsedAtoms, by handle)
+    uint64_t *batchMoves;  // [2*queueCap] (lo,hi) intervals of queued moves of earlier rounds (mProposedMoves)
+    uint32_t *batchMoveCount;
+    const uint64_t *lcgMul, *lcgInc; // k-step PCG jump coefficients, k = 0 .. 2*GEN_WIN+1
+    uint64_t binLength;    // mBinLength
+    uint64_t domainLenU;   // ConcurrentAtomicDomain::mDomainLength (exact)
+    double domainLenD;     // ProposalQueue::mDomainLength
+    double numBins, alphaD;
+    uint64_t rboundNone;   // static_cast<uint64_t>(mDomainLength), ProposalQueue.cpp:216
+    GenScalars *gs;
+    // ---- optional trace (parity tests) -------------------------------------------------------
+    PropRec *trace;        // [traceCap] copies of queued proposals
+    uint32_t *traceBatchNproc, *traceBatchQlen; // [traceCap]
+};

@@ -1,0 +1,46 @@
+// platform.h -- the thin layer between the sampler kernels and the machine they run on.
+//
+// Product build (hipcc, gfx950): everything maps straight onto HIP / CDNA4 intrinsics.
+// Test build (-DCOGAPS_EMUL, g++, tests/emul only): the SAME kernel source runs on a cooperative
+// fiber-per-lane workgroup emulator so that the device-side populate / flush logic can be unit
+// tested against the oracle on a machine without a GPU.  The emulator is test infrastructure; the
+// product library never contains it and the Python package never loads it.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(COGAPS_EMUL)
+#include "emul_runtime.h"   // tests/emul/
+#else
+#include <hip/hip_runtime.h>
+
+#define CG_HD __host__ __device__ __forceinline__
+#define CG_DEVICE __device__ __forceinline__
+#define CG_KERNEL __global__
+#define CG_SHARED __shared__
+#define CG_LAUNCH_BOUNDS(n) __launch_bounds__(n)
+
+CG_DEVICE unsigned cg_tid() { return threadIdx.x; }
+CG_DEVICE unsigned cg_bid() { return blockIdx.x; }
+CG_DEVICE unsigned cg_bdim() { return blockDim.x; }
+CG_DEVICE unsigned cg_gdim() { return gridDim.x; }
+CG_DEVICE void cg_sync() { __syncthreads(); }
+
+// global-memory atomics (device scope)
+CG_DEVICE uint32_t cg_atomic_add_u32(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
+CG_DEVICE uint32_t cg_atomic_sub_u32(uint32_t *p, uint32_t v) { return atomicSub(p, v); }
+CG_DEVICE uint32_t cg_atomic_min_u32(uint32_t *p, uint32_t v) { return atomicMin(p, v); }
+CG_DEVICE uint32_t cg_atomic_or_u32(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
+CG_DEVICE unsigned long long cg_atomic_add_u64(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
+CG_DEVICE unsigned long long cg_atomic_max_u64(unsigned long long *p, unsigned long long v) { return atomicMax(p, v); }
+CG_DEVICE unsigned long long cg_atomic_or_u64(unsigned long long *p, unsigned long long v) { return atomicOr(p, v); }
+CG_DEVICE unsigned long long cg_atomic_and_u64(unsigned long long *p, unsigned long long v) { return atomicAnd(p, v); }
+
+// wave64 cross-lane
+CG_DEVICE float cg_shfl_xor_f32(float v, int mask) { return __shfl_xor(v, mask, 64); }
+CG_DEVICE int cg_clz64(unsigned long long x) { return __clzll((long long)x); }
+CG_DEVICE int cg_ctz64(unsigned long long x) { return __ffsll((long long)x) - 1; }
+
+#endif // COGAPS_EMUL
+
+#define CG_NONE 0xFFFFFFFFu

@@ -1,0 +1,59 @@
+// rt.h -- host-side runtime shim: device memory, copies, launches.  HIP in the product build; plain
+// host memory + the fiber emulator in the test-only COGAPS_EMUL build (tests/emul).
+#pragma once
+#include "platform.h"
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <stdexcept>
+
+#if defined(COGAPS_EMUL)
+
+typedef int rt_stream_t;
+inline void *rt_malloc(size_t n) { void *p = calloc(n ? n : 1, 1); if (!p) throw std::runtime_error("out of memory"); return p; }
+inline void rt_free(void *p) { free(p); }
+inline void *rt_malloc_host(size_t n) { return rt_malloc(n); }
+inline void rt_free_host(void *p) { free(p); }
+inline void rt_h2d(void *d, const void *h, size_t n, rt_stream_t) { memcpy(d, h, n); }
+inline void rt_d2h(void *h, const void *d, size_t n, rt_stream_t) { memcpy(h, d, n); }
+inline void rt_d2d(void *d, const void *s, size_t n, rt_stream_t) { memcpy(d, s, n); }
+inline void rt_memset(void *d, int v, size_t n, rt_stream_t) { memset(d, v, n); }
+inline void rt_sync(rt_stream_t) {}
+inline void rt_set_device(int) {}
+inline rt_stream_t rt_stream_create() { return 0; }
+inline void rt_stream_destroy(rt_stream_t) {}
+#define RT_LAUNCH(kernel, grid, block, stream, ...) cgemu::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })
+struct rt_event_pair { };
+inline void rt_event_create(rt_event_pair &) {}
+inline void rt_event_destroy(rt_event_pair &) {}
+inline void rt_event_start(rt_event_pair &, rt_stream_t) {}
+inline void rt_event_stop(rt_event_pair &, rt_stream_t) {}
+inline float rt_event_ms(rt_event_pair &) { return 0.f; }
+inline const char *rt_platform_name() { return "emulator (test only)"; }
+
+#else
+
+#define RT_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+typedef hipStream_t rt_stream_t;
+inline void *rt_malloc(size_t n) { void *p = nullptr; RT_CHECK(hipMalloc(&p, n ? n : 1)); RT_CHECK(hipMemset(p, 0, n ? n : 1)); return p; }
+inline void rt_free(void *p) { if (p) (void)hipFree(p); }
+inline void *rt_malloc_host(size_t n) { void *p = nullptr; RT_CHECK(hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault)); return p; }
+inline void rt_free_host(void *p) { if (p) (void)hipHostFree(p); }
+inline void rt_h2d(void *d, const void *h, size_t n, rt_stream_t s) { RT_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s)); }
+inline void rt_d2h(void *h, const void *d, size_t n, rt_stream_t s) { RT_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s)); }
+inline void rt_d2d(void *d, const void *sr, size_t n, rt_stream_t s) { RT_CHECK(hipMemcpyAsync(d, sr, n, hipMemcpyDeviceToDevice, s)); }
+inline void rt_memset(void *d, int v, size_t n, rt_stream_t s) { RT_CHECK(hipMemsetAsync(d, v, n, s)); }
+inline void rt_sync(rt_stream_t s) { RT_CHECK(hipStreamSynchronize(s)); }
+inline void rt_set_device(int d) { if (d >= 0) RT_CHECK(hipSetDevice(d)); }
+inline rt_stream_t rt_stream_create() { hipStream_t s; RT_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); return s; }
+inline void rt_stream_destroy(rt_stream_t s) { (void)hipStreamDestroy(s); }
+#define RT_LAUNCH(kernel, grid, block, stream, ...) do { hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (stream), __VA_ARGS__); RT_CHECK(hipGetLastError()); } while (0)
+struct rt_event_pair { hipEvent_t a, b; };
+inline void rt_event_create(rt_event_pair &e) { RT_CHECK(hipEventCreate(&e.a)); RT_CHECK(hipEventCreate(&e.b)); }
+inline void rt_event_destroy(rt_event_pair &e) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+inline void rt_event_start(rt_event_pair &e, rt_stream_t s) { RT_CHECK(hipEventRecord(e.a, s)); }
+inline void rt_event_stop(rt_event_pair &e, rt_stream_t s) { RT_CHECK(hipEventRecord(e.b, s)); }
+inline float rt_event_ms(rt_event_pair &e) { float ms = 0.f; RT_CHECK(hipEventSynchronize(e.b)); RT_CHECK(hipEventElapsedTime(&ms, e.a, e.b)); return ms; }
+inline const char *rt_platform_name() { return "HIP gfx950"; }
+
+#endif

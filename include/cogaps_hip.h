@@ -1,0 +1,148 @@
+/*
+ * cogaps_hip.h -- C ABI of libcogaps_hip.so, the MI355X (gfx950) implementation of the CoGAPS
+ * asynchronous Gibbs sampler hot path.
+ *
+ * The boundary it replaces is the reference's language-neutral core entry
+ *     GapsResult gaps::run(const Matrix &data, GapsParameters &params,
+ *                          const Matrix &uncertainty, GapsRandomState *randState)
+ * (reference src/GapsRunner.h:17-22, src/GapsRunner.cpp:113-123), which Rcpp's cogaps_cpp
+ * (src/Cogaps.cpp:205-215, R/RcppExports.R:8-10) reaches through cogapsRun (src/Cogaps.cpp:148-186).
+ * INTEGRATION.md shows the Rcpp stub that binds these entry points in place of gaps::run.
+ *
+ * Plain pointers and sizes only; the callee copies its inputs; results are callee-allocated and
+ * released with cogaps_result_free.  All functions return 0 on success and a non-zero code plus a
+ * message (cogaps_last_error) on failure; nothing calls exit() (reference: utils/GapsAssert.h:19-25).
+ * One host thread drives one GPU; the library keeps no global mutable state besides the last error.
+ */
+#ifndef COGAPS_HIP_H
+#define COGAPS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* POD mirror of GapsParameters (reference src/GapsParameters.h:35-66; defaults :79-111) */
+typedef struct cogaps_params {
+    uint32_t seed;
+    uint32_t nPatterns;          /* default 3 */
+    uint32_t nIterations;        /* default 1000, per phase */
+    uint32_t maxThreads;         /* accepted for API parity; the GPU path ignores it */
+    uint32_t outputFrequency;    /* default 500 */
+    uint32_t checkpointInterval; /* accepted, must be 0 (checkpoints are disabled, Cogaps.cpp:224-231) */
+    uint32_t snapshotFrequency;  /* accepted, must be 0 in this round */
+    float alphaA, alphaP;        /* default 0.01 */
+    float maxGibbsMassA, maxGibbsMassP; /* default 100 */
+    int32_t transposeData;
+    int32_t printMessages;
+    int32_t subsetData;          /* dataIndicesSubset in use */
+    int32_t subsetGenes;         /* subsetDim == 1 (rows of A) else samples */
+    const uint32_t *dataIndicesSubset; /* 1-based indices, as R passes them (Matrix.cpp:55-62) */
+    uint32_t nSubset;
+    int32_t useSparseOptimization; /* must be 0: SparseNormalModel is not built in this round */
+    int32_t takePumpSamples;       /* must be 0 in this round */
+    int32_t asynchronousUpdates;   /* must be 1: this library IS the asynchronous sampler */
+    char whichMatrixFixed;         /* 'N', 'A' or 'P' */
+    const float *fixedPatterns;    /* row-major [fixedRows][nPatterns] when whichMatrixFixed != 'N' */
+    uint32_t fixedRows;
+    uint32_t workerID;
+    int32_t runningDistributed;
+    int32_t device;                /* HIP device ordinal, -1 = current */
+    int (*interrupt)(void *);      /* polled once per iteration (GapsRunner.cpp:280); non-zero aborts */
+    void *interruptArg;
+} cogaps_params;
+
+/* POD mirror of GapsResult (reference src/GapsResult.h:17-36) + the names cogapsRun returns */
+typedef struct cogaps_result {
+    uint32_t nGenes, nSamples, nPatterns;
+    float *Amean, *Asd;          /* row-major [nGenes][nPatterns] */
+    float *Pmean, *Psd;          /* row-major [nSamples][nPatterns] */
+    uint32_t nHistory;
+    float *chisqHistory;         /* diagnostics$chisq */
+    uint32_t *atomHistoryA;      /* diagnostics$atomsA */
+    uint32_t *atomHistoryP;      /* diagnostics$atomsP */
+    uint64_t totalUpdates;
+    uint32_t seed;
+    uint32_t totalRunningTime;   /* seconds */
+    float meanChiSq;
+    float averageQueueLengthA, averageQueueLengthP;
+    double samplerSeconds;       /* wall time of the two phases, for proposals/s */
+} cogaps_result;
+
+void cogaps_default_params(cogaps_params *p);
+
+/* gaps::run for an in-memory matrix: data row-major [nrow][ncol] fp32 (genes x samples unless
+ * transposeData), uncertainty the same shape or NULL.  Host pointers. */
+int cogaps_run(const float *data, uint32_t nrow, uint32_t ncol, const cogaps_params *params,
+               const float *uncertainty, cogaps_result *out);
+void cogaps_result_free(cogaps_result *r);
+const char *cogaps_last_error(void);
+
+/* the three trivial exports next to cogaps_cpp (src/Cogaps.cpp:217-246) */
+const char *cogaps_build_report(void);
+int cogaps_checkpoints_enabled(void);
+int cogaps_compiled_with_openmp(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Session interface: the same run, one step at a time.  Used by bench.py (inputs resident in HBM
+ * before the timed region; `data_on_device` accepts a device pointer) and by the parity tests
+ * (per-batch proposal traces).  cogaps_run is cogaps_session_create + phases + finish.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct cogaps_session cogaps_session;
+
+typedef struct cogaps_trace_rec {   /* one queued proposal, ProposalQueue.h:15-28 */
+    uint64_t pos, rng_state;
+    uint32_t atom1, atom2;          /* indices in the unsorted atom vector, 0xFFFFFFFF = none */
+    uint32_t r1, c1, r2, c2;
+    uint32_t type;                  /* 'B','D','M','E' */
+    uint32_t batch;
+} cogaps_trace_rec;
+
+cogaps_session *cogaps_session_create(const float *data, uint32_t nrow, uint32_t ncol,
+                                      const cogaps_params *params, const float *uncertainty,
+                                      int data_on_device);
+void cogaps_session_destroy(cogaps_session *s);
+/* annealing temperature of both samplers (runOnePhase sets min(1, 2*iter/nIter) while equilibrating) */
+int cogaps_session_set_annealing(cogaps_session *s, float temp);
+/* nA, nP ~ Poisson(max(nAtoms,10)) from the runner's generator (GapsRunner.cpp:294-295) */
+int cogaps_session_draw_steps(cogaps_session *s, uint32_t *nA, uint32_t *nP);
+/* AsynchronousGibbsSampler::update for sampler `which` ('A' or 'P'); optional proposal trace */
+int cogaps_session_update(cogaps_session *s, char which, uint32_t nSteps,
+                          cogaps_trace_rec *trace, uint32_t traceCap, uint32_t *nTrace,
+                          uint32_t *batchNproc, uint32_t *batchQlen, uint32_t batchCap, uint32_t *nBatches);
+/* DenseNormalModel::sync for sampler `which` (copies the transposed AP of the other sampler) */
+int cogaps_session_sync(cogaps_session *s, char which);
+/* one iteration of runOnePhase: updateSampler(nA, nP) (+ statistics when sampling != 0) */
+int cogaps_session_iterate(cogaps_session *s, uint32_t nA, uint32_t nP, int sampling);
+/* `n` complete iterations of a phase starting at iteration `firstIter` (anneal, draw, update, stats,
+ * history); phase 1 = equilibration, 2 = sampling.  Adds to *updates the proposals processed. */
+int cogaps_session_run_iterations(cogaps_session *s, int phase, uint32_t firstIter, uint32_t n, uint64_t *updates);
+int cogaps_session_natoms(cogaps_session *s, char which, uint32_t *n);
+int cogaps_session_chisq(cogaps_session *s, char which, float *chisq);
+/* copy-outs (host buffers): matrix row-major [M][K]; AP [M][N]; atoms in vector order */
+int cogaps_session_get_matrix(cogaps_session *s, char which, float *out);
+int cogaps_session_get_ap(cogaps_session *s, char which, float *out);
+int cogaps_session_get_atoms(cogaps_session *s, char which, uint64_t *pos, float *mass,
+                             uint32_t *left, uint32_t *right);
+int cogaps_session_dims(cogaps_session *s, char which, uint32_t *M, uint32_t *N, uint32_t *K);
+int cogaps_session_avg_queue(cogaps_session *s, char which, float *avg);
+int cogaps_session_finish(cogaps_session *s, cogaps_result *out);
+/* counters for the roofline report: algorithmic bytes moved by the evaluation kernel so far, number
+ * of evaluation launches, batches generated, and the accumulated HIP-event time of each kernel */
+typedef struct cogaps_perf {
+    uint64_t evalBytes;       /* sum over evaluated proposals of 16N/20N/32N + 12N per AP update */
+    uint64_t evalLaunches, genLaunches, batches, proposalsQueued;
+    double evalMs, genMs, syncMs;   /* HIP-event time when timing is enabled */
+} cogaps_perf;
+int cogaps_session_set_timing(cogaps_session *s, int on);
+int cogaps_session_perf(cogaps_session *s, cogaps_perf *out);
+
+/* lanes of the evaluation workgroup for data vectors of length N (the reduction-order contract) */
+uint32_t cogaps_reduction_width(uint32_t N);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

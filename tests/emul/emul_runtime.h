@@ -1,0 +1,41 @@
+// emul_runtime.h -- TEST-ONLY workgroup emulator (x86-64, single OS thread, one cooperative fiber
+// per lane).  Lets the HIP kernel sources under cogaps_amd/csrc run on the CPU for the "not gpu"
+// unit tests.  Never part of the product library.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include <functional>
+
+#define CG_HD inline
+#define CG_DEVICE inline
+#define CG_KERNEL
+#define CG_SHARED static
+#define CG_LAUNCH_BOUNDS(n)
+
+namespace cgemu {
+struct LaneCtx { unsigned tid, bid, bdim, gdim; };
+extern LaneCtx g_lane;
+void block_barrier();                       // __syncthreads()
+float wave_exchange_f32(float v, int src_lane_xor); // shfl_xor across the 64-lane wave
+void launch(unsigned grid, unsigned block, const std::function<void()> &body);
+}
+
+inline unsigned cg_tid() { return cgemu::g_lane.tid; }
+inline unsigned cg_bid() { return cgemu::g_lane.bid; }
+inline unsigned cg_bdim() { return cgemu::g_lane.bdim; }
+inline unsigned cg_gdim() { return cgemu::g_lane.gdim; }
+inline void cg_sync() { cgemu::block_barrier(); }
+
+// fibers only switch at barriers / wave exchanges, so plain read-modify-write is atomic here
+inline uint32_t cg_atomic_add_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
+inline uint32_t cg_atomic_sub_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o - v; return o; }
+inline uint32_t cg_atomic_min_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
+inline uint32_t cg_atomic_or_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
+inline unsigned long long cg_atomic_add_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
+inline unsigned long long cg_atomic_max_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; if (v > o) *p = v; return o; }
+inline unsigned long long cg_atomic_or_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o | v; return o; }
+inline unsigned long long cg_atomic_and_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o & v; return o; }
+
+inline float cg_shfl_xor_f32(float v, int mask) { return cgemu::wave_exchange_f32(v, mask); }
+inline int cg_clz64(unsigned long long x) { return x ? __builtin_clzll(x) : 64; }
+inline int cg_ctz64(unsigned long long x) { return x ? __builtin_ctzll(x) : -1; }
