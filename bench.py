@@ -1,0 +1,177 @@
+#!/usr/bin/env python
+"""bench.py -- Gibbs atom proposals/sec of the asynchronous sampler hot path on MI355X.
+
+A "step" is one Gibbs iteration (A.update, P.sync, P.update, A.sync [+ statistics when sampling]) =
+one pass of runOnePhase's loop body (reference src/GapsRunner.cpp:272-327).  The workload at N=1 is
+BASELINE.json configs[2]: synthetic dense 20000x2000 fp32, nPatterns=50, asynchronous sampler,
+seed 42, default uncertainty, alpha 0.01, maxGibbsMass 100.  The chain runs W+K iterations: the
+first ceil((W+K)/2) equilibrate (annealed), the rest sample; the first W are untimed warm-up and
+exactly K are timed.  With --gpus N each rank runs one GWCoGAPS gene-wise shard of that size
+(BASELINE.json configs[3], nSets = N): independent chains, no data-path collective; the single
+exchange of the path, the all-gather of each shard's sample factor for findConsensusMatrix
+(reference R/DistributedCogaps.R:71-78), is issued once after the timed iterations, inside the
+timed region.
+
+value = proposals (the reference's totalUpdates counter, GapsRunner.cpp:297,476) processed by all
+ranks in the timed region / max-over-ranks wall time.  Inputs are resident in HBM before the timed
+region starts (session creation uploads them).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "Gibbs atom proposals/sec, 20000x2000 dense D, nPatterns=50, at 1/2/4/8 GPUs"
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def synthetic_dense(n_genes, n_samples, rank=10, seed=12345):
+    """D = (A0 P0^T) * (0.9 + 0.2 u), true rank 10, A0 70% zeros else Gamma(2, 0.5), P0 50% zeros else
+    Gamma(2, 0.5) (SURVEY.md section 8d recipe; numpy MT19937 stream)."""
+    rng = np.random.Generator(np.random.MT19937(seed))
+    a0 = rng.gamma(2.0, 0.5, size=(n_genes, rank)) * (rng.random((n_genes, rank)) >= 0.7)
+    p0 = rng.gamma(2.0, 0.5, size=(n_samples, rank)) * (rng.random((n_samples, rank)) >= 0.5)
+    d = (a0 @ p0.T) * (0.9 + 0.2 * rng.random((n_genes, n_samples)))
+    return np.ascontiguousarray(d, dtype=np.float32)
+
+
+def cpu_baseline(data, params, budget_s):
+    """The oracle (oracle/gaps_oracle.c, OpenMP over the queue exactly like the reference's
+    `#pragma omp parallel for`, sequential fp32 reductions = the reference's scalar build) timed on
+    this host on the first iterations of the SAME chain, until `budget_s` seconds are spent."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    cores = os.cpu_count() or 1
+    O = po.Session(data, omp=True, maxThreads=cores, math_mode=po.MATH_LIBM, redW_A=1, redW_P=1, redG=1, **params)
+    n_iter = params["nIterations"]
+    props, it, t0 = 0, 0, time.time()
+    while it < n_iter and time.time() - t0 < budget_s:
+        O.set_annealing(min(1.0, 2.0 * it / n_iter))
+        nA, nP = O.draw_steps()
+        O.iterate(nA, nP)
+        props += nA + nP
+        it += 1
+    dt = time.time() - t0
+    O.close()
+    return {"value": props / dt, "unit": "proposals/s", "cores": cores, "kind": "port",
+            "sample": "first %d equilibration iterations of the same chain (%d proposals, %.1f s)" % (it, props, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=190)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--genes", type=int, default=20000)
+    ap.add_argument("--samples", type=int, default=2000)
+    ap.add_argument("--patterns", type=int, default=50)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
+
+    from cogaps_amd import _capi
+
+    K, W = args.steps, args.warmup
+    n_iter = (W + K + 1) // 2
+    # shard `rank` of the gene-wise partition: its own 20000-gene block (contiguous explicit sets)
+    data = synthetic_dense(args.genes, args.samples, seed=12345 + rank)
+    params = dict(nPatterns=args.patterns, nIterations=n_iter, seed=42, outputFrequency=max(1, n_iter // 10))
+    S = _capi.Session(data, device=local_rank, **params)
+
+    def run_steps(first, n):
+        done, upd = 0, 0
+        while done < n:
+            it = first + done
+            if it < n_iter:
+                m = min(n - done, n_iter - it)
+                upd += S.run_iterations(1, it, m)
+            else:
+                m = n - done
+                upd += S.run_iterations(2, it - n_iter, m)
+            done += m
+        return upd
+
+    run_steps(0, W)
+    perf0 = S.perf()
+    S.set_timing(True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    updates = run_steps(W, K)
+    if dist is not None:
+        # the one exchange of the GWCoGAPS path: all-gather of the shared-dimension factor
+        fac = torch.from_numpy(S.matrix("P")).cuda()
+        gathered = [torch.empty_like(fac) for _ in range(world)]
+        dist.all_gather(gathered, fac)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    S.set_timing(False)
+    perf1 = S.perf()
+
+    tot_updates, max_dt = float(updates), dt
+    if dist is not None:
+        t = torch.tensor([float(updates), dt], dtype=torch.float64, device="cuda")
+        u = t.clone()
+        dist.all_reduce(u, op=dist.ReduceOp.SUM)
+        m = t.clone()
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        tot_updates, max_dt = float(u[0].item()), float(m[1].item())
+
+    if rank == 0:
+        ev_bytes = perf1["evalBytes"] - perf0["evalBytes"]
+        ev_launch = perf1["evalLaunches"] - perf0["evalLaunches"]
+        ev_ms = perf1["evalMs"] - perf0["evalMs"]
+        gen_ms = perf1["genMs"] - perf0["genMs"]
+        batches = perf1["batches"] - perf0["batches"]
+        achieved = (ev_bytes / 1e9) / (ev_ms / 1e3) if ev_ms > 0 else 0.0
+        out = {
+            "metric": METRIC, "value": tot_updates / max_dt, "unit": "proposals/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * max_dt / K,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "synthetic dense %dx%d fp32 per GPU, nPatterns=%d, asynchronous sampler, seed 42 (BASELINE configs[2]%s)"
+                                   % (args.genes, args.samples, args.patterns, "; GWCoGAPS nSets=%d gene-wise shards, configs[3]" % world if world > 1 else ""),
+                       "nIterations": n_iter, "proposals_timed": int(tot_updates), "batches_rank0": int(batches),
+                       "avg_queue_A": S.avg_queue("A"), "avg_queue_P": S.avg_queue("P"),
+                       "atoms_A": S.natoms("A"), "atoms_P": S.natoms("P"),
+                       "gen_kernel_ms_rank0": gen_ms, "eval_kernel_ms_rank0": ev_ms,
+                       "launches_per_batch": (perf1["evalLaunches"] + perf1["genLaunches"] - perf0["evalLaunches"] - perf0["genLaunches"]) / max(1, batches)},
+            "roofline": {"bound": "hbm", "kernel": "eval_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_launch": ev_bytes / max(1, ev_launch), "avg_launch_us": 1e3 * ev_ms / max(1, ev_launch)},
+        }
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(data, params, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    S.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -68,7 +68,7 @@ EXPORTS = [
     "cogaps_session_chisq", "cogaps_session_get_matrix", "cogaps_session_get_ap",
     "cogaps_session_get_atoms", "cogaps_session_dims", "cogaps_session_avg_queue",
     "cogaps_session_finish", "cogaps_session_set_timing", "cogaps_session_perf",
-    "cogaps_reduction_width",
+    "cogaps_reduction_width", "cogaps_session_debug_prof",
 ]
 
 
@@ -102,6 +102,7 @@ def bind(L):
     L.cogaps_session_finish.argtypes = [vp, C.POINTER(CogapsResultC)]
     L.cogaps_session_set_timing.argtypes = [vp, C.c_int]
     L.cogaps_session_perf.argtypes = [vp, C.POINTER(CogapsPerfC)]
+    L.cogaps_session_debug_prof.argtypes = [vp, C.c_char, C.POINTER(C.c_uint64)]
     L.cogaps_reduction_width.restype = C.c_uint32
     L.cogaps_reduction_width.argtypes = [C.c_uint32]
     return L
@@ -298,6 +299,11 @@ class Session:
         p = CogapsPerfC()
         self._ck(self.L.cogaps_session_perf(self.h, C.byref(p)))
         return {f[0]: getattr(p, f[0]) for f in CogapsPerfC._fields_}
+
+    def debug_prof(self, which):
+        out = (C.c_uint64 * 16)()
+        self._ck(self.L.cogaps_session_debug_prof(self.h, which.encode(), out))
+        return list(out)
 
     def finish(self):
         r = CogapsResultC()

@@ -146,7 +146,8 @@ struct cogaps_session {
     unsigned statUpdates = 0;
     std::vector<float> chisqHist; std::vector<uint32_t> atomHistA, atomHistP;
     uint64_t totalUpdates = 0; double samplerSeconds = 0; double syncMs = 0;
-    bool timing = false; rt_event_pair ev; bool evInit = false;
+    bool timing = false; bool evInit = false;
+    std::vector<rt_event_pair> evPool; std::vector<int> evKind; std::vector<HostSampler *> evOwner; size_t evUsed = 0;
     GenScalars *hGs = nullptr;    // pinned staging
 };
 
@@ -254,21 +255,38 @@ static void grow_atoms(cogaps_session *s, HostSampler &h, uint32_t need)
     d.atomCap = cap;
 }
 
+// HIP-event timing of a sample of the launches (every 8th), on the stream the kernels run on; the
+// events are resolved after the chunk's synchronisation so that timing never stalls the queue
+static int timing_slot(cogaps_session *s, HostSampler &h, int kind, uint64_t ordinal)
+{
+    if (!s->timing || (ordinal % 8) != 0 || s->evUsed >= s->evPool.size()) return -1;
+    const int i = (int)s->evUsed++;
+    s->evKind[i] = kind; s->evOwner[i] = &h;
+    rt_event_start(s->evPool[i], s->stream);
+    return i;
+}
+static void timing_resolve(cogaps_session *s)
+{
+    for (size_t i = 0; i < s->evUsed; ++i) {
+        const float ms = rt_event_ms(s->evPool[i]);
+        HostSampler *h = s->evOwner[i];
+        if (s->evKind[i] == 0) { h->genMs += ms; h->genTimed++; } else { h->evalMs += ms; h->evalTimed++; }
+    }
+    s->evUsed = 0;
+}
 static void launch_gen(cogaps_session *s, HostSampler &h)
 {
-    const bool timed = s->timing && (h.genLaunches % 8 == 0);
-    if (timed) rt_event_start(s->ev, s->stream);
+    const int slot = timing_slot(s, h, 0, h.genLaunches);
     RT_LAUNCH(gen_kernel<GEN_WIN>, 1, GEN_WIN, s->stream, h.d);
-    if (timed) { rt_event_stop(s->ev, s->stream); h.genMs += rt_event_ms(s->ev); h.genTimed++; }
+    if (slot >= 0) rt_event_stop(s->evPool[slot], s->stream);
     h.genLaunches++;
 }
 static void launch_eval(cogaps_session *s, HostSampler &h)
 {
     const uint32_t grid = std::min<uint32_t>(h.d.queueCap, h.d.redW >= 512 ? 256u : 512u);
-    const bool timed = s->timing && (h.evalLaunches % 8 == 0);
-    if (timed) rt_event_start(s->ev, s->stream);
+    const int slot = timing_slot(s, h, 1, h.evalLaunches);
     RT_LAUNCH(eval_kernel, grid, h.d.redW, s->stream, h.d);
-    if (timed) { rt_event_stop(s->ev, s->stream); h.evalMs += rt_event_ms(s->ev); h.evalTimed++; }
+    if (slot >= 0) rt_event_stop(s->evPool[slot], s->stream);
     h.evalLaunches++;
 }
 
@@ -310,6 +328,7 @@ static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool t
         if (chunk > 4096u) chunk = 4096u;
         for (uint32_t b = 0; b < chunk; ++b) { launch_gen(s, h); launch_eval(s, h); }
         read_gs(s, h);
+        timing_resolve(s);
         if (s->hGs->error) return fail(std::string("device error code ") + std::to_string(s->hGs->error) + " in sampler " + h.name);
         if (s->hGs->updateFlushed) break;
         if (s->hGs->nBatches > 0) avgq = std::max(1.f, (float)s->hGs->nDone / (float)s->hGs->nBatches);
@@ -425,7 +444,7 @@ void cogaps_session_destroy(cogaps_session *s)
     rt_free(s->dErf); rt_free(s->dErfinv); rt_free(s->dQgamma); rt_free(s->dLcgMul); rt_free(s->dLcgInc);
     rt_free(s->Asum); rt_free(s->Asq); rt_free(s->Psum); rt_free(s->Psq);
     rt_free_host(s->hGs);
-    if (s->evInit) rt_event_destroy(s->ev);
+    for (auto &e : s->evPool) rt_event_destroy(e);
     rt_stream_destroy(s->stream);
     delete s;
 }
@@ -600,10 +619,21 @@ int cogaps_session_finish(cogaps_session *s, cogaps_result *out)
     SESSION_END
 }
 
+int cogaps_session_debug_prof(cogaps_session *s, char which, uint64_t *out16)
+{
+    SESSION_TRY
+    read_gs(s, pick(s, which));
+    for (int i = 0; i < 16; ++i) out16[i] = s->hGs->prof[i];
+    SESSION_END
+}
 int cogaps_session_set_timing(cogaps_session *s, int on)
 {
     SESSION_TRY
-    if (on && !s->evInit) { rt_event_create(s->ev); s->evInit = true; }
+    if (on && !s->evInit) {
+        s->evPool.resize(2048); s->evKind.resize(2048); s->evOwner.resize(2048);
+        for (auto &e : s->evPool) rt_event_create(e);
+        s->evInit = true;
+    }
     s->timing = on != 0;
     SESSION_END
 }

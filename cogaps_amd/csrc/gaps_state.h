@@ -53,6 +53,7 @@ struct GenScalars {
     unsigned long long evalBytes;   // algorithmic HBM bytes of the evaluation kernel (roofline numerator)
     unsigned long long evalProps;   // proposals evaluated
     uint32_t pad[2];
+    unsigned long long prof[16];    // GEN_PROFILE builds: cycles per generator phase
 };
 
 enum GapsError { GAPS_OK = 0, GAPS_ERR_ATOM_CAP = 1, GAPS_ERR_QUEUE_CAP = 2, GAPS_ERR_ERASE_CAP = 3, GAPS_ERR_SPIN = 4 };

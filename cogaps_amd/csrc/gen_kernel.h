@@ -16,6 +16,11 @@
 #pragma once
 #include "gaps_state.h"
 
+#if defined(GEN_PROFILE)
+#define GEN_PROF(i) do { if (t == 0) { unsigned long long now_ = cg_clock(); gs->prof[i] += now_ - prof_last; prof_last = now_; } } while (0)
+#else
+#define GEN_PROF(i) do { } while (0)
+#endif
 #define GEN_T_NONE 0
 #define GEN_F_INLINE 1u     // same-bin move / exchange: applied at populate time, not queued
 #define GEN_F_FAIL 2u       // genuine conflict or indeterminate B/D: the batch ends here
@@ -292,7 +297,9 @@ CG_DEVICE void gen_body(const SamplerDev &S)
     const unsigned t = cg_tid();
     GenScalars *gs = S.gs;
 
+    unsigned long long prof_last = cg_clock(); (void)prof_last;
     gen_flush<WIN>(S, sh);
+    GEN_PROF(0);
 
     if (t == 0) {
         sh.done = (gs->nDone >= gs->nSteps) ? 1u : 0u;
@@ -336,6 +343,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
         const uint32_t packed = (guess == 'B' ? 1u : 0u) | (guess == 'D' ? 0x10000u : 0u);
         const uint32_t before = gen_excl_scan<WIN>(sh.scan, t, active ? packed : 0u);
         const uint32_t bBefore = before & 0xFFFFu, dBefore = before >> 16;
+        GEN_PROF(1);
         uint32_t type = guess; uint32_t flags = 0;
         if (active) {
             const uint32_t exact = gen_decide(S, u1, u2, (uint64_t)minR - dBefore, (uint64_t)nR + bBefore);
@@ -396,6 +404,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
                 }
             }
         }
+        GEN_PROF(2);
         // publish the candidate
         sh.rng[t] = rng; sh.pos[t] = pos; sh.cpos[t] = cpos; sh.lbpos[t] = lbpos; sh.rbpos[t] = rbpos;
         sh.h1[t] = h1; sh.h2[t] = h2; sh.i1[t] = i1; sh.i2[t] = i2; sh.hl[t] = hl; sh.hr[t] = hr;
@@ -420,6 +429,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
             }
         }
         cg_sync();
+        GEN_PROF(3);
 
         // ------------------------------------------------------------------ B2: conflicts and hazards
         if (live) {
@@ -477,6 +487,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
         sh.flags[t] = (uint8_t)flags;
         if (active && (flags & (GEN_F_HAZARD | GEN_F_FAIL))) cg_atomic_min_u32(&sh.stopKey, 2u * t + ((flags & GEN_F_HAZARD) ? 0u : 1u));
         cg_sync();
+        GEN_PROF(4);
 
         // ------------------------------------------------------------------ C: commit [0, stopT)
         const uint32_t stopKey = sh.stopKey;
@@ -487,6 +498,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
         const uint32_t packed2 = (queued ? 1u : 0u) | ((commit && type == 'B') ? 0x10000u : 0u) | 0u;
         const uint32_t before2 = gen_excl_scan<WIN>(sh.scan, t, packed2);
         const uint32_t qBefore = before2 & 0xFFFFu, bRank = before2 >> 16;
+        GEN_PROF(5);
         if (commit) {
             uint32_t hb = CG_NONE;
             if (type == 'B') {
@@ -535,6 +547,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
             }
         }
         cg_sync();
+        GEN_PROF(6);
         // births that share a snapshot gap: link one by one in attempt order
         if (t == 0 && sh.needSerialBirths) {
             uint32_t fr = gs->front;
@@ -561,6 +574,8 @@ CG_DEVICE void gen_body(const SamplerDev &S)
             sh.stopT = stopT; sh.stopFail = stopFail ? 1u : 0u;
         }
         cg_sync();
+        GEN_PROF(7);
+        if (t == 0) gs->prof[15] += 1;   // rounds
         const bool endBatch = sh.stopFail || (sh.processed >= sh.remaining);
         if (endBatch) {
             if (t == 0) {

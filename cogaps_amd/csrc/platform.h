@@ -38,6 +38,7 @@ CG_DEVICE unsigned long long cg_atomic_and_u64(unsigned long long *p, unsigned l
 
 // wave64 cross-lane
 CG_DEVICE float cg_shfl_xor_f32(float v, int mask) { return __shfl_xor(v, mask, 64); }
+CG_DEVICE unsigned long long cg_clock() { return __builtin_readcyclecounter(); }
 CG_DEVICE int cg_clz64(unsigned long long x) { return __clzll((long long)x); }
 CG_DEVICE int cg_ctz64(unsigned long long x) { return __ffsll((long long)x) - 1; }
 

@@ -139,6 +139,9 @@ typedef struct cogaps_perf {
 int cogaps_session_set_timing(cogaps_session *s, int on);
 int cogaps_session_perf(cogaps_session *s, cogaps_perf *out);
 
+/* development aid: per-phase cycle counters of the generator kernel (all zero unless built with -DGEN_PROFILE) */
+int cogaps_session_debug_prof(cogaps_session *s, char which, uint64_t *out16);
+
 /* lanes of the evaluation workgroup for data vectors of length N (the reduction-order contract) */
 uint32_t cogaps_reduction_width(uint32_t N);
 

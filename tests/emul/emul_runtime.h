@@ -37,5 +37,6 @@ inline unsigned long long cg_atomic_or_u64(unsigned long long *p, unsigned long 
 inline unsigned long long cg_atomic_and_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o & v; return o; }
 
 inline float cg_shfl_xor_f32(float v, int mask) { return cgemu::wave_exchange_f32(v, mask); }
+inline unsigned long long cg_clock() { return 0; }
 inline int cg_clz64(unsigned long long x) { return x ? __builtin_clzll(x) : 64; }
 inline int cg_ctz64(unsigned long long x) { return x ? __builtin_ctzll(x) : -1; }
