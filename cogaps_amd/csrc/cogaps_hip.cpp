@@ -161,7 +161,7 @@ static void free_sampler(HostSampler &h)
     rt_free((void *)d.D); rt_free((void *)d.S2); rt_free(d.AP); rt_free(d.mat); rt_free(d.colPos);
     rt_free(d.atoms); rt_free(d.vec); rt_free(d.freeHandles); rt_free(d.binHead);
     rt_free(d.bits0); rt_free(d.bits1); rt_free(d.bits2); rt_free(d.eraseList); rt_free(d.queue);
-    rt_free(d.rowRound); rt_free(d.rowBatch); rt_free(d.atomRound); rt_free(d.atomBatch); rt_free(d.batchMoves);
+    rt_free(d.rowStamp); rt_free(d.atomStamp); rt_free(d.gapStamp); rt_free(d.inlineStamp); rt_free(d.atomDest);
     rt_free(d.gs); rt_free(d.trace); rt_free(d.traceBatchNproc); rt_free(d.traceBatchQlen);
     rt_free(h.Sraw); rt_free(h.seeds); rt_free_host(h.hSeeds); rt_free(h.partial);
 }
@@ -216,15 +216,18 @@ static void build_sampler(cogaps_session *s, HostSampler &h, char name, const fl
     d.bits0 = dalloc<unsigned long long>(d.nWords0); d.bits1 = dalloc<unsigned long long>(d.nWords1); d.bits2 = dalloc<unsigned long long>(d.nWords2);
     d.queueCap = d.M + 8; d.eraseCap = d.queueCap;
     d.eraseList = dalloc<uint32_t>(d.eraseCap); d.queue = dalloc<PropRec>(d.queueCap);
-    d.rowRound = dalloc<unsigned long long>(d.M); d.rowBatch = dalloc<unsigned long long>(d.M);
-    d.atomRound = dalloc<unsigned long long>(d.atomCap); d.atomBatch = dalloc<unsigned long long>(d.atomCap);
-    d.batchMoves = dalloc<uint64_t>(2 * (size_t)d.queueCap);
+    d.rowStamp = dalloc<unsigned long long>(d.M);
+    d.atomStamp = dalloc<unsigned long long>(d.atomCap); d.gapStamp = dalloc<unsigned long long>((size_t)d.atomCap + 1);
+    d.inlineStamp = dalloc<unsigned long long>(d.atomCap); d.atomDest = dalloc<uint64_t>(d.atomCap);
     d.lcgMul = s->dLcgMul; d.lcgInc = s->dLcgInc;
     d.binLength = 0xFFFFFFFFFFFFFFFFull / nBins;               // ProposalQueue.cpp:27
     d.domainLenU = d.binLength * nBins;                         // ConcurrentAtomicDomain.cpp:16-18
     d.domainLenD = (double)d.domainLenU;                        // ProposalQueue.cpp:30
     d.numBins = (double)nBins; d.alphaD = (double)alpha;
+    d.invBinLen = 1.0 / (double)d.binLength;
+    if (nBins >= 0xFFFFFFF0ull) throw std::runtime_error("rows x nPatterns must stay below 2^32");
     d.rboundNone = gm_u64_from_double_x86(d.domainLenD);
+    d.iPartL = 0xFFFFFFFFFFFFFFFFull / d.domainLenU; d.limitL = d.domainLenU * d.iPartL;   // uniform64(1, L)
     d.gs = dalloc<GenScalars>(1);
     GenScalars g; memset(&g, 0, sizeof(g));
     g.front = CG_NONE;
@@ -251,7 +254,8 @@ static void grow_atoms(cogaps_session *s, HostSampler &h, uint32_t need)
         rt_free(ptr); ptr = (decltype(ptr))n;
     };
     regrow(d.atoms, sizeof(AtomRec)); regrow(d.vec, 4); regrow(d.freeHandles, 4);
-    regrow(d.atomRound, 8); regrow(d.atomBatch, 8);
+    regrow(d.atomStamp, 8); regrow(d.inlineStamp, 8); regrow(d.atomDest, 8);
+    { void *n = rt_malloc(((size_t)cap + 1) * 8); rt_d2d(n, d.gapStamp, ((size_t)d.atomCap + 1) * 8, s->stream); rt_sync(s->stream); rt_free(d.gapStamp); d.gapStamp = (unsigned long long *)n; }
     d.atomCap = cap;
 }
 

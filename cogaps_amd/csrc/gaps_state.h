@@ -90,16 +90,22 @@ struct SamplerDev {
     PropRec *queue;    // [queueCap]
     uint32_t queueCap;
     const uint64_t *seeds;  // seeder outputs for this update(): candidate k of the update uses seeds[k]
-    unsigned long long *rowRound, *rowBatch;   // [M]   conflict stamps (FixedHashSetU32 mUsedMatrixIndices)
-    unsigned long long *atomRound, *atomBatch; // [atomCap] (SmallHashSetU64 mUsedAtoms, by handle)
-    uint64_t *batchMoves;  // [2*queueCap] (lo,hi) intervals of queued moves of earlier rounds (mProposedMoves)
-    uint32_t *batchMoveCount;
+    // conflict stamps, one 64-bit word per key: [batch epoch:40][round:12][priority:12], written with
+    // atomicMax.  priority 4094-t for attempt t of the current window (earliest attempt wins), 0xFFFFFF
+    // in the low 24 bits once the registering attempt is committed.
+    unsigned long long *rowStamp;     // [M]         mUsedMatrixIndices (FixedHashSetU32)
+    unsigned long long *atomStamp;    // [atomCap]   mUsedAtoms (SmallHashSetU64), keyed by handle
+    unsigned long long *gapStamp;     // [atomCap+1] a birth landed right of atom h (key h+1) / before the front (key 0)
+    unsigned long long *inlineStamp;  // [atomCap]   atom touched by a same-bin move/exchange of the current window
+    uint64_t *atomDest;               // [atomCap]   destination of the committed queued move of this atom, else 0 (mProposedMoves)
     const uint64_t *lcgMul, *lcgInc; // k-step PCG jump coefficients, k = 0 .. 2*GEN_WIN+1
     uint64_t binLength;    // mBinLength
     uint64_t domainLenU;   // ConcurrentAtomicDomain::mDomainLength (exact)
     double domainLenD;     // ProposalQueue::mDomainLength
     double numBins, alphaD;
+    double invBinLen;      // 1.0 / binLength (quotient estimate of gen_bin_of)
     uint64_t rboundNone;   // static_cast<uint64_t>(mDomainLength), ProposalQueue.cpp:216
+    uint64_t iPartL, limitL; // uniform64(1, domainLenU): iPart = UINT64_MAX / L, limit = L * iPart (Random.cpp:112-117)
     GenScalars *gs;
     // ---- optional trace (parity tests) -------------------------------------------------------
     PropRec *trace;        // [traceCap] copies of queued proposals

@@ -75,6 +75,18 @@ float wave_exchange_f32(float v, int mask)
     return r;
 }
 
+unsigned long long wave_ballot(bool p)
+{
+    unsigned me = g_cur;
+    g_fibers[me].xch = p ? 1.f : 0.f;
+    yield_to_sched(WAIT_WAVE);
+    unsigned lo = me & ~63u;
+    unsigned long long m = 0;
+    for (unsigned i = 0; i < 64 && lo + i < g_bdim; ++i) if (g_fibers[lo + i].st != DONE && g_fibers[lo + i].xch != 0.f) m |= 1ull << i;
+    yield_to_sched(WAIT_WAVE);
+    return m;
+}
+
 static char *get_stack(unsigned i)
 {
     while (g_stack_pool.size() <= i) {

@@ -17,6 +17,7 @@ struct LaneCtx { unsigned tid, bid, bdim, gdim; };
 extern LaneCtx g_lane;
 void block_barrier();                       // __syncthreads()
 float wave_exchange_f32(float v, int src_lane_xor); // shfl_xor across the 64-lane wave
+unsigned long long wave_ballot(bool p);
 void launch(unsigned grid, unsigned block, const std::function<void()> &body);
 }
 
@@ -36,6 +37,9 @@ inline unsigned long long cg_atomic_max_u64(unsigned long long *p, unsigned long
 inline unsigned long long cg_atomic_or_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o | v; return o; }
 inline unsigned long long cg_atomic_and_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o & v; return o; }
 
+inline unsigned long long cg_ballot(bool p) { return cgemu::wave_ballot(p); }
+inline int cg_popc64(unsigned long long x) { return __builtin_popcountll(x); }
+inline unsigned long long cg_load_l2_u64(const unsigned long long *p) { return *p; }
 inline float cg_shfl_xor_f32(float v, int mask) { return cgemu::wave_exchange_f32(v, mask); }
 inline unsigned long long cg_clock() { return 0; }
 inline int cg_clz64(unsigned long long x) { return x ? __builtin_clzll(x) : 64; }
