@@ -68,7 +68,7 @@ EXPORTS = [
     "cogaps_session_chisq", "cogaps_session_get_matrix", "cogaps_session_get_ap",
     "cogaps_session_get_atoms", "cogaps_session_dims", "cogaps_session_avg_queue",
     "cogaps_session_finish", "cogaps_session_set_timing", "cogaps_session_perf",
-    "cogaps_reduction_width", "cogaps_session_debug_prof",
+    "cogaps_reduction_width", "cogaps_session_debug_prof", "cogaps_session_debug_replay",
 ]
 
 
@@ -103,6 +103,7 @@ def bind(L):
     L.cogaps_session_set_timing.argtypes = [vp, C.c_int]
     L.cogaps_session_perf.argtypes = [vp, C.POINTER(CogapsPerfC)]
     L.cogaps_session_debug_prof.argtypes = [vp, C.c_char, C.POINTER(C.c_uint64)]
+    L.cogaps_session_debug_replay.argtypes = [vp, C.c_char, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
     L.cogaps_reduction_width.restype = C.c_uint32
     L.cogaps_reduction_width.argtypes = [C.c_uint32]
     return L
@@ -299,6 +300,11 @@ class Session:
         p = CogapsPerfC()
         self._ck(self.L.cogaps_session_perf(self.h, C.byref(p)))
         return {f[0]: getattr(p, f[0]) for f in CogapsPerfC._fields_}
+
+    def debug_replay(self, which, kind, n, flags=0):
+        us = C.c_double()
+        self._ck(self.L.cogaps_session_debug_replay(self.h, which.encode(), kind, n, flags, C.byref(us)))
+        return us.value
 
     def debug_prof(self, which):
         out = (C.c_uint64 * 16)()

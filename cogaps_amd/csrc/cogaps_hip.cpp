@@ -160,7 +160,7 @@ static void free_sampler(HostSampler &h)
     SamplerDev &d = h.d;
     rt_free((void *)d.D); rt_free((void *)d.S2); rt_free(d.AP); rt_free(d.mat); rt_free(d.colPos);
     rt_free(d.atoms); rt_free(d.vec); rt_free(d.freeHandles); rt_free(d.binHead);
-    rt_free(d.bits0); rt_free(d.bits1); rt_free(d.bits2); rt_free(d.eraseList); rt_free(d.queue);
+    rt_free(d.bits0); rt_free(d.bits1); rt_free(d.bits2); rt_free(d.eraseList); rt_free(d.queue); rt_free(d.queueUnits);
     rt_free(d.rowStamp); rt_free(d.atomStamp); rt_free(d.gapStamp); rt_free(d.inlineStamp); rt_free(d.atomDest);
     rt_free(d.gs); rt_free(d.trace); rt_free(d.traceBatchNproc); rt_free(d.traceBatchQlen);
     rt_free(h.Sraw); rt_free(h.seeds); rt_free_host(h.hSeeds); rt_free(h.partial);
@@ -215,7 +215,7 @@ static void build_sampler(cogaps_session *s, HostSampler &h, char name, const fl
     d.nWords0 = (uint32_t)((nBins + 63) / 64); d.nWords1 = (d.nWords0 + 63) / 64; d.nWords2 = (d.nWords1 + 63) / 64;
     d.bits0 = dalloc<unsigned long long>(d.nWords0); d.bits1 = dalloc<unsigned long long>(d.nWords1); d.bits2 = dalloc<unsigned long long>(d.nWords2);
     d.queueCap = d.M + 8; d.eraseCap = d.queueCap;
-    d.eraseList = dalloc<uint32_t>(d.eraseCap); d.queue = dalloc<PropRec>(d.queueCap);
+    d.eraseList = dalloc<uint32_t>(d.eraseCap); d.queue = dalloc<PropRec>(d.queueCap); d.queueUnits = dalloc<uint32_t>(d.queueCap);
     d.rowStamp = dalloc<unsigned long long>(d.M);
     d.atomStamp = dalloc<unsigned long long>(d.atomCap); d.gapStamp = dalloc<unsigned long long>((size_t)d.atomCap + 1);
     d.inlineStamp = dalloc<unsigned long long>(d.atomCap); d.atomDest = dalloc<uint64_t>(d.atomCap);
@@ -289,7 +289,8 @@ static void launch_eval(cogaps_session *s, HostSampler &h)
 {
     const uint32_t grid = std::min<uint32_t>(h.d.queueCap, h.d.redW >= 512 ? 256u : 512u);
     const int slot = timing_slot(s, h, 1, h.evalLaunches);
-    RT_LAUNCH(eval_kernel, grid, h.d.redW, s->stream, h.d);
+    if (h.d.redW <= 256u) RT_LAUNCH(eval_kernel<8>, grid, h.d.redW, s->stream, h.d);
+    else RT_LAUNCH(eval_kernel<4>, grid, h.d.redW, s->stream, h.d);
     if (slot >= 0) rt_event_stop(s->evPool[slot], s->stream);
     h.evalLaunches++;
 }
@@ -623,6 +624,32 @@ int cogaps_session_finish(cogaps_session *s, cogaps_result *out)
     SESSION_END
 }
 
+// development aid: relaunch the evaluation (kind 1) or generator (kind 0) kernel `n` times on the current
+// device state and return the mean wall time per launch in microseconds (the chain state is garbage afterwards)
+int cogaps_session_debug_replay(cogaps_session *s, char which, int kind, uint32_t n, uint32_t dbgFlags, double *usPerLaunch)
+{
+    SESSION_TRY
+    HostSampler &h = pick(s, which);
+    {   // arm a fresh update of 4096 steps and generate one batch so that the queue is populated
+        read_gs(s, h);
+        GenScalars g = *s->hGs;
+        if (h.seedCap < 4096) { rt_free(h.seeds); h.seedCap = 8192; h.seeds = dalloc<uint64_t>(h.seedCap); }
+        std::vector<uint64_t> sd(4096); for (auto &x : sd) x = s->seeder.next();
+        rt_h2d(h.seeds, sd.data(), sd.size() * 8, s->stream); h.d.seeds = h.seeds;
+        g.nSteps = 4096; g.nDone = 0; g.updateFlushed = 0; g.qlen = 0; g.traceOn = 0;
+        *s->hGs = g; rt_h2d(h.d.gs, s->hGs, sizeof(GenScalars), s->stream);
+        launch_gen(s, h);
+        if (kind == 0) launch_eval(s, h);
+    }
+    rt_sync(s->stream);
+    h.d.dbg = dbgFlags;
+    const double t0 = now_s();
+    for (uint32_t i = 0; i < n; ++i) { if (kind == 0) { launch_gen(s, h); launch_eval(s, h); } else launch_eval(s, h); }
+    rt_sync(s->stream);
+    *usPerLaunch = 1e6 * (now_s() - t0) / (double)n;
+    h.d.dbg = 0;
+    SESSION_END
+}
 int cogaps_session_debug_prof(cogaps_session *s, char which, uint64_t *out16)
 {
     SESSION_TRY

@@ -8,10 +8,14 @@
 //
 // HBM traffic per proposal (N = data-vector length): alpha with or without change 16N bytes,
 // 2-site same row 20N, different rows 32N, AP update 12N.  Rows are read as coalesced float4.
+// The step is latency bound (a batch is only ~50-160 proposals), so the kernel is organised as few
+// dependent memory round trips as possible: {queue record} -> {the proposal's scalars + every row
+// chunk of the reduction, all in flight together} -> {two LUT reads} -> {AP update: re-read from L2,
+// store}.
 //
-// Reduction order (the parity contract with oracle redW/redG=4): lane L accumulates float4 chunks
-// j = L, L+W, L+2W ... in increasing j (x,y,z,w in order) from +0; then an ascending xor butterfly
-// 1,2,4,...,W/2 (the reference's AVX hadd tree, SIMD.h:102-107, widened from 8 to W lanes).
+// Reduction order (the parity contract with the oracle's redW / redG=4): lane L accumulates float4
+// chunks j = L, L+W, L+2W ... in increasing j (x,y,z,w in order) from +0; then an ascending xor
+// butterfly 1,2,4,...,W/2 (the reference's AVX hadd tree, SIMD.h:102-107, widened from 8 to W lanes).
 #pragma once
 #include "gaps_state.h"
 #include "gen_kernel.h"   // gen_bin_of, bm_set, bm_clear
@@ -24,6 +28,8 @@ typedef float4 cg_f4;
 
 CG_DEVICE cg_f4 ld4(const float *base, uint32_t j) { return reinterpret_cast<const cg_f4 *>(base)[j]; }
 CG_DEVICE void st4(float *base, uint32_t j, cg_f4 v) { reinterpret_cast<cg_f4 *>(base)[j] = v; }
+CG_DEVICE cg_f4 f4_zero() { cg_f4 z; z.x = 0.f; z.y = 0.f; z.z = 0.f; z.w = 0.f; return z; }
+CG_DEVICE cg_f4 f4_one() { cg_f4 z; z.x = 1.f; z.y = 1.f; z.z = 1.f; z.w = 1.f; return z; }
 
 struct EvalAcc { float s, m; };
 
@@ -31,38 +37,63 @@ struct EvalAcc { float s, m; };
 #define EVAL_ELEM(V, DD, SS, AA) { float ratio = (V) / (SS); a.s = a.s + (V) * ratio; a.m = a.m + ratio * ((DD) - (AA)); }
 #define EVAL_ELEM_CH(V, DD, SS, AA) { float ratio = (V) / (SS); a.s = a.s + (V) * ratio; a.m = a.m + ratio * ((DD) - ((AA) + ch * (V))); }
 
+// UN chunks per lane are loaded before any is consumed (4*UN independent float4 loads in flight), so a
+// row costs one memory round trip when it has at most UN*W chunks.  A chunk index past the row reads
+// nothing and contributes (v=0, S2=1, D=AP=0) -> +0 to both sums, which leaves them bit-unchanged.
+template <int UN>
 CG_DEVICE EvalAcc eval_partial_one(const SamplerDev &S, uint32_t row, uint32_t col, bool withCh, float ch)
 {
     const uint32_t nq = S.Npad >> 2, W = cg_bdim(), t = cg_tid();
     const float *D = S.D + (size_t)row * S.Npad, *S2 = S.S2 + (size_t)row * S.Npad, *AP = S.AP + (size_t)row * S.Npad;
     const float *V = S.other + (size_t)col * S.Npad;
     EvalAcc a; a.s = 0.f; a.m = 0.f;
-    if (withCh) {
-        for (uint32_t j = t; j < nq; j += W) {
-            const cg_f4 v = ld4(V, j), d = ld4(D, j), s = ld4(S2, j), p = ld4(AP, j);
-            EVAL_ELEM_CH(v.x, d.x, s.x, p.x) EVAL_ELEM_CH(v.y, d.y, s.y, p.y) EVAL_ELEM_CH(v.z, d.z, s.z, p.z) EVAL_ELEM_CH(v.w, d.w, s.w, p.w)
+#if defined(GEN_PROFILE)
+    if (S.dbg & 4u) return a;
+#endif
+    for (uint32_t j0 = t; j0 < nq; j0 += UN * W) {
+        cg_f4 v[UN], d[UN], s[UN], p[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const uint32_t j = j0 + (uint32_t)u * W;
+            if (j < nq) { v[u] = ld4(V, j); d[u] = ld4(D, j); s[u] = ld4(S2, j); p[u] = ld4(AP, j); }
+            else { v[u] = f4_zero(); d[u] = f4_zero(); s[u] = f4_one(); p[u] = f4_zero(); }
         }
-    } else {
-        for (uint32_t j = t; j < nq; j += W) {
-            const cg_f4 v = ld4(V, j), d = ld4(D, j), s = ld4(S2, j), p = ld4(AP, j);
-            EVAL_ELEM(v.x, d.x, s.x, p.x) EVAL_ELEM(v.y, d.y, s.y, p.y) EVAL_ELEM(v.z, d.z, s.z, p.z) EVAL_ELEM(v.w, d.w, s.w, p.w)
+        if (withCh) {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) { EVAL_ELEM_CH(v[u].x, d[u].x, s[u].x, p[u].x) EVAL_ELEM_CH(v[u].y, d[u].y, s[u].y, p[u].y) EVAL_ELEM_CH(v[u].z, d[u].z, s[u].z, p[u].z) EVAL_ELEM_CH(v[u].w, d[u].w, s[u].w, p[u].w) }
+        } else {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) { EVAL_ELEM(v[u].x, d[u].x, s[u].x, p[u].x) EVAL_ELEM(v[u].y, d[u].y, s[u].y, p[u].y) EVAL_ELEM(v[u].z, d[u].z, s[u].z, p[u].z) EVAL_ELEM(v[u].w, d[u].w, s[u].w, p[u].w) }
         }
     }
     return a;
 }
 // DenseNormalModel.cpp:200-212: same row, v = other[:,c1] - other[:,c2]
+template <int UN>
 CG_DEVICE EvalAcc eval_partial_two_same(const SamplerDev &S, uint32_t row, uint32_t c1, uint32_t c2)
 {
     const uint32_t nq = S.Npad >> 2, W = cg_bdim(), t = cg_tid();
     const float *D = S.D + (size_t)row * S.Npad, *S2 = S.S2 + (size_t)row * S.Npad, *AP = S.AP + (size_t)row * S.Npad;
     const float *V1 = S.other + (size_t)c1 * S.Npad, *V2 = S.other + (size_t)c2 * S.Npad;
     EvalAcc a; a.s = 0.f; a.m = 0.f;
-    for (uint32_t j = t; j < nq; j += W) {
-        const cg_f4 v1 = ld4(V1, j), v2 = ld4(V2, j), d = ld4(D, j), s = ld4(S2, j), p = ld4(AP, j);
-        { float v = v1.x - v2.x; EVAL_ELEM(v, d.x, s.x, p.x) }
-        { float v = v1.y - v2.y; EVAL_ELEM(v, d.y, s.y, p.y) }
-        { float v = v1.z - v2.z; EVAL_ELEM(v, d.z, s.z, p.z) }
-        { float v = v1.w - v2.w; EVAL_ELEM(v, d.w, s.w, p.w) }
+#if defined(GEN_PROFILE)
+    if (S.dbg & 4u) return a;
+#endif
+    for (uint32_t j0 = t; j0 < nq; j0 += UN * W) {
+        cg_f4 v1[UN], v2[UN], d[UN], s[UN], p[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const uint32_t j = j0 + (uint32_t)u * W;
+            if (j < nq) { v1[u] = ld4(V1, j); v2[u] = ld4(V2, j); d[u] = ld4(D, j); s[u] = ld4(S2, j); p[u] = ld4(AP, j); }
+            else { v1[u] = f4_zero(); v2[u] = f4_zero(); d[u] = f4_zero(); s[u] = f4_one(); p[u] = f4_zero(); }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            { float v = v1[u].x - v2[u].x; EVAL_ELEM(v, d[u].x, s[u].x, p[u].x) }
+            { float v = v1[u].y - v2[u].y; EVAL_ELEM(v, d[u].y, s[u].y, p[u].y) }
+            { float v = v1[u].z - v2[u].z; EVAL_ELEM(v, d[u].z, s[u].z, p[u].z) }
+            { float v = v1[u].w - v2[u].w; EVAL_ELEM(v, d[u].w, s[u].w, p[u].w) }
+        }
     }
     return a;
 }
@@ -90,16 +121,28 @@ CG_DEVICE EvalAcc eval_block_reduce(EvalAcc a, float *lds /* [32] */)
 }
 
 // DenseNormalModel.cpp:243-258: AP[:,row] += delta * other[:,col]
+template <int UN>
 CG_DEVICE void eval_update_ap(const SamplerDev &S, uint32_t row, uint32_t col, float delta)
 {
     const uint32_t nq = S.Npad >> 2, W = cg_bdim(), t = cg_tid();
     float *AP = S.AP + (size_t)row * S.Npad;
     const float *V = S.other + (size_t)col * S.Npad;
-    if (t == 0) cg_atomic_add_u64(&S.gs->evalBytes, 12ull * S.N);
-    for (uint32_t j = t; j < nq; j += W) {
-        const cg_f4 v = ld4(V, j); cg_f4 p = ld4(AP, j);
-        p.x = p.x + delta * v.x; p.y = p.y + delta * v.y; p.z = p.z + delta * v.z; p.w = p.w + delta * v.w;
-        st4(AP, j, p);
+#if defined(GEN_PROFILE)
+    if (S.dbg & 2u) return;
+#endif
+    for (uint32_t j0 = t; j0 < nq; j0 += UN * W) {
+        cg_f4 v[UN], p[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) { const uint32_t j = j0 + (uint32_t)u * W; if (j < nq) { v[u] = ld4(V, j); p[u] = ld4(AP, j); } else { v[u] = f4_zero(); p[u] = f4_zero(); } }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const uint32_t j = j0 + (uint32_t)u * W;
+            if (j < nq) {
+                cg_f4 q = p[u];
+                q.x = q.x + delta * v[u].x; q.y = q.y + delta * v[u].y; q.z = q.z + delta * v[u].z; q.w = q.w + delta * v[u].w;
+                st4(AP, j, q);
+            }
+        }
     }
 }
 
@@ -129,17 +172,32 @@ CG_DEVICE void eval_domain_move(const SamplerDev &S, uint32_t h, uint64_t oldPos
     bm_set(S, b2);
 }
 
+#if defined(GEN_PROFILE)
+#define EVAL_PROF(i) do { if (t == 0 && cg_bid() == 0) { unsigned long long now_ = cg_clock(); cg_atomic_add_u64(&S.gs->prof[8 + (i)], now_ - eprof_last); eprof_last = now_; } } while (0)
+#else
+#define EVAL_PROF(i) do { } while (0)
+#endif
+
+template <int UN>
 CG_DEVICE void eval_body(const SamplerDev &S)
 {
     CG_SHARED float lds[32];
+    CG_SHARED float decf; CG_SHARED uint32_t deci;     // decision of wave 0, broadcast to the other waves
     const uint32_t t = cg_tid();
-    const uint32_t qlen = S.gs->qlen;
+    unsigned long long eprof_last = cg_clock(); (void)eprof_last;
     const float T = S.annealTemp, lambda = S.lambda;
-    for (uint32_t q = cg_bid(); q < qlen; q += cg_gdim()) {
-        const PropRec p = S.queue[q];
-        uint64_t rng = p.rng;
-        // every lane reads the scalars this proposal depends on, then a barrier: lane 0 rewrites them
-        // at the end of the step and must not overtake a slower wave's reads
+    const bool multiWave = cg_bdim() > 64u;
+    const bool scalarLane = !multiWave || t < 64u;       // the per-proposal scalar math (LUTs, fp64 log) runs in wave 0 only
+#define EVAL_BCAST(F0, I0) do { if (multiWave) { if (t == 0) { decf = (F0); deci = (I0); } cg_sync(); (F0) = decf; (I0) = deci; } } while (0)
+    for (uint32_t q = cg_bid(); ; q += cg_gdim()) {
+        // the record is fetched together with the queue length (slot q always exists: q < queueCap)
+        const PropRec p = S.queue[q < S.queueCap ? q : 0u];
+        const uint32_t qlen = S.gs->qlen;
+        if (q >= qlen) break;
+        uint64_t rng = p.rng; uint32_t nUpd = 0;
+        // the scalars this proposal depends on: issued now, consumed after the row loads are in flight.
+        // lane 0 rewrites them at the end of the step; the barriers inside the reduction (or the explicit
+        // one on the paths without a reduction) keep it from overtaking a slower wave's reads.
         const bool two = (p.type == 'M' || p.type == 'E');
         const float m1 = (p.type == 'B') ? 0.f : S.atoms[p.h1].mass;
         const float m2 = (p.type == 'E') ? S.atoms[p.h2].mass : 0.f;
@@ -148,61 +206,78 @@ CG_DEVICE void eval_body(const SamplerDev &S)
         const uint64_t curPos = (p.type == 'M') ? S.atoms[p.h1].pos : 0ull;
         const bool gibbs1 = S.otherColPos[p.c1] > 0u;
         const bool gibbs2 = two ? (S.otherColPos[p.c2] > 0u) : false;
-        cg_sync();
+        EVAL_PROF(0);
+#if defined(GEN_PROFILE)
+        if (S.dbg & 1u) { if (p.type == 0xFFu || m1 == -1.f) S.queueUnits[q] = (uint32_t)old1; break; }   // record + scalars only
+#endif
         if (p.type == 'B') {
             // ---------------------------------------------------------------- birth (:127-144)
-            OptF mass;
+            OptF mass; mass.v = 0.f; mass.has = false;
+            float bv = 0.f; uint32_t bhas = 0;
             if (gibbs1) {
-                EvalAcc a = eval_block_reduce(eval_partial_one(S, p.r1, p.c1, false, 0.f), lds);
-                mass = gm_gibbs_mass(a.s * T, a.m * T, 0.f, S.maxGibbsMass, rng, S.luts, true, lambda);
-            } else { mass.v = pcg_exponential(rng, lambda); mass.has = true; }
+                EvalAcc a = eval_block_reduce(eval_partial_one<UN>(S, p.r1, p.c1, false, 0.f), lds);
+                if (scalarLane) { OptF g = gm_gibbs_mass(a.s * T, a.m * T, 0.f, S.maxGibbsMass, rng, S.luts, true, lambda); bv = g.v; bhas = g.has ? 1u : 0u; }
+            } else if (scalarLane) { bv = pcg_exponential(rng, lambda); bhas = 1u; }
+            EVAL_BCAST(bv, bhas);
+            mass.v = bv; mass.has = bhas != 0u;
             if (mass.has && mass.v >= GAPS_EPSILON) {
-                eval_update_ap(S, p.r1, p.c1, mass.v);                              // changeMatrix
+                eval_update_ap<UN>(S, p.r1, p.c1, mass.v); ++nUpd;                          // changeMatrix
                 if (t == 0) { S.atoms[p.h1].mass = mass.v; eval_store_matrix(S, p.r1, p.c1, old1, old1 + mass.v); }
             } else if (t == 0) eval_cache_erase(S, p.h1);
         } else if (p.type == 'D') {
             // ---------------------------------------------------------------- death / rebirth (:148-180)
             float rebirth = m1;
-            EvalAcc a = eval_block_reduce(eval_partial_one(S, p.r1, p.c1, true, -1.f * m1), lds);
+            EvalAcc a = eval_block_reduce(eval_partial_one<UN>(S, p.r1, p.c1, true, -1.f * m1), lds);
             const float s = a.s * T, smu = a.m * T;
-            if (gibbs1) {
-                OptF g = gm_gibbs_mass(s, smu, 0.f, S.maxGibbsMass, rng, S.luts, true, lambda);
-                if (g.has) rebirth = g.v;
+            EVAL_PROF(1);
+            uint32_t acc = 0;
+            if (scalarLane) {
+                if (gibbs1) {
+                    OptF g = gm_gibbs_mass(s, smu, 0.f, S.maxGibbsMass, rng, S.luts, true, lambda);
+                    if (g.has) rebirth = g.v;
+                }
+                const float deltaLL = rebirth * (smu - s * rebirth / 2.f);
+                acc = (gm_logf(pcg_uniform(rng)) < deltaLL) ? 1u : 0u;
             }
-            const float deltaLL = rebirth * (smu - s * rebirth / 2.f);
-            if (gm_logf(pcg_uniform(rng)) < deltaLL) {
+            EVAL_BCAST(rebirth, acc);
+            const bool accept = acc != 0u;
+            EVAL_PROF(2);
+            if (accept) {
                 if (rebirth != m1) {
                     const float nv = gm_max(old1 + (rebirth - m1), 0.f);            // safelyChangeMatrix
-                    eval_update_ap(S, p.r1, p.c1, nv - old1);
+                    eval_update_ap<UN>(S, p.r1, p.c1, nv - old1); ++nUpd;
                     if (t == 0) { eval_store_matrix(S, p.r1, p.c1, old1, nv); S.atoms[p.h1].mass = rebirth; }
                 }
             } else {
                 const float nv = gm_max(old1 + (-1.f * m1), 0.f);
-                eval_update_ap(S, p.r1, p.c1, nv - old1);
+                eval_update_ap<UN>(S, p.r1, p.c1, nv - old1); ++nUpd;
                 if (t == 0) { eval_store_matrix(S, p.r1, p.c1, old1, nv); eval_cache_erase(S, p.h1); }
             }
+            EVAL_PROF(3);
         } else {
             // ---------------------------------------------------------------- 2-site alpha (:186-214)
             float s = 0.f, smu = 0.f;
             const bool need = (p.type == 'M') || gibbs1 || gibbs2;                  // exchange: canUseGibbs(c1,c2)
             if (need) {
                 if (p.r1 == p.r2) {
-                    EvalAcc a = eval_block_reduce(eval_partial_two_same(S, p.r1, p.c1, p.c2), lds);
+                    EvalAcc a = eval_block_reduce(eval_partial_two_same<UN>(S, p.r1, p.c1, p.c2), lds);
                     s = a.s; smu = a.m;
                 } else {
-                    EvalAcc a = eval_block_reduce(eval_partial_one(S, p.r1, p.c1, false, 0.f), lds);
-                    EvalAcc b = eval_block_reduce(eval_partial_one(S, p.r2, p.c2, false, 0.f), lds);
+                    EvalAcc a = eval_block_reduce(eval_partial_one<UN>(S, p.r1, p.c1, false, 0.f), lds);
+                    EvalAcc b = eval_block_reduce(eval_partial_one<UN>(S, p.r2, p.c2, false, 0.f), lds);
                     s = a.s + b.s; smu = a.m - b.m;                                 // AlphaParameters.cpp:11-14
                 }
                 s = s * T; smu = smu * T;
-            }
+            } else if (multiWave) cg_sync();
             if (p.type == 'M') {
                 // ------------------------------------------------------------ move (:184-196)
-                const float deltaLL = -1.f * m1 * (smu + s * m1 / 2.f);
-                if (gm_logf(pcg_uniform(rng)) < deltaLL) {
+                uint32_t acc = 0; float unused = 0.f;
+                if (scalarLane) { const float deltaLL = -1.f * m1 * (smu + s * m1 / 2.f); acc = (gm_logf(pcg_uniform(rng)) < deltaLL) ? 1u : 0u; }
+                EVAL_BCAST(unused, acc);
+                if (acc) {
                     const float nv1 = gm_max(old1 + (-m1), 0.f);                    // safelyChangeMatrix(r1,c1,-m)
-                    eval_update_ap(S, p.r1, p.c1, nv1 - old1);
-                    eval_update_ap(S, p.r2, p.c2, m1);                              // changeMatrix(r2,c2,+m); same lane owns the same elements
+                    eval_update_ap<UN>(S, p.r1, p.c1, nv1 - old1); ++nUpd;
+                    eval_update_ap<UN>(S, p.r2, p.c2, m1); ++nUpd;                          // changeMatrix(r2,c2,+m); same lane owns the same elements
                     if (t == 0) {
                         eval_domain_move(S, p.h1, curPos, p.pos);
                         eval_store_matrix(S, p.r1, p.c1, old1, nv1);
@@ -211,13 +286,16 @@ CG_DEVICE void eval_body(const SamplerDev &S)
                 }
             } else if (need) {
                 // ------------------------------------------------------------ exchange (:201-219)
-                OptF g = gm_gibbs_mass(s, smu, -m1, m2, rng, S.luts, false, 0.f);
+                OptF g; g.v = 0.f; g.has = false;
+                { float gv = 0.f; uint32_t gh = 0;
+                  if (scalarLane) { OptF g0 = gm_gibbs_mass(s, smu, -m1, m2, rng, S.luts, false, 0.f); gv = g0.v; gh = g0.has ? 1u : 0u; }
+                  EVAL_BCAST(gv, gh); g.v = gv; g.has = gh != 0u; }
                 const float n1 = m1 + g.v, n2 = m2 - g.v;
                 if (g.has && n1 > GAPS_EPSILON && n2 > GAPS_EPSILON) {
                     const float nv1 = gm_max(old1 + (n1 - m1), 0.f);
-                    eval_update_ap(S, p.r1, p.c1, nv1 - old1);
+                    eval_update_ap<UN>(S, p.r1, p.c1, nv1 - old1); ++nUpd;
                     const float nv2 = gm_max(old2 + (n2 - m2), 0.f);
-                    eval_update_ap(S, p.r2, p.c2, nv2 - old2);
+                    eval_update_ap<UN>(S, p.r2, p.c2, nv2 - old2); ++nUpd;
                     if (t == 0) {
                         eval_store_matrix(S, p.r1, p.c1, old1, nv1);
                         eval_store_matrix(S, p.r2, p.c2, old2, nv2);
@@ -226,17 +304,19 @@ CG_DEVICE void eval_body(const SamplerDev &S)
                 }
             }
         }
-        if (t == 0) {   // roofline bookkeeping: algorithmic bytes of this proposal (16N / 20N / 32N per alpha, 12N per AP update)
-            const unsigned long long nb = 4ull * S.N;
-            unsigned long long bytes = 0;
-            if (p.type == 'B') bytes = gibbs1 ? 4 * nb : 0;
-            else if (p.type == 'D') bytes = 4 * nb;
-            else if (p.type == 'M' || gibbs1 || gibbs2) bytes = (p.r1 == p.r2) ? 5 * nb : 8 * nb;
-            cg_atomic_add_u64(&S.gs->evalBytes, bytes);
-            cg_atomic_add_u64(&S.gs->evalProps, 1ull);
+        if (t == 0) {   // roofline bookkeeping: algorithmic traffic of this proposal in units of 4N bytes
+            // (alpha: 4 one-site, 5 two-site same row, 8 different rows; 3 per AP update); the generator sums the slots
+            uint32_t units = nUpd * 3u;
+            if (p.type == 'B') units += gibbs1 ? 4u : 0u;
+            else if (p.type == 'D') units += 4u;
+            else if (p.type == 'M' || gibbs1 || gibbs2) units += (p.r1 == p.r2) ? 5u : 8u;
+            S.queueUnits[q] = units;
         }
+        if (q + cg_gdim() >= qlen) break;   // last proposal of this workgroup: nothing left to order
         cg_sync();   // lane 0's scalar writes are ordered before the next proposal's reads
     }
 }
 
-CG_KERNEL void eval_kernel(SamplerDev S) { eval_body(S); }
+// UN = 8: workgroups of up to 256 lanes (512-VGPR budget); UN = 4: up to 1024 lanes (128 VGPRs per lane)
+template <int UN>
+CG_KERNEL void CG_LAUNCH_BOUNDS(UN == 8 ? 256 : 1024) eval_kernel(SamplerDev S) { eval_body<UN>(S); }

@@ -88,6 +88,7 @@ struct SamplerDev {
     uint32_t eraseCap;
     // ---- ProposalQueue -------------------------------------------------------------------------
     PropRec *queue;    // [queueCap]
+    uint32_t *queueUnits; // [queueCap] algorithmic traffic of each evaluated proposal, in units of 4N bytes
     uint32_t queueCap;
     const uint64_t *seeds;  // seeder outputs for this update(): candidate k of the update uses seeds[k]
     // conflict stamps, one 64-bit word per key: [batch epoch:40][round:12][priority:12], written with
@@ -110,4 +111,5 @@ struct SamplerDev {
     // ---- optional trace (parity tests) -------------------------------------------------------
     PropRec *trace;        // [traceCap] copies of queued proposals
     uint32_t *traceBatchNproc, *traceBatchQlen; // [traceCap]
+    uint32_t dbg;          // GEN_PROFILE builds: skip parts of the evaluation kernel (timing experiments)
 };

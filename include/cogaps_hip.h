@@ -141,6 +141,7 @@ int cogaps_session_perf(cogaps_session *s, cogaps_perf *out);
 
 /* development aid: per-phase cycle counters of the generator kernel (all zero unless built with -DGEN_PROFILE) */
 int cogaps_session_debug_prof(cogaps_session *s, char which, uint64_t *out16);
+int cogaps_session_debug_replay(cogaps_session *s, char which, int kind, uint32_t n, uint32_t dbgFlags, double *usPerLaunch);
 
 /* lanes of the evaluation workgroup for data vectors of length N (the reduction-order contract) */
 uint32_t cogaps_reduction_width(uint32_t N);

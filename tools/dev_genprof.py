@@ -19,3 +19,6 @@ for w in 'AP':
     print(w, 'rounds', pr[15], 'total Mcycles %.1f' % (tot / 1e6))
     for i, n in enumerate(names):
         print('   %-28s %6.1f%%  %8.0f cycles/round' % (n, 100 * pr[i] / tot, pr[i] / max(1, pr[15])))
+for w in 'AP':
+    pr = S.debug_prof(w)
+    print(w, 'eval block0 marks (cycles total): queue-rec %d | scalars+sync %d | death: alpha+reduce %d | death: gibbs+log %d | rest(update etc) %d' % tuple(pr[8:13]))
