@@ -1,0 +1,244 @@
+"""GWCoGAPS / scCoGAPS -- distributedCogaps (reference R/DistributedCogaps.R:40-127) with one data
+subset per GPU.
+
+  createSets                       R/SubsetData.R:85-116  (explicitSets, or a uniform partition)
+  pass 1: one chain per subset     R/DistributedCogaps.R:64-68   -> rank r runs the subsets i with i % world == r
+  all-gather of the shared factor  :71-74  (sampleFactors for genome-wide, featureLoadings for single-cell)
+                                   -> torch.distributed.all_gather (RCCL over xGMI on GPUs, gloo in CPU tests)
+  findConsensusMatrix              :129-217 (cor -> 1-cor -> complete linkage -> cutree -> split -> cubic-weighted
+                                   mean -> max-normalise), computed redundantly on every rank
+  pass 2: fixed matrix             :86-97
+  stitchTogether                   :226-278
+
+Differences from the reference, both documented in DESIGN.md: (1) the reference forces its sequential
+sampler inside workers (:28-29); this library is the asynchronous sampler, so each shard is an asynchronous
+chain (the per-shard oracle is the asynchronous reference run with the same dataIndicesSubset); (2) the
+uniform partition uses numpy's generator, not R's sample(): results with explicitSets are comparable, the
+random partition is not.  The reference's quirk that the shared factor comes back all-zero from pass 2
+(:236-237, src/GapsRunner.cpp:301-306) is reproduced in Pmean/Amean; the consensus actually used is
+returned under diagnostics["consensus"].
+"""
+import numpy as np
+
+from . import _capi
+
+
+# ------------------------------------------------------------------------------------------------
+def create_sets(total, params):
+    """1-based index sets (R convention), R/SubsetData.R:85-116"""
+    if params.explicitSets is not None:
+        if len(params.explicitSets) != params.nSets:
+            raise ValueError("nSets does not match number of explicit sets given")
+        return [np.sort(np.asarray(s, dtype=np.int64)) for s in params.explicitSets]
+    rng = np.random.Generator(np.random.MT19937(int(params.seed)))
+    set_size = total // params.nSets
+    remaining = np.arange(1, total + 1)
+    sets = []
+    for _ in range(params.nSets - 1):                      # sampleUniformly, SubsetData.R:63-76
+        sel = rng.choice(remaining, set_size, replace=False)
+        sets.append(np.sort(sel))
+        remaining = np.setdiff1d(remaining, sel)
+    sets.append(np.sort(remaining))
+    return sets
+
+
+# ------------------------------------------------------------------------------------------------
+def _complete_linkage_cutree(dist, k):
+    """cluster::agnes(diss, method="complete") + stats::cutree(k): labels numbered by first appearance"""
+    n = dist.shape[0]
+    if k >= n:
+        return np.arange(1, n + 1)
+    members = {i: [i] for i in range(n)}
+    d = dist.astype(np.float64).copy()
+    np.fill_diagonal(d, np.inf)
+    active = list(range(n))
+    while len(active) > k:
+        sub = d[np.ix_(active, active)]
+        a, b = np.unravel_index(np.argmin(sub), sub.shape)
+        i, j = active[min(a, b)], active[max(a, b)]
+        for o in active:                                   # complete linkage: distance = max over members
+            if o != i and o != j:
+                d[i, o] = d[o, i] = max(d[i, o], d[j, o])
+        members[i] += members.pop(j)
+        active.remove(j)
+    labels = np.zeros(n, dtype=np.int64)
+    nxt = 1
+    for obs in range(n):
+        if labels[obs] == 0:
+            root = next(r for r, m in members.items() if obs in m)
+            labels[members[root]] = nxt
+            nxt += 1
+    return labels
+
+
+def _cor(m):
+    """stats::cor of the columns (Pearson)"""
+    x = m.astype(np.float64)
+    x = x - x.mean(axis=0, keepdims=True)
+    s = np.sqrt((x * x).sum(axis=0))
+    return (x.T @ x) / np.outer(s, s)
+
+
+def corcut(all_patterns, cut, min_ns):
+    """R/DistributedCogaps.R:197-217: list of column-index arrays, one per kept cluster"""
+    corr_dist = 1.0 - _cor(all_patterns)
+    if np.isnan(corr_dist).any():
+        raise ValueError("NA values in correlation of patterns")
+    ids = _complete_linkage_cutree(corr_dist, cut)
+    out = []
+    for c in dict.fromkeys(ids.tolist()):                  # unique(), order of first appearance
+        cols = np.nonzero(ids == c)[0]
+        if cols.size >= min_ns:
+            out.append(cols)
+    return out
+
+
+def corr_to_mean_pattern(cluster):
+    """R/DistributedCogaps.R:186-190: round(cor(column, rowMeans), 3)"""
+    mean_pat = cluster.astype(np.float64).mean(axis=1)
+    out = []
+    for j in range(cluster.shape[1]):
+        x = cluster[:, j].astype(np.float64)
+        c = np.corrcoef(x, mean_pat)[0, 1]
+        out.append(np.round(c, 3))
+    return np.array(out)
+
+
+def pattern_match(all_patterns, params):
+    """R/DistributedCogaps.R:145-177"""
+    clusters = [all_patterns[:, c] for c in corcut(all_patterns, params.cut, params.minNS)]
+    while True:                                            # split clusters larger than maxNS in two
+        big = [i for i, c in enumerate(clusters) if c.shape[1] > params.maxNS]
+        if not big:
+            break
+        i = big[0]
+        split = corcut(clusters[i], 2, params.minNS)
+        parts = [clusters[i][:, s] for s in split]
+        if not parts:                                      # neither half reaches minNS: R would index NULL; drop the cluster
+            clusters.pop(i)
+            continue
+        clusters[i] = parts[0]
+        if len(parts) > 1:
+            clusters.append(parts[1])
+        elif parts[0].shape[1] == clusters[i].shape[1] and parts[0].shape[1] > params.maxNS:
+            break
+    if not clusters:
+        raise ValueError("no cluster of patterns reaches minNS members")
+    mean_patterns = np.stack([
+        (c.astype(np.float64) * (corr_to_mean_pattern(c) ** 3)[None, :]).sum(axis=1) / (corr_to_mean_pattern(c) ** 3).sum()
+        for c in clusters], axis=1)                        # weighted.mean(row, corrToMeanPattern^3)
+    consensus = mean_patterns / mean_patterns.max(axis=0, keepdims=True)
+    return {"clusteredPatterns": clusters, "consensus": consensus.astype(np.float32)}
+
+
+def find_consensus_matrix(unmatched, params):
+    """R/DistributedCogaps.R:129-135"""
+    return pattern_match(np.concatenate(unmatched, axis=1), params)
+
+
+# ------------------------------------------------------------------------------------------------
+def _dist():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist
+    except Exception:
+        pass
+    return None
+
+
+def _all_gather_arrays(local, shapes, dist, device):
+    """all-gather a list of equally shaped fp32 matrices per owned subset; returns them in subset order"""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n_sets = len(shapes)
+    per_rank = (n_sets + world - 1) // world
+    buf = torch.zeros((per_rank,) + tuple(shapes[0]), dtype=torch.float32, device=device)
+    for slot, i in enumerate(range(rank, n_sets, world)):
+        buf[slot] = torch.from_numpy(np.ascontiguousarray(local[i], dtype=np.float32)).to(device)
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf)
+    res = [None] * n_sets
+    for r in range(world):
+        for slot, i in enumerate(range(r, n_sets, world)):
+            res[i] = out[r][slot].cpu().numpy()
+    return res
+
+
+def distributedCogaps(data, params, uncertainty=None, messages=False, outputFrequency=1000, transposeData=False,
+                      device=-1, run_fn=None, comm_device=None):
+    run_fn = run_fn or _capi.run
+    genome_wide = params.distributed == "genome-wide"
+    subset_rows = bool(transposeData) != genome_wide          # xor, SubsetData.R:87-88
+    total = data.shape[0] if subset_rows else data.shape[1]
+    sets = create_sets(total, params)
+    if min(len(s) for s in sets) < params.nPatterns:
+        raise ValueError("data subset dimension less than nPatterns")
+    dist = _dist()
+    world, rank = (dist.get_world_size(), dist.get_rank()) if dist else (1, 0)
+    if comm_device is None:
+        comm_device = "cpu"
+        if dist is not None and dist.get_backend() == "nccl":
+            import torch
+            comm_device = torch.device("cuda", torch.cuda.current_device())
+    mine = list(range(rank, len(sets), world))
+    common = dict(nIterations=params.nIterations, seed=params.seed, outputFrequency=outputFrequency, alphaA=params.alphaA,
+                  alphaP=params.alphaP, maxGibbsMassA=params.maxGibbsMassA, maxGibbsMassP=params.maxGibbsMassP,
+                  transposeData=transposeData, sparseOptimization=params.sparseOptimization, device=device)
+
+    def call(i, n_patterns, fixed=None, which="N"):            # callInternalCoGAPS, DistributedCogaps.R:12-35
+        return run_fn(data, unc=uncertainty, nPatterns=n_patterns, subsetIndices=sets[i].astype(np.uint32),
+                      subsetDim=1 if genome_wide else 2, workerID=i + 1, messages=messages, whichMatrixFixed=which,
+                      fixedPatterns=fixed, **common)
+
+    initial, unmatched, matched = None, None, None
+    if params.fixedPatterns is None:
+        initial = {i: call(i, params.nPatterns) for i in mine}
+        key = "Pmean" if genome_wide else "Amean"
+        local = {i: initial[i][key] for i in mine}
+        if dist is not None:
+            shape = next(iter(local.values())).shape if local else None
+            shapes = [shape] * len(sets)
+            if shape is None:
+                raise ValueError("more ranks than subsets")
+            unmatched = _all_gather_arrays(local, shapes, dist, comm_device)
+        else:
+            unmatched = [local[i] for i in range(len(sets))]
+        matched = find_consensus_matrix(unmatched, params)
+    else:
+        matched = {"consensus": np.asarray(params.fixedPatterns, dtype=np.float32), "clusteredPatterns": None}
+
+    consensus = matched["consensus"]
+    which = "P" if genome_wide else "A"
+    final = {i: call(i, consensus.shape[1], fixed=consensus, which=which) for i in mine}
+
+    # stitchTogether (DistributedCogaps.R:226-278): collect the per-subset free factor on every rank
+    free_key, free_sd = ("Amean", "Asd") if genome_wide else ("Pmean", "Psd")
+    if dist is not None:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, {i: {k: final[i][k] for k in (free_key, free_sd, "Pmean", "Amean", "meanChiSq")} for i in mine})
+        allf = {}
+        for g in gathered:
+            allf.update(g)
+    else:
+        allf = final
+    order = list(range(len(sets)))
+    free_mean = np.concatenate([allf[i][free_key] for i in order], axis=0)
+    free_dev = np.concatenate([allf[i][free_sd] for i in order], axis=0)
+    set_indices = np.concatenate(sets)
+    if free_mean.shape[0] == set_indices.size and np.array_equal(np.sort(set_indices), np.arange(1, free_mean.shape[0] + 1)):
+        reorder = np.argsort(set_indices, kind="stable")           # match(1:n, setIndices)
+        free_mean, free_dev = free_mean[reorder], free_dev[reorder]
+    shared = allf[0]["Pmean" if genome_wide else "Amean"]           # "same for all sets": zeros, see module docstring
+    out = {
+        "Amean": free_mean if genome_wide else shared, "Asd": free_dev if genome_wide else np.zeros_like(shared),
+        "Pmean": shared if genome_wide else free_mean, "Psd": np.zeros_like(shared) if genome_wide else free_dev,
+        "seed": params.seed, "meanChiSq": float(sum(allf[i]["meanChiSq"] for i in order)),
+        "subsets": sets, "consensus": consensus,
+    }
+    if initial is not None:
+        out["firstPass"] = initial
+        out["unmatchedPatterns"] = unmatched
+        out["clusteredPatterns"] = matched["clusteredPatterns"]
+        out["CorrToMeanPattern"] = [corr_to_mean_pattern(c) for c in matched["clusteredPatterns"]]
+    return out

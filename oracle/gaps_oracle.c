@@ -1310,6 +1310,24 @@ static float mean_chisq(const go_session *s)
     const go_sampler *P = &s->P;
     float chisq = 0.f;
     const float n2 = (float)s->statUpdates * (float)s->statUpdates;
+    if (P->redW > 1) {
+        /* lane mode (as sampler_chisq): per sample vector j a lane-strided partial over the genes, then
+         * the vectors are added sequentially */
+        for (uint32_t j = 0; j < P->M; ++j) {
+            lane_acc a; const uint32_t W = P->redW, G = P->redG;
+            for (uint32_t L = 0; L < W; ++L) { a.s[L] = 0.f; a.m[L] = 0.f; }
+            for (uint32_t i = 0; i < P->N; ++i) {
+                float m = 0.f;
+                for (uint32_t k = 0; k < s->K; ++k) m += s->Amean[(size_t)k * s->nGenes + i] * s->Pmean[(size_t)k * s->nSamples + j];
+                m /= n2;
+                float d = P->D[(size_t)j * P->N + i], sd = P->S[(size_t)j * P->N + i];
+                a.s[(i / G) % W] += ((d - m) * (d - m)) / (sd * sd);
+            }
+            float ps, pm; lanes_finish(&a, W, &ps, &pm);
+            chisq += ps;
+        }
+        return chisq;
+    }
     for (uint32_t i = 0; i < P->N; ++i)          /* genes */
         for (uint32_t j = 0; j < P->M; ++j) {    /* samples */
             float m = 0.f;

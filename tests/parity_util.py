@@ -1,0 +1,76 @@
+"""Shared step-wise comparison of a library session (HIP, or the test-only emulator build) with the
+oracle: per-batch proposal traces (type, rows, columns, positions, PCG states, atom indices), atom
+vectors (position, mass, neighbour links in vector order), factor matrices, AP caches, chi2,
+average queue length -- all bit-exact."""
+import numpy as np
+
+from cogaps_amd import _capi
+import pyoracle as po
+
+
+def make_pair(lib, data, **kw):
+    S = _capi.Session(data, lib=lib, **kw)
+    wA = lib.cogaps_reduction_width(S.dims("A")[1])
+    wP = lib.cogaps_reduction_width(S.dims("P")[1])
+    okw = dict(kw)
+    okw.pop("device", None)
+    O = po.Session(data, math_mode=po.MATH_PORTABLE, redW_A=wA, redW_P=wP, redG=4, **okw)
+    return S, O
+
+
+def assert_trace_equal(a, b, tag):
+    assert np.array_equal(a["nproc"], b["nproc"]), tag + ": batch sizes (nProcessed) differ"
+    assert np.array_equal(a["qlen"], b["qlen"]), tag + ": queue lengths differ"
+    assert len(a["rec"]) == len(b["rec"]), tag + ": number of queued proposals differs"
+    ra, rb = a["rec"], b["rec"]
+    for f in ("type", "r1", "c1", "r2", "c2", "rng_state", "atom1", "batch"):
+        assert np.array_equal(ra[f], rb[f]), "%s: field %s differs first at %d" % (tag, f, int(np.nonzero(ra[f] != rb[f])[0][0]))
+    m = ra["type"] == ord("M")
+    assert np.array_equal(ra["pos"][m], rb["pos"][m]), tag + ": move destinations differ"
+    e = ra["type"] == ord("E")
+    assert np.array_equal(ra["atom2"][e], rb["atom2"][e]), tag + ": exchange partners differ"
+
+
+def assert_state_equal(S, O, tag, chisq=True):
+    for w in "AP":
+        a, b = S.atoms(w), O.atoms(w)
+        for f in ("pos", "mass", "left", "right"):
+            assert np.array_equal(a[f], b[f]), "%s %s: atom %s differs" % (tag, w, f)
+        assert np.array_equal(S.matrix(w), O.matrix(w)), "%s %s: factor matrix differs" % (tag, w)
+        assert np.array_equal(S.ap(w), O.ap(w)), "%s %s: AP cache differs" % (tag, w)
+        assert S.avg_queue(w) == O.avg_queue(w), "%s %s: average queue length differs" % (tag, w)
+        if chisq:
+            assert S.chisq(w) == O.chisq(w), "%s %s: chi2 differs" % (tag, w)
+
+
+def run_stepwise(lib, data, n_iter, trace=True, total_iter=None, check_every=1, **kw):
+    total_iter = total_iter or max(n_iter, 2)
+    kw.setdefault("nIterations", total_iter)
+    S, O = make_pair(lib, data, **kw)
+    fixed = kw.get("whichMatrixFixed", "N")
+    props = 0
+    for it in range(n_iter):
+        t = min(1.0, 2.0 * it / total_iter)
+        S.set_annealing(t), O.set_annealing(t)
+        nA, nP = S.draw_steps()
+        assert (nA, nP) == O.draw_steps(), "Poisson step counts differ at iteration %d" % it
+        props += nA + nP
+        if trace and fixed == "N":
+            assert_trace_equal(S.update("A", nA, 1 << 16), O.update("A", nA, 1 << 16), "it%d A" % it)
+            S.sync("P"), O.sync("P")
+            assert_trace_equal(S.update("P", nP, 1 << 16), O.update("P", nP, 1 << 16), "it%d P" % it)
+            S.sync("A"), O.sync("A")
+        else:
+            S.iterate(nA, nP), O.iterate(nA, nP)
+        if (it + 1) % check_every == 0 or it == n_iter - 1:
+            assert_state_equal(S, O, "it%d" % it)
+    out = (S.natoms("A"), S.natoms("P"), props)
+    S.close(), O.close()
+    return out
+
+
+def synthetic(genes, samples, rank=3, seed=7):
+    rng = np.random.default_rng(seed)
+    a0 = rng.gamma(2.0, 0.5, (genes, rank)) * (rng.random((genes, rank)) > 0.5)
+    p0 = rng.gamma(2.0, 0.5, (samples, rank)) * (rng.random((samples, rank)) > 0.3)
+    return ((a0 @ p0.T) * (0.9 + 0.2 * rng.random((genes, samples))) + 0.01).astype(np.float32)

@@ -1,0 +1,104 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/cogaps_hip.h declares; the
+front-end mirrors the reference's parameter names, defaults and validation (R/class-CogapsParams.R,
+R/HelperFunctions.R:194-249).  No compute is launched here."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def test_library_builds_loads_and_exports_header_symbols():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "cogaps_amd", "csrc")])
+    from cogaps_amd import _capi
+    lib = _capi.load()
+    header = open(os.path.join(ROOT, "include", "cogaps_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)        # declarations only, not the comments
+    declared = set(re.findall(r"\b(cogaps_[a-z_0-9]+)\s*\(", header))
+    declared -= {"cogaps_session"}
+    assert declared, "no declarations found"
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libcogaps_hip.so does not export " + name
+    assert set(_capi.EXPORTS) <= declared
+    assert b"gfx950" in lib.cogaps_build_report()
+    assert lib.cogaps_checkpoints_enabled() == 0 and lib.cogaps_compiled_with_openmp() == 0
+    assert [lib.cogaps_reduction_width(n) for n in (9, 2000, 2049, 4100, 20000, 50000)] == [64, 64, 128, 256, 1024, 1024]
+
+
+def test_struct_layouts_match_header():
+    from cogaps_amd import _capi
+    lib = _capi.load()
+    p = _capi.CogapsParamsC()
+    lib.cogaps_default_params(ctypes.byref(p))
+    # GapsParameters.h:79-111 defaults
+    assert (p.nPatterns, p.nIterations, p.outputFrequency, p.maxThreads) == (3, 1000, 500, 1)
+    assert abs(p.alphaA - 0.01) < 1e-9 and abs(p.maxGibbsMassP - 100.0) < 1e-9
+    assert p.whichMatrixFixed == b"N" and p.asynchronousUpdates == 1 and p.device == -1
+
+
+def test_no_cpu_fallback_when_library_missing(monkeypatch, tmp_path):
+    from cogaps_amd import _capi
+    monkeypatch.setattr(_capi, "_lib", None)
+    monkeypatch.setattr(_capi, "LIB_PATH", str(tmp_path / "missing.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _capi.load()
+
+
+def test_product_never_touches_the_oracle():
+    for d, _, files in os.walk(os.path.join(ROOT, "cogaps_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".cpp", ".hip")):
+                txt = open(os.path.join(d, f)).read()
+                assert "pyoracle" not in txt and "gaps_oracle" not in txt and "liboracle" not in txt, f
+
+
+def test_params_defaults_and_validation():
+    from cogaps_amd import CogapsParams
+    p = CogapsParams(nPatterns=5, seed=11)
+    # R/class-CogapsParams.R:99-123
+    assert (p.nIterations, p.alphaA, p.maxGibbsMassA, p.nSets, p.cut, p.minNS, p.maxNS) == (50000, 0.01, 100.0, 4, 5, 2, 6)
+    assert p.whichMatrixFixed == "N" and p.distributed is None and p.sparseOptimization is False
+    p.setParam("alpha", 0.05)
+    assert p.alphaA == p.alphaP == 0.05
+    with pytest.raises(ValueError):
+        p.setParam("nSets", 3)
+    with pytest.raises(ValueError):
+        p.setParam("nPatterns", 0)
+    with pytest.raises(ValueError):
+        CogapsParams(distributed="everywhere")
+    with pytest.raises(ValueError):
+        p.setFixedPatterns(np.ones((3, 5)), "Q")
+    p.setParam("distributed", "genome-wide")
+    p.setDistributedParams(nSets=8)
+    assert (p.nSets, p.minNS, p.maxNS) == (8, 4, 12)
+
+
+def test_check_inputs_rules():
+    from cogaps_amd import CogapsParams
+    from cogaps_amd.api import check_inputs
+    p = CogapsParams(nPatterns=3, seed=1)
+    ok = np.ones((10, 8), dtype=np.float32)
+    check_inputs(ok, None, p)
+    with pytest.raises(ValueError, match="negative"):
+        check_inputs(-ok, None, p)
+    with pytest.raises(ValueError, match="nPatterns must be less"):
+        check_inputs(np.ones((3, 8), np.float32), None, p)
+    bad = ok.copy(); bad[0, 0] = np.nan
+    with pytest.raises(ValueError, match="NA"):
+        check_inputs(bad, None, p)
+    with pytest.raises(ValueError, match="checkpoints"):
+        check_inputs(ok, None, p, checkpointInFile="x")
+
+
+def test_readers(tmp_path, gist):
+    from cogaps_amd.io import read_matrix
+    from conftest import GOLDEN
+    m = read_matrix(os.path.join(GOLDEN, "GIST.mtx"))
+    assert m.shape == (1363, 9) and np.array_equal(m, gist)
+    p = tmp_path / "x.csv"
+    p.write_text(",s1,s2\ng1,1.5,2\ng2,3,4e-1\n")
+    assert np.array_equal(read_matrix(str(p)), np.array([[1.5, 2], [3, 0.4]], dtype=np.float32))

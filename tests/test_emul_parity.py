@@ -1,0 +1,69 @@
+"""Host logic + kernel logic on the TEST-ONLY workgroup emulator (tests/emul), bit-compared with the
+oracle batch by batch.  No GPU: the same kernel sources are compiled with g++ against a fiber-per-lane
+emulator; the product library is not involved.  The generator's speculative window is exercised at three
+widths (64 forces many multi-round batches and window cuts; 1024 is wider than any batch)."""
+import numpy as np
+import pytest
+
+import parity_util as pu
+
+
+@pytest.mark.parametrize("win", [64, 256])
+def test_modsim_stepwise(emul_lib, modsim, win):
+    a, p, props = pu.run_stepwise(emul_lib(win), modsim, 120 if win == 64 else 60, nPatterns=3, seed=42, total_iter=120)
+    assert props > 2000
+
+
+@pytest.mark.parametrize("win,n", [(64, 14), (256, 10), (1024, 6)])
+def test_gist_stepwise(emul_lib, gist, win, n):
+    pu.run_stepwise(emul_lib(win), gist, n, nPatterns=7, seed=42, total_iter=40)
+
+
+def test_tiny_domain_hazards(emul_lib):
+    """5 rows x 2 patterns: every window is full of row conflicts, same-bin moves and neighbour hazards"""
+    data = pu.synthetic(5, 6, rank=2, seed=3)
+    pu.run_stepwise(emul_lib(64), data, 150, nPatterns=2, seed=9, total_iter=100)
+    pu.run_stepwise(emul_lib(256), data, 60, nPatterns=2, seed=10, total_iter=100)
+
+
+def test_multiwave_evaluation(emul_lib):
+    """P-side data vectors of 4100 elements -> 256-lane evaluation workgroups (cross-wave butterfly)"""
+    data = pu.synthetic(4100, 12)
+    pu.run_stepwise(emul_lib(256), data, 5, trace=False, nPatterns=3, seed=123, total_iter=10)
+
+
+def test_transposed_and_uncertainty(emul_lib, modsim):
+    unc = (np.maximum(modsim * 0.2, 0.05)).astype(np.float32)
+    S, O = pu.make_pair(emul_lib(256), np.ascontiguousarray(modsim.T), unc=None, nPatterns=3, seed=4, nIterations=20, transposeData=True)
+    S.close(), O.close()
+    from cogaps_amd import _capi
+    import pyoracle as po
+    lib = emul_lib(256)
+    S = _capi.Session(modsim, unc=unc, lib=lib, nPatterns=3, seed=4, nIterations=20)
+    O = po.Session(modsim, unc=unc, math_mode=po.MATH_PORTABLE, redW_A=64, redW_P=64, redG=4, nPatterns=3, seed=4, nIterations=20)
+    for it in range(20):
+        nA, nP = S.draw_steps()
+        assert (nA, nP) == O.draw_steps()
+        S.iterate(nA, nP), O.iterate(nA, nP)
+    pu.assert_state_equal(S, O, "uncertainty")
+
+
+def test_gene_subset_and_fixed_matrix(emul_lib, gist):
+    idx = np.arange(1, 301, dtype=np.uint32)
+    lib = emul_lib(256)
+    pu.run_stepwise(lib, gist, 6, trace=False, nPatterns=4, seed=7, total_iter=12, subsetIndices=idx, subsetDim=1)
+    fixedP = np.abs(np.random.default_rng(1).normal(size=(9, 4))).astype(np.float32)
+    pu.run_stepwise(lib, gist, 6, trace=False, nPatterns=4, seed=7, total_iter=12, subsetIndices=idx, subsetDim=1,
+                    whichMatrixFixed="P", fixedPatterns=fixedP)
+
+
+def test_full_run_matches_oracle(emul_lib, modsim, oracle):
+    """cogaps_run end to end: histories, statistics, meanChiSq"""
+    from cogaps_amd import _capi
+    lib = emul_lib(256)
+    r = _capi.run(modsim, lib=lib, nPatterns=3, nIterations=40, seed=42, outputFrequency=10)
+    o = oracle.run(modsim, nPatterns=3, nIterations=40, seed=42, outputFrequency=10, math_mode=oracle.MATH_PORTABLE, redW_A=64, redW_P=64, redG=4)
+    for f in ("atomsA", "atomsP", "chisq", "Amean", "Pmean", "Asd", "Psd"):
+        assert np.array_equal(r[f], o[f]), f
+    assert r["totalUpdates"] == o["totalUpdates"] and r["meanChiSq"] == o["meanChiSq"]
+    assert r["averageQueueLengthA"] == o["averageQueueLengthA"]
