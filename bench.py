@@ -42,25 +42,34 @@ def synthetic_dense(n_genes, n_samples, rank=10, seed=12345):
 
 
 def cpu_baseline(data, params, budget_s):
-    """The oracle (oracle/gaps_oracle.c, OpenMP over the queue exactly like the reference's
-    `#pragma omp parallel for`, sequential fp32 reductions = the reference's scalar build) timed on
-    this host on the first iterations of the SAME chain, until `budget_s` seconds are spent."""
+    """The oracle (oracle/gaps_oracle.c: OpenMP over the queue exactly like the reference's
+    `#pragma omp parallel for`, sequential fp32 reductions + libm = the reference's scalar build) timed on
+    this host on the first iterations of the SAME chain.  A batch holds only ~50-160 proposals, so more
+    threads than that only add fork/join cost: a few thread counts share the time budget and the best
+    rate is reported (cores = the thread count that produced it)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
-    cores = os.cpu_count() or 1
-    O = po.Session(data, omp=True, maxThreads=cores, math_mode=po.MATH_LIBM, redW_A=1, redW_P=1, redG=1, **params)
+    ncpu = os.cpu_count() or 1
+    cands = sorted({min(ncpu, c) for c in (8, 16, 32, 64)})
     n_iter = params["nIterations"]
-    props, it, t0 = 0, 0, time.time()
-    while it < n_iter and time.time() - t0 < budget_s:
-        O.set_annealing(min(1.0, 2.0 * it / n_iter))
-        nA, nP = O.draw_steps()
-        O.iterate(nA, nP)
-        props += nA + nP
-        it += 1
-    dt = time.time() - t0
-    O.close()
-    return {"value": props / dt, "unit": "proposals/s", "cores": cores, "kind": "port",
-            "sample": "first %d equilibration iterations of the same chain (%d proposals, %.1f s)" % (it, props, dt)}
+    best = None
+    for threads in cands:
+        O = po.Session(data, omp=True, maxThreads=threads, math_mode=po.MATH_LIBM, redW_A=1, redW_P=1, redG=1, **params)
+        props, it, t0 = 0, 0, time.time()
+        while it < n_iter and time.time() - t0 < budget_s / len(cands):
+            O.set_annealing(min(1.0, 2.0 * it / n_iter))
+            nA, nP = O.draw_steps()
+            O.iterate(nA, nP)
+            props += nA + nP
+            it += 1
+        dt = time.time() - t0
+        O.close()
+        rate = props / dt
+        if best is None or rate > best["value"]:
+            best = {"value": rate, "unit": "proposals/s", "cores": threads, "kind": "port", "host_cpus": ncpu,
+                    "sample": "first %d equilibration iterations of the same chain (%d proposals, %.1f s); best of OMP threads %s"
+                              % (it, props, dt, cands)}
+    return best
 
 
 def main():
@@ -143,9 +152,19 @@ def main():
     if rank == 0:
         ev_bytes = perf1["evalBytes"] - perf0["evalBytes"]
         ev_launch = perf1["evalLaunches"] - perf0["evalLaunches"]
-        ev_ms = perf1["evalMs"] - perf0["evalMs"]
-        gen_ms = perf1["genMs"] - perf0["genMs"]
         batches = perf1["batches"] - perf0["batches"]
+        # HIP events bracket a sample of the launches on the kernels' stream.  A bracket also contains the
+        # fixed launch overhead; the launches enqueued past the end of an update (empty queue) measure exactly
+        # that overhead, so kernel time = (mean over batch-processing launches) - (mean over empty launches).
+        n_noop = perf1["evalNoopTimed"] - perf0["evalNoopTimed"]
+        noop_us = 1e3 * (perf1["evalNoopMs"] - perf0["evalNoopMs"]) / n_noop if n_noop else 0.0
+        g_noop = perf1["genNoopTimed"] - perf0["genNoopTimed"]
+        gnoop_us = 1e3 * (perf1["genNoopMs"] - perf0["genNoopMs"]) / g_noop if g_noop else 0.0
+        ev_raw_us = 1e3 * (perf1["evalMs"] - perf0["evalMs"]) / max(1, batches)
+        gen_raw_us = 1e3 * (perf1["genMs"] - perf0["genMs"]) / max(1, batches)
+        ev_us, gen_us = max(ev_raw_us - noop_us, 1e-3), max(gen_raw_us - gnoop_us, 1e-3)
+        ev_ms, gen_ms = ev_us * batches / 1e3, gen_us * batches / 1e3
+        ev_launch = batches
         achieved = (ev_bytes / 1e9) / (ev_ms / 1e3) if ev_ms > 0 else 0.0
         out = {
             "metric": METRIC, "value": tot_updates / max_dt, "unit": "proposals/s",
@@ -161,7 +180,9 @@ def main():
                        "launches_per_batch": (perf1["evalLaunches"] + perf1["genLaunches"] - perf0["evalLaunches"] - perf0["genLaunches"]) / max(1, batches)},
             "roofline": {"bound": "hbm", "kernel": "eval_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "bytes_per_launch": ev_bytes / max(1, ev_launch), "avg_launch_us": 1e3 * ev_ms / max(1, ev_launch)},
+                         "bytes_per_launch": ev_bytes / max(1, ev_launch), "avg_launch_us": ev_us,
+                         "event_bracket_us": ev_raw_us, "empty_launch_us": noop_us,
+                         "note": "one launch = one batch; avg over launches that processed a batch (A and P samplers together)"},
         }
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(data, params, args.cpu_seconds)

@@ -50,6 +50,7 @@ class CogapsPerfC(C.Structure):
         ("evalBytes", C.c_uint64), ("evalLaunches", C.c_uint64), ("genLaunches", C.c_uint64),
         ("batches", C.c_uint64), ("proposalsQueued", C.c_uint64),
         ("evalMs", C.c_double), ("genMs", C.c_double), ("syncMs", C.c_double),
+        ("evalNoopMs", C.c_double), ("genNoopMs", C.c_double), ("evalNoopTimed", C.c_uint64), ("genNoopTimed", C.c_uint64),
     ]
 
 

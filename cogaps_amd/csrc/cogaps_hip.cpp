@@ -131,7 +131,9 @@ struct HostSampler {
     char name = 'A';
     // perf accounting
     uint64_t evalLaunches = 0, genLaunches = 0, batches = 0;
-    double evalMs = 0, genMs = 0; uint64_t evalTimed = 0, genTimed = 0;
+    // HIP-event samples, split into launches that processed a batch and launches past the end of an update
+    double evalMs = 0, genMs = 0, evalNoopMs = 0, genNoopMs = 0; uint64_t evalTimed = 0, genTimed = 0, evalNoopTimed = 0, genNoopTimed = 0;
+    uint64_t updLaunches = 0;    // (generator, evaluation) pairs enqueued in the current update
 };
 
 struct cogaps_session {
@@ -147,7 +149,7 @@ struct cogaps_session {
     std::vector<float> chisqHist; std::vector<uint32_t> atomHistA, atomHistP;
     uint64_t totalUpdates = 0; double samplerSeconds = 0; double syncMs = 0;
     bool timing = false; bool evInit = false;
-    std::vector<rt_event_pair> evPool; std::vector<int> evKind; std::vector<HostSampler *> evOwner; size_t evUsed = 0;
+    std::vector<rt_event_pair> evPool; std::vector<int> evKind; std::vector<HostSampler *> evOwner; std::vector<uint64_t> evOrd; size_t evUsed = 0;
     GenScalars *hGs = nullptr;    // pinned staging
 };
 
@@ -265,16 +267,19 @@ static int timing_slot(cogaps_session *s, HostSampler &h, int kind, uint64_t ord
 {
     if (!s->timing || (ordinal % 8) != 0 || s->evUsed >= s->evPool.size()) return -1;
     const int i = (int)s->evUsed++;
-    s->evKind[i] = kind; s->evOwner[i] = &h;
+    s->evKind[i] = kind; s->evOwner[i] = &h; s->evOrd[i] = h.updLaunches;
     rt_event_start(s->evPool[i], s->stream);
     return i;
 }
-static void timing_resolve(cogaps_session *s)
+// `realBatches` = batches the current update has generated so far: pair number k processed a batch iff k < realBatches
+static void timing_resolve(cogaps_session *s, uint64_t realBatches)
 {
     for (size_t i = 0; i < s->evUsed; ++i) {
         const float ms = rt_event_ms(s->evPool[i]);
         HostSampler *h = s->evOwner[i];
-        if (s->evKind[i] == 0) { h->genMs += ms; h->genTimed++; } else { h->evalMs += ms; h->evalTimed++; }
+        const bool real = s->evOrd[i] < realBatches;
+        if (s->evKind[i] == 0) { if (real) { h->genMs += ms; h->genTimed++; } else { h->genNoopMs += ms; h->genNoopTimed++; } }
+        else { if (real) { h->evalMs += ms; h->evalTimed++; } else { h->evalNoopMs += ms; h->evalNoopTimed++; } }
     }
     s->evUsed = 0;
 }
@@ -326,14 +331,15 @@ static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool t
     rt_h2d(d.gs, s->hGs, sizeof(GenScalars), s->stream);
     rt_sync(s->stream);
     if (nSteps == 0) return 0;
+    h.updLaunches = 0;
     float avgq = g.avgQueue > 1.f ? g.avgQueue : 1.f;
     for (;;) {
         const uint32_t remaining = nSteps - s->hGs->nDone;
         uint32_t chunk = (uint32_t)((double)remaining / avgq * 1.1) + 4u;
         if (chunk > 4096u) chunk = 4096u;
-        for (uint32_t b = 0; b < chunk; ++b) { launch_gen(s, h); launch_eval(s, h); }
+        for (uint32_t b = 0; b < chunk; ++b) { launch_gen(s, h); launch_eval(s, h); h.updLaunches++; }
         read_gs(s, h);
-        timing_resolve(s);
+        timing_resolve(s, s->hGs->nBatches);
         if (s->hGs->error) return fail(std::string("device error code ") + std::to_string(s->hGs->error) + " in sampler " + h.name);
         if (s->hGs->updateFlushed) break;
         if (s->hGs->nBatches > 0) avgq = std::max(1.f, (float)s->hGs->nDone / (float)s->hGs->nBatches);
@@ -661,7 +667,7 @@ int cogaps_session_set_timing(cogaps_session *s, int on)
 {
     SESSION_TRY
     if (on && !s->evInit) {
-        s->evPool.resize(2048); s->evKind.resize(2048); s->evOwner.resize(2048);
+        s->evPool.resize(2048); s->evKind.resize(2048); s->evOwner.resize(2048); s->evOrd.resize(2048);
         for (auto &e : s->evPool) rt_event_create(e);
         s->evInit = true;
     }
@@ -677,8 +683,11 @@ int cogaps_session_perf(cogaps_session *s, cogaps_perf *out)
         out->evalBytes += s->hGs->evalBytes; out->proposalsQueued += s->hGs->evalProps;
         out->evalLaunches += h->evalLaunches; out->genLaunches += h->genLaunches; out->batches += h->batches;
         // sampled event timing (every 8th launch) scaled to all launches
-        if (h->evalTimed) out->evalMs += h->evalMs * (double)h->evalLaunches / (double)h->evalTimed;
-        if (h->genTimed) out->genMs += h->genMs * (double)h->genLaunches / (double)h->genTimed;
+        // sampled event timing (every 8th launch) scaled to the launches that processed a batch
+        if (h->evalTimed) out->evalMs += h->evalMs * (double)h->batches / (double)h->evalTimed;
+        if (h->genTimed) out->genMs += h->genMs * (double)h->batches / (double)h->genTimed;
+        out->evalNoopMs += h->evalNoopMs; out->evalNoopTimed += h->evalNoopTimed;
+        out->genNoopMs += h->genNoopMs; out->genNoopTimed += h->genNoopTimed;
     }
     out->syncMs = s->syncMs;
     SESSION_END

@@ -41,6 +41,13 @@
 #define GEN_F_WORDZERO 256u // ... and its whole level-0 bitmap word was empty (hints must be set)
 
 #define GEN_STAMP_COMMITTED 0xFFFFFFull
+#define GEN_TAB 4096                 // LDS conflict table entries (round 1 of a batch)
+#define GEN_K_ROW 0u
+#define GEN_K_ATOM 1u
+#define GEN_K_GAP 2u
+#define GEN_K_INL 3u
+#define FLUSH_MAX 64                 // erase caches up to this size are flushed in parallel
+#define CG_KEEP 0xFFFFFFFEu          // "front unchanged" marker
 
 template <int WIN>
 struct GenShared {
@@ -52,7 +59,12 @@ struct GenShared {
     uint16_t perm[WIN];                  // lane -> attempt after sorting attempts by type
     unsigned long long mq[WIN / 64], mb[WIN / 64], md[WIN / 64];   // committed attempts: queued / birth / death bit masks
     uint32_t wtotA[3][WIN / 64], wtotB[3][WIN / 64];
-    uint64_t fpos[WIN]; uint32_t fh[WIN], sorted[WIN];   // flush: erase cache positions / handles
+    // flush: erase cache sorted by position (handles, links, vector indices, bins), the tail of the unsorted
+    // vector and the net writes of the swap-with-last replay
+    uint64_t fpos[FLUSH_MAX]; uint32_t fh[FLUSH_MAX], fl[FLUSH_MAX], fr[FLUSH_MAX], fidx[FLUSH_MAX], fbin[FLUSH_MAX], vt[FLUSH_MAX], lowSlot[FLUSH_MAX], lowH[FLUSH_MAX];
+    uint32_t nLow, newFront, flushM, flushBase, unitSum;
+    uint32_t tkey[GEN_TAB], tval[GEN_TAB];   // conflict sets of round 1: key = kind<<30 | id, value = earliest attempt
+    GenScalars g;                        // the generator's scalars, LDS-resident for the launch
     uint64_t qrngRound, batchEpoch;
     uint32_t roundNo, stopKey;
     uint32_t nR, minAtoms, processed, qlen, skip, remaining, done, stopT, stopFail;
@@ -210,45 +222,6 @@ CG_DEVICE void gen_erase_one(const SamplerDev &S, uint32_t h, uint32_t &n, uint3
     S.freeHandles[freeCount++] = h;
 }
 
-// ---- flushEraseCache (ConcurrentAtomicDomain.cpp:71-79): sort by position, erase in that order --
-template <int WIN>
-CG_DEVICE void gen_flush(const SamplerDev &S, GenShared<WIN> &sh)
-{
-    const unsigned t = cg_tid();
-    GenScalars *gs = S.gs;
-    const uint32_t m = gs->eraseCount;
-    if (m == 0) return;           // uniform across the block
-    if (m <= (uint32_t)WIN) {
-        // rank sort in LDS: rank = number of entries with a smaller position (positions are unique)
-        if (t < m) { uint32_t h = S.eraseList[t]; sh.fh[t] = h; sh.fpos[t] = S.atoms[h].pos; }
-        cg_sync();
-        uint32_t myRank = 0, myH = 0;
-        if (t < m) {
-            const uint64_t p = sh.fpos[t]; myH = sh.fh[t];
-            for (uint32_t j = 0; j < m; ++j) myRank += (sh.fpos[j] < p) ? 1u : 0u;
-        }
-        cg_sync();
-        if (t < m) sh.sorted[myRank] = myH;
-        cg_sync();
-        if (t == 0) {
-            uint32_t n = gs->nAtoms, fc = gs->freeCount, fr = gs->front;
-            for (uint32_t i = 0; i < m; ++i) gen_erase_one(S, sh.sorted[i], n, fc, fr);
-            gs->nAtoms = n; gs->freeCount = fc; gs->front = fr; gs->eraseCount = 0;
-        }
-    } else if (t == 0) {
-        // rare: more erasures than lanes -- insertion sort in place
-        for (uint32_t i = 1; i < m; ++i) {
-            uint32_t h = S.eraseList[i]; uint64_t p = S.atoms[h].pos; uint32_t j = i;
-            while (j > 0 && S.atoms[S.eraseList[j - 1]].pos > p) { S.eraseList[j] = S.eraseList[j - 1]; --j; }
-            S.eraseList[j] = h;
-        }
-        uint32_t n = gs->nAtoms, fc = gs->freeCount, fr = gs->front;
-        for (uint32_t i = 0; i < m; ++i) gen_erase_one(S, S.eraseList[i], n, fc, fr);
-        gs->nAtoms = n; gs->freeCount = fc; gs->front = fr; gs->eraseCount = 0;
-    }
-    cg_sync();
-}
-
 // exclusive counts of flags a,b,c before this lane + block totals (wave ballots + one LDS hop, one
 // barrier; `w` must not be reused before the next barrier after the call)
 template <int WIN>
@@ -298,6 +271,33 @@ CG_DEVICE int gen_probe(unsigned long long v, uint64_t batchEpoch, uint32_t roun
     const uint32_t i = 4094u - (low & 0xFFFu);
     *idx = i;
     return i < t ? 2 : 0;
+}
+
+// LDS conflict table: open addressing, key = kind << 30 | id, value = smallest registering attempt ordinal
+template <int WIN>
+CG_DEVICE void gen_tab_insert(GenShared<WIN> &sh, uint32_t key, uint32_t idx)
+{
+    uint32_t s = (key * 2654435761u) >> 20;
+    for (;;) {
+        const uint32_t old = cg_atomic_cas_u32(&sh.tkey[s], 0xFFFFFFFFu, key);
+        if (old == 0xFFFFFFFFu || old == key) { cg_atomic_min_u32(&sh.tval[s], idx); return; }
+        s = (s + 1u) & (uint32_t)(GEN_TAB - 1);
+    }
+}
+template <int WIN>
+CG_DEVICE uint32_t gen_tab_lookup(const GenShared<WIN> &sh, uint32_t key)
+{
+    uint32_t s = (key * 2654435761u) >> 20;
+    for (;;) {
+        const uint32_t k = sh.tkey[s];
+        if (k == key) return sh.tval[s];
+        if (k == 0xFFFFFFFFu) return 0xFFFFFFFFu;
+        s = (s + 1u) & (uint32_t)(GEN_TAB - 1);
+    }
+}
+CG_DEVICE unsigned long long *gen_stamp_ptr(const SamplerDev &S, uint32_t kind, uint32_t id)
+{
+    return kind == GEN_K_ROW ? &S.rowStamp[id] : (kind == GEN_K_ATOM ? &S.atomStamp[id] : (kind == GEN_K_GAP ? &S.gapStamp[id] : &S.inlineStamp[id]));
 }
 
 // =================================================================================================

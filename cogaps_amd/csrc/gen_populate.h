@@ -6,6 +6,89 @@
 // conflict stamps compare.  Per-attempt prefix counts (queue slot, birth rank) come from LDS bit masks.
 #pragma once
 
+// ---- flushEraseCache (ConcurrentAtomicDomain.cpp:71-79 + erase :109-124) --------------------------------
+// The reference sorts the erase cache by position and erases one atom after the other.  Here: rank sort in
+// LDS; the list surgery and the bin-head index are done by one lane per erased atom (after the sort, an
+// erased neighbour of erased atom k can only be k-1 / k+1, so runs of adjacent erased atoms are walked in
+// LDS); the swap-with-last sequence on the unsorted vector -- order dependent -- is replayed by one lane on
+// indices held in LDS (no memory traffic), and only its net effect (<= m slots) is written back.
+template <int WIN>
+CG_DEVICE void gen_flush_parallel(const SamplerDev &S, GenShared<WIN> &sh, const uint32_t m, const uint32_t n, const uint32_t fc0, const uint32_t specH)
+{
+    const unsigned t = cg_tid();
+    GenScalars &g = sh.g;
+    if (t == 0) { sh.flushM = 0; sh.flushBase = fc0; }
+    if (m == 0) return;                      // uniform across the block
+    if (m > (uint32_t)FLUSH_MAX) {           // rare: serial fallback, exactly the reference's procedure
+        if (t == 0) {
+            for (uint32_t i = 1; i < m; ++i) {
+                uint32_t h = S.eraseList[i]; uint64_t p = S.atoms[h].pos; uint32_t j = i;
+                while (j > 0 && S.atoms[S.eraseList[j - 1]].pos > p) { S.eraseList[j] = S.eraseList[j - 1]; --j; }
+                S.eraseList[j] = h;
+            }
+            uint32_t nn = n, fc = g.freeCount, fr = g.front;
+            for (uint32_t i = 0; i < m; ++i) gen_erase_one(S, S.eraseList[i], nn, fc, fr);
+            g.nAtoms = nn; g.freeCount = fc; g.front = fr; g.eraseCount = 0;
+        }
+        cg_sync();
+        return;
+    }
+    // 1. fetch the erased atoms and the tail of the unsorted vector
+    uint32_t myH = 0; AtomRec rec; rec.pos = 0; rec.left = CG_NONE; rec.right = CG_NONE; rec.mass = 0.f; rec.idx = 0;
+    if (t < m) { myH = specH; rec = S.atoms[myH]; sh.fpos[t] = rec.pos; sh.vt[t] = S.vec[n - m + t]; }
+    cg_sync();
+    // 2. rank sort by position (positions are unique)
+    if (t < m) {
+        uint32_t r = 0;
+        for (uint32_t j = 0; j < m; ++j) r += (sh.fpos[j] < rec.pos) ? 1u : 0u;
+        sh.fh[r] = myH; sh.fl[r] = rec.left; sh.fr[r] = rec.right; sh.fidx[r] = rec.idx; sh.fbin[r] = gen_bin_of(S, rec.pos);
+    }
+    cg_sync();
+    // 3. list surgery + bin heads (reads the pre-flush links only)
+    if (t < m) {
+        const uint32_t k = t, h = sh.fh[k];
+        const bool leftErased = (k > 0) && (sh.fh[k - 1] == sh.fl[k]);
+        if (!leftErased) {                    // head of a run of adjacent erased atoms
+            uint32_t j = k;
+            while (j + 1 < m && sh.fh[j + 1] == sh.fr[j]) ++j;
+            const uint32_t L = sh.fl[k], R = sh.fr[j];
+            if (L != CG_NONE) S.atoms[L].right = R; else sh.newFront = R;
+            if (R != CG_NONE) S.atoms[R].left = L;
+        }
+        const uint32_t b = sh.fbin[k];
+        if (S.binHead[b] == h) {              // the lowest atom of its bin goes: the next surviving atom of the bin takes over
+            uint32_t j = k;
+            while (j + 1 < m && sh.fh[j + 1] == sh.fr[j]) ++j;
+            const uint32_t cand = sh.fr[j];
+            if (cand != CG_NONE && gen_bin_of(S, S.atoms[cand].pos) == b) S.binHead[b] = cand;
+            else { S.binHead[b] = CG_NONE; bm_clear(S, b); }
+        }
+        S.freeHandles[fc0 + k] = h;           // pushed in erase order
+    }
+    // 4. swap-with-last replay on indices (mAtoms[idx] = mAtoms.back(); pop_back), one lane, LDS only
+    if (t == 0) {
+        uint32_t curN = n, nl = 0;
+        const uint32_t base = n - m;
+        for (uint32_t k = 0; k < m; ++k) {
+            const uint32_t i = sh.fidx[k];
+            const uint32_t hl = sh.vt[curN - 1u - base];           // occupant of the last slot
+            if (i >= base) sh.vt[i - base] = hl;
+            else {
+                uint32_t e = 0; while (e < nl && sh.lowSlot[e] != i) ++e;
+                sh.lowSlot[e] = i; sh.lowH[e] = hl; if (e == nl) ++nl;
+            }
+            for (uint32_t q = k + 1; q < m; ++q) if (sh.fh[q] == hl) sh.fidx[q] = i;   // a later victim was moved
+            --curN;
+        }
+        sh.nLow = nl; sh.flushM = m;
+        g.nAtoms = n - m; g.freeCount += m; g.eraseCount = 0;
+    }
+    cg_sync();
+    if (t < sh.nLow) { const uint32_t slot = sh.lowSlot[t], h = sh.lowH[t]; S.vec[slot] = h; S.atoms[h].idx = slot; }
+    if (t == 0 && sh.newFront != CG_KEEP) { g.front = sh.newFront; }
+    cg_sync();
+}
+
 template <int WIN>
 CG_DEVICE void gen_body(const SamplerDev &S)
 {
@@ -17,32 +100,44 @@ CG_DEVICE void gen_body(const SamplerDev &S)
     // k-step PCG jumps for this lane's (u1,u2): k = 2t, or 2(t-1) when attempt 0 replays cached values
     const uint64_t jm0 = S.lcgMul[2u * t], ji0 = S.lcgInc[2u * t];
     const uint64_t jm1 = S.lcgMul[t ? 2u * (t - 1u) : 0u], ji1 = S.lcgInc[t ? 2u * (t - 1u) : 0u];
-    // generator scalars the flush does not touch: read them while the flush runs
-    uint64_t g_qrng = 0, g_epoch = 0; uint32_t g_nSteps = 0, g_nDone = 0, g_cached = 0; float g_u1 = 0.f, g_u2 = 0.f;
-    if (t == 0) { g_qrng = gs->qrng; g_epoch = gs->batchEpoch; g_nSteps = gs->nSteps; g_nDone = gs->nDone; g_cached = gs->useCached; g_u1 = gs->u1; g_u2 = gs->u2; }
-    {   // roofline bookkeeping: add up the traffic units the evaluation kernel left per queue slot
-        const uint32_t prevQ = gs->qlen;
-        uint32_t u = 0;
-        for (uint32_t q = t; q < prevQ; q += WIN) u += S.queueUnits[q];
-        if (u) cg_atomic_add_u64(&gs->evalBytes, (unsigned long long)u * 4ull * S.N);
-        if (t == 0 && prevQ) cg_atomic_add_u64(&gs->evalProps, (unsigned long long)prevQ);
+    // first memory trip of the launch, everything independent: the scalars every lane needs (same address
+    // for all lanes: one transaction), the erase cache and traffic-unit slots read speculatively, and lane
+    // 0's copy of the generator's scalars into LDS, where they live for the whole launch
+    const uint32_t e_m = gs->eraseCount, e_n = gs->nAtoms, e_fc = gs->freeCount, e_prevQ = gs->qlen, e_nDone = gs->nDone, e_nSteps = gs->nSteps;
+    const uint32_t specH = (t < (unsigned)FLUSH_MAX && t < S.eraseCap) ? S.eraseList[t] : 0u;
+    uint32_t units = (t < S.queueCap) ? S.queueUnits[t] : 0u;
+    if (t == 0) { sh.g = *gs; sh.newFront = CG_KEEP; sh.unitSum = 0; }
+    for (uint32_t i = t; i < (uint32_t)GEN_TAB; i += WIN) { sh.tkey[i] = 0xFFFFFFFFu; sh.tval[i] = 0xFFFFFFFFu; }
+    cg_sync();
+    GEN_PROF(14);
+    // second trip (addresses from the first), in flight while the flush runs: this round's seeds
+    const uint64_t seed1 = (e_nDone + t < e_nSteps) ? S.seeds[e_nDone + t] : 0ull;
+    {   // roofline bookkeeping: add up the traffic units the evaluation kernel left per queue slot (this
+        // workgroup is the only writer of evalBytes / evalProps: plain LDS accumulation, written back at the end)
+        if (t >= e_prevQ) units = 0;
+        for (uint32_t q = t + WIN; q < e_prevQ; q += WIN) units += S.queueUnits[q];
+        if (units) cg_atomic_add_u32(&sh.unitSum, units);
     }
-    gen_flush<WIN>(S, sh);
+    gen_flush_parallel<WIN>(S, sh, e_m, e_n, e_fc, specH);
     GEN_PROF(0);
 
     if (t == 0) {
-        sh.done = (g_nDone >= g_nSteps) ? 1u : 0u;
-        sh.batchEpoch = g_epoch + 1;
+        sh.done = (sh.g.nDone >= sh.g.nSteps) ? 1u : 0u;
+        sh.batchEpoch = sh.g.batchEpoch + 1;
         sh.roundNo = 0;
-        sh.qrngRound = g_qrng;
-        const uint32_t n = gs->nAtoms;
+        sh.qrngRound = sh.g.qrng;
+        const uint32_t n = sh.g.nAtoms;
         sh.nR = n; sh.minAtoms = n;
-        sh.processed = 0; sh.qlen = 0; sh.skip = g_cached ? 1u : 0u;
-        sh.remaining = g_nSteps - g_nDone;
-        sh.u1c = g_u1; sh.u2c = g_u2; sh.updBase = g_nDone;
+        sh.processed = 0; sh.qlen = 0; sh.skip = sh.g.useCached ? 1u : 0u;
+        sh.remaining = sh.g.nSteps - sh.g.nDone;
+        sh.u1c = sh.g.u1; sh.u2c = sh.g.u2; sh.updBase = sh.g.nDone;
     }
     cg_sync();
-    if (sh.done) { if (t == 0) { gs->qlen = 0; gs->batchNproc = 0; gs->updateFlushed = 1; } return; }
+    if (sh.done) {
+        if (t == 0) { gs->nAtoms = sh.g.nAtoms; gs->front = sh.g.front; gs->freeCount = sh.g.freeCount; gs->eraseCount = 0; gs->qlen = 0; gs->batchNproc = 0; gs->updateFlushed = 1;
+                      gs->evalBytes = sh.g.evalBytes + (unsigned long long)sh.unitSum * 4ull * S.N; gs->evalProps = sh.g.evalProps + e_prevQ; }
+        return;
+    }
 
     const uint64_t batchEpoch = sh.batchEpoch;
     const uint32_t updBase = sh.updBase;        // attempts consumed by earlier batches of this update
@@ -50,7 +145,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
 
     for (;;) {
         // ------------------------------------------------------------------ round set-up
-        if (t == 0) { sh.roundNo += 1; sh.stopKey = 0xFFFFFFFFu; if (sh.roundNo >= 4094u) gs->error = GAPS_ERR_SPIN; }
+        if (t == 0) { sh.roundNo += 1; sh.stopKey = 0xFFFFFFFFu; sh.newFront = CG_NONE; if (sh.roundNo >= 4094u) gs->error = GAPS_ERR_SPIN; }
         if (t < (unsigned)(WIN / 64)) { sh.mq[t] = 0ull; sh.mb[t] = 0ull; sh.md[t] = 0ull; }
         cg_sync();
         const uint32_t roundNo = sh.roundNo;
@@ -61,7 +156,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
         // ------------------------------------------------------------------ A1 (lane = attempt): (u1,u2), B/D/M/E
         {
             const bool active = t < winN;
-            if (active) sh.seed[t] = S.seeds[updBase + processed + t];     // consumed after the type sort
+            const uint64_t mySeed = !active ? 0ull : (processed == 0u ? seed1 : S.seeds[updBase + processed + t]);   // round 1: prefetched
             float u1 = 0.f, u2 = 0.f;
             uint32_t guess = GEN_T_NONE;
             if (active) {
@@ -92,6 +187,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
                 const uint32_t slot = k0 ? e0 : (k1 ? T0 + e1 : T0 + T1 + e2);
                 sh.perm[slot] = (uint16_t)t;
                 sh.info[t] = guess | (bBefore << 8);
+                sh.seed[t] = mySeed;                                     // consumed after the type sort
             }
             if (t == 0) sh.nWork = T0 + T1 + T2;
         }
@@ -150,7 +246,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
             const uint32_t b1 = gen_bin_of(S, cpos);
             r1 = b1 / K; c1 = b1 - r1 * K;
             if (type == 'M') { hl = a.left; hr = a.right; }
-            else if (type == 'E') { hr = a.right; h2 = (hr != CG_NONE) ? hr : gs->front; }
+            else if (type == 'E') { hr = a.right; h2 = (hr != CG_NONE) ? hr : sh.g.front; }
         }
         if (isB && !slowB) b3 = S.atoms[v2];
         if (pick && type == 'M') { if (hl != CG_NONE) lp = S.atoms[hl].pos; if (hr != CG_NONE) rp = S.atoms[hr].pos; }
@@ -199,73 +295,87 @@ CG_DEVICE void gen_body(const SamplerDev &S)
         GEN_PROF(2);
 
         // ------------------------------------------------------------------ B1: register rows / atoms / gaps
+        // Round 1 of a batch (95 % of all rounds) keeps the conflict sets in an LDS hash table; later rounds,
+        // which must also see what earlier rounds of the batch committed, use the stamp tables in HBM.
         const bool live = go && !(flags & GEN_F_FAIL);
         const bool queuedM = live && type == 'M' && !(flags & GEN_F_INLINE);
+        const bool ldsRound = roundNo == 1u;
         if (go) { sh.cpos[ct] = cpos; sh.pos[ct] = pos; sh.type[ct] = queuedM ? (uint8_t)'M' : (uint8_t)0; }
         if (live) {
-            const unsigned long long st = gen_stamp(batchEpoch, roundNo, ct);
-            if (type == 'B') { cg_atomic_max_u64(&S.rowStamp[r1], st); cg_atomic_max_u64(&S.gapStamp[hl == CG_NONE ? 0u : hl + 1u], st); }
-            else if (type == 'D') { cg_atomic_max_u64(&S.rowStamp[r1], st); cg_atomic_max_u64(&S.atomStamp[h1], st); }
+            // up to three keys: (kind, id)
+            uint32_t rk[3], rid[3]; int nk = 0;
+            const bool inl = (flags & GEN_F_INLINE) != 0;
+            if (type == 'B') { rk[0] = GEN_K_ROW; rid[0] = r1; rk[1] = GEN_K_GAP; rid[1] = (hl == CG_NONE) ? 0u : hl + 1u; nk = 2; }
+            else if (type == 'D') { rk[0] = GEN_K_ROW; rid[0] = r1; rk[1] = GEN_K_ATOM; rid[1] = h1; nk = 2; }
             else if (type == 'M') {
-                if (flags & GEN_F_INLINE) cg_atomic_max_u64(&S.inlineStamp[h1], st);
-                else { cg_atomic_max_u64(&S.rowStamp[r1], st); cg_atomic_max_u64(&S.rowStamp[r2], st); cg_atomic_max_u64(&S.atomStamp[h1], st); }
+                if (inl) { rk[0] = GEN_K_INL; rid[0] = h1; nk = 1; }
+                else { rk[0] = GEN_K_ROW; rid[0] = r1; rk[1] = GEN_K_ROW; rid[1] = r2; rk[2] = GEN_K_ATOM; rid[2] = h1; nk = 3; }
             } else {
-                if (flags & GEN_F_INLINE) { cg_atomic_max_u64(&S.inlineStamp[h1], st); cg_atomic_max_u64(&S.inlineStamp[h2], st); }
-                else { cg_atomic_max_u64(&S.rowStamp[r1], st); cg_atomic_max_u64(&S.rowStamp[r2], st); }
+                if (inl) { rk[0] = GEN_K_INL; rid[0] = h1; rk[1] = GEN_K_INL; rid[1] = h2; nk = 2; }
+                else { rk[0] = GEN_K_ROW; rid[0] = r1; rk[1] = GEN_K_ROW; rid[1] = r2; nk = 2; }
+            }
+            if (ldsRound) { for (int k = 0; k < nk; ++k) gen_tab_insert<WIN>(sh, (rk[k] << 30) | rid[k], ct); }
+            else {
+                const unsigned long long st = gen_stamp(batchEpoch, roundNo, ct);
+                for (int k = 0; k < nk; ++k) cg_atomic_max_u64(gen_stamp_ptr(S, rk[k], rid[k]), st);
             }
         }
         cg_sync();
         GEN_PROF(3);
 
-        // ------------------------------------------------------------------ B2: probe -- every lane issues the same
-        // eleven loads (unused slots read a harmless word), then the per-type logic runs on registers
+        // ------------------------------------------------------------------ B2: probe the sets (all probes of a lane
+        // are independent: issued together, then the per-type logic runs on registers)
         if (live) {
             const bool tB = type == 'B', tM = type == 'M', tE = type == 'E', inl = (flags & GEN_F_INLINE) != 0;
             const uint32_t keyL = (hl == CG_NONE) ? 0u : hl + 1u;
-            const unsigned long long *p1 = &S.rowStamp[(tM || tE) ? r2 : r1];
-            const unsigned long long *p2 = ((tM || tB) && hl != CG_NONE) ? &S.atomStamp[hl] : &S.gapStamp[0];
-            const unsigned long long *p3 = ((tM || tB) && hr != CG_NONE) ? &S.atomStamp[hr] : &S.gapStamp[0];
-            const unsigned long long *p4 = &S.gapStamp[(tB || tM) ? keyL : (tE ? h1 + 1u : 0u)];
-            const unsigned long long *p5 = &S.gapStamp[tM ? h1 + 1u : 0u];
-            const unsigned long long *p6 = tM ? &S.inlineStamp[h1] : ((tB && hl != CG_NONE) ? &S.inlineStamp[hl] : ((tE && inl) ? &S.inlineStamp[h1] : &S.gapStamp[0]));
-            const unsigned long long *p7 = (tM && hl != CG_NONE) ? &S.inlineStamp[hl] : ((tB && hr != CG_NONE) ? &S.inlineStamp[hr] : ((tE && inl) ? &S.inlineStamp[h2] : &S.gapStamp[0]));
-            const unsigned long long *p8 = (tM && hr != CG_NONE) ? &S.inlineStamp[hr] : &S.gapStamp[0];
-            const uint64_t *p9 = (tB && hl != CG_NONE) ? &S.atomDest[hl] : &S.atomDest[0];
-            const uint64_t *p10 = (tB && hr != CG_NONE) ? &S.atomDest[hr] : &S.atomDest[0];
-            const unsigned long long v0 = cg_load_l2_u64(&S.rowStamp[r1]);
-            const unsigned long long v1_ = cg_load_l2_u64(p1), v2_ = cg_load_l2_u64(p2), v3_ = cg_load_l2_u64(p3), v4_ = cg_load_l2_u64(p4);
-            const unsigned long long v5_ = cg_load_l2_u64(p5), v6_ = cg_load_l2_u64(p6), v7_ = cg_load_l2_u64(p7), v8_ = cg_load_l2_u64(p8);
-            const uint64_t d9 = *p9, d10 = *p10;
-            bool fail = false, haz = false; uint32_t ix = 0;
-            fail = gen_probe(v0, batchEpoch, roundNo, ct, &ix) != 0;                       // row r1 in use
-            if (tM || tE) { if (gen_probe(v1_, batchEpoch, roundNo, ct, &ix) != 0) fail = true; }   // row r2 in use
+            uint32_t pk[9], pid[9]; bool pu[9];
+            pk[0] = GEN_K_ROW; pid[0] = r1; pu[0] = true;
+            pk[1] = GEN_K_ROW; pid[1] = r2; pu[1] = tM || tE;
+            pk[2] = GEN_K_ATOM; pid[2] = hl; pu[2] = (tM || tB) && hl != CG_NONE;
+            pk[3] = GEN_K_ATOM; pid[3] = hr; pu[3] = (tM || tB) && hr != CG_NONE;
+            pk[4] = GEN_K_GAP; pid[4] = (tB || tM) ? keyL : h1 + 1u; pu[4] = tB || tM || tE;
+            pk[5] = GEN_K_GAP; pid[5] = tM ? h1 + 1u : 0u; pu[5] = tM || (tE && !(flags & GEN_F_HASRIGHT));
+            pk[6] = GEN_K_INL; pid[6] = tB ? hl : h1; pu[6] = tM || (tB && hl != CG_NONE) || (tE && inl);
+            pk[7] = GEN_K_INL; pid[7] = tM ? hl : (tB ? hr : h2); pu[7] = (tM && hl != CG_NONE) || (tB && hr != CG_NONE) || (tE && inl);
+            pk[8] = GEN_K_INL; pid[8] = hr; pu[8] = tM && hr != CG_NONE;
+            int res[9]; uint32_t rix[9]; uint64_t d9 = 0, d10 = 0;
+            if (ldsRound) {
+                for (int k = 0; k < 9; ++k) {
+                    rix[k] = 0; res[k] = 0;
+                    if (pu[k]) { const uint32_t v = gen_tab_lookup<WIN>(sh, (pk[k] << 30) | pid[k]); rix[k] = v; res[k] = (v < ct) ? 2 : 0; }
+                }
+            } else {
+                unsigned long long v[9];
+                for (int k = 0; k < 9; ++k) v[k] = cg_load_l2_u64(pu[k] ? gen_stamp_ptr(S, pk[k], pid[k]) : &S.gapStamp[0]);
+                d9 = (tB && hl != CG_NONE) ? S.atomDest[hl] : 0ull; d10 = (tB && hr != CG_NONE) ? S.atomDest[hr] : 0ull;
+                for (int k = 0; k < 9; ++k) { rix[k] = 0; res[k] = pu[k] ? gen_probe(v[k], batchEpoch, roundNo, ct, &rix[k]) : 0; }
+            }
+            bool fail = res[0] != 0, haz = false;                                        // row r1 in use
+            if (res[1] != 0) fail = true;                                                // row r2 in use
             if (tB) {
-                if (gen_probe(v4_, batchEpoch, roundNo, ct, &ix) == 2) haz = true;          // an earlier birth of this window in the same gap
-                const uint32_t nb[2] = {hl, hr}; const unsigned long long sa[2] = {v2_, v3_}, si[2] = {v6_, v7_}; const uint64_t dest[2] = {d9, d10};
+                if (res[4] == 2) haz = true;                                             // an earlier birth of this window in the same gap
+                const uint32_t nb[2] = {hl, hr}; const uint64_t dest[2] = {d9, d10};
                 for (int k = 0; k < 2; ++k) {
                     if (nb[k] == CG_NONE) continue;
                     // mProposedMoves.overlap(pos): the neighbour has a queued move whose interval covers pos
-                    const int u = gen_probe(sa[k], batchEpoch, roundNo, ct, &ix);
+                    const int u = res[2 + k]; const uint32_t ix = rix[2 + k];
                     uint64_t ma = 0, mb = 0; bool mv = false;
                     if (u == 1 && dest[k] != 0ull) { ma = S.atoms[nb[k]].pos; mb = dest[k]; mv = true; }
                     else if (u == 2 && sh.type[ix] == 'M') { ma = sh.cpos[ix]; mb = sh.pos[ix]; mv = true; }
                     if (mv) { const uint64_t lo = ma < mb ? ma : mb, hi = ma < mb ? mb : ma; if (lo < pos && pos < hi) fail = true; }
                     // an earlier same-bin move of this window shifted the neighbour this gap search compared against
-                    if (gen_probe(si[k], batchEpoch, roundNo, ct, &ix) == 2) haz = true;
+                    if (res[6 + k] == 2) haz = true;
                 }
             } else if (tM) {
-                if ((hl != CG_NONE && gen_probe(v2_, batchEpoch, roundNo, ct, &ix) != 0) || (hr != CG_NONE && gen_probe(v3_, batchEpoch, roundNo, ct, &ix) != 0)) fail = true;   // mUsedAtoms
+                if (res[2] != 0 || res[3] != 0) fail = true;                             // mUsedAtoms: a neighbour is in use
                 // a birth earlier in this window inside (left, right) is the true neighbour, and it is "used"
-                if (gen_probe(v4_, batchEpoch, roundNo, ct, &ix) == 2 || gen_probe(v5_, batchEpoch, roundNo, ct, &ix) == 2) fail = true;
+                if (res[4] == 2 || res[5] == 2) fail = true;
                 // an earlier same-bin move/exchange of this window touched the centre or a neighbour: positions stale
-                if (gen_probe(v6_, batchEpoch, roundNo, ct, &ix) == 2) haz = true;
-                if (hl != CG_NONE && gen_probe(v7_, batchEpoch, roundNo, ct, &ix) == 2) haz = true;
-                if (hr != CG_NONE && gen_probe(v8_, batchEpoch, roundNo, ct, &ix) == 2) haz = true;
+                if (res[6] == 2 || res[7] == 2 || res[8] == 2) haz = true;
             } else if (tE) {
                 // an earlier birth right of the centre is the true partner (or, for the last atom, a new front())
-                if (gen_probe(v4_, batchEpoch, roundNo, ct, &ix) == 2) fail = true;
-                if (!(flags & GEN_F_HASRIGHT) && gen_probe(v5_, batchEpoch, roundNo, ct, &ix) == 2) fail = true;
-                if (inl) { if (gen_probe(v6_, batchEpoch, roundNo, ct, &ix) == 2 || gen_probe(v7_, batchEpoch, roundNo, ct, &ix) == 2) haz = true; }
+                if (res[4] == 2 || res[5] == 2) fail = true;
+                if (inl && (res[6] == 2 || res[7] == 2)) haz = true;
             }
             if (haz) flags |= GEN_F_HAZARD; else if (fail) flags |= GEN_F_FAIL;
         }
@@ -295,32 +405,36 @@ CG_DEVICE void gen_body(const SamplerDev &S)
                 qBefore += (uint32_t)cg_popc64(sh.mq[wq] & lt); bRank += (uint32_t)cg_popc64(sh.mb[wq] & lt);
             }
             const unsigned long long done = (batchEpoch << 24) | GEN_STAMP_COMMITTED;
+            const bool more = !stopFail && (processed + stopT < sh.remaining);   // another round of this batch follows: it reads these
             if (type == 'B') {
                 // handle allocation: free stack first (deterministic by rank), then bump
-                const uint32_t fc = gs->freeCount;
-                uint32_t hb = (bRank < fc) ? S.freeHandles[fc - 1u - bRank] : gs->handleHi + (bRank - fc);
+                const uint32_t fc = sh.g.freeCount;
+                // the top of the stack is what this launch's flush pushed, still in LDS
+                uint32_t hb;
+                if (bRank < fc) { const uint32_t fi = fc - 1u - bRank; hb = (fi >= sh.flushBase && fi - sh.flushBase < sh.flushM) ? sh.fh[fi - sh.flushBase] : S.freeHandles[fi]; }
+                else hb = sh.g.handleHi + (bRank - fc);
                 const uint32_t idx = nR + bRank;
                 if (hb >= S.atomCap || idx >= S.atomCap) { gs->error = GAPS_ERR_ATOM_CAP; hb = 0; }
                 S.vec[idx] = hb;
                 AtomRec n; n.pos = pos; n.left = hl; n.right = hr; n.mass = 0.f; n.idx = idx; n.pad0 = 0; n.pad1 = 0;
                 S.atoms[hb] = n;
                 h1 = hb;
-                if (hl != CG_NONE) S.atoms[hl].right = hb; else gs->front = hb;
+                if (hl != CG_NONE) S.atoms[hl].right = hb; else sh.newFront = hb;
                 if (hr != CG_NONE) S.atoms[hr].left = hb;
                 if (flags & GEN_F_NEWHEAD) S.binHead[bin] = hb;
                 if (flags & GEN_F_BINEMPTY) {
                     cg_atomic_or_u64(&S.bits0[bin >> 6], 1ull << (bin & 63u));
                     if (flags & GEN_F_WORDZERO) { const uint32_t wa = bin >> 6, wb = wa >> 6, wc = wb >> 6; cg_atomic_or_u64(&S.bits1[wb], 1ull << (wa & 63u)); cg_atomic_or_u64(&S.bits2[wc], 1ull << (wb & 63u)); }
                 }
-                S.rowStamp[r1] = done; S.atomStamp[hb] = done; S.atomDest[hb] = 0ull;
+                if (more) { S.rowStamp[r1] = done; S.atomStamp[hb] = done; S.atomDest[hb] = 0ull; }
             } else if (type == 'D') {
-                S.rowStamp[r1] = done; S.atomStamp[h1] = done; S.atomDest[h1] = 0ull;
+                if (more) { S.rowStamp[r1] = done; S.atomStamp[h1] = done; S.atomDest[h1] = 0ull; }
             } else if (type == 'M') {
                 if (flags & GEN_F_INLINE) S.atoms[h1].pos = pos;                  // domain.move, same bin
-                else { S.rowStamp[r1] = done; S.rowStamp[r2] = done; S.atomStamp[h1] = done; S.atomDest[h1] = pos; }
+                else if (more) { S.rowStamp[r1] = done; S.rowStamp[r2] = done; S.atomStamp[h1] = done; S.atomDest[h1] = pos; }
             } else {
                 if (flags & GEN_F_INLINE) { if (flags & GEN_F_APPLY) { S.atoms[h1].mass = nm1; S.atoms[h2].mass = nm2; } }
-                else { S.rowStamp[r1] = done; S.rowStamp[r2] = done; }
+                else if (more) { S.rowStamp[r1] = done; S.rowStamp[r2] = done; }
             }
             if (queued) {
                 const uint32_t slot = sh.qlen + qBefore;
@@ -329,7 +443,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
                     PropRec p; p.pos = (type == 'M') ? pos : 0ull; p.rng = rng; p.h1 = h1; p.h2 = h2; p.i1 = i1; p.i2 = i2;
                     p.r1 = r1; p.c1 = c1; p.r2 = r2; p.c2 = c2; p.type = type; p.pad[0] = p.pad[1] = p.pad[2] = 0;
                     S.queue[slot] = p;
-                    if (gs->traceOn) { const uint32_t ti = gs->traceCount + slot; if (ti < gs->traceCap) { p.pad[0] = gs->nBatches; S.trace[ti] = p; } }
+                    if (sh.g.traceOn) { const uint32_t ti = sh.g.traceCount + slot; if (ti < sh.g.traceCap) { p.pad[0] = sh.g.nBatches; S.trace[ti] = p; } }
                 }
             }
         }
@@ -339,7 +453,8 @@ CG_DEVICE void gen_body(const SamplerDev &S)
         if (t == 0) {
             uint32_t totQ = 0, totB = 0, totD = 0;
             for (uint32_t w = 0; w < (uint32_t)(WIN / 64); ++w) { totQ += (uint32_t)cg_popc64(sh.mq[w]); totB += (uint32_t)cg_popc64(sh.mb[w]); totD += (uint32_t)cg_popc64(sh.md[w]); }
-            if (totB) { const uint32_t fc = gs->freeCount; if (totB <= fc) gs->freeCount = fc - totB; else { gs->freeCount = 0; gs->handleHi += totB - fc; } gs->nAtoms = nR + totB; }
+            if (totB) { const uint32_t fc = sh.g.freeCount; if (totB <= fc) sh.g.freeCount = fc - totB; else { sh.g.freeCount = 0; sh.g.handleHi += totB - fc; } sh.g.nAtoms = nR + totB; }
+            if (sh.newFront != CG_NONE) { sh.g.front = sh.newFront; sh.newFront = CG_NONE; }
             sh.nR = nR + totB; sh.minAtoms = minR - totD;
             sh.qlen += totQ; sh.processed = processed + stopT;
             const uint32_t attempted = stopT + (stopFail ? 1u : 0u);
@@ -357,26 +472,34 @@ CG_DEVICE void gen_body(const SamplerDev &S)
         const bool endBatch = sh.stopFail || (sh.processed >= sh.remaining);
         if (endBatch) {
             if (t == 0) {
-                gs->qrng = sh.qrngRound;
-                if (sh.stopFail) { gs->useCached = 1; gs->u1 = sh.u1[sh.stopT]; gs->u2 = sh.u2[sh.stopT]; }
-                else gs->useCached = 0;
+                GenScalars &g = sh.g;
+                g.qrng = sh.qrngRound;
+                if (sh.stopFail) { g.useCached = 1; g.u1 = sh.u1[sh.stopT]; g.u2 = sh.u2[sh.stopT]; }
+                else g.useCached = 0;
                 const uint32_t nDone = updBase + sh.processed;
-                gs->nDone = nDone;
-                gs->qlen = sh.qlen; gs->batchNproc = sh.processed;
-                gs->batchEpoch = batchEpoch;
-                if (nDone < sh.remaining + updBase) {           // n < nSteps: AsynchronousGibbsSampler.h:97-102
-                    const float ns = gs->nQueueSamples + 1.f;
-                    float avg = gs->avgQueue;
+                g.nDone = nDone;
+                g.qlen = sh.qlen; g.batchNproc = sh.processed;
+                g.batchEpoch = batchEpoch; g.eraseCount = 0;
+                if (nDone < g.nSteps) {           // n < nSteps: AsynchronousGibbsSampler.h:97-102
+                    const float ns = g.nQueueSamples + 1.f;
+                    float avg = g.avgQueue;
                     avg *= (ns - 1.f) / ns;
                     avg += (float)sh.qlen / ns;
-                    gs->nQueueSamples = ns; gs->avgQueue = avg;
+                    g.nQueueSamples = ns; g.avgQueue = avg;
                 }
-                if (gs->traceOn) {
-                    const uint32_t bi = gs->traceBatchCount;
-                    if (bi < gs->traceCap) { S.traceBatchNproc[bi] = sh.processed; S.traceBatchQlen[bi] = sh.qlen; }
-                    gs->traceBatchCount = bi + 1; gs->traceCount += sh.qlen;
+                if (g.traceOn) {
+                    const uint32_t bi = g.traceBatchCount;
+                    if (bi < g.traceCap) { S.traceBatchNproc[bi] = sh.processed; S.traceBatchQlen[bi] = sh.qlen; }
+                    g.traceBatchCount = bi + 1; g.traceCount += sh.qlen;
                 }
-                gs->nBatches += 1;
+                g.nBatches += 1;
+                // write back everything the generator owns (error / evalBytes / evalProps / prof are updated in place)
+                gs->qrng = g.qrng; gs->batchEpoch = g.batchEpoch; gs->nAtoms = g.nAtoms; gs->front = g.front;
+                gs->freeCount = g.freeCount; gs->handleHi = g.handleHi; gs->nDone = g.nDone; gs->qlen = g.qlen;
+                gs->batchNproc = g.batchNproc; gs->eraseCount = 0; gs->useCached = g.useCached; gs->u1 = g.u1; gs->u2 = g.u2;
+                gs->avgQueue = g.avgQueue; gs->nQueueSamples = g.nQueueSamples; gs->nBatches = g.nBatches;
+                gs->traceCount = g.traceCount; gs->traceBatchCount = g.traceBatchCount;
+                gs->evalBytes = g.evalBytes + (unsigned long long)sh.unitSum * 4ull * S.N; gs->evalProps = g.evalProps + e_prevQ;
             }
             return;
         }

@@ -22,3 +22,6 @@ for w in 'AP':
 for w in 'AP':
     pr = S.debug_prof(w)
     print(w, 'eval block0 marks (cycles total): queue-rec %d | scalars+sync %d | death: alpha+reduce %d | death: gibbs+log %d | rest(update etc) %d' % tuple(pr[8:13]))
+for w in 'AP':
+    pr = S.debug_prof(w)
+    print(w, 'prologue (entry loads + sync) cycles/round: %.0f' % (pr[14] / max(1, pr[15])))
