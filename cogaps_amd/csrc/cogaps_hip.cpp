@@ -663,6 +663,16 @@ int cogaps_session_debug_prof(cogaps_session *s, char which, uint64_t *out16)
     for (int i = 0; i < 16; ++i) out16[i] = s->hGs->prof[i];
     SESSION_END
 }
+#if defined(GEN_PROFILE)
+extern "C" int cogaps_debug_timeline(unsigned long long *out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * (size_t)n);
+}
+extern "C" int cogaps_debug_eval_timeline(unsigned long long *out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_eval_timeline), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
 int cogaps_session_set_timing(cogaps_session *s, int on)
 {
     SESSION_TRY

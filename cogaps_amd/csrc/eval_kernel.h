@@ -172,20 +172,37 @@ CG_DEVICE void eval_domain_move(const SamplerDev &S, uint32_t h, uint64_t oldPos
     bm_set(S, b2);
 }
 
-#if defined(GEN_PROFILE)
+#if defined(GEN_PROFILE) && !defined(GEN_SUBMARKS) && !defined(GEN_ROUNDMARKS)
 #define EVAL_PROF(i) do { if (t == 0 && cg_bid() == 0) { unsigned long long now_ = cg_clock(); cg_atomic_add_u64(&S.gs->prof[8 + (i)], now_ - eprof_last); eprof_last = now_; } } while (0)
 #else
 #define EVAL_PROF(i) do { } while (0)
 #endif
 
+#if defined(GEN_PROFILE) && !defined(COGAPS_EMUL)
+// dev: timestamps of the first 16 workgroups of a launch (lane 0 of the first and of the last wave)
+__device__ unsigned long long g_eval_timeline[16 * 2 * 12];
+#define EVAL_TS(id) do { if ((t & 63u) == 0u && ets_n < 11u) { ets[ets_n++] = ((unsigned long long)cg_clock() << 8) | (unsigned long long)(id); } } while (0)
+#define EVAL_TS_DUMP(ty) do { const uint32_t lastW_ = (cg_bdim() - 1u) >> 6; if (cg_bid() < 16u && (t & 63u) == 0u && ((t >> 6) == 0u || (t >> 6) == lastW_) && qlen >= 100u) { \
+    unsigned long long *o_ = &g_eval_timeline[(cg_bid() * 2u + ((t >> 6) ? 1u : 0u)) * 12u]; o_[0] = (unsigned long long)(ty); for (uint32_t i_ = 0; i_ < 11u; ++i_) o_[1 + i_] = i_ < ets_n ? ets[i_] : 0ull; } } while (0)
+#define EVAL_PIN(x) asm volatile("" : "+v"(x) :: "memory")
+#else
+#define EVAL_TS(id) do { } while (0)
+#define EVAL_TS_DUMP(ty) do { } while (0)
+#define EVAL_PIN(x) do { } while (0)
+#endif
+
 template <int UN>
 CG_DEVICE void eval_body(const SamplerDev &S)
 {
+#if defined(GEN_PROFILE) && !defined(COGAPS_EMUL)
+    unsigned long long ets[11]; uint32_t ets_n = 0;
+#endif
     CG_SHARED float lds[32];
     CG_SHARED float decf; CG_SHARED uint32_t deci;     // decision of wave 0, broadcast to the other waves
     const uint32_t t = cg_tid();
     unsigned long long eprof_last = cg_clock(); (void)eprof_last;
     const float T = S.annealTemp, lambda = S.lambda;
+    EVAL_TS(0);
     const bool multiWave = cg_bdim() > 64u;
     const bool scalarLane = !multiWave || t < 64u;       // the per-proposal scalar math (LUTs, fp64 log) runs in wave 0 only
 #define EVAL_BCAST(F0, I0) do { if (multiWave) { if (t == 0) { decf = (F0); deci = (I0); } cg_sync(); (F0) = decf; (I0) = deci; } } while (0)
@@ -194,6 +211,8 @@ CG_DEVICE void eval_body(const SamplerDev &S)
         const PropRec p = S.queue[q < S.queueCap ? q : 0u];
         const uint32_t qlen = S.gs->qlen;
         if (q >= qlen) break;
+        { uint32_t ty_ = p.type; EVAL_PIN(ty_); }
+        EVAL_TS(1);
         uint64_t rng = p.rng; uint32_t nUpd = 0;
         // the scalars this proposal depends on: issued now, consumed after the row loads are in flight.
         // lane 0 rewrites them at the end of the step; the barriers inside the reduction (or the explicit
@@ -207,6 +226,8 @@ CG_DEVICE void eval_body(const SamplerDev &S)
         const bool gibbs1 = S.otherColPos[p.c1] > 0u;
         const bool gibbs2 = two ? (S.otherColPos[p.c2] > 0u) : false;
         EVAL_PROF(0);
+        { float a_ = m1, b_ = m2, c_ = old1, d_ = old2; uint32_t g_ = (gibbs1 ? 1u : 0u) | (gibbs2 ? 2u : 0u); EVAL_PIN(a_); EVAL_PIN(b_); EVAL_PIN(c_); EVAL_PIN(d_); EVAL_PIN(g_); }
+        EVAL_TS(2);
 #if defined(GEN_PROFILE)
         if (S.dbg & 1u) { if (p.type == 0xFFu || m1 == -1.f) S.queueUnits[q] = (uint32_t)old1; break; }   // record + scalars only
 #endif
@@ -216,9 +237,12 @@ CG_DEVICE void eval_body(const SamplerDev &S)
             float bv = 0.f; uint32_t bhas = 0;
             if (gibbs1) {
                 EvalAcc a = eval_block_reduce(eval_partial_one<UN>(S, p.r1, p.c1, false, 0.f), lds);
+                EVAL_PIN(a.s); EVAL_TS(3);
                 if (scalarLane) { OptF g = gm_gibbs_mass(a.s * T, a.m * T, 0.f, S.maxGibbsMass, rng, S.luts, true, lambda); bv = g.v; bhas = g.has ? 1u : 0u; }
             } else if (scalarLane) { bv = pcg_exponential(rng, lambda); bhas = 1u; }
+            EVAL_PIN(bv); EVAL_TS(4);
             EVAL_BCAST(bv, bhas);
+            EVAL_TS(5);
             mass.v = bv; mass.has = bhas != 0u;
             if (mass.has && mass.v >= GAPS_EPSILON) {
                 eval_update_ap<UN>(S, p.r1, p.c1, mass.v); ++nUpd;                          // changeMatrix
@@ -230,6 +254,7 @@ CG_DEVICE void eval_body(const SamplerDev &S)
             EvalAcc a = eval_block_reduce(eval_partial_one<UN>(S, p.r1, p.c1, true, -1.f * m1), lds);
             const float s = a.s * T, smu = a.m * T;
             EVAL_PROF(1);
+            EVAL_PIN(a.s); EVAL_TS(3);
             uint32_t acc = 0;
             if (scalarLane) {
                 if (gibbs1) {
@@ -239,7 +264,9 @@ CG_DEVICE void eval_body(const SamplerDev &S)
                 const float deltaLL = rebirth * (smu - s * rebirth / 2.f);
                 acc = (gm_logf(pcg_uniform(rng)) < deltaLL) ? 1u : 0u;
             }
+            EVAL_PIN(acc); EVAL_TS(4);
             EVAL_BCAST(rebirth, acc);
+            EVAL_TS(5);
             const bool accept = acc != 0u;
             EVAL_PROF(2);
             if (accept) {
@@ -269,11 +296,14 @@ CG_DEVICE void eval_body(const SamplerDev &S)
                 }
                 s = s * T; smu = smu * T;
             } else if (multiWave) cg_sync();
+            EVAL_PIN(s); EVAL_TS(3);
             if (p.type == 'M') {
                 // ------------------------------------------------------------ move (:184-196)
                 uint32_t acc = 0; float unused = 0.f;
                 if (scalarLane) { const float deltaLL = -1.f * m1 * (smu + s * m1 / 2.f); acc = (gm_logf(pcg_uniform(rng)) < deltaLL) ? 1u : 0u; }
+                EVAL_PIN(acc); EVAL_TS(4);
                 EVAL_BCAST(unused, acc);
+                EVAL_TS(5);
                 if (acc) {
                     const float nv1 = gm_max(old1 + (-m1), 0.f);                    // safelyChangeMatrix(r1,c1,-m)
                     eval_update_ap<UN>(S, p.r1, p.c1, nv1 - old1); ++nUpd;
@@ -289,7 +319,9 @@ CG_DEVICE void eval_body(const SamplerDev &S)
                 OptF g; g.v = 0.f; g.has = false;
                 { float gv = 0.f; uint32_t gh = 0;
                   if (scalarLane) { OptF g0 = gm_gibbs_mass(s, smu, -m1, m2, rng, S.luts, false, 0.f); gv = g0.v; gh = g0.has ? 1u : 0u; }
+                  EVAL_PIN(gv); EVAL_TS(4);
                   EVAL_BCAST(gv, gh); g.v = gv; g.has = gh != 0u; }
+                EVAL_TS(5);
                 const float n1 = m1 + g.v, n2 = m2 - g.v;
                 if (g.has && n1 > GAPS_EPSILON && n2 > GAPS_EPSILON) {
                     const float nv1 = gm_max(old1 + (n1 - m1), 0.f);
@@ -304,6 +336,8 @@ CG_DEVICE void eval_body(const SamplerDev &S)
                 }
             }
         }
+        EVAL_TS(6);
+        EVAL_TS_DUMP(p.type | (nUpd << 8) | ((p.r1 == p.r2 ? 1u : 0u) << 16));
         if (t == 0) {   // roofline bookkeeping: algorithmic traffic of this proposal in units of 4N bytes
             // (alpha: 4 one-site, 5 two-site same row, 8 different rows; 3 per AP update); the generator sums the slots
             uint32_t units = nUpd * 3u;

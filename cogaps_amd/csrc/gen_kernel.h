@@ -24,9 +24,36 @@
 #include "gaps_state.h"
 
 #if defined(GEN_PROFILE)
-#define GEN_PROF(i) do { if (t == 0) { unsigned long long now_ = cg_clock(); cg_atomic_add_u64(&gs->prof[i], now_ - prof_last); prof_last = now_; } } while (0)
+#define GEN_PROF(i) do { if (t == 0) { unsigned long long now_ = cg_clock(); prof_acc[i] += now_ - prof_last; prof_last = now_; } } while (0)
+#define GEN_PROF_FLUSH() do { if (t == 0) { for (int i_ = 0; i_ < 16; ++i_) if (prof_acc[i_]) cg_atomic_add_u64(&gs->prof[i_], prof_acc[i_]); } } while (0)
 #else
 #define GEN_PROF(i) do { } while (0)
+#define GEN_PROF_FLUSH() do { } while (0)
+#endif
+#if defined(GEN_PROFILE) && !defined(COGAPS_EMUL)
+// per-wave timeline of one typical launch (lane 0 of every wave records (clock << 8 | id)); dev tool only
+__device__ unsigned long long g_timeline[(GEN_WIN / 64) * 64];
+#define GEN_TS(id) do { if ((t & 63u) == 0u && ts_n < 64u) { sh.ts[(t & ~63u) + ts_n] = ((unsigned long long)cg_clock() << 8) | (unsigned long long)(id); ++ts_n; } } while (0)
+#define GEN_TS_DUMP() do { if ((t & 63u) == 0u) sh.tsn[t >> 6] = ts_n; cg_sync(); if (sh.processed >= 100u && sh.roundNo == 1u) { for (uint32_t i_ = t; i_ < (uint32_t)(WIN / 64) * 64u; i_ += WIN) g_timeline[i_] = ((i_ & 63u) < sh.tsn[i_ >> 6]) ? sh.ts[i_] : 0ull; } } while (0)
+#define GEN_TS_INIT() uint32_t ts_n = 0
+#define GEN_PIN(x) asm volatile("" : "+v"(x) :: "memory")      // the value is computed before the next timestamp
+#else
+#define GEN_TS(id) do { } while (0)
+#define GEN_TS_INIT() do { } while (0)
+#define GEN_PIN(x) do { } while (0)
+#define GEN_TS_DUMP() do { } while (0)
+#endif
+#if defined(GEN_ROUNDMARKS)
+#define GEN_PROF_R(i, j) do { if (roundNo > 1u) { GEN_PROF(j); if (t == 0 && (j) == 8) prof_acc[14] += 1ull << 40; } else GEN_PROF(i); } while (0)
+#else
+#define GEN_PROF_R(i, j) GEN_PROF(i)
+#endif
+#if defined(GEN_SUBMARKS)
+#define GEN_SUB(i) GEN_PROF(i)
+#define GEN_SUBS(i) do { cg_sync(); GEN_PROF(i); } while (0)
+#else
+#define GEN_SUB(i) do { } while (0)
+#define GEN_SUBS(i) do { } while (0)
 #endif
 
 #define GEN_T_NONE 0
@@ -41,13 +68,16 @@
 #define GEN_F_WORDZERO 256u // ... and its whole level-0 bitmap word was empty (hints must be set)
 
 #define GEN_STAMP_COMMITTED 0xFFFFFFull
-#define GEN_TAB 4096                 // LDS conflict table entries (round 1 of a batch)
+#define GEN_TAB_BITS 11
+#define GEN_TAB (1 << GEN_TAB_BITS)   // LDS conflict table entries (round 1 of a batch): >= 2.6 x the keys a 256-attempt window can register
 #define GEN_K_ROW 0u
 #define GEN_K_ATOM 1u
 #define GEN_K_GAP 2u
 #define GEN_K_INL 3u
 #define FLUSH_MAX 64                 // erase caches up to this size are flushed in parallel
 #define CG_KEEP 0xFFFFFFFEu          // "front unchanged" marker
+
+struct GenTabEnt { uint32_t key, used, gap, inl; };
 
 template <int WIN>
 struct GenShared {
@@ -63,7 +93,12 @@ struct GenShared {
     // vector and the net writes of the swap-with-last replay
     uint64_t fpos[FLUSH_MAX]; uint32_t fh[FLUSH_MAX], fl[FLUSH_MAX], fr[FLUSH_MAX], fidx[FLUSH_MAX], fbin[FLUSH_MAX], vt[FLUSH_MAX], lowSlot[FLUSH_MAX], lowH[FLUSH_MAX];
     uint32_t nLow, newFront, flushM, flushBase, unitSum;
-    uint32_t tkey[GEN_TAB], tval[GEN_TAB];   // conflict sets of round 1: key = kind<<30 | id, value = earliest attempt
+#if defined(GEN_PROFILE)
+    unsigned long long ts[(WIN / 64) * 64]; uint32_t tsn[WIN / 64];
+#endif
+    alignas(16) GenTabEnt tab[GEN_TAB];      // conflict sets of round 1
+    float dpLo[WIN], dpHi[WIN];              // deathProb(minAtoms - k), deathProb(nAtoms + k) for this round
+    uint64_t jmul[WIN + 1], jinc[WIN + 1];   // PCG jump by 2k steps, k = 0 .. WIN
     GenScalars g;                        // the generator's scalars, LDS-resident for the launch
     uint64_t qrngRound, batchEpoch;
     uint32_t roundNo, stopKey;
@@ -242,13 +277,12 @@ CG_DEVICE void gen_count3(uint32_t (*w)[WIN / 64], unsigned t, bool a, bool b, b
 }
 
 // ProposalQueue::makeProposal type choice (ProposalQueue.cpp:129-160); 0 = indeterminate
-CG_DEVICE uint32_t gen_decide(const SamplerDev &S, float u1, float u2, uint64_t minAtoms, uint64_t maxAtoms)
+// lowerBound / upperBound = deathProb(minAtoms) / deathProb(maxAtoms), from the window's table
+CG_DEVICE uint32_t gen_decide(float u1, float u2, uint64_t minAtoms, uint64_t maxAtoms, float lowerBound, float upperBound)
 {
     if (minAtoms < 2 && maxAtoms >= 2) return GEN_T_NONE;
     if (maxAtoms < 2) return 'B';
     if (u1 < 0.5f) {
-        float lowerBound = gm_death_prob((double)minAtoms, S.domainLenD, S.alphaD, S.numBins);
-        float upperBound = gm_death_prob((double)maxAtoms, S.domainLenD, S.alphaD, S.numBins);
         if (u2 < lowerBound) return 'D';
         if (u2 >= upperBound) return 'B';
         return GEN_T_NONE;
@@ -273,27 +307,32 @@ CG_DEVICE int gen_probe(unsigned long long v, uint64_t batchEpoch, uint32_t roun
     return i < t ? 2 : 0;
 }
 
-// LDS conflict table: open addressing, key = kind << 30 | id, value = smallest registering attempt ordinal
+// LDS conflict table of round 1 of a batch: open addressing, one 16-byte entry per key.  Keys are matrix rows
+// (bit 31 set) and atom handles; the three value words hold the smallest attempt ordinal that registered
+//   used: the row / the atom as in use (mUsedMatrixIndices / mUsedAtoms)
+//   gap : a birth landing right of the atom (before the front atom: pseudo-handle GEN_TAB_FRONT)
+//   inl : a same-bin move / exchange touching the atom
+// An empty entry is all ones, so a lookup that ends on it reads "nobody".
+#define GEN_TAB_ROW 0x80000000u
+#define GEN_TAB_FRONT 0x7FFFFFFFu     // pseudo-handle: its gap word = a birth landing before the front atom
+CG_DEVICE uint32_t gen_tab_hash(uint32_t key) { return (key * 2654435761u) >> (32 - GEN_TAB_BITS); }
 template <int WIN>
-CG_DEVICE void gen_tab_insert(GenShared<WIN> &sh, uint32_t key, uint32_t idx)
+CG_DEVICE uint32_t gen_tab_claim(GenShared<WIN> &sh, uint32_t key)
 {
-    uint32_t s = (key * 2654435761u) >> 20;
+    uint32_t s = (key * 2654435761u) >> (32 - GEN_TAB_BITS);
     for (;;) {
-        const uint32_t old = cg_atomic_cas_u32(&sh.tkey[s], 0xFFFFFFFFu, key);
-        if (old == 0xFFFFFFFFu || old == key) { cg_atomic_min_u32(&sh.tval[s], idx); return; }
+        const uint32_t old = cg_atomic_cas_u32(&sh.tab[s].key, 0xFFFFFFFFu, key);
+        if (old == 0xFFFFFFFFu || old == key) return s;
         s = (s + 1u) & (uint32_t)(GEN_TAB - 1);
     }
 }
 template <int WIN>
-CG_DEVICE uint32_t gen_tab_lookup(const GenShared<WIN> &sh, uint32_t key)
+CG_DEVICE GenTabEnt gen_tab_find(const GenShared<WIN> &sh, uint32_t key)
 {
-    uint32_t s = (key * 2654435761u) >> 20;
-    for (;;) {
-        const uint32_t k = sh.tkey[s];
-        if (k == key) return sh.tval[s];
-        if (k == 0xFFFFFFFFu) return 0xFFFFFFFFu;
-        s = (s + 1u) & (uint32_t)(GEN_TAB - 1);
-    }
+    uint32_t s = (key * 2654435761u) >> (32 - GEN_TAB_BITS);
+    GenTabEnt e = sh.tab[s];
+    while (e.key != key && e.key != 0xFFFFFFFFu) { s = (s + 1u) & (uint32_t)(GEN_TAB - 1); e = sh.tab[s]; }
+    return e;
 }
 CG_DEVICE unsigned long long *gen_stamp_ptr(const SamplerDev &S, uint32_t kind, uint32_t id)
 {

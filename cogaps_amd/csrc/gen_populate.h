@@ -96,7 +96,8 @@ CG_DEVICE void gen_body(const SamplerDev &S)
     const unsigned t = cg_tid();
     GenScalars *gs = S.gs;
 
-    unsigned long long prof_last = cg_clock(); (void)prof_last;
+    unsigned long long prof_last = cg_clock(), prof_acc[16] = {0}; (void)prof_last; (void)prof_acc;
+    GEN_TS_INIT(); GEN_TS(0); GEN_TS(0);
     // k-step PCG jumps for this lane's (u1,u2): k = 2t, or 2(t-1) when attempt 0 replays cached values
     const uint64_t jm0 = S.lcgMul[2u * t], ji0 = S.lcgInc[2u * t];
     const uint64_t jm1 = S.lcgMul[t ? 2u * (t - 1u) : 0u], ji1 = S.lcgInc[t ? 2u * (t - 1u) : 0u];
@@ -107,9 +108,12 @@ CG_DEVICE void gen_body(const SamplerDev &S)
     const uint32_t specH = (t < (unsigned)FLUSH_MAX && t < S.eraseCap) ? S.eraseList[t] : 0u;
     uint32_t units = (t < S.queueCap) ? S.queueUnits[t] : 0u;
     if (t == 0) { sh.g = *gs; sh.newFront = CG_KEEP; sh.unitSum = 0; }
-    for (uint32_t i = t; i < (uint32_t)GEN_TAB; i += WIN) { sh.tkey[i] = 0xFFFFFFFFu; sh.tval[i] = 0xFFFFFFFFu; }
+    { GenTabEnt none; none.key = none.used = none.gap = none.inl = 0xFFFFFFFFu; for (uint32_t i = t; i < (uint32_t)GEN_TAB; i += WIN) sh.tab[i] = none; }
+    if (t == 0) { sh.jmul[WIN] = S.lcgMul[2 * WIN]; sh.jinc[WIN] = S.lcgInc[2 * WIN]; }
+    sh.jmul[t] = jm0; sh.jinc[t] = ji0;        // even-step PCG jumps, for the round bookkeeping
     cg_sync();
     GEN_PROF(14);
+    GEN_TS(1);
     // second trip (addresses from the first), in flight while the flush runs: this round's seeds
     const uint64_t seed1 = (e_nDone + t < e_nSteps) ? S.seeds[e_nDone + t] : 0ull;
     {   // roofline bookkeeping: add up the traffic units the evaluation kernel left per queue slot (this
@@ -120,6 +124,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
     }
     gen_flush_parallel<WIN>(S, sh, e_m, e_n, e_fc, specH);
     GEN_PROF(0);
+    GEN_TS(2);
 
     if (t == 0) {
         sh.done = (sh.g.nDone >= sh.g.nSteps) ? 1u : 0u;
@@ -136,6 +141,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
     if (sh.done) {
         if (t == 0) { gs->nAtoms = sh.g.nAtoms; gs->front = sh.g.front; gs->freeCount = sh.g.freeCount; gs->eraseCount = 0; gs->qlen = 0; gs->batchNproc = 0; gs->updateFlushed = 1;
                       gs->evalBytes = sh.g.evalBytes + (unsigned long long)sh.unitSum * 4ull * S.N; gs->evalProps = sh.g.evalProps + e_prevQ; }
+        GEN_PROF_FLUSH();
         return;
     }
 
@@ -147,7 +153,15 @@ CG_DEVICE void gen_body(const SamplerDev &S)
         // ------------------------------------------------------------------ round set-up
         if (t == 0) { sh.roundNo += 1; sh.stopKey = 0xFFFFFFFFu; sh.newFront = CG_NONE; if (sh.roundNo >= 4094u) gs->error = GAPS_ERR_SPIN; }
         if (t < (unsigned)(WIN / 64)) { sh.mq[t] = 0ull; sh.mb[t] = 0ull; sh.md[t] = 0ull; }
+        {   // death probability (ProposalQueue::deathProb) for every atom count an attempt of this window can
+            // see: lane t fills the entries for t births / t deaths ahead of it (sh.nR / sh.minAtoms were
+            // published before the previous barrier)
+            const uint32_t n0 = sh.nR, m0 = sh.minAtoms;
+            sh.dpHi[t] = gm_death_prob((double)((uint64_t)n0 + t), S.domainLenD, S.alphaD, S.numBins);
+            sh.dpLo[t] = (m0 >= t) ? gm_death_prob((double)(uint64_t)(m0 - t), S.domainLenD, S.alphaD, S.numBins) : 0.f;
+        }
         cg_sync();
+        GEN_TS(4);
         const uint32_t roundNo = sh.roundNo;
         const uint32_t nR = sh.nR, minR = sh.minAtoms, skip = sh.skip, processed = sh.processed;
         const uint32_t left_ = sh.remaining - processed;
@@ -165,19 +179,24 @@ CG_DEVICE void gen_body(const SamplerDev &S)
                     uint64_t s = (skip ? jm1 : jm0) * sh.qrngRound + (skip ? ji1 : ji0);
                     u1 = pcg_uniform(s); u2 = pcg_uniform(s);
                 }
-                guess = gen_decide(S, u1, u2, minR, nR);
+                guess = gen_decide(u1, u2, minR, nR, sh.dpLo[0], sh.dpHi[0]);
             }
+            GEN_PIN(guess); GEN_PIN(u1); GEN_PIN(u2);
+            GEN_TS(5);
             sh.u1[t] = u1; sh.u2[t] = u2;
             uint32_t bBefore, dBefore, e3, tB, tD, t3;
             gen_count3<WIN>(sh.wtotA, t, active && guess == 'B', active && guess == 'D', false, bBefore, dBefore, e3, tB, tD, t3);
+            GEN_TS(6);
             uint32_t aflags = 0;
             if (active && (bBefore | dBefore)) {
                 // the exact B/D/indeterminate decision depends on how many births / deaths precede this attempt
-                const uint32_t exact = (u1 < 0.5f || minR < 2u + dBefore || nR + bBefore < 2u) ? gen_decide(S, u1, u2, (uint64_t)minR - dBefore, (uint64_t)nR + bBefore) : guess;
+                const uint32_t exact = (u1 < 0.5f || minR < 2u + dBefore || nR + bBefore < 2u) ? gen_decide(u1, u2, (uint64_t)minR - dBefore, (uint64_t)nR + bBefore, sh.dpLo[dBefore], sh.dpHi[bBefore]) : guess;
                 if (exact != guess) aflags |= GEN_F_HAZARD;
             }
             if (active && !(aflags & GEN_F_HAZARD) && guess == GEN_T_NONE) aflags |= GEN_F_FAIL;   // indeterminate: batch ends, no seed used
             if (active && aflags) cg_atomic_min_u32(&sh.stopKey, 2u * t + ((aflags & GEN_F_HAZARD) ? 0u : 1u));
+            GEN_PIN(aflags);
+            GEN_TS(7);
             // sort the attempts that go on by code path: births+deaths | moves | exchanges
             const bool go = active && !aflags;
             const bool k0 = go && (guess == 'B' || guess == 'D'), k1 = go && guess == 'M', k2 = go && guess == 'E';
@@ -189,10 +208,12 @@ CG_DEVICE void gen_body(const SamplerDev &S)
                 sh.info[t] = guess | (bBefore << 8);
                 sh.seed[t] = mySeed;                                     // consumed after the type sort
             }
+            GEN_TS(8);
             if (t == 0) sh.nWork = T0 + T1 + T2;
         }
         cg_sync();
-        GEN_PROF(1);
+        GEN_PROF_R(1, 8);
+        GEN_TS(9);
 
         // ------------------------------------------------------------------ A2 (lane = sorted slot): populate-phase draws
         const bool go = t < sh.nWork;
@@ -221,9 +242,18 @@ CG_DEVICE void gen_body(const SamplerDev &S)
             i1 = pcg_uniform32(rng, 0u, nT - 1u);
             if (i1 >= nR) { flags |= GEN_F_FAIL; pick = false; }   // an atom born earlier in this window: its row is in use
         }
+        GEN_PIN(i1); GEN_PIN(bin); GEN_PIN(pos);
+        GEN_TS(10);
+        GEN_SUBS(9);
         uint32_t v1 = CG_NONE;
         if (isB) w0 = S.bits0[bin >> 6];
         if (pick) v1 = S.vec[i1];
+#if defined(GEN_SUBMARKS)
+        if (v1 == 12345678u || w0 == 0x123456789ull) flags |= 0x80000000u;
+#endif
+        GEN_PIN(v1); GEN_PIN(w0);
+        GEN_TS(11);
+        GEN_SUBS(10);
         // stage 2 ---------------------------------------------------------------------------------
         bool slowB = false;
         if (isB) {
@@ -238,6 +268,12 @@ CG_DEVICE void gen_body(const SamplerDev &S)
         uint32_t v2 = CG_NONE; AtomRec a; a.pos = 0; a.left = CG_NONE; a.right = CG_NONE; a.mass = 0.f; a.idx = 0;
         if (isB && !slowB) v2 = S.binHead[headBin];
         if (pick) { h1 = v1; a = S.atoms[h1]; }
+#if defined(GEN_SUBMARKS)
+        if (v2 == 12345678u || a.pos == 0x123456789ull) flags |= 0x80000000u;
+#endif
+        GEN_PIN(v2); GEN_PIN(a.pos); GEN_PIN(a.left);
+        GEN_TS(12);
+        GEN_SUBS(11);
         // stage 3 ---------------------------------------------------------------------------------
         AtomRec b3; b3.pos = 0; b3.left = CG_NONE; b3.right = CG_NONE; b3.mass = 0.f; b3.idx = 0;
         uint64_t lp = 0, rp = 0;
@@ -251,6 +287,12 @@ CG_DEVICE void gen_body(const SamplerDev &S)
         if (isB && !slowB) b3 = S.atoms[v2];
         if (pick && type == 'M') { if (hl != CG_NONE) lp = S.atoms[hl].pos; if (hr != CG_NONE) rp = S.atoms[hr].pos; }
         if (pick && type == 'E') b3 = S.atoms[h2];
+#if defined(GEN_SUBMARKS)
+        if (b3.pos == 12345678u || lp == 0x123456789ull || rp == 0x123456789ull) flags |= 0x80000000u;
+#endif
+        GEN_PIN(b3.pos); GEN_PIN(lp); GEN_PIN(rp);
+        GEN_TS(13);
+        GEN_SUBS(12);
         // finish ----------------------------------------------------------------------------------
         if (isB) {
             if (!slowB) {
@@ -292,7 +334,9 @@ CG_DEVICE void gen_body(const SamplerDev &S)
                 }
             }
         }
-        GEN_PROF(2);
+        GEN_PIN(pos); GEN_PIN(flags); GEN_PIN(r2); GEN_PIN(c2); GEN_PIN(rbpos); GEN_PIN(nm1);
+        GEN_TS(14);
+        GEN_PROF_R(2, 9);
 
         // ------------------------------------------------------------------ B1: register rows / atoms / gaps
         // Round 1 of a batch (95 % of all rounds) keeps the conflict sets in an LDS hash table; later rounds,
@@ -301,7 +345,26 @@ CG_DEVICE void gen_body(const SamplerDev &S)
         const bool queuedM = live && type == 'M' && !(flags & GEN_F_INLINE);
         const bool ldsRound = roundNo == 1u;
         if (go) { sh.cpos[ct] = cpos; sh.pos[ct] = pos; sh.type[ct] = queuedM ? (uint8_t)'M' : (uint8_t)0; }
-        if (live) {
+        if (live && ldsRound) {
+            // up to three (key, field) registrations, straight-line: an unused slot repeats the first one
+            const bool inl = (flags & GEN_F_INLINE) != 0, tB = type == 'B', tD = type == 'D', tM = type == 'M';
+            const uint32_t k0 = inl ? h1 : (GEN_TAB_ROW | r1), f0 = inl ? 3u : 1u;
+            const bool use1 = !(inl && tM), use2 = tM && !inl;
+            const uint32_t k1 = !use1 ? k0 : (inl ? h2 : (tB ? (hl == CG_NONE ? GEN_TAB_FRONT : hl) : (tD ? h1 : (GEN_TAB_ROW | r2))));
+            const uint32_t f1 = !use1 ? f0 : (inl ? 3u : (tB ? 2u : 1u));
+            const uint32_t k2 = use2 ? h1 : k0, f2 = use2 ? 1u : f0;
+            uint32_t s0 = gen_tab_hash(k0), s1 = gen_tab_hash(k1), s2 = gen_tab_hash(k2);
+            const uint32_t o0 = cg_atomic_cas_u32(&sh.tab[s0].key, 0xFFFFFFFFu, k0);
+            const uint32_t o1 = cg_atomic_cas_u32(&sh.tab[s1].key, 0xFFFFFFFFu, k1);
+            const uint32_t o2 = cg_atomic_cas_u32(&sh.tab[s2].key, 0xFFFFFFFFu, k2);
+            if ((o0 != 0xFFFFFFFFu && o0 != k0) || (o1 != 0xFFFFFFFFu && o1 != k1) || (o2 != 0xFFFFFFFFu && o2 != k2)) {   // rare: a probe sequence
+                s0 = gen_tab_claim<WIN>(sh, k0); s1 = gen_tab_claim<WIN>(sh, k1); s2 = gen_tab_claim<WIN>(sh, k2);
+            }
+            uint32_t *words = &sh.tab[0].key;
+            cg_atomic_min_u32(&words[4u * s0 + f0], ct);
+            cg_atomic_min_u32(&words[4u * s1 + f1], ct);
+            cg_atomic_min_u32(&words[4u * s2 + f2], ct);
+        } else if (live) {
             // up to three keys: (kind, id)
             uint32_t rk[3], rid[3]; int nk = 0;
             const bool inl = (flags & GEN_F_INLINE) != 0;
@@ -314,18 +377,59 @@ CG_DEVICE void gen_body(const SamplerDev &S)
                 if (inl) { rk[0] = GEN_K_INL; rid[0] = h1; rk[1] = GEN_K_INL; rid[1] = h2; nk = 2; }
                 else { rk[0] = GEN_K_ROW; rid[0] = r1; rk[1] = GEN_K_ROW; rid[1] = r2; nk = 2; }
             }
-            if (ldsRound) { for (int k = 0; k < nk; ++k) gen_tab_insert<WIN>(sh, (rk[k] << 30) | rid[k], ct); }
-            else {
-                const unsigned long long st = gen_stamp(batchEpoch, roundNo, ct);
-                for (int k = 0; k < nk; ++k) cg_atomic_max_u64(gen_stamp_ptr(S, rk[k], rid[k]), st);
-            }
+            const unsigned long long st = gen_stamp(batchEpoch, roundNo, ct);
+            for (int k = 0; k < nk; ++k) cg_atomic_max_u64(gen_stamp_ptr(S, rk[k], rid[k]), st);
         }
+        GEN_TS(15);
         cg_sync();
-        GEN_PROF(3);
+        GEN_PROF_R(3, 10);
+        GEN_TS(16);
 
         // ------------------------------------------------------------------ B2: probe the sets (all probes of a lane
         // are independent: issued together, then the per-type logic runs on registers)
-        if (live) {
+        if (live && ldsRound) {
+            // six table reads, all issued before any is used; an entry that is not this lane's key reads "nobody"
+            const bool tB = type == 'B', tM = type == 'M', tE = type == 'E', inl = (flags & GEN_F_INLINE) != 0;
+            uint32_t key[6]; bool use[6];
+            key[0] = GEN_TAB_ROW | r1; use[0] = true;
+            key[1] = GEN_TAB_ROW | r2; use[1] = tM || tE;
+            key[2] = ((tM || tB) && hl != CG_NONE) ? hl : GEN_TAB_FRONT; use[2] = tM || tB || (tE && !(flags & GEN_F_HASRIGHT));
+            key[3] = hr; use[3] = (tM || tB) && hr != CG_NONE;
+            key[4] = h1; use[4] = tM || tE;
+            key[5] = h2; use[5] = tE && inl;
+            GenTabEnt e[6];
+            for (int k = 0; k < 6; ++k) e[k] = sh.tab[gen_tab_hash(key[k])];
+            bool coll = false;
+            for (int k = 0; k < 6; ++k) coll = coll || (use[k] && e[k].key != key[k] && e[k].key != 0xFFFFFFFFu);
+            if (coll) { for (int k = 0; k < 6; ++k) if (use[k]) e[k] = gen_tab_find<WIN>(sh, key[k]); }          // rare: a probe sequence
+            for (int k = 0; k < 6; ++k) if (!use[k] || e[k].key != key[k]) { e[k].used = 0xFFFFFFFFu; e[k].gap = 0xFFFFFFFFu; e[k].inl = 0xFFFFFFFFu; }
+            #define GEN_EARLIER(v) ((v) < ct)
+            bool fail = GEN_EARLIER(e[0].used) || GEN_EARLIER(e[1].used);                 // a row in use
+            bool haz = false;
+            if (tB) {
+                haz = GEN_EARLIER(e[2].gap) || GEN_EARLIER(e[2].inl) || GEN_EARLIER(e[3].inl);
+                // mProposedMoves.overlap(pos): a neighbour has a queued move whose interval covers pos
+                for (int k = 2; k < 4; ++k) {
+                    const uint32_t ix = e[k].used;
+                    if (GEN_EARLIER(ix) && sh.type[ix] == 'M') {
+                        const uint64_t ma = sh.cpos[ix], mb = sh.pos[ix], lo = ma < mb ? ma : mb, hi = ma < mb ? mb : ma;
+                        if (lo < pos && pos < hi) fail = true;
+                    }
+                }
+            } else if (tM) {
+                // a neighbour in use (mUsedAtoms), or a birth earlier in this window inside (left, right)
+                fail = fail || GEN_EARLIER(e[2].used) || GEN_EARLIER(e[3].used) || GEN_EARLIER(e[2].gap) || GEN_EARLIER(e[4].gap);
+                haz = GEN_EARLIER(e[4].inl) || GEN_EARLIER(e[2].inl) || GEN_EARLIER(e[3].inl);
+            } else if (tE) {
+                // an earlier birth right of the centre is the true partner (or, for the last atom, a new front())
+                fail = fail || GEN_EARLIER(e[4].gap) || GEN_EARLIER(e[2].gap);
+                haz = inl && (GEN_EARLIER(e[4].inl) || GEN_EARLIER(e[5].inl));
+            }
+            #undef GEN_EARLIER
+            GEN_PIN(flags);
+            GEN_TS(17);
+            if (haz) flags |= GEN_F_HAZARD; else if (fail) flags |= GEN_F_FAIL;
+        } else if (live) {
             const bool tB = type == 'B', tM = type == 'M', tE = type == 'E', inl = (flags & GEN_F_INLINE) != 0;
             const uint32_t keyL = (hl == CG_NONE) ? 0u : hl + 1u;
             uint32_t pk[9], pid[9]; bool pu[9];
@@ -339,17 +443,13 @@ CG_DEVICE void gen_body(const SamplerDev &S)
             pk[7] = GEN_K_INL; pid[7] = tM ? hl : (tB ? hr : h2); pu[7] = (tM && hl != CG_NONE) || (tB && hr != CG_NONE) || (tE && inl);
             pk[8] = GEN_K_INL; pid[8] = hr; pu[8] = tM && hr != CG_NONE;
             int res[9]; uint32_t rix[9]; uint64_t d9 = 0, d10 = 0;
-            if (ldsRound) {
-                for (int k = 0; k < 9; ++k) {
-                    rix[k] = 0; res[k] = 0;
-                    if (pu[k]) { const uint32_t v = gen_tab_lookup<WIN>(sh, (pk[k] << 30) | pid[k]); rix[k] = v; res[k] = (v < ct) ? 2 : 0; }
-                }
-            } else {
+            {
                 unsigned long long v[9];
                 for (int k = 0; k < 9; ++k) v[k] = cg_load_l2_u64(pu[k] ? gen_stamp_ptr(S, pk[k], pid[k]) : &S.gapStamp[0]);
                 d9 = (tB && hl != CG_NONE) ? S.atomDest[hl] : 0ull; d10 = (tB && hr != CG_NONE) ? S.atomDest[hr] : 0ull;
                 for (int k = 0; k < 9; ++k) { rix[k] = 0; res[k] = pu[k] ? gen_probe(v[k], batchEpoch, roundNo, ct, &rix[k]) : 0; }
             }
+            GEN_SUB(8);
             bool fail = res[0] != 0, haz = false;                                        // row r1 in use
             if (res[1] != 0) fail = true;                                                // row r2 in use
             if (tB) {
@@ -379,9 +479,11 @@ CG_DEVICE void gen_body(const SamplerDev &S)
             }
             if (haz) flags |= GEN_F_HAZARD; else if (fail) flags |= GEN_F_FAIL;
         }
+        GEN_TS(18);
         if (go && (flags & (GEN_F_HAZARD | GEN_F_FAIL))) cg_atomic_min_u32(&sh.stopKey, 2u * ct + ((flags & GEN_F_HAZARD) ? 0u : 1u));
         cg_sync();
         GEN_PROF(4);
+        GEN_TS(19);
 
         // ------------------------------------------------------------------ C: commit attempts [0, stopT)
         const uint32_t stopKey = sh.stopKey;
@@ -397,6 +499,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
         }
         cg_sync();
         GEN_PROF(5);
+        GEN_TS(20);
         if (commit) {
             uint32_t qBefore = 0, bRank = 0;
             {
@@ -447,8 +550,10 @@ CG_DEVICE void gen_body(const SamplerDev &S)
                 }
             }
         }
+        GEN_TS(21);
         cg_sync();
-        GEN_PROF(6);
+        GEN_PROF_R(6, 11);
+        GEN_TS(22);
         // ------------------------------------------------------------------ round bookkeeping
         if (t == 0) {
             uint32_t totQ = 0, totB = 0, totD = 0;
@@ -459,16 +564,17 @@ CG_DEVICE void gen_body(const SamplerDev &S)
             sh.qlen += totQ; sh.processed = processed + stopT;
             const uint32_t attempted = stopT + (stopFail ? 1u : 0u);
             const uint32_t draws = 2u * (attempted - ((skip && attempted) ? 1u : 0u));
-            uint64_t jm, ji; pcg_jump_coeffs(draws, jm, ji);
+            const uint64_t jm = sh.jmul[draws >> 1], ji = sh.jinc[draws >> 1];
             sh.qrngRound = jm * sh.qrngRound + ji;
             if (attempted) sh.skip = 0;
             sh.stopT = stopT; sh.stopFail = stopFail ? 1u : 0u;
 #if defined(GEN_PROFILE)
-            cg_atomic_add_u64(&gs->prof[15], 1ull);
+            prof_acc[15] += 1ull;
 #endif
         }
         cg_sync();
-        GEN_PROF(7);
+        GEN_PROF_R(7, 12);
+        GEN_TS(23);
         const bool endBatch = sh.stopFail || (sh.processed >= sh.remaining);
         if (endBatch) {
             if (t == 0) {
@@ -501,6 +607,11 @@ CG_DEVICE void gen_body(const SamplerDev &S)
                 gs->traceCount = g.traceCount; gs->traceBatchCount = g.traceBatchCount;
                 gs->evalBytes = g.evalBytes + (unsigned long long)sh.unitSum * 4ull * S.N; gs->evalProps = g.evalProps + e_prevQ;
             }
+            GEN_TS(24);
+            cg_sync();
+            GEN_TS_DUMP();
+            GEN_PROF(13);
+            GEN_PROF_FLUSH();
             return;
         }
     }

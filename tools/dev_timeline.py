@@ -1,0 +1,48 @@
+"""dev: per-wave timeline (cycles since kernel entry) of one typical generator launch (profile build)."""
+import sys, os, ctypes, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cogaps_amd import _capi
+from bench import synthetic_dense
+PL = _capi.bind(ctypes.CDLL(os.path.join(os.path.dirname(_capi.LIB_PATH), 'libcogaps_hip_PROFILE_DEV.so')))
+S = _capi.Session(synthetic_dense(20000, 2000), lib=PL, nPatterns=50, nIterations=100, seed=42)
+S.run_iterations(1, 0, int(sys.argv[1]) if len(sys.argv) > 1 else 40)
+names = {0: 'entry', 1: 'entry loads+sync', 2: 'flush', 4: 'round set-up sync', 5: 'A1 pcg+guess', 6: 'A1 count3 #1', 7: 'A1 exact decide', 8: 'A1 count3 #2+perm',
+         9: 'A1 sync', 10: 'A2 stage1 rng/addr', 11: 'A2 stage2 (vec/bits0 used)', 12: 'A2 stage3 (atoms/binHead used)', 13: 'A2 neighbour loads issued', 14: 'A2 finish',
+         15: 'B1 inserts', 16: 'B1 sync', 17: 'B2 lookups', 18: 'B2 logic', 19: 'B2 sync', 20: 'C scan sync', 21: 'C commit', 22: 'C commit sync', 23: 'bookkeeping sync', 24: 'write-back'}
+buf = (ctypes.c_uint64 * 256)()
+PL.cogaps_debug_timeline.argtypes = [ctypes.c_void_p, ctypes.c_int]
+assert PL.cogaps_debug_timeline(buf, 256) == 0
+a = np.array(buf).reshape(4, 64)
+t0 = min(int(a[w, 0]) >> 8 for w in range(4) if a[w, 0])
+print('%-34s' % 'mark' + ''.join('   wave%d (+delta)' % w for w in range(4)))
+seq = {w: [(int(x) & 0xFF, (int(x) >> 8) - t0) for x in a[w] if x] for w in range(4)}
+order = []
+for w in range(4):
+    for ident, _ in seq[w]:
+        if ident not in order: order.append(ident)
+order.sort()
+for ident in order:
+    row = '%-34s' % names.get(ident, str(ident))
+    for w in range(4):
+        hit = [i for i, (d, _) in enumerate(seq[w]) if d == ident]
+        if not hit: row += ' ' * 17; continue
+        i = hit[-1]; c = seq[w][i][1]; d = c - seq[w][i - 1][1] if i else 0
+        row += ' %7d (%5d) ' % (c, d)
+    print(row)
+
+# ---- evaluation kernel: first 16 workgroups of the last big launch (P sampler ran last: 1024 lanes; A: 64 lanes)
+ebuf = (ctypes.c_uint64 * (16 * 2 * 12))()
+PL.cogaps_debug_eval_timeline.argtypes = [ctypes.c_void_p, ctypes.c_int]
+assert PL.cogaps_debug_eval_timeline(ebuf, 16 * 2 * 12) == 0
+e = np.array(ebuf).reshape(16, 2, 12)
+en = {0: 'entry', 1: 'record', 2: 'scalars', 3: 'rows+reduce', 4: 'scalar math', 5: 'broadcast', 6: 'AP update'}
+print()
+print('evaluation kernel, cycles since workgroup entry (first wave | last wave):')
+for b in range(16):
+    if e[b, 0, 1] == 0: continue
+    ty = int(e[b, 0, 0])
+    for w in range(2):
+        ts = [(int(x) & 0xFF, int(x) >> 8) for x in e[b, w, 1:] if x]
+        if not ts: continue
+        t0 = ts[0][1]
+        print('  wg %2d %s nUpd %d sameRow %d wave %s: ' % (b, chr(ty & 0xFF), (ty >> 8) & 0xFF, ty >> 16, 'first' if w == 0 else 'last ') + '  '.join('%s %d' % (en.get(i, str(i)), c - t0) for i, c in ts[1:]))
