@@ -227,6 +227,7 @@ static void build_sampler(cogaps_session *s, HostSampler &h, char name, const fl
     d.domainLenD = (double)d.domainLenU;                        // ProposalQueue.cpp:30
     d.numBins = (double)nBins; d.alphaD = (double)alpha;
     d.invBinLen = 1.0 / (double)d.binLength;
+    d.invK = 1.0 / (double)d.K;
     if (nBins >= 0xFFFFFFF0ull) throw std::runtime_error("rows x nPatterns must stay below 2^32");
     d.rboundNone = gm_u64_from_double_x86(d.domainLenD);
     d.iPartL = 0xFFFFFFFFFFFFFFFFull / d.domainLenU; d.limitL = d.domainLenU * d.iPartL;   // uniform64(1, L)

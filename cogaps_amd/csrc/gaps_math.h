@@ -129,15 +129,31 @@ CG_HD uint64_t pcg_u64(uint64_t &s)
     uint64_t low = pcg_u32(s);
     return high | low;
 }
+// a / b for b >= 1, exact.  The compiler's 64-bit division is a ~130-instruction routine on gfx950; this is two
+// double-precision quotient estimates (each leaves an error far below the next one's range) and a +-1 fix-up.
+CG_HD uint64_t gm_udiv64(uint64_t a, uint64_t b)
+{
+    if (b >> 62) { uint64_t q = 0; while (a >= b) { a -= b; ++q; } return q; }      // quotient <= 3
+    const double inv = 1.0 / (double)b;
+    double qd = (double)a * inv;
+    qd = qd < 18446744073709549568.0 ? qd : 18446744073709549568.0;                  // largest double below 2^64
+    uint64_t q = (uint64_t)qd;
+    int64_t r = (int64_t)(a - q * b);                                                // |r| < 2^13 + b
+    const int64_t q2 = (int64_t)((double)r * inv);
+    q += (uint64_t)q2; r -= q2 * (int64_t)b;
+    for (int k = 0; k < 2; ++k) { const uint64_t neg = r < 0; q -= neg; r += neg ? (int64_t)b : 0; }
+    for (int k = 0; k < 2; ++k) { const uint64_t big = r >= (int64_t)b; q += big; r -= big ? (int64_t)b : 0; }
+    return q;
+}
 // Random.cpp:105-123
 CG_HD uint64_t pcg_uniform64(uint64_t &s, uint64_t a, uint64_t b)
 {
     if (b == a) return a;
     uint64_t range = b + 1ull - a;
     uint64_t x = pcg_u64(s);
-    uint64_t iPart = 0xFFFFFFFFFFFFFFFFull / range;
+    uint64_t iPart = gm_udiv64(0xFFFFFFFFFFFFFFFFull, range);
     while (x >= range * iPart) x = pcg_u64(s);
-    return x / iPart + a;
+    return gm_udiv64(x, iPart) + a;
 }
 // LCG jump: state after k advances = mulK * s + incK  (k-step affine map)
 CG_HD void pcg_jump_coeffs(uint64_t k, uint64_t &mulK, uint64_t &incK)

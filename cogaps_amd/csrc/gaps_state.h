@@ -105,6 +105,7 @@ struct SamplerDev {
     double domainLenD;     // ProposalQueue::mDomainLength
     double numBins, alphaD;
     double invBinLen;      // 1.0 / binLength (quotient estimate of gen_bin_of)
+    double invK;           // 1.0 / nPatterns (gen_div_k)
     uint64_t rboundNone;   // static_cast<uint64_t>(mDomainLength), ProposalQueue.cpp:216
     uint64_t iPartL, limitL; // uniform64(1, domainLenU): iPart = UINT64_MAX / L, limit = L * iPart (Random.cpp:112-117)
     GenScalars *gs;

@@ -68,8 +68,10 @@ __device__ unsigned long long g_timeline[(GEN_WIN / 64) * 64];
 #define GEN_F_WORDZERO 256u // ... and its whole level-0 bitmap word was empty (hints must be set)
 
 #define GEN_STAMP_COMMITTED 0xFFFFFFull
-#define GEN_TAB_BITS 11
-#define GEN_TAB (1 << GEN_TAB_BITS)   // LDS conflict table entries (round 1 of a batch): >= 2.6 x the keys a 256-attempt window can register
+#ifndef GEN_TAB_BBITS
+#define GEN_TAB_BBITS 10
+#endif
+#define GEN_TAB_NB (1 << GEN_TAB_BBITS)   // buckets of the LDS conflict table (round 1 of a batch); 4 slots each
 #define GEN_K_ROW 0u
 #define GEN_K_ATOM 1u
 #define GEN_K_GAP 2u
@@ -77,7 +79,8 @@ __device__ unsigned long long g_timeline[(GEN_WIN / 64) * 64];
 #define FLUSH_MAX 64                 // erase caches up to this size are flushed in parallel
 #define CG_KEEP 0xFFFFFFFEu          // "front unchanged" marker
 
-struct GenTabEnt { uint32_t key, used, gap, inl; };
+struct GenTabVal { uint32_t used, gap, inl, pad; };
+struct GenTabKeys { uint32_t k[4]; };
 
 template <int WIN>
 struct GenShared {
@@ -96,7 +99,8 @@ struct GenShared {
 #if defined(GEN_PROFILE)
     unsigned long long ts[(WIN / 64) * 64]; uint32_t tsn[WIN / 64];
 #endif
-    alignas(16) GenTabEnt tab[GEN_TAB];      // conflict sets of round 1
+    alignas(16) uint32_t bkey[4 * GEN_TAB_NB];      // conflict sets of round 1: keys, bucket-major
+    alignas(16) GenTabVal bval[4 * GEN_TAB_NB];     // ... and the ordinals registered under each key
     float dpLo[WIN], dpHi[WIN];              // deathProb(minAtoms - k), deathProb(nAtoms + k) for this round
     uint64_t jmul[WIN + 1], jinc[WIN + 1];   // PCG jump by 2k steps, k = 0 .. WIN
     GenScalars g;                        // the generator's scalars, LDS-resident for the launch
@@ -115,6 +119,15 @@ CG_DEVICE uint32_t gen_bin_of(const SamplerDev &S, uint64_t pos)
     const uint64_t prod = (uint64_t)q * S.binLength;
     if (prod > pos) --q;
     else if (pos - prod >= S.binLength) ++q;
+    return q;
+}
+
+// bin / nPatterns, exact: the double product is below the true quotient by far less than 1/K, so the truncation
+// is right or one short
+CG_DEVICE uint32_t gen_div_k(const SamplerDev &S, uint32_t bin)
+{
+    uint32_t q = (uint32_t)((double)bin * S.invK);
+    q += (uint32_t)(bin - q * S.K >= S.K);
     return q;
 }
 
@@ -271,23 +284,23 @@ CG_DEVICE void gen_count3(uint32_t (*w)[WIN / 64], unsigned t, bool a, bool b, b
     ea = (uint32_t)cg_popc64(ma & lt); eb = (uint32_t)cg_popc64(mb & lt); ec = (uint32_t)cg_popc64(mc & lt); ta = 0; tb = 0; tc = 0;
     for (unsigned k = 0; k < (unsigned)(WIN / 64); ++k) {
         const uint32_t xa = w[0][k], xb = w[1][k], xc = w[2][k];
-        if (k < wave) { ea += xa; eb += xb; ec += xc; }
+        const uint32_t before = k < wave ? 0xFFFFFFFFu : 0u;
+        ea += xa & before; eb += xb & before; ec += xc & before;
         ta += xa; tb += xb; tc += xc;
     }
 }
 
 // ProposalQueue::makeProposal type choice (ProposalQueue.cpp:129-160); 0 = indeterminate
-// lowerBound / upperBound = deathProb(minAtoms) / deathProb(maxAtoms), from the window's table
+// lowerBound / upperBound = deathProb(minAtoms) / deathProb(maxAtoms), from the window's table.  Selects only.
 CG_DEVICE uint32_t gen_decide(float u1, float u2, uint64_t minAtoms, uint64_t maxAtoms, float lowerBound, float upperBound)
 {
-    if (minAtoms < 2 && maxAtoms >= 2) return GEN_T_NONE;
-    if (maxAtoms < 2) return 'B';
-    if (u1 < 0.5f) {
-        if (u2 < lowerBound) return 'D';
-        if (u2 >= upperBound) return 'B';
-        return GEN_T_NONE;
-    }
-    return (u1 < 0.75f) ? 'M' : 'E';
+    uint32_t r = (u2 >= upperBound) ? (uint32_t)'B' : (uint32_t)GEN_T_NONE;
+    r = (u2 < lowerBound) ? (uint32_t)'D' : r;
+    const uint32_t me = (u1 < 0.75f) ? (uint32_t)'M' : (uint32_t)'E';
+    r = (u1 < 0.5f) ? r : me;
+    r = (maxAtoms < 2) ? (uint32_t)'B' : r;
+    r = ((uint32_t)(minAtoms < 2) & (uint32_t)(maxAtoms >= 2)) ? (uint32_t)GEN_T_NONE : r;
+    return r;
 }
 
 // stamp helpers -----------------------------------------------------------------------------------
@@ -307,32 +320,50 @@ CG_DEVICE int gen_probe(unsigned long long v, uint64_t batchEpoch, uint32_t roun
     return i < t ? 2 : 0;
 }
 
-// LDS conflict table of round 1 of a batch: open addressing, one 16-byte entry per key.  Keys are matrix rows
-// (bit 31 set) and atom handles; the three value words hold the smallest attempt ordinal that registered
+// LDS conflict table of round 1 of a batch: GEN_TAB_NB buckets of four slots, keys and values in separate
+// arrays so that one 16-byte read shows a whole bucket.  Keys are matrix rows (bit 31 set) and atom handles;
+// the value words hold the smallest attempt ordinal that registered
 //   used: the row / the atom as in use (mUsedMatrixIndices / mUsedAtoms)
 //   gap : a birth landing right of the atom (before the front atom: pseudo-handle GEN_TAB_FRONT)
 //   inl : a same-bin move / exchange touching the atom
-// An empty entry is all ones, so a lookup that ends on it reads "nobody".
+// A key probes the slots of its bucket from a hash-chosen start, then the next bucket; nothing is ever removed,
+// so a key sits in the first slot of its probe sequence that was empty when it arrived and a lookup may stop
+// at the first empty slot.  Empty keys and values are all ones ("nobody").
 #define GEN_TAB_ROW 0x80000000u
-#define GEN_TAB_FRONT 0x7FFFFFFFu     // pseudo-handle: its gap word = a birth landing before the front atom
-CG_DEVICE uint32_t gen_tab_hash(uint32_t key) { return (key * 2654435761u) >> (32 - GEN_TAB_BITS); }
+#define GEN_TAB_FRONT 0x7FFFFFFFu
+#define GEN_TAB_EMPTY 0xFFFFFFFFu
+CG_DEVICE uint32_t gen_tab_hash(uint32_t key) { return key * 2654435761u; }
+CG_DEVICE uint32_t gen_tab_bucket(uint32_t h) { return h >> (32 - GEN_TAB_BBITS); }
+CG_DEVICE uint32_t gen_tab_start(uint32_t h) { return (h >> (30 - GEN_TAB_BBITS)) & 3u; }
 template <int WIN>
 CG_DEVICE uint32_t gen_tab_claim(GenShared<WIN> &sh, uint32_t key)
 {
-    uint32_t s = (key * 2654435761u) >> (32 - GEN_TAB_BITS);
+    const uint32_t h = gen_tab_hash(key), j = gen_tab_start(h);
+    uint32_t b = gen_tab_bucket(h);
     for (;;) {
-        const uint32_t old = cg_atomic_cas_u32(&sh.tab[s].key, 0xFFFFFFFFu, key);
-        if (old == 0xFFFFFFFFu || old == key) return s;
-        s = (s + 1u) & (uint32_t)(GEN_TAB - 1);
+        for (uint32_t i = 0; i < 4u; ++i) {
+            const uint32_t s = 4u * b + ((j + i) & 3u);
+            const uint32_t old = cg_atomic_cas_u32(&sh.bkey[s], GEN_TAB_EMPTY, key);
+            if (old == GEN_TAB_EMPTY || old == key) return s;
+        }
+        b = (b + 1u) & (uint32_t)(GEN_TAB_NB - 1);
     }
 }
+// slot of `key`, or GEN_TAB_EMPTY when it was never registered
 template <int WIN>
-CG_DEVICE GenTabEnt gen_tab_find(const GenShared<WIN> &sh, uint32_t key)
+CG_DEVICE uint32_t gen_tab_find(const GenShared<WIN> &sh, uint32_t key)
 {
-    uint32_t s = (key * 2654435761u) >> (32 - GEN_TAB_BITS);
-    GenTabEnt e = sh.tab[s];
-    while (e.key != key && e.key != 0xFFFFFFFFu) { s = (s + 1u) & (uint32_t)(GEN_TAB - 1); e = sh.tab[s]; }
-    return e;
+    const uint32_t h = gen_tab_hash(key), j = gen_tab_start(h);
+    uint32_t b = gen_tab_bucket(h);
+    for (;;) {
+        for (uint32_t i = 0; i < 4u; ++i) {
+            const uint32_t s = 4u * b + ((j + i) & 3u);
+            const uint32_t k = sh.bkey[s];
+            if (k == key) return s;
+            if (k == GEN_TAB_EMPTY) return GEN_TAB_EMPTY;
+        }
+        b = (b + 1u) & (uint32_t)(GEN_TAB_NB - 1);
+    }
 }
 CG_DEVICE unsigned long long *gen_stamp_ptr(const SamplerDev &S, uint32_t kind, uint32_t id)
 {

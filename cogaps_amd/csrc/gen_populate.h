@@ -108,7 +108,11 @@ CG_DEVICE void gen_body(const SamplerDev &S)
     const uint32_t specH = (t < (unsigned)FLUSH_MAX && t < S.eraseCap) ? S.eraseList[t] : 0u;
     uint32_t units = (t < S.queueCap) ? S.queueUnits[t] : 0u;
     if (t == 0) { sh.g = *gs; sh.newFront = CG_KEEP; sh.unitSum = 0; }
-    { GenTabEnt none; none.key = none.used = none.gap = none.inl = 0xFFFFFFFFu; for (uint32_t i = t; i < (uint32_t)GEN_TAB; i += WIN) sh.tab[i] = none; }
+    {   // empty conflict table
+        // (keys only: whoever claims a slot initialises its value words)
+        GenTabKeys none; none.k[0] = none.k[1] = none.k[2] = none.k[3] = GEN_TAB_EMPTY;
+        for (uint32_t i = t; i < (uint32_t)GEN_TAB_NB; i += WIN) *(GenTabKeys *)&sh.bkey[4u * i] = none;
+    }
     if (t == 0) { sh.jmul[WIN] = S.lcgMul[2 * WIN]; sh.jinc[WIN] = S.lcgInc[2 * WIN]; }
     sh.jmul[t] = jm0; sh.jinc[t] = ji0;        // even-step PCG jumps, for the round bookkeeping
     cg_sync();
@@ -169,41 +173,40 @@ CG_DEVICE void gen_body(const SamplerDev &S)
 
         // ------------------------------------------------------------------ A1 (lane = attempt): (u1,u2), B/D/M/E
         {
-            const bool active = t < winN;
-            const uint64_t mySeed = !active ? 0ull : (processed == 0u ? seed1 : S.seeds[updBase + processed + t]);   // round 1: prefetched
-            float u1 = 0.f, u2 = 0.f;
-            uint32_t guess = GEN_T_NONE;
-            if (active) {
-                if (skip && t == 0) { u1 = sh.u1c; u2 = sh.u2c; }
-                else {
-                    uint64_t s = (skip ? jm1 : jm0) * sh.qrngRound + (skip ? ji1 : ji0);
-                    u1 = pcg_uniform(s); u2 = pcg_uniform(s);
-                }
-                guess = gen_decide(u1, u2, minR, nR, sh.dpLo[0], sh.dpHi[0]);
-            }
+            // (0/1 words and selects instead of short-circuit logic: with one wave per SIMD a branch costs more
+            // than the arithmetic it would skip)
+            const uint32_t active = t < winN;
+            const uint32_t tt = active ? t : 0u;
+            const uint64_t mySeed = (processed == 0u) ? seed1 : S.seeds[updBase + processed + tt];      // round 1: prefetched
+            uint64_t s = (skip ? jm1 : jm0) * sh.qrngRound + (skip ? ji1 : ji0);
+            float u1 = pcg_uniform(s), u2 = pcg_uniform(s);
+            const uint32_t cached = (skip != 0u) & (uint32_t)(t == 0u);       // attempt 0 replays the cached pair
+            u1 = cached ? sh.u1c : u1; u2 = cached ? sh.u2c : u2;
+            uint32_t guess = gen_decide(u1, u2, minR, nR, sh.dpLo[0], sh.dpHi[0]);
+            guess = active ? guess : (uint32_t)GEN_T_NONE;
             GEN_PIN(guess); GEN_PIN(u1); GEN_PIN(u2);
             GEN_TS(5);
             sh.u1[t] = u1; sh.u2[t] = u2;
             uint32_t bBefore, dBefore, e3, tB, tD, t3;
-            gen_count3<WIN>(sh.wtotA, t, active && guess == 'B', active && guess == 'D', false, bBefore, dBefore, e3, tB, tD, t3);
+            gen_count3<WIN>(sh.wtotA, t, guess == 'B', guess == 'D', false, bBefore, dBefore, e3, tB, tD, t3);
             GEN_TS(6);
-            uint32_t aflags = 0;
-            if (active && (bBefore | dBefore)) {
-                // the exact B/D/indeterminate decision depends on how many births / deaths precede this attempt
-                const uint32_t exact = (u1 < 0.5f || minR < 2u + dBefore || nR + bBefore < 2u) ? gen_decide(u1, u2, (uint64_t)minR - dBefore, (uint64_t)nR + bBefore, sh.dpLo[dBefore], sh.dpHi[bBefore]) : guess;
-                if (exact != guess) aflags |= GEN_F_HAZARD;
-            }
-            if (active && !(aflags & GEN_F_HAZARD) && guess == GEN_T_NONE) aflags |= GEN_F_FAIL;   // indeterminate: batch ends, no seed used
-            if (active && aflags) cg_atomic_min_u32(&sh.stopKey, 2u * t + ((aflags & GEN_F_HAZARD) ? 0u : 1u));
+            // the exact B/D/indeterminate decision depends on how many births / deaths precede this attempt
+            const uint32_t exact = gen_decide(u1, u2, (uint64_t)minR - dBefore, (uint64_t)nR + bBefore, sh.dpLo[dBefore], sh.dpHi[bBefore]);
+            const uint32_t hazA = active & (uint32_t)(exact != guess);
+            const uint32_t failA = active & (hazA ^ 1u) & (uint32_t)(guess == GEN_T_NONE);   // indeterminate: batch ends, no seed used
+            uint32_t aflags = hazA ? GEN_F_HAZARD : (failA ? GEN_F_FAIL : 0u);
+            if (aflags) cg_atomic_min_u32(&sh.stopKey, 2u * t + (hazA ^ 1u));
             GEN_PIN(aflags);
             GEN_TS(7);
             // sort the attempts that go on by code path: births+deaths | moves | exchanges
-            const bool go = active && !aflags;
-            const bool k0 = go && (guess == 'B' || guess == 'D'), k1 = go && guess == 'M', k2 = go && guess == 'E';
+            const uint32_t go = active & (uint32_t)(aflags == 0u);
+            const uint32_t k0 = go & ((uint32_t)(guess == 'B') | (uint32_t)(guess == 'D')), k1 = go & (uint32_t)(guess == 'M'), k2 = go & (uint32_t)(guess == 'E');
             uint32_t e0, e1, e2, T0, T1, T2;
-            gen_count3<WIN>(sh.wtotB, t, k0, k1, k2, e0, e1, e2, T0, T1, T2);
+            gen_count3<WIN>(sh.wtotB, t, k0 != 0u, k1 != 0u, k2 != 0u, e0, e1, e2, T0, T1, T2);
             if (go) {
-                const uint32_t slot = k0 ? e0 : (k1 ? T0 + e1 : T0 + T1 + e2);
+                uint32_t slot = T0 + T1 + e2;
+                slot = k1 ? T0 + e1 : slot;
+                slot = k0 ? e0 : slot;
                 sh.perm[slot] = (uint16_t)t;
                 sh.info[t] = guess | (bBefore << 8);
                 sh.seed[t] = mySeed;                                     // consumed after the type sort
@@ -236,7 +239,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
             uint64_t x = pcg_u64(rng);
             while (x >= S.limitL) x = pcg_u64(rng);
             pos = (S.iPartL == 1ull ? x : x / S.iPartL) + 1ull;
-            bin = gen_bin_of(S, pos); r1 = bin / K; c1 = bin - r1 * K;
+            bin = gen_bin_of(S, pos); r1 = gen_div_k(S, bin); c1 = bin - r1 * K;
             i1 = nT;
         } else if (pick) {
             i1 = pcg_uniform32(rng, 0u, nT - 1u);
@@ -280,7 +283,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
         if (pick) {
             cpos = a.pos;
             const uint32_t b1 = gen_bin_of(S, cpos);
-            r1 = b1 / K; c1 = b1 - r1 * K;
+            r1 = gen_div_k(S, b1); c1 = b1 - r1 * K;
             if (type == 'M') { hl = a.left; hr = a.right; }
             else if (type == 'E') { hr = a.right; h2 = (hr != CG_NONE) ? hr : sh.g.front; }
         }
@@ -305,7 +308,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
                 gen_find_gap(S, pos, bin, &hl, &hr, &occ, &nh);
                 while (occ) {           // randomFreePosition retry (ConcurrentAtomicDomain.cpp:46-54)
                     pos = pcg_uniform64(rng, 1ull, S.domainLenU);
-                    bin = gen_bin_of(S, pos); r1 = bin / K; c1 = bin - r1 * K;
+                    bin = gen_bin_of(S, pos); r1 = gen_div_k(S, bin); c1 = bin - r1 * K;
                     gen_find_gap(S, pos, bin, &hl, &hr, &occ, &nh);
                 }
                 flags &= ~(GEN_F_BINEMPTY | GEN_F_WORDZERO | GEN_F_NEWHEAD);
@@ -318,13 +321,13 @@ CG_DEVICE void gen_body(const SamplerDev &S)
                 if (hr != CG_NONE) { flags |= GEN_F_HASRIGHT; rbpos = rp; } else rbpos = S.rboundNone;
                 pos = pcg_uniform64(rng, lbpos + 1ull, rbpos - 1ull);
                 const uint32_t bin2 = gen_bin_of(S, pos);
-                r2 = bin2 / K; c2 = bin2 - r2 * K;
+                r2 = gen_div_k(S, bin2); c2 = bin2 - r2 * K;
                 if (r1 == r2 && c1 == c2) flags |= GEN_F_INLINE;
             } else if (type == 'E') {
                 if (hr != CG_NONE) flags |= GEN_F_HASRIGHT;
                 rbpos = b3.pos; i2 = b3.idx;
                 const uint32_t bin2 = gen_bin_of(S, rbpos);
-                r2 = bin2 / K; c2 = bin2 - r2 * K;
+                r2 = gen_div_k(S, bin2); c2 = bin2 - r2 * K;
                 if (r1 == r2 && c1 == c2) {
                     flags |= GEN_F_INLINE;
                     const float m1 = a.mass, m2 = b3.mass;
@@ -345,25 +348,47 @@ CG_DEVICE void gen_body(const SamplerDev &S)
         const bool queuedM = live && type == 'M' && !(flags & GEN_F_INLINE);
         const bool ldsRound = roundNo == 1u;
         if (go) { sh.cpos[ct] = cpos; sh.pos[ct] = pos; sh.type[ct] = queuedM ? (uint8_t)'M' : (uint8_t)0; }
+        uint32_t rs0 = 0, rs1 = 0, rs2 = 0, rf0 = 0, rf1 = 0, rf2 = 0;
         if (live && ldsRound) {
-            // up to three (key, field) registrations, straight-line: an unused slot repeats the first one
-            const bool inl = (flags & GEN_F_INLINE) != 0, tB = type == 'B', tD = type == 'D', tM = type == 'M';
-            const uint32_t k0 = inl ? h1 : (GEN_TAB_ROW | r1), f0 = inl ? 3u : 1u;
-            const bool use1 = !(inl && tM), use2 = tM && !inl;
-            const uint32_t k1 = !use1 ? k0 : (inl ? h2 : (tB ? (hl == CG_NONE ? GEN_TAB_FRONT : hl) : (tD ? h1 : (GEN_TAB_ROW | r2))));
-            const uint32_t f1 = !use1 ? f0 : (inl ? 3u : (tB ? 2u : 1u));
-            const uint32_t k2 = use2 ? h1 : k0, f2 = use2 ? 1u : f0;
-            uint32_t s0 = gen_tab_hash(k0), s1 = gen_tab_hash(k1), s2 = gen_tab_hash(k2);
-            const uint32_t o0 = cg_atomic_cas_u32(&sh.tab[s0].key, 0xFFFFFFFFu, k0);
-            const uint32_t o1 = cg_atomic_cas_u32(&sh.tab[s1].key, 0xFFFFFFFFu, k1);
-            const uint32_t o2 = cg_atomic_cas_u32(&sh.tab[s2].key, 0xFFFFFFFFu, k2);
-            if ((o0 != 0xFFFFFFFFu && o0 != k0) || (o1 != 0xFFFFFFFFu && o1 != k1) || (o2 != 0xFFFFFFFFu && o2 != k2)) {   // rare: a probe sequence
-                s0 = gen_tab_claim<WIN>(sh, k0); s1 = gen_tab_claim<WIN>(sh, k1); s2 = gen_tab_claim<WIN>(sh, k2);
+            // up to three (key, field) registrations; an unused one repeats the first.  Predicates are 0/1 words
+            // combined with bit operations: every short-circuit would be a branch, and a branch costs more
+            // than the arithmetic it skips when one wave owns the SIMD
+            const uint32_t inl = flags & GEN_F_INLINE, tB = type == 'B', tD = type == 'D', tM = type == 'M';
+            const uint32_t k0 = inl ? h1 : (GEN_TAB_ROW | r1), f0 = inl << 1;
+            const uint32_t use1 = 1u ^ (inl & tM), use2 = tM & (inl ^ 1u);
+            const uint32_t hlKey = (hl == CG_NONE) ? GEN_TAB_FRONT : hl;
+            uint32_t k1 = GEN_TAB_ROW | r2;              // queued move / exchange: the second row
+            k1 = tD ? h1 : k1;                           // death: the atom
+            k1 = tB ? hlKey : k1;                        // birth: the gap right of the left neighbour
+            k1 = inl ? h2 : k1;                          // same-bin exchange: the partner
+            k1 = use1 ? k1 : k0;
+            uint32_t f1 = inl ? 2u : tB; f1 = use1 ? f1 : f0;
+            const uint32_t k2 = use2 ? h1 : k0, f2 = use2 ? 0u : f0;
+            // claim the three slots together: one compare-and-swap each per probe step (a placed key
+            // repeats the swap on its own slot, which changes nothing)
+            const uint32_t hh0 = gen_tab_hash(k0), hh1 = gen_tab_hash(k1), hh2 = gen_tab_hash(k2);
+            uint32_t b0 = gen_tab_bucket(hh0), b1_ = gen_tab_bucket(hh1), b2_ = gen_tab_bucket(hh2);
+            const uint32_t j0 = gen_tab_start(hh0), j1 = gen_tab_start(hh1), j2 = gen_tab_start(hh2);
+            uint32_t s0 = 0, s1 = 0, s2 = 0, d0 = 0, d1 = 0, d2 = 0, w0_ = 0, w1_ = 0, w2_ = 0;
+            for (uint32_t i = 0; ; ++i) {
+                const uint32_t p0 = d0 ? s0 : 4u * b0 + ((j0 + i) & 3u), p1 = d1 ? s1 : 4u * b1_ + ((j1 + i) & 3u), p2 = d2 ? s2 : 4u * b2_ + ((j2 + i) & 3u);
+                const uint32_t o0 = cg_atomic_cas_u32(&sh.bkey[p0], GEN_TAB_EMPTY, k0);
+                const uint32_t o1 = cg_atomic_cas_u32(&sh.bkey[p1], GEN_TAB_EMPTY, k1);
+                const uint32_t o2 = cg_atomic_cas_u32(&sh.bkey[p2], GEN_TAB_EMPTY, k2);
+                s0 = p0; s1 = p1; s2 = p2;
+                w0_ |= o0 == GEN_TAB_EMPTY; w1_ |= o1 == GEN_TAB_EMPTY; w2_ |= o2 == GEN_TAB_EMPTY;     // this lane opened the slot
+                d0 |= (uint32_t)(o0 == GEN_TAB_EMPTY) | (uint32_t)(o0 == k0);
+                d1 |= (uint32_t)(o1 == GEN_TAB_EMPTY) | (uint32_t)(o1 == k1);
+                d2 |= (uint32_t)(o2 == GEN_TAB_EMPTY) | (uint32_t)(o2 == k2);
+                if (d0 & d1 & d2) break;
+                const uint32_t wrap = (i & 3u) == 3u;      // bucket exhausted: the next one
+                b0 = (b0 + wrap) & (uint32_t)(GEN_TAB_NB - 1); b1_ = (b1_ + wrap) & (uint32_t)(GEN_TAB_NB - 1); b2_ = (b2_ + wrap) & (uint32_t)(GEN_TAB_NB - 1);
             }
-            uint32_t *words = &sh.tab[0].key;
-            cg_atomic_min_u32(&words[4u * s0 + f0], ct);
-            cg_atomic_min_u32(&words[4u * s1 + f1], ct);
-            cg_atomic_min_u32(&words[4u * s2 + f2], ct);
+            GenTabVal nobody; nobody.used = nobody.gap = nobody.inl = nobody.pad = GEN_TAB_EMPTY;
+            if (w0_) sh.bval[s0] = nobody;
+            if (w1_) sh.bval[s1] = nobody;
+            if (w2_) sh.bval[s2] = nobody;
+            rs0 = s0; rs1 = s1; rs2 = s2; rf0 = f0; rf1 = f1; rf2 = f2;
         } else if (live) {
             // up to three keys: (kind, id)
             uint32_t rk[3], rid[3]; int nk = 0;
@@ -382,53 +407,75 @@ CG_DEVICE void gen_body(const SamplerDev &S)
         }
         GEN_TS(15);
         cg_sync();
+        if (ldsRound) {
+            if (live) {
+                uint32_t *words = &sh.bval[0].used;       // word 0 = used, 1 = gap, 2 = inl
+                cg_atomic_min_u32(&words[4u * rs0 + rf0], ct);
+                cg_atomic_min_u32(&words[4u * rs1 + rf1], ct);
+                cg_atomic_min_u32(&words[4u * rs2 + rf2], ct);
+            }
+            cg_sync();
+        }
         GEN_PROF_R(3, 10);
         GEN_TS(16);
 
         // ------------------------------------------------------------------ B2: probe the sets (all probes of a lane
         // are independent: issued together, then the per-type logic runs on registers)
         if (live && ldsRound) {
-            // six table reads, all issued before any is used; an entry that is not this lane's key reads "nobody"
-            const bool tB = type == 'B', tM = type == 'M', tE = type == 'E', inl = (flags & GEN_F_INLINE) != 0;
-            uint32_t key[6]; bool use[6];
-            key[0] = GEN_TAB_ROW | r1; use[0] = true;
-            key[1] = GEN_TAB_ROW | r2; use[1] = tM || tE;
-            key[2] = ((tM || tB) && hl != CG_NONE) ? hl : GEN_TAB_FRONT; use[2] = tM || tB || (tE && !(flags & GEN_F_HASRIGHT));
-            key[3] = hr; use[3] = (tM || tB) && hr != CG_NONE;
-            key[4] = h1; use[4] = tM || tE;
-            key[5] = h2; use[5] = tE && inl;
-            GenTabEnt e[6];
-            for (int k = 0; k < 6; ++k) e[k] = sh.tab[gen_tab_hash(key[k])];
-            bool coll = false;
-            for (int k = 0; k < 6; ++k) coll = coll || (use[k] && e[k].key != key[k] && e[k].key != 0xFFFFFFFFu);
-            if (coll) { for (int k = 0; k < 6; ++k) if (use[k]) e[k] = gen_tab_find<WIN>(sh, key[k]); }          // rare: a probe sequence
-            for (int k = 0; k < 6; ++k) if (!use[k] || e[k].key != key[k]) { e[k].used = 0xFFFFFFFFu; e[k].gap = 0xFFFFFFFFu; e[k].inl = 0xFFFFFFFFu; }
-            #define GEN_EARLIER(v) ((v) < ct)
-            bool fail = GEN_EARLIER(e[0].used) || GEN_EARLIER(e[1].used);                 // a row in use
-            bool haz = false;
-            if (tB) {
-                haz = GEN_EARLIER(e[2].gap) || GEN_EARLIER(e[2].inl) || GEN_EARLIER(e[3].inl);
-                // mProposedMoves.overlap(pos): a neighbour has a queued move whose interval covers pos
-                for (int k = 2; k < 4; ++k) {
-                    const uint32_t ix = e[k].used;
-                    if (GEN_EARLIER(ix) && sh.type[ix] == 'M') {
-                        const uint64_t ma = sh.cpos[ix], mb = sh.pos[ix], lo = ma < mb ? ma : mb, hi = ma < mb ? mb : ma;
-                        if (lo < pos && pos < hi) fail = true;
-                    }
-                }
-            } else if (tM) {
-                // a neighbour in use (mUsedAtoms), or a birth earlier in this window inside (left, right)
-                fail = fail || GEN_EARLIER(e[2].used) || GEN_EARLIER(e[3].used) || GEN_EARLIER(e[2].gap) || GEN_EARLIER(e[4].gap);
-                haz = GEN_EARLIER(e[4].inl) || GEN_EARLIER(e[2].inl) || GEN_EARLIER(e[3].inl);
-            } else if (tE) {
-                // an earlier birth right of the centre is the true partner (or, for the last atom, a new front())
-                fail = fail || GEN_EARLIER(e[4].gap) || GEN_EARLIER(e[2].gap);
-                haz = inl && (GEN_EARLIER(e[4].inl) || GEN_EARLIER(e[5].inl));
+            // six bucket reads, then the six value reads of the matching slots; a key that is not in the table
+            // reads "nobody".  0/1 words and bit operations again (see B1).
+            const uint32_t tB = type == 'B', tM = type == 'M', tE = type == 'E', inl = flags & GEN_F_INLINE;
+            const uint32_t hasL = hl != CG_NONE, hasR = hr != CG_NONE, noRight = (flags & GEN_F_HASRIGHT) == 0u;
+            uint32_t key[6], use[6];
+            key[0] = GEN_TAB_ROW | r1; use[0] = 1u;
+            key[1] = GEN_TAB_ROW | r2; use[1] = tM | tE;
+            key[2] = ((tM | tB) & hasL) ? hl : GEN_TAB_FRONT; use[2] = tM | tB | (tE & noRight);
+            key[3] = hr; use[3] = (tM | tB) & hasR;
+            key[4] = h1; use[4] = tM | tE;
+            key[5] = h2; use[5] = tE & inl;
+            uint32_t bk[6]; GenTabKeys kq[6];
+            for (int k = 0; k < 6; ++k) { bk[k] = gen_tab_bucket(gen_tab_hash(key[k])); kq[k] = *(const GenTabKeys *)&sh.bkey[4u * bk[k]]; }
+            uint32_t sl[6], hit[6], over = 0;
+            for (int k = 0; k < 6; ++k) {
+                const uint32_t *q4 = kq[k].k;
+                const uint32_t e1 = q4[1] == key[k], e2 = q4[2] == key[k], e3 = q4[3] == key[k];
+                const uint32_t found = (uint32_t)(q4[0] == key[k]) | e1 | e2 | e3;
+                const uint32_t hole = (uint32_t)(q4[0] == GEN_TAB_EMPTY) | (uint32_t)(q4[1] == GEN_TAB_EMPTY) | (uint32_t)(q4[2] == GEN_TAB_EMPTY) | (uint32_t)(q4[3] == GEN_TAB_EMPTY);
+                sl[k] = 4u * bk[k] + e1 + 2u * e2 + 3u * e3;
+                hit[k] = use[k] & found;
+                over |= use[k] & (found ^ 1u) & (hole ^ 1u);             // the key may have spilled into the next bucket
             }
-            #undef GEN_EARLIER
+            if (over) {                                                   // rare
+                for (int k = 0; k < 6; ++k) if (use[k]) { const uint32_t f = gen_tab_find<WIN>(sh, key[k]); hit[k] = f != GEN_TAB_EMPTY; sl[k] = hit[k] ? f : 0u; }
+            }
+            GenTabVal e[6];
+            for (int k = 0; k < 6; ++k) e[k] = sh.bval[hit[k] ? sl[k] : 0u];
+            // E(v) = 1 when an earlier attempt of this window registered under the word
+            #define GEN_E(k, w) (hit[k] & (uint32_t)(e[k].w < ct))
+            uint32_t fail = GEN_E(0, used) | GEN_E(1, used);                              // a row in use
+            // move: a neighbour in use (mUsedAtoms), or a birth earlier in this window inside (left, right)
+            fail |= tM & (GEN_E(2, used) | GEN_E(3, used) | GEN_E(2, gap) | GEN_E(4, gap));
+            // exchange: an earlier birth right of the centre is the true partner (or, for the last atom, a new front())
+            fail |= tE & (GEN_E(4, gap) | GEN_E(2, gap));
+            // birth: an earlier birth in the same gap; move / birth / same-bin exchange: an earlier same-bin
+            // move or exchange of this window touched an atom whose position this attempt relied on
+            uint32_t haz = tB & (GEN_E(2, gap) | GEN_E(2, inl) | GEN_E(3, inl));
+            haz |= tM & (GEN_E(4, inl) | GEN_E(2, inl) | GEN_E(3, inl));
+            haz |= tE & inl & (GEN_E(4, inl) | GEN_E(5, inl));
+            if (tB) {
+                // mProposedMoves.overlap(pos): a neighbour has a queued move whose interval covers pos
+                const uint32_t uL = GEN_E(2, used), uR = GEN_E(3, used);
+                const uint32_t iL = uL ? e[2].used : 0u, iR = uR ? e[3].used : 0u;
+                const uint64_t aL = sh.cpos[iL], bL = sh.pos[iL], aR = sh.cpos[iR], bR = sh.pos[iR];
+                const uint32_t mL = uL & (uint32_t)(sh.type[iL] == 'M'), mR = uR & (uint32_t)(sh.type[iR] == 'M');
+                const uint64_t loL = aL < bL ? aL : bL, hiL = aL < bL ? bL : aL, loR = aR < bR ? aR : bR, hiR = aR < bR ? bR : aR;
+                fail |= mL & (uint32_t)(loL < pos) & (uint32_t)(pos < hiL);
+                fail |= mR & (uint32_t)(loR < pos) & (uint32_t)(pos < hiR);
+            }
+            #undef GEN_E
             GEN_PIN(flags);
             GEN_TS(17);
-            if (haz) flags |= GEN_F_HAZARD; else if (fail) flags |= GEN_F_FAIL;
+            flags |= haz ? GEN_F_HAZARD : (fail ? GEN_F_FAIL : 0u);
         } else if (live) {
             const bool tB = type == 'B', tM = type == 'M', tE = type == 'E', inl = (flags & GEN_F_INLINE) != 0;
             const uint32_t keyL = (hl == CG_NONE) ? 0u : hl + 1u;
