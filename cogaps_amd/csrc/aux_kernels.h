@@ -58,21 +58,26 @@ CG_KERNEL void count_pos_kernel(SamplerDev S)
 // DenseNormalModel::chiSq (DenseNormalModel.cpp:56-68): per-vector partials in the (W, float4) lane order;
 // the host adds the M partials sequentially.  One workgroup of redW lanes per vector.
 // chiSq needs the un-squared uncertainty to reproduce ((D-AP)/S)^2 bit for bit: Sraw is [M][Npad]
-CG_KERNEL void chisq_rows_kernel_s(SamplerDev S, const float *Sraw, float *partial)
+template <int V>
+CG_KERNEL void CG_LAUNCH_BOUNDS(1024) chisq_rows_kernel_s(SamplerDev S, const float *Sraw, float *partial)
 {
-    CG_SHARED float lds[32];
-    const uint32_t row = cg_bid(), t = cg_tid(), W = cg_bdim(), nq = S.Npad >> 2;
+    CG_SHARED float lds[16 * V];
+    const uint32_t row = cg_bid(), t = cg_tid(), BS = cg_bdim(), W = (uint32_t)V * BS, nq = S.Npad >> 2;
     const float *D = S.D + (size_t)row * S.Npad, *SR = Sraw + (size_t)row * S.Npad, *AP = S.AP + (size_t)row * S.Npad;
-    EvalAcc a; a.s = 0.f; a.m = 0.f;
-    for (uint32_t j = t; j < nq; j += W) {
-        const cg_f4 d = ld4(D, j), s = ld4(SR, j), p = ld4(AP, j);
-        { float q = (d.x - p.x) / s.x; a.s = a.s + q * q; }
-        { float q = (d.y - p.y) / s.y; a.s = a.s + q * q; }
-        { float q = (d.z - p.z) / s.z; a.s = a.s + q * q; }
-        { float q = (d.w - p.w) / s.w; a.s = a.s + q * q; }
+    float tot[1] = {0.f};
+    for (int j = 0; j < V; ++j) {
+        float acc = 0.f;
+        for (uint32_t c = (uint32_t)j * BS + t; c < nq; c += W) {
+            const cg_f4 d = ld4(D, c), s = ld4(SR, c), p = ld4(AP, c);
+            { float q = (d.x - p.x) / s.x; acc = acc + q * q; }
+            { float q = (d.y - p.y) / s.y; acc = acc + q * q; }
+            { float q = (d.z - p.z) / s.z; acc = acc + q * q; }
+            { float q = (d.w - p.w) / s.w; acc = acc + q * q; }
+        }
+        eval_vpark<V>(acc, j, lds, tot);
     }
-    a = eval_block_reduce(a, lds);
-    if (t == 0) partial[row] = a.s;
+    if (BS > 64u) { cg_sync(); eval_vfinish<1, V>(lds, tot); }
+    if (t == 0) partial[row] = tot[0];
 }
 
 // GapsStatistics::update / updateA / updateP (GapsStatistics.h:130-185), one workgroup per pattern.
@@ -98,25 +103,30 @@ CG_KERNEL void stats_kernel(SamplerDev A, SamplerDev P, float *Asum, float *Asq,
 
 // GapsStatistics::meanChiSq (GapsStatistics.cpp:63-86) per-vector partials over the P sampler's data
 // (vector j = sample j, elements i = genes), lane order as chiSq.  Asum: [K][A.Mpad], Psum: [K][P.Mpad].
-CG_KERNEL void mean_chisq_rows_kernel(SamplerDev P, const float *Sraw, const float *Asum, const float *Psum, uint32_t AMpad, float n2, float *partial)
+template <int V>
+CG_KERNEL void CG_LAUNCH_BOUNDS(1024) mean_chisq_rows_kernel(SamplerDev P, const float *Sraw, const float *Asum, const float *Psum, uint32_t AMpad, float n2, float *partial)
 {
-    CG_SHARED float lds[32];
-    const uint32_t j = cg_bid(), t = cg_tid(), W = cg_bdim(), nq = P.Npad >> 2;
+    CG_SHARED float lds[16 * V];
+    const uint32_t j = cg_bid(), t = cg_tid(), BS = cg_bdim(), W = (uint32_t)V * BS, nq = P.Npad >> 2;
     const float *D = P.D + (size_t)j * P.Npad, *SR = Sraw + (size_t)j * P.Npad;
-    EvalAcc a; a.s = 0.f; a.m = 0.f;
-    for (uint32_t c = t; c < nq; c += W) {
-        const cg_f4 d = ld4(D, c), s = ld4(SR, c);
-        float dd[4] = {d.x, d.y, d.z, d.w}, ss[4] = {s.x, s.y, s.z, s.w};
-        for (uint32_t e = 0; e < 4; ++e) {
-            const uint32_t i = 4 * c + e;
-            if (i < P.N) {
-                float m = 0.f;
-                for (uint32_t k = 0; k < P.K; ++k) m = m + Asum[(size_t)k * AMpad + i] * Psum[(size_t)k * P.Mpad + j];
-                m = m / n2;
-                a.s = a.s + ((dd[e] - m) * (dd[e] - m)) / (ss[e] * ss[e]);
+    float tot[1] = {0.f};
+    for (int slot = 0; slot < V; ++slot) {
+        float acc = 0.f;
+        for (uint32_t c = (uint32_t)slot * BS + t; c < nq; c += W) {
+            const cg_f4 d = ld4(D, c), s = ld4(SR, c);
+            float dd[4] = {d.x, d.y, d.z, d.w}, ss[4] = {s.x, s.y, s.z, s.w};
+            for (uint32_t e = 0; e < 4; ++e) {
+                const uint32_t i = 4 * c + e;
+                if (i < P.N) {
+                    float m = 0.f;
+                    for (uint32_t k = 0; k < P.K; ++k) m = m + Asum[(size_t)k * AMpad + i] * Psum[(size_t)k * P.Mpad + j];
+                    m = m / n2;
+                    acc = acc + ((dd[e] - m) * (dd[e] - m)) / (ss[e] * ss[e]);
+                }
             }
         }
+        eval_vpark<V>(acc, slot, lds, tot);
     }
-    a = eval_block_reduce(a, lds);
-    if (t == 0) partial[j] = a.s;
+    if (BS > 64u) { cg_sync(); eval_vfinish<1, V>(lds, tot); }
+    if (t == 0) partial[j] = tot[0];
 }

@@ -111,12 +111,19 @@ static void build_luts(std::vector<float> &e, std::vector<float> &ei, std::vecto
     qg[GAPS_QGAMMA_N - 1] = qgam(0.9998f);
 }
 
+// Virtual lanes of the row reductions: one float4 chunk per lane while the vector has at most 16384 chunks
+// (eval_kernel.h).  Workgroups have min(W, 1024) threads.
 extern "C" uint32_t cogaps_reduction_width(uint32_t N)
 {
-    uint32_t need = (N + 31u) / 32u, w = 64;
-    while (w < need && w < 1024u) w <<= 1;
+    uint32_t need = (N + 3u) / 4u, w = 64;
+    while (w < need && w < 16384u) w <<= 1;
     return w;
 }
+// launch a kernel template<int V> with V = W / threads virtual lanes per thread
+#define LAUNCH_V(KERNEL, W, grid, stream, ...) do { const uint32_t bs_ = (W) < 1024u ? (W) : 1024u; \
+    switch ((W) / bs_) { case 1: RT_LAUNCH(KERNEL<1>, grid, bs_, stream, __VA_ARGS__); break; case 2: RT_LAUNCH(KERNEL<2>, grid, bs_, stream, __VA_ARGS__); break; \
+                         case 4: RT_LAUNCH(KERNEL<4>, grid, bs_, stream, __VA_ARGS__); break; case 8: RT_LAUNCH(KERNEL<8>, grid, bs_, stream, __VA_ARGS__); break; \
+                         default: RT_LAUNCH(KERNEL<16>, grid, bs_, stream, __VA_ARGS__); break; } } while (0)
 
 // ------------------------------------------------------------------------------------------------
 struct HostSampler {
@@ -127,6 +134,10 @@ struct HostSampler {
     float *partial = nullptr;     // [M] chi2 partials
     uint32_t nAtoms = 0;          // host copy after the last update
     float avgQueue = 0.f;
+    float stepsPerBatch = 0.f;
+    float anneal = 1.f;           // annealing temperature of the next update
+    rt_graph graph;               // GRAPH_PAIRS (generate, evaluate) pairs, replayed while the kernel parameters stay the same
+    SamplerDev graphKey; bool graphValid = false;    // proposals per batch in the last update (chunk-size predictor)
     size_t traceCap = 0;
     char name = 'A';
     // perf accounting
@@ -200,7 +211,6 @@ static void build_sampler(cogaps_session *s, HostSampler &h, char name, const fl
     d.alpha = alpha;
     d.lambda = alpha * sqrtf((float)(uint64_t)d.K / meanD);
     d.maxGibbsMass = maxGibbsMass / d.lambda;
-    d.annealTemp = 1.f;
     float *dD = dalloc<float>(tot), *dS2 = dalloc<float>(tot); h.Sraw = dalloc<float>(tot);
     rt_h2d(dD, D.data(), tot * 4, s->stream); rt_h2d(dS2, S2.data(), tot * 4, s->stream); rt_h2d(h.Sraw, SR.data(), tot * 4, s->stream);
     rt_sync(s->stream);
@@ -295,10 +305,27 @@ static void launch_eval(cogaps_session *s, HostSampler &h)
 {
     const uint32_t grid = std::min<uint32_t>(h.d.queueCap, h.d.redW >= 512 ? 256u : 512u);
     const int slot = timing_slot(s, h, 1, h.evalLaunches);
-    if (h.d.redW <= 256u) RT_LAUNCH(eval_kernel<8>, grid, h.d.redW, s->stream, h.d);
-    else RT_LAUNCH(eval_kernel<4>, grid, h.d.redW, s->stream, h.d);
+    LAUNCH_V(eval_kernel, h.d.redW, grid, s->stream, h.d);
     if (slot >= 0) rt_event_stop(s->evPool[slot], s->stream);
     h.evalLaunches++;
+}
+
+// A dependent kernel pair costs ~3.5 us per launch on the host and leaves a ~5 us bubble on the GPU when it is
+// launched call by call; replayed from a captured graph the same pair leaves ~1.6 us per kernel boundary.  The
+// kernels take their whole state through SamplerDev (by value), so one graph serves until a pointer in it
+// changes (atom arrays regrown, seed buffer reallocated).
+static const uint32_t GRAPH_PAIRS = 64;
+static void ensure_graph(cogaps_session *s, HostSampler &h)
+{
+    if (h.graphValid && memcmp(&h.graphKey, &h.d, sizeof(SamplerDev)) == 0) return;
+    if (h.graphValid) { rt_graph_destroy(h.graph); h.graphValid = false; }
+    const bool timing = s->timing; s->timing = false;              // no event records inside a capture
+    const uint64_t g0 = h.genLaunches, e0 = h.evalLaunches;
+    rt_capture_begin(s->stream);
+    for (uint32_t b = 0; b < GRAPH_PAIRS; ++b) { launch_gen(s, h); launch_eval(s, h); }
+    rt_capture_end(s->stream, h.graph);
+    h.genLaunches = g0; h.evalLaunches = e0; s->timing = timing;
+    memcpy(&h.graphKey, &h.d, sizeof(SamplerDev)); h.graphValid = true;
 }
 
 // AsynchronousGibbsSampler::update (AsynchronousGibbsSampler.h:88-122): batches of generate + evaluate
@@ -326,6 +353,7 @@ static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool t
             h.traceCap = traceCap;
         }
     }
+    g.annealTemp = h.anneal;
     g.nSteps = nSteps; g.nDone = 0; g.nBatches = 0; g.updateFlushed = 0; g.qlen = 0;
     g.traceOn = trace ? 1u : 0u; g.traceCount = 0; g.traceCap = trace ? traceCap : 0; g.traceBatchCount = 0;
     *s->hGs = g;
@@ -333,12 +361,23 @@ static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool t
     rt_sync(s->stream);
     if (nSteps == 0) return 0;
     h.updLaunches = 0;
-    float avgq = g.avgQueue > 1.f ? g.avgQueue : 1.f;
+    // proposals per batch: the previous update of this sampler is the best predictor
+    float avgq = h.stepsPerBatch > 1.f ? h.stepsPerBatch : (g.avgQueue > 1.f ? g.avgQueue : 1.f);
+    bool firstChunk = true;
     for (;;) {
         const uint32_t remaining = nSteps - s->hGs->nDone;
-        uint32_t chunk = (uint32_t)((double)remaining / avgq * 1.1) + 4u;
+        // a pair enqueued past the end of the update is two wasted launches, a progress read-back is one short
+        // pipeline bubble: enqueue slightly fewer pairs than the estimate says and converge on the tail
+        uint32_t chunk = (uint32_t)((double)remaining / avgq * (firstChunk ? 0.97 : 1.0)) + (firstChunk ? 0u : 2u);
+        if (chunk < 6u) chunk = 6u;
         if (chunk > 4096u) chunk = 4096u;
-        for (uint32_t b = 0; b < chunk; ++b) { launch_gen(s, h); launch_eval(s, h); h.updLaunches++; }
+        firstChunk = false;
+        uint32_t plain = chunk;
+        if (rt_graphs_supported() && !trace && plain >= GRAPH_PAIRS) {
+            ensure_graph(s, h);
+            for (; plain >= GRAPH_PAIRS; plain -= GRAPH_PAIRS) { rt_graph_launch(h.graph, s->stream); h.genLaunches += GRAPH_PAIRS; h.evalLaunches += GRAPH_PAIRS; h.updLaunches += GRAPH_PAIRS; }
+        }
+        for (uint32_t b = 0; b < plain; ++b) { launch_gen(s, h); launch_eval(s, h); h.updLaunches++; }
         read_gs(s, h);
         timing_resolve(s, s->hGs->nBatches);
         if (s->hGs->error) return fail(std::string("device error code ") + std::to_string(s->hGs->error) + " in sampler " + h.name);
@@ -346,6 +385,7 @@ static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool t
         if (s->hGs->nBatches > 0) avgq = std::max(1.f, (float)s->hGs->nDone / (float)s->hGs->nBatches);
     }
     h.nAtoms = s->hGs->nAtoms; h.avgQueue = s->hGs->avgQueue; h.batches += s->hGs->nBatches;
+    if (s->hGs->nBatches >= 8u) h.stepsPerBatch = (float)nSteps / (float)s->hGs->nBatches;
     return 0;
 }
 
@@ -357,7 +397,7 @@ static void do_sync(cogaps_session *s, HostSampler &dst, HostSampler &src)
 
 static float chisq_of(cogaps_session *s, HostSampler &h)
 {
-    RT_LAUNCH(chisq_rows_kernel_s, h.d.M, h.d.redW, s->stream, h.d, (const float *)h.Sraw, h.partial);
+    LAUNCH_V(chisq_rows_kernel_s, h.d.redW, h.d.M, s->stream, h.d, (const float *)h.Sraw, h.partial);
     std::vector<float> part(h.d.M);
     rt_d2h(part.data(), h.partial, (size_t)h.d.M * 4, s->stream); rt_sync(s->stream);
     float c = 0.f;
@@ -452,6 +492,7 @@ cogaps_session *cogaps_session_create(const float *data, uint32_t nrow, uint32_t
 void cogaps_session_destroy(cogaps_session *s)
 {
     if (!s) return;
+    rt_graph_destroy(s->A.graph); rt_graph_destroy(s->P.graph);
     free_sampler(s->A); free_sampler(s->P);
     rt_free(s->dErf); rt_free(s->dErfinv); rt_free(s->dQgamma); rt_free(s->dLcgMul); rt_free(s->dLcgInc);
     rt_free(s->Asum); rt_free(s->Asq); rt_free(s->Psum); rt_free(s->Psq);
@@ -466,7 +507,7 @@ void cogaps_session_destroy(cogaps_session *s)
 
 static HostSampler &pick(cogaps_session *s, char w) { return w == 'A' ? s->A : s->P; }
 
-int cogaps_session_set_annealing(cogaps_session *s, float temp) { s->A.d.annealTemp = temp; s->P.d.annealTemp = temp; return 0; }
+int cogaps_session_set_annealing(cogaps_session *s, float temp) { s->A.anneal = temp; s->P.anneal = temp; return 0; }
 
 int cogaps_session_draw_steps(cogaps_session *s, uint32_t *nA, uint32_t *nP)
 {
@@ -493,7 +534,7 @@ int cogaps_session_update(cogaps_session *s, char which, uint32_t nSteps, cogaps
         rt_sync(s->stream);
         for (uint32_t i = 0; i < n && i < traceCap; ++i) {
             cogaps_trace_rec &o = trace[i]; const PropRec &r = rec[i];
-            o.pos = r.pos; o.rng_state = r.rng; o.atom1 = r.i1; o.atom2 = r.i2; o.r1 = r.r1; o.c1 = r.c1; o.r2 = r.r2; o.c2 = r.c2; o.type = r.type; o.batch = r.pad[0];
+            o.pos = r.pos; o.rng_state = r.rng; o.atom1 = r.i1; o.atom2 = r.i2; o.r1 = r.r1; o.c1 = r.c1; o.r2 = r.r2; o.c2 = r.c2; o.type = r.type; o.batch = r.batch;
         }
         for (uint32_t i = 0; i < nb && i < batchCap; ++i) { if (batchNproc) batchNproc[i] = bn[i]; if (batchQlen) batchQlen[i] = bq[i]; }
         if (nTrace) *nTrace = s->hGs->traceCount;
@@ -622,7 +663,7 @@ int cogaps_session_finish(cogaps_session *s, cogaps_result *out)
     out->meanChiSq = 0.f;                                                             // GapsRunner.cpp:478-484
     if (s->p.whichMatrixFixed == 'N' && s->statUpdates > 0) {
         const float n2 = (float)s->statUpdates * (float)s->statUpdates;
-        RT_LAUNCH(mean_chisq_rows_kernel, s->P.d.M, s->P.d.redW, s->stream, s->P.d, (const float *)s->P.Sraw, (const float *)s->Asum, (const float *)s->Psum, s->A.d.Mpad, n2, s->P.partial);
+        LAUNCH_V(mean_chisq_rows_kernel, s->P.d.redW, s->P.d.M, s->stream, s->P.d, (const float *)s->P.Sraw, (const float *)s->Asum, (const float *)s->Psum, s->A.d.Mpad, n2, s->P.partial);
         std::vector<float> part(s->P.d.M);
         rt_d2h(part.data(), s->P.partial, (size_t)s->P.d.M * 4, s->stream); rt_sync(s->stream);
         float c = 0.f; for (uint32_t j = 0; j < s->P.d.M; ++j) c += part[j];

@@ -2,20 +2,22 @@
 // AsynchronousGibbsSampler.h:127-219 over the DenseNormalModel reductions marked PERFORMANCE
 // CRITICAL in DenseNormalModel.cpp:161-258.
 //
-// One workgroup of W = S.redW lanes per queued proposal (W = 64: one wavefront; wider for long data
-// vectors).  A proposal touches one or two factor rows, the queue guarantees that no two proposals
-// of a batch share a row, so workgroups never write the same AP row / matrix entry / atom.
+// One workgroup per queued proposal.  A proposal touches one or two factor rows, the queue guarantees that
+// no two proposals of a batch share a row, so workgroups never write the same AP row / matrix entry / atom.
 //
 // HBM traffic per proposal (N = data-vector length): alpha with or without change 16N bytes,
 // 2-site same row 20N, different rows 32N, AP update 12N.  Rows are read as coalesced float4.
 // The step is latency bound (a batch is only ~50-160 proposals), so the kernel is organised as few
-// dependent memory round trips as possible: {queue record} -> {the proposal's scalars + every row
-// chunk of the reduction, all in flight together} -> {two LUT reads} -> {AP update: re-read from L2,
-// store}.
+// dependent memory round trips as possible: {queue record, which carries the proposal's scalars} ->
+// {every row chunk of the reduction, both rows of a two-row step together} -> {two LUT reads} ->
+// {AP update: re-read from L2, store}.
 //
-// Reduction order (the parity contract with the oracle's redW / redG=4): lane L accumulates float4
-// chunks j = L, L+W, L+2W ... in increasing j (x,y,z,w in order) from +0; then an ascending xor
-// butterfly 1,2,4,...,W/2 (the reference's AVX hadd tree, SIMD.h:102-107, widened from 8 to W lanes).
+// Reduction order (the parity contract with the oracle's redW / redG=4): W = cogaps_reduction_width(N) virtual
+// lanes, one float4 chunk each whenever N <= 4*W: virtual lane L accumulates chunks j = L, L+W, ... in
+// increasing j (x,y,z,w in order) from +0; then an ascending xor butterfly 1,2,4,...,W/2 (the reference's AVX
+// hadd tree, SIMD.h:102-107, widened from 8 to W lanes).  A workgroup has BS = min(W,1024) threads and thread t
+// owns the V = W/BS virtual lanes t, t+BS, ...: butterfly bits 0-5 are wave shuffles, bits 6.. a tree over the
+// waves' totals in LDS, the top log2(V) bits a tree over the thread's own V slots.
 #pragma once
 #include "gaps_state.h"
 #include "gen_kernel.h"   // gen_bin_of, bm_set, bm_clear
@@ -37,106 +39,130 @@ struct EvalAcc { float s, m; };
 #define EVAL_ELEM(V, DD, SS, AA) { float ratio = (V) / (SS); a.s = a.s + (V) * ratio; a.m = a.m + ratio * ((DD) - (AA)); }
 #define EVAL_ELEM_CH(V, DD, SS, AA) { float ratio = (V) / (SS); a.s = a.s + (V) * ratio; a.m = a.m + ratio * ((DD) - ((AA) + ch * (V))); }
 
-// UN chunks per lane are loaded before any is consumed (4*UN independent float4 loads in flight), so a
-// row costs one memory round trip when it has at most UN*W chunks.  A chunk index past the row reads
-// nothing and contributes (v=0, S2=1, D=AP=0) -> +0 to both sums, which leaves them bit-unchanged.
-template <int UN>
-CG_DEVICE EvalAcc eval_partial_one(const SamplerDev &S, uint32_t row, uint32_t col, bool withCh, float ch)
+#define EVAL_MODE_ONE 0      // v = other[:,c1]
+#define EVAL_MODE_CH 1       // ... with the change ch*v added to AP (death)
+#define EVAL_MODE_SAME 2     // v = other[:,c1] - other[:,c2], one row (DenseNormalModel.cpp:200-212)
+
+// lane-order sum of the NC components whose per-wave, per-slot partials sit in lds[wave][NC][V] (after a
+// barrier): wave 0 folds them, lane i < NC*V over the waves (bits 6.. of the virtual lane index), then the
+// thread-slot bits across lanes.  Totals are returned in wave 0.
+template <int NC, int V>
+CG_DEVICE void eval_vfinish(const float *lds, float (&tot)[NC])
 {
-    const uint32_t nq = S.Npad >> 2, W = cg_bdim(), t = cg_tid();
-    const float *D = S.D + (size_t)row * S.Npad, *S2 = S.S2 + (size_t)row * S.Npad, *AP = S.AP + (size_t)row * S.Npad;
-    const float *V = S.other + (size_t)col * S.Npad;
-    EvalAcc a; a.s = 0.f; a.m = 0.f;
-#if defined(GEN_PROFILE)
-    if (S.dbg & 4u) return a;
-#endif
-    for (uint32_t j0 = t; j0 < nq; j0 += UN * W) {
-        cg_f4 v[UN], d[UN], s[UN], p[UN];
+    constexpr int NV = NC * V;
+    const uint32_t t = cg_tid(), nw = cg_bdim() >> 6;
+    if (t < 64u) {
+        const uint32_t i = t < (uint32_t)NV ? t : 0u;
+        float y[16];
+        for (uint32_t w = 0; w < 16; ++w) y[w] = w < nw ? lds[w * NV + i] : 0.f;
+        for (uint32_t stride = 1; stride < nw; stride <<= 1)
+            for (uint32_t k = 0; k + stride < 16; k += 2 * stride) y[k] = y[k] + y[k + stride];
+        float z = y[0];
+        for (int off = 1; off < V; off <<= 1) z = z + cg_shfl_xor_f32(z, off);     // lanes c*V .. c*V+V-1: the V slots of component c
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const uint32_t j = j0 + (uint32_t)u * W;
-            if (j < nq) { v[u] = ld4(V, j); d[u] = ld4(D, j); s[u] = ld4(S2, j); p[u] = ld4(AP, j); }
-            else { v[u] = f4_zero(); d[u] = f4_zero(); s[u] = f4_one(); p[u] = f4_zero(); }
-        }
-        if (withCh) {
-#pragma unroll
-            for (int u = 0; u < UN; ++u) { EVAL_ELEM_CH(v[u].x, d[u].x, s[u].x, p[u].x) EVAL_ELEM_CH(v[u].y, d[u].y, s[u].y, p[u].y) EVAL_ELEM_CH(v[u].z, d[u].z, s[u].z, p[u].z) EVAL_ELEM_CH(v[u].w, d[u].w, s[u].w, p[u].w) }
-        } else {
-#pragma unroll
-            for (int u = 0; u < UN; ++u) { EVAL_ELEM(v[u].x, d[u].x, s[u].x, p[u].x) EVAL_ELEM(v[u].y, d[u].y, s[u].y, p[u].y) EVAL_ELEM(v[u].z, d[u].z, s[u].z, p[u].z) EVAL_ELEM(v[u].w, d[u].w, s[u].w, p[u].w) }
-        }
+        for (int c = 0; c < NC; ++c) tot[c] = cg_shfl_f32(z, c * V);
     }
-    return a;
-}
-// DenseNormalModel.cpp:200-212: same row, v = other[:,c1] - other[:,c2]
-template <int UN>
-CG_DEVICE EvalAcc eval_partial_two_same(const SamplerDev &S, uint32_t row, uint32_t c1, uint32_t c2)
-{
-    const uint32_t nq = S.Npad >> 2, W = cg_bdim(), t = cg_tid();
-    const float *D = S.D + (size_t)row * S.Npad, *S2 = S.S2 + (size_t)row * S.Npad, *AP = S.AP + (size_t)row * S.Npad;
-    const float *V1 = S.other + (size_t)c1 * S.Npad, *V2 = S.other + (size_t)c2 * S.Npad;
-    EvalAcc a; a.s = 0.f; a.m = 0.f;
-#if defined(GEN_PROFILE)
-    if (S.dbg & 4u) return a;
-#endif
-    for (uint32_t j0 = t; j0 < nq; j0 += UN * W) {
-        cg_f4 v1[UN], v2[UN], d[UN], s[UN], p[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const uint32_t j = j0 + (uint32_t)u * W;
-            if (j < nq) { v1[u] = ld4(V1, j); v2[u] = ld4(V2, j); d[u] = ld4(D, j); s[u] = ld4(S2, j); p[u] = ld4(AP, j); }
-            else { v1[u] = f4_zero(); v2[u] = f4_zero(); d[u] = f4_zero(); s[u] = f4_one(); p[u] = f4_zero(); }
-        }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            { float v = v1[u].x - v2[u].x; EVAL_ELEM(v, d[u].x, s[u].x, p[u].x) }
-            { float v = v1[u].y - v2[u].y; EVAL_ELEM(v, d[u].y, s[u].y, p[u].y) }
-            { float v = v1[u].z - v2[u].z; EVAL_ELEM(v, d[u].z, s[u].z, p[u].z) }
-            { float v = v1[u].w - v2[u].w; EVAL_ELEM(v, d[u].w, s[u].w, p[u].w) }
-        }
-    }
-    return a;
 }
 
-// ascending xor butterfly over the W lanes of the workgroup; every lane returns the same bits
-CG_DEVICE EvalAcc eval_block_reduce(EvalAcc a, float *lds /* [32] */)
+// one component: wave butterfly of slot `j`'s partial, parked for eval_vfinish<1, V> (one wave: the total)
+template <int V>
+CG_DEVICE void eval_vpark(float x, int j, float *lds, float (&tot)[1])
 {
-    for (int off = 1; off < 64; off <<= 1) {
-        a.s = a.s + cg_shfl_xor_f32(a.s, off);
-        a.m = a.m + cg_shfl_xor_f32(a.m, off);
+    for (int off = 1; off < 64; off <<= 1) x = x + cg_shfl_xor_f32(x, off);
+    const uint32_t t = cg_tid();
+    if (cg_bdim() > 64u) { if ((t & 63u) == 0) lds[(t >> 6) * V + j] = x; }
+    else tot[0] = x;
+}
+
+// Alpha parameters of NR rows (NR = 2: the two rows of a move / exchange across rows, loaded together), summed
+// in lane order; tot = {s, s_mu} per row, valid in wave 0 (in every lane of a one-wave workgroup).  The slots
+// are processed G at a time: their chunks are loaded before any is consumed (4*G*NR independent float4 loads
+// in flight), reduced over the wave and parked in LDS, so a thread never holds more than G slots.  A chunk
+// index past the row reads nothing and contributes (v=0, S2=1, D=AP=0) -> +0 to both sums, which leaves them
+// bit-unchanged.  lds: [16][2*NR][V].
+template <int V, int G, int NR, int MODE>
+CG_DEVICE void eval_alpha(const SamplerDev &S, const uint32_t (&row)[NR], const uint32_t (&col)[NR], uint32_t col2, float ch, float *lds, float (&tot)[2 * NR])
+{
+    constexpr int NC = 2 * NR, NV = NC * V;
+    const uint32_t nq = S.Npad >> 2, BS = cg_bdim(), t = cg_tid(), W = (uint32_t)V * BS, nw = BS >> 6;
+#pragma unroll 1
+    for (int g0 = 0; g0 < V; g0 += G) {
+        float ps[NR][G], pm[NR][G];
+        for (int r = 0; r < NR; ++r) for (int u = 0; u < G; ++u) { ps[r][u] = 0.f; pm[r][u] = 0.f; }
+#if defined(GEN_PROFILE)
+        if (!(S.dbg & 4u))
+#endif
+        for (uint32_t base = (uint32_t)g0 * BS; base < nq; base += W) {
+            cg_f4 v[NR][G], w2[G], d[NR][G], s[NR][G], p[NR][G];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const float *Dr = S.D + (size_t)row[r] * S.Npad, *Sr = S.S2 + (size_t)row[r] * S.Npad, *Ar = S.AP + (size_t)row[r] * S.Npad;
+                const float *Vr = S.other + (size_t)col[r] * S.Npad, *V2 = S.other + (size_t)col2 * S.Npad;
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const uint32_t j = base + (uint32_t)u * BS + t;
+                    if (j < nq) { v[r][u] = ld4(Vr, j); d[r][u] = ld4(Dr, j); s[r][u] = ld4(Sr, j); p[r][u] = ld4(Ar, j); if (MODE == EVAL_MODE_SAME) w2[u] = ld4(V2, j); }
+                    else { v[r][u] = f4_zero(); d[r][u] = f4_zero(); s[r][u] = f4_one(); p[r][u] = f4_zero(); if (MODE == EVAL_MODE_SAME) w2[u] = f4_zero(); }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    EvalAcc a; a.s = ps[r][u]; a.m = pm[r][u];
+                    if (MODE == EVAL_MODE_CH) { EVAL_ELEM_CH(v[r][u].x, d[r][u].x, s[r][u].x, p[r][u].x) EVAL_ELEM_CH(v[r][u].y, d[r][u].y, s[r][u].y, p[r][u].y) EVAL_ELEM_CH(v[r][u].z, d[r][u].z, s[r][u].z, p[r][u].z) EVAL_ELEM_CH(v[r][u].w, d[r][u].w, s[r][u].w, p[r][u].w) }
+                    else if (MODE == EVAL_MODE_SAME) {
+                        { float x = v[r][u].x - w2[u].x; EVAL_ELEM(x, d[r][u].x, s[r][u].x, p[r][u].x) }
+                        { float x = v[r][u].y - w2[u].y; EVAL_ELEM(x, d[r][u].y, s[r][u].y, p[r][u].y) }
+                        { float x = v[r][u].z - w2[u].z; EVAL_ELEM(x, d[r][u].z, s[r][u].z, p[r][u].z) }
+                        { float x = v[r][u].w - w2[u].w; EVAL_ELEM(x, d[r][u].w, s[r][u].w, p[r][u].w) }
+                    } else { EVAL_ELEM(v[r][u].x, d[r][u].x, s[r][u].x, p[r][u].x) EVAL_ELEM(v[r][u].y, d[r][u].y, s[r][u].y, p[r][u].y) EVAL_ELEM(v[r][u].z, d[r][u].z, s[r][u].z, p[r][u].z) EVAL_ELEM(v[r][u].w, d[r][u].w, s[r][u].w, p[r][u].w) }
+                    ps[r][u] = a.s; pm[r][u] = a.m;
+                }
+            }
+        }
+        // bits 0-5 of the virtual lane index: the wave butterfly
+        for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+#pragma unroll
+                for (int u = 0; u < G; ++u) { ps[r][u] = ps[r][u] + cg_shfl_xor_f32(ps[r][u], off); pm[r][u] = pm[r][u] + cg_shfl_xor_f32(pm[r][u], off); }
+            }
+        }
+        if (nw > 1) {
+            if ((t & 63u) == 0) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+#pragma unroll
+                    for (int u = 0; u < G; ++u) { lds[(t >> 6) * NV + (2 * r) * V + g0 + u] = ps[r][u]; lds[(t >> 6) * NV + (2 * r + 1) * V + g0 + u] = pm[r][u]; }
+                }
+            }
+        } else {
+            // one wave: V == 1, the butterfly left the totals in every lane
+#pragma unroll
+            for (int r = 0; r < NR; ++r) { tot[2 * r] = ps[r][0]; tot[2 * r + 1] = pm[r][0]; }
+        }
     }
-    const uint32_t nw = cg_bdim() >> 6;
-    if (nw > 1) {
-        const uint32_t t = cg_tid();
-        if ((t & 63u) == 0) { lds[t >> 6] = a.s; lds[16 + (t >> 6)] = a.m; }
-        cg_sync();
-        float ws[16], wm[16];
-        for (uint32_t i = 0; i < 16; ++i) { ws[i] = i < nw ? lds[i] : 0.f; wm[i] = i < nw ? lds[16 + i] : 0.f; }
-        for (uint32_t stride = 1; stride < nw; stride <<= 1)
-            for (uint32_t i = 0; i + stride < 16; i += 2 * stride) { ws[i] = ws[i] + ws[i + stride]; wm[i] = wm[i] + wm[i + stride]; }
-        a.s = ws[0]; a.m = wm[0];
-        cg_sync();
-    }
-    return a;
+    if (nw > 1) { cg_sync(); eval_vfinish<NC, V>(lds, tot); }
 }
 
 // DenseNormalModel.cpp:243-258: AP[:,row] += delta * other[:,col]
 template <int UN>
 CG_DEVICE void eval_update_ap(const SamplerDev &S, uint32_t row, uint32_t col, float delta)
 {
-    const uint32_t nq = S.Npad >> 2, W = cg_bdim(), t = cg_tid();
+    const uint32_t nq = S.Npad >> 2, BS = cg_bdim(), t = cg_tid();
     float *AP = S.AP + (size_t)row * S.Npad;
-    const float *V = S.other + (size_t)col * S.Npad;
+    const float *Vc = S.other + (size_t)col * S.Npad;
 #if defined(GEN_PROFILE)
     if (S.dbg & 2u) return;
 #endif
-    for (uint32_t j0 = t; j0 < nq; j0 += UN * W) {
+    for (uint32_t j0 = t; j0 < nq; j0 += UN * BS) {
         cg_f4 v[UN], p[UN];
 #pragma unroll
-        for (int u = 0; u < UN; ++u) { const uint32_t j = j0 + (uint32_t)u * W; if (j < nq) { v[u] = ld4(V, j); p[u] = ld4(AP, j); } else { v[u] = f4_zero(); p[u] = f4_zero(); } }
+        for (int u = 0; u < UN; ++u) { const uint32_t j = j0 + (uint32_t)u * BS; if (j < nq) { v[u] = ld4(Vc, j); p[u] = ld4(AP, j); } else { v[u] = f4_zero(); p[u] = f4_zero(); } }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const uint32_t j = j0 + (uint32_t)u * W;
+            const uint32_t j = j0 + (uint32_t)u * BS;
             if (j < nq) {
                 cg_f4 q = p[u];
                 q.x = q.x + delta * v[u].x; q.y = q.y + delta * v[u].y; q.z = q.z + delta * v[u].z; q.w = q.w + delta * v[u].w;
@@ -180,10 +206,10 @@ CG_DEVICE void eval_domain_move(const SamplerDev &S, uint32_t h, uint64_t oldPos
 
 #if defined(GEN_PROFILE) && !defined(COGAPS_EMUL)
 // dev: timestamps of the first 16 workgroups of a launch (lane 0 of the first and of the last wave)
-__device__ unsigned long long g_eval_timeline[16 * 2 * 12];
+__device__ unsigned long long g_eval_timeline[2 * 16 * 2 * 12];     // [narrow | wide workgroups]
 #define EVAL_TS(id) do { if ((t & 63u) == 0u && ets_n < 11u) { ets[ets_n++] = ((unsigned long long)cg_clock() << 8) | (unsigned long long)(id); } } while (0)
-#define EVAL_TS_DUMP(ty) do { const uint32_t lastW_ = (cg_bdim() - 1u) >> 6; if (cg_bid() < 16u && (t & 63u) == 0u && ((t >> 6) == 0u || (t >> 6) == lastW_) && qlen >= 100u) { \
-    unsigned long long *o_ = &g_eval_timeline[(cg_bid() * 2u + ((t >> 6) ? 1u : 0u)) * 12u]; o_[0] = (unsigned long long)(ty); for (uint32_t i_ = 0; i_ < 11u; ++i_) o_[1 + i_] = i_ < ets_n ? ets[i_] : 0ull; } } while (0)
+#define EVAL_TS_DUMP(ty) do { const uint32_t lastW_ = (cg_bdim() - 1u) >> 6; if (cg_bid() < 16u && (t & 63u) == 0u && ((t >> 6) == 0u || (t >> 6) == lastW_) && qlen >= 40u) { \
+    unsigned long long *o_ = &g_eval_timeline[((cg_bdim() > 256u ? 16u : 0u) * 2u + cg_bid() * 2u + ((t >> 6) ? 1u : 0u)) * 12u]; o_[0] = (unsigned long long)(ty); for (uint32_t i_ = 0; i_ < 11u; ++i_) o_[1 + i_] = i_ < ets_n ? ets[i_] : 0ull; } } while (0)
 #define EVAL_PIN(x) asm volatile("" : "+v"(x) :: "memory")
 #else
 #define EVAL_TS(id) do { } while (0)
@@ -191,70 +217,69 @@ __device__ unsigned long long g_eval_timeline[16 * 2 * 12];
 #define EVAL_PIN(x) do { } while (0)
 #endif
 
-template <int UN>
+// G: virtual lanes whose chunks are in flight together (registers: 16*G*NR floats per thread)
+template <int V, int NR> struct EvalGroup { static constexpr int G = (V < 4 / NR) ? V : 4 / NR; };
+
+template <int V>
 CG_DEVICE void eval_body(const SamplerDev &S)
 {
 #if defined(GEN_PROFILE) && !defined(COGAPS_EMUL)
     unsigned long long ets[11]; uint32_t ets_n = 0;
 #endif
-    CG_SHARED float lds[32];
+    CG_SHARED float lds[16 * 4 * V];
     CG_SHARED float decf; CG_SHARED uint32_t deci;     // decision of wave 0, broadcast to the other waves
     const uint32_t t = cg_tid();
     unsigned long long eprof_last = cg_clock(); (void)eprof_last;
-    const float T = S.annealTemp, lambda = S.lambda;
+    const float lambda = S.lambda;
     EVAL_TS(0);
     const bool multiWave = cg_bdim() > 64u;
     const bool scalarLane = !multiWave || t < 64u;       // the per-proposal scalar math (LUTs, fp64 log) runs in wave 0 only
 #define EVAL_BCAST(F0, I0) do { if (multiWave) { if (t == 0) { decf = (F0); deci = (I0); } cg_sync(); (F0) = decf; (I0) = deci; } } while (0)
     for (uint32_t q = cg_bid(); ; q += cg_gdim()) {
-        // the record is fetched together with the queue length (slot q always exists: q < queueCap)
+        // one trip: the record (slot q always exists: q < queueCap), the queue length, the annealing temperature
         const PropRec p = S.queue[q < S.queueCap ? q : 0u];
         const uint32_t qlen = S.gs->qlen;
+        const float T = S.gs->annealTemp;
         if (q >= qlen) break;
         { uint32_t ty_ = p.type; EVAL_PIN(ty_); }
         EVAL_TS(1);
         uint64_t rng = p.rng; uint32_t nUpd = 0;
-        // the scalars this proposal depends on: issued now, consumed after the row loads are in flight.
-        // lane 0 rewrites them at the end of the step; the barriers inside the reduction (or the explicit
-        // one on the paths without a reduction) keep it from overtaking a slower wave's reads.
         const bool two = (p.type == 'M' || p.type == 'E');
-        const float m1 = (p.type == 'B') ? 0.f : S.atoms[p.h1].mass;
-        const float m2 = (p.type == 'E') ? S.atoms[p.h2].mass : 0.f;
-        const float old1 = S.mat[(size_t)p.c1 * S.Mpad + p.r1];
-        const float old2 = two ? S.mat[(size_t)p.c2 * S.Mpad + p.r2] : 0.f;
-        const uint64_t curPos = (p.type == 'M') ? S.atoms[p.h1].pos : 0ull;
-        const bool gibbs1 = S.otherColPos[p.c1] > 0u;
-        const bool gibbs2 = two ? (S.otherColPos[p.c2] > 0u) : false;
+        const float m1 = p.m1, m2 = p.m2, old1 = p.old1, old2 = p.old2;
+        const uint64_t curPos = p.curPos;
+        const bool gibbs1 = (p.gibbs & 1u) != 0u, gibbs2 = (p.gibbs & 2u) != 0u;
         EVAL_PROF(0);
-        { float a_ = m1, b_ = m2, c_ = old1, d_ = old2; uint32_t g_ = (gibbs1 ? 1u : 0u) | (gibbs2 ? 2u : 0u); EVAL_PIN(a_); EVAL_PIN(b_); EVAL_PIN(c_); EVAL_PIN(d_); EVAL_PIN(g_); }
         EVAL_TS(2);
 #if defined(GEN_PROFILE)
-        if (S.dbg & 1u) { if (p.type == 0xFFu || m1 == -1.f) S.queueUnits[q] = (uint32_t)old1; break; }   // record + scalars only
+        if (S.dbg & 1u) { if (p.type == 0xFFu || m1 == -1.f) S.queueUnits[q] = (uint32_t)old1; break; }   // record only
 #endif
+        const uint32_t rowA[1] = {p.r1}, colA[1] = {p.c1};
         if (p.type == 'B') {
             // ---------------------------------------------------------------- birth (:127-144)
             OptF mass; mass.v = 0.f; mass.has = false;
             float bv = 0.f; uint32_t bhas = 0;
             if (gibbs1) {
-                EvalAcc a = eval_block_reduce(eval_partial_one<UN>(S, p.r1, p.c1, false, 0.f), lds);
-                EVAL_PIN(a.s); EVAL_TS(3);
-                if (scalarLane) { OptF g = gm_gibbs_mass(a.s * T, a.m * T, 0.f, S.maxGibbsMass, rng, S.luts, true, lambda); bv = g.v; bhas = g.has ? 1u : 0u; }
+                float tot[2] = {0.f, 0.f};
+                eval_alpha<V, EvalGroup<V, 1>::G, 1, EVAL_MODE_ONE>(S, rowA, colA, 0u, 0.f, lds, tot);
+                EVAL_PIN(tot[0]); EVAL_TS(3);
+                if (scalarLane) { OptF g = gm_gibbs_mass(tot[0] * T, tot[1] * T, 0.f, S.maxGibbsMass, rng, S.luts, true, lambda); bv = g.v; bhas = g.has ? 1u : 0u; }
             } else if (scalarLane) { bv = pcg_exponential(rng, lambda); bhas = 1u; }
             EVAL_PIN(bv); EVAL_TS(4);
             EVAL_BCAST(bv, bhas);
             EVAL_TS(5);
             mass.v = bv; mass.has = bhas != 0u;
             if (mass.has && mass.v >= GAPS_EPSILON) {
-                eval_update_ap<UN>(S, p.r1, p.c1, mass.v); ++nUpd;                          // changeMatrix
+                eval_update_ap<(V >= 4 ? 4 : 8)>(S, p.r1, p.c1, mass.v); ++nUpd;                          // changeMatrix
                 if (t == 0) { S.atoms[p.h1].mass = mass.v; eval_store_matrix(S, p.r1, p.c1, old1, old1 + mass.v); }
             } else if (t == 0) eval_cache_erase(S, p.h1);
         } else if (p.type == 'D') {
             // ---------------------------------------------------------------- death / rebirth (:148-180)
             float rebirth = m1;
-            EvalAcc a = eval_block_reduce(eval_partial_one<UN>(S, p.r1, p.c1, true, -1.f * m1), lds);
-            const float s = a.s * T, smu = a.m * T;
+            float tot[2] = {0.f, 0.f};
+            eval_alpha<V, EvalGroup<V, 1>::G, 1, EVAL_MODE_CH>(S, rowA, colA, 0u, -1.f * m1, lds, tot);
+            const float s = tot[0] * T, smu = tot[1] * T;
             EVAL_PROF(1);
-            EVAL_PIN(a.s); EVAL_TS(3);
+            EVAL_PIN(tot[0]); EVAL_TS(3);
             uint32_t acc = 0;
             if (scalarLane) {
                 if (gibbs1) {
@@ -272,12 +297,12 @@ CG_DEVICE void eval_body(const SamplerDev &S)
             if (accept) {
                 if (rebirth != m1) {
                     const float nv = gm_max(old1 + (rebirth - m1), 0.f);            // safelyChangeMatrix
-                    eval_update_ap<UN>(S, p.r1, p.c1, nv - old1); ++nUpd;
+                    eval_update_ap<(V >= 4 ? 4 : 8)>(S, p.r1, p.c1, nv - old1); ++nUpd;
                     if (t == 0) { eval_store_matrix(S, p.r1, p.c1, old1, nv); S.atoms[p.h1].mass = rebirth; }
                 }
             } else {
                 const float nv = gm_max(old1 + (-1.f * m1), 0.f);
-                eval_update_ap<UN>(S, p.r1, p.c1, nv - old1); ++nUpd;
+                eval_update_ap<(V >= 4 ? 4 : 8)>(S, p.r1, p.c1, nv - old1); ++nUpd;
                 if (t == 0) { eval_store_matrix(S, p.r1, p.c1, old1, nv); eval_cache_erase(S, p.h1); }
             }
             EVAL_PROF(3);
@@ -287,15 +312,17 @@ CG_DEVICE void eval_body(const SamplerDev &S)
             const bool need = (p.type == 'M') || gibbs1 || gibbs2;                  // exchange: canUseGibbs(c1,c2)
             if (need) {
                 if (p.r1 == p.r2) {
-                    EvalAcc a = eval_block_reduce(eval_partial_two_same<UN>(S, p.r1, p.c1, p.c2), lds);
-                    s = a.s; smu = a.m;
+                    float tot[2] = {0.f, 0.f};
+                    eval_alpha<V, EvalGroup<V, 1>::G, 1, EVAL_MODE_SAME>(S, rowA, colA, p.c2, 0.f, lds, tot);
+                    s = tot[0]; smu = tot[1];
                 } else {
-                    EvalAcc a = eval_block_reduce(eval_partial_one<UN>(S, p.r1, p.c1, false, 0.f), lds);
-                    EvalAcc b = eval_block_reduce(eval_partial_one<UN>(S, p.r2, p.c2, false, 0.f), lds);
-                    s = a.s + b.s; smu = a.m - b.m;                                 // AlphaParameters.cpp:11-14
+                    const uint32_t rowAB[2] = {p.r1, p.r2}, colAB[2] = {p.c1, p.c2};
+                    float tot[4] = {0.f, 0.f, 0.f, 0.f};
+                    eval_alpha<V, EvalGroup<V, 2>::G, 2, EVAL_MODE_ONE>(S, rowAB, colAB, 0u, 0.f, lds, tot);
+                    s = tot[0] + tot[2]; smu = tot[1] - tot[3];                     // AlphaParameters.cpp:11-14
                 }
                 s = s * T; smu = smu * T;
-            } else if (multiWave) cg_sync();
+            }
             EVAL_PIN(s); EVAL_TS(3);
             if (p.type == 'M') {
                 // ------------------------------------------------------------ move (:184-196)
@@ -306,8 +333,8 @@ CG_DEVICE void eval_body(const SamplerDev &S)
                 EVAL_TS(5);
                 if (acc) {
                     const float nv1 = gm_max(old1 + (-m1), 0.f);                    // safelyChangeMatrix(r1,c1,-m)
-                    eval_update_ap<UN>(S, p.r1, p.c1, nv1 - old1); ++nUpd;
-                    eval_update_ap<UN>(S, p.r2, p.c2, m1); ++nUpd;                          // changeMatrix(r2,c2,+m); same lane owns the same elements
+                    eval_update_ap<(V >= 4 ? 4 : 8)>(S, p.r1, p.c1, nv1 - old1); ++nUpd;
+                    eval_update_ap<(V >= 4 ? 4 : 8)>(S, p.r2, p.c2, m1); ++nUpd;                          // changeMatrix(r2,c2,+m); same lane owns the same elements
                     if (t == 0) {
                         eval_domain_move(S, p.h1, curPos, p.pos);
                         eval_store_matrix(S, p.r1, p.c1, old1, nv1);
@@ -325,9 +352,9 @@ CG_DEVICE void eval_body(const SamplerDev &S)
                 const float n1 = m1 + g.v, n2 = m2 - g.v;
                 if (g.has && n1 > GAPS_EPSILON && n2 > GAPS_EPSILON) {
                     const float nv1 = gm_max(old1 + (n1 - m1), 0.f);
-                    eval_update_ap<UN>(S, p.r1, p.c1, nv1 - old1); ++nUpd;
+                    eval_update_ap<(V >= 4 ? 4 : 8)>(S, p.r1, p.c1, nv1 - old1); ++nUpd;
                     const float nv2 = gm_max(old2 + (n2 - m2), 0.f);
-                    eval_update_ap<UN>(S, p.r2, p.c2, nv2 - old2); ++nUpd;
+                    eval_update_ap<(V >= 4 ? 4 : 8)>(S, p.r2, p.c2, nv2 - old2); ++nUpd;
                     if (t == 0) {
                         eval_store_matrix(S, p.r1, p.c1, old1, nv1);
                         eval_store_matrix(S, p.r2, p.c2, old2, nv2);
@@ -346,11 +373,11 @@ CG_DEVICE void eval_body(const SamplerDev &S)
             else if (p.type == 'M' || gibbs1 || gibbs2) units += (p.r1 == p.r2) ? 5u : 8u;
             S.queueUnits[q] = units;
         }
-        if (q + cg_gdim() >= qlen) break;   // last proposal of this workgroup: nothing left to order
-        cg_sync();   // lane 0's scalar writes are ordered before the next proposal's reads
+        if (q + cg_gdim() >= qlen) break;   // last proposal of this workgroup
+        cg_sync();   // the LDS scratch is reused by the next proposal
     }
 }
 
-// UN = 8: workgroups of up to 256 lanes (512-VGPR budget); UN = 4: up to 1024 lanes (128 VGPRs per lane)
-template <int UN>
-CG_KERNEL void CG_LAUNCH_BOUNDS(UN == 8 ? 256 : 1024) eval_kernel(SamplerDev S) { eval_body<UN>(S); }
+// V = virtual lanes per thread: workgroups of BS = W / V <= 1024 threads
+template <int V>
+CG_KERNEL void CG_LAUNCH_BOUNDS(1024) eval_kernel(SamplerDev S) { eval_body<V>(S); }

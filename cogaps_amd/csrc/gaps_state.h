@@ -18,7 +18,11 @@ struct alignas(32) AtomRec {
     uint32_t pad0, pad1;
 };
 
-// One queued proposal (ProposalQueue.h:15-28).  64 bytes.
+// One queued proposal (ProposalQueue.h:15-28) plus every scalar its evaluation starts from, so that the
+// evaluation kernel's first memory trip (this record) is also its last dependent one before the row loads.
+// 96 bytes.  The copied values cannot go stale: a batch never holds two proposals on one row or one atom, the
+// matrix only changes in evaluation kernels, and an attempt that follows a same-bin exchange of its atoms in
+// the same window is cut off as a hazard and re-drawn in the next round.
 struct alignas(16) PropRec {
     uint64_t pos;        // move destination
     uint64_t rng;        // PCG state after the populate-phase draws
@@ -26,6 +30,11 @@ struct alignas(16) PropRec {
     uint32_t i1, i2;     // their indices in `vec` at populate time (trace / parity only)
     uint32_t r1, c1, r2, c2;
     uint32_t type;       // 'B','D','M','E'
+    uint32_t gibbs;      // bit 0 / 1: canUseGibbs(c1) / (c2), i.e. the other matrix has a positive entry in that pattern
+    float m1, m2;        // atom masses (death, move: m1; exchange: both)
+    float old1, old2;    // mMatrix(r1,c1), mMatrix(r2,c2)
+    uint64_t curPos;     // move: the atom's position
+    uint32_t batch;      // trace only
     uint32_t pad[3];
 };
 
@@ -49,7 +58,7 @@ struct GenScalars {
     uint32_t error;           // sticky error code (capacity overflow ...)
     uint32_t traceOn, traceCount, traceCap, traceBatchCount;
     uint32_t updateFlushed;   // set by the generator once nDone == nSteps and the last erase cache is flushed
-    uint32_t pad0;
+    float annealTemp;         // DenseNormalModel::mAnnealingTemp for this update (kernel parameters stay constant so that launches can be replayed from a graph)
     unsigned long long evalBytes;   // algorithmic HBM bytes of the evaluation kernel (roofline numerator)
     unsigned long long evalProps;   // proposals evaluated
     uint32_t pad[2];
@@ -74,7 +83,7 @@ struct SamplerDev {
     const float *other;// the other sampler's mat: [K][Npad]
     uint32_t *colPos;  // [K] number of entries > 0 in each column of `mat`
     const uint32_t *otherColPos; // the other sampler's colPos (canUseGibbs, DenseNormalModel.cpp:100-108)
-    float lambda, maxGibbsMass, annealTemp, alpha;
+    float lambda, maxGibbsMass, alpha;   // (the annealing temperature changes per iteration: GenScalars::annealTemp)
     GapsLuts luts;
     // ---- ConcurrentAtomicDomain ---------------------------------------------------------------
     AtomRec *atoms;    // [atomCap] by handle

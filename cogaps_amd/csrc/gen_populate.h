@@ -293,6 +293,9 @@ CG_DEVICE void gen_body(const SamplerDev &S)
 #if defined(GEN_SUBMARKS)
         if (b3.pos == 12345678u || lp == 0x123456789ull || rp == 0x123456789ull) flags |= 0x80000000u;
 #endif
+        // the scalars the evaluation starts from travel in the queue record (consumed at commit)
+        float old1 = 0.f, old2 = 0.f; uint32_t gib1 = 0, gib2 = 0;
+        if (isB || pick) { old1 = S.mat[(size_t)c1 * S.Mpad + r1]; gib1 = S.otherColPos[c1]; }
         GEN_PIN(b3.pos); GEN_PIN(lp); GEN_PIN(rp);
         GEN_TS(13);
         GEN_SUBS(12);
@@ -314,6 +317,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
                 flags &= ~(GEN_F_BINEMPTY | GEN_F_WORDZERO | GEN_F_NEWHEAD);
                 if (nh) flags |= GEN_F_NEWHEAD;
                 if (S.binHead[bin] == CG_NONE) { flags |= GEN_F_BINEMPTY; if (S.bits0[bin >> 6] == 0ull) flags |= GEN_F_WORDZERO; }
+                old1 = S.mat[(size_t)c1 * S.Mpad + r1]; gib1 = S.otherColPos[c1];      // the retry may have moved the birth to another bin
             }
         } else if (pick) {
             if (type == 'M') {
@@ -337,6 +341,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
                 }
             }
         }
+        if (pick && (type == 'M' || type == 'E')) { old2 = S.mat[(size_t)c2 * S.Mpad + r2]; gib2 = S.otherColPos[c2]; }
         GEN_PIN(pos); GEN_PIN(flags); GEN_PIN(r2); GEN_PIN(c2); GEN_PIN(rbpos); GEN_PIN(nm1);
         GEN_TS(14);
         GEN_PROF_R(2, 9);
@@ -431,8 +436,9 @@ CG_DEVICE void gen_body(const SamplerDev &S)
             key[1] = GEN_TAB_ROW | r2; use[1] = tM | tE;
             key[2] = ((tM | tB) & hasL) ? hl : GEN_TAB_FRONT; use[2] = tM | tB | (tE & noRight);
             key[3] = hr; use[3] = (tM | tB) & hasR;
-            key[4] = h1; use[4] = tM | tE;
-            key[5] = h2; use[5] = tE & inl;
+            const uint32_t tD = type == 'D';
+            key[4] = h1; use[4] = tM | tE | tD;
+            key[5] = h2; use[5] = tE;
             uint32_t bk[6]; GenTabKeys kq[6];
             for (int k = 0; k < 6; ++k) { bk[k] = gen_tab_bucket(gen_tab_hash(key[k])); kq[k] = *(const GenTabKeys *)&sh.bkey[4u * bk[k]]; }
             uint32_t sl[6], hit[6], over = 0;
@@ -461,7 +467,9 @@ CG_DEVICE void gen_body(const SamplerDev &S)
             // move or exchange of this window touched an atom whose position this attempt relied on
             uint32_t haz = tB & (GEN_E(2, gap) | GEN_E(2, inl) | GEN_E(3, inl));
             haz |= tM & (GEN_E(4, inl) | GEN_E(2, inl) | GEN_E(3, inl));
-            haz |= tE & inl & (GEN_E(4, inl) | GEN_E(5, inl));
+            // death / exchange: the masses in the queue record were read before an earlier same-bin exchange of
+            // this window rewrote them
+            haz |= (tE | tD) & (GEN_E(4, inl) | GEN_E(5, inl));
             if (tB) {
                 // mProposedMoves.overlap(pos): a neighbour has a queued move whose interval covers pos
                 const uint32_t uL = GEN_E(2, used), uR = GEN_E(3, used);
@@ -486,8 +494,9 @@ CG_DEVICE void gen_body(const SamplerDev &S)
             pk[3] = GEN_K_ATOM; pid[3] = hr; pu[3] = (tM || tB) && hr != CG_NONE;
             pk[4] = GEN_K_GAP; pid[4] = (tB || tM) ? keyL : h1 + 1u; pu[4] = tB || tM || tE;
             pk[5] = GEN_K_GAP; pid[5] = tM ? h1 + 1u : 0u; pu[5] = tM || (tE && !(flags & GEN_F_HASRIGHT));
-            pk[6] = GEN_K_INL; pid[6] = tB ? hl : h1; pu[6] = tM || (tB && hl != CG_NONE) || (tE && inl);
-            pk[7] = GEN_K_INL; pid[7] = tM ? hl : (tB ? hr : h2); pu[7] = (tM && hl != CG_NONE) || (tB && hr != CG_NONE) || (tE && inl);
+            const bool tD = type == 'D';
+            pk[6] = GEN_K_INL; pid[6] = tB ? hl : h1; pu[6] = tM || (tB && hl != CG_NONE) || tE || tD;
+            pk[7] = GEN_K_INL; pid[7] = tM ? hl : (tB ? hr : h2); pu[7] = (tM && hl != CG_NONE) || (tB && hr != CG_NONE) || tE;
             pk[8] = GEN_K_INL; pid[8] = hr; pu[8] = tM && hr != CG_NONE;
             int res[9]; uint32_t rix[9]; uint64_t d9 = 0, d10 = 0;
             {
@@ -522,7 +531,10 @@ CG_DEVICE void gen_body(const SamplerDev &S)
             } else if (tE) {
                 // an earlier birth right of the centre is the true partner (or, for the last atom, a new front())
                 if (res[4] == 2 || res[5] == 2) fail = true;
-                if (inl && (res[6] == 2 || res[7] == 2)) haz = true;
+                // the masses in the queue record were read before an earlier same-bin exchange of this window rewrote them
+                if (res[6] == 2 || res[7] == 2) haz = true;
+            } else if (tD) {
+                if (res[6] == 2) haz = true;
             }
             if (haz) flags |= GEN_F_HAZARD; else if (fail) flags |= GEN_F_FAIL;
         }
@@ -591,9 +603,13 @@ CG_DEVICE void gen_body(const SamplerDev &S)
                 if (slot >= S.queueCap) gs->error = GAPS_ERR_QUEUE_CAP;
                 else {
                     PropRec p; p.pos = (type == 'M') ? pos : 0ull; p.rng = rng; p.h1 = h1; p.h2 = h2; p.i1 = i1; p.i2 = i2;
-                    p.r1 = r1; p.c1 = c1; p.r2 = r2; p.c2 = c2; p.type = type; p.pad[0] = p.pad[1] = p.pad[2] = 0;
+                    p.r1 = r1; p.c1 = c1; p.r2 = r2; p.c2 = c2; p.type = type; p.batch = 0; p.pad[0] = p.pad[1] = p.pad[2] = 0;
+                    const bool two = type == 'M' || type == 'E';
+                    p.gibbs = (gib1 > 0u ? 1u : 0u) | ((two && gib2 > 0u) ? 2u : 0u);
+                    p.m1 = (type == 'B') ? 0.f : a.mass; p.m2 = (type == 'E') ? b3.mass : 0.f;
+                    p.old1 = old1; p.old2 = two ? old2 : 0.f; p.curPos = (type == 'M') ? cpos : 0ull;
                     S.queue[slot] = p;
-                    if (sh.g.traceOn) { const uint32_t ti = sh.g.traceCount + slot; if (ti < sh.g.traceCap) { p.pad[0] = sh.g.nBatches; S.trace[ti] = p; } }
+                    if (sh.g.traceOn) { const uint32_t ti = sh.g.traceCount + slot; if (ti < sh.g.traceCap) { p.batch = sh.g.nBatches; S.trace[ti] = p; } }
                 }
             }
         }

@@ -43,6 +43,7 @@ CG_DEVICE int cg_popc64(unsigned long long x) { return __popcll(x); }
 // loads of words that other waves of the workgroup update with L2 atomics: bypass the CU's L1
 CG_DEVICE unsigned long long cg_load_l2_u64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 CG_DEVICE float cg_shfl_xor_f32(float v, int mask) { return __shfl_xor(v, mask, 64); }
+CG_DEVICE float cg_shfl_f32(float v, int lane) { return __shfl(v, lane, 64); }
 CG_DEVICE unsigned long long cg_clock() { return __builtin_readcyclecounter(); }
 CG_DEVICE int cg_clz64(unsigned long long x) { return __clzll((long long)x); }
 CG_DEVICE int cg_ctz64(unsigned long long x) { return __ffsll((long long)x) - 1; }

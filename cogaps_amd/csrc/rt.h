@@ -29,6 +29,12 @@ inline void rt_event_destroy(rt_event_pair &) {}
 inline void rt_event_start(rt_event_pair &, rt_stream_t) {}
 inline void rt_event_stop(rt_event_pair &, rt_stream_t) {}
 inline float rt_event_ms(rt_event_pair &) { return 0.f; }
+struct rt_graph { };
+inline bool rt_graphs_supported() { return false; }
+inline void rt_capture_begin(rt_stream_t) {}
+inline void rt_capture_end(rt_stream_t, rt_graph &) {}
+inline void rt_graph_launch(rt_graph &, rt_stream_t) {}
+inline void rt_graph_destroy(rt_graph &) {}
 inline const char *rt_platform_name() { return "emulator (test only)"; }
 
 #else
@@ -54,6 +60,12 @@ inline void rt_event_destroy(rt_event_pair &e) { (void)hipEventDestroy(e.a); (vo
 inline void rt_event_start(rt_event_pair &e, rt_stream_t s) { RT_CHECK(hipEventRecord(e.a, s)); }
 inline void rt_event_stop(rt_event_pair &e, rt_stream_t s) { RT_CHECK(hipEventRecord(e.b, s)); }
 inline float rt_event_ms(rt_event_pair &e) { float ms = 0.f; RT_CHECK(hipEventSynchronize(e.b)); RT_CHECK(hipEventElapsedTime(&ms, e.a, e.b)); return ms; }
+struct rt_graph { hipGraph_t g = nullptr; hipGraphExec_t e = nullptr; };
+inline bool rt_graphs_supported() { return true; }
+inline void rt_capture_begin(rt_stream_t s) { RT_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal)); }
+inline void rt_capture_end(rt_stream_t s, rt_graph &gr) { RT_CHECK(hipStreamEndCapture(s, &gr.g)); RT_CHECK(hipGraphInstantiate(&gr.e, gr.g, nullptr, nullptr, 0)); }
+inline void rt_graph_launch(rt_graph &gr, rt_stream_t s) { RT_CHECK(hipGraphLaunch(gr.e, s)); }
+inline void rt_graph_destroy(rt_graph &gr) { if (gr.e) (void)hipGraphExecDestroy(gr.e); if (gr.g) (void)hipGraphDestroy(gr.g); gr.e = nullptr; gr.g = nullptr; }
 inline const char *rt_platform_name() { return "HIP gfx950"; }
 
 #endif

@@ -820,7 +820,7 @@ typedef struct go_sampler {
 /* lane-strided reduction (generalises SIMD.h PackedFloat: SIMD_INC lanes, here W lanes with G
  * consecutive elements per lane slot) followed by an ascending xor butterfly (the AVX hadd tree
  * of SIMD.h:102-107 widened to W lanes).  W <= 1 is the scalar build's sequential order. */
-#define GO_MAXW 1024
+#define GO_MAXW 16384
 typedef struct { float s[GO_MAXW], m[GO_MAXW]; } lane_acc;
 
 static void lanes_finish(lane_acc *a, uint32_t W, float *s, float *smu)

@@ -75,6 +75,17 @@ float wave_exchange_f32(float v, int mask)
     return r;
 }
 
+float wave_read_f32(float v, int lane)
+{
+    unsigned me = g_cur;
+    g_fibers[me].xch = v;
+    yield_to_sched(WAIT_WAVE);
+    unsigned src = (me & ~63u) | ((unsigned)lane & 63u);
+    float r = src < g_bdim ? g_fibers[src].xch : v;
+    yield_to_sched(WAIT_WAVE);
+    return r;
+}
+
 unsigned long long wave_ballot(bool p)
 {
     unsigned me = g_cur;

@@ -17,6 +17,7 @@ struct LaneCtx { unsigned tid, bid, bdim, gdim; };
 extern LaneCtx g_lane;
 void block_barrier();                       // __syncthreads()
 float wave_exchange_f32(float v, int src_lane_xor); // shfl_xor across the 64-lane wave
+float wave_read_f32(float v, int src_lane);         // shfl: read lane src_lane of the wave
 unsigned long long wave_ballot(bool p);
 void launch(unsigned grid, unsigned block, const std::function<void()> &body);
 }
@@ -42,6 +43,7 @@ inline unsigned long long cg_ballot(bool p) { return cgemu::wave_ballot(p); }
 inline int cg_popc64(unsigned long long x) { return __builtin_popcountll(x); }
 inline unsigned long long cg_load_l2_u64(const unsigned long long *p) { return *p; }
 inline float cg_shfl_xor_f32(float v, int mask) { return cgemu::wave_exchange_f32(v, mask); }
+inline float cg_shfl_f32(float v, int lane) { return cgemu::wave_read_f32(v, lane); }
 inline unsigned long long cg_clock() { return 0; }
 inline int cg_clz64(unsigned long long x) { return x ? __builtin_clzll(x) : 64; }
 inline int cg_ctz64(unsigned long long x) { return x ? __builtin_ctzll(x) : -1; }
