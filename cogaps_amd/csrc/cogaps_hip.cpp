@@ -173,7 +173,7 @@ static void free_sampler(HostSampler &h)
     SamplerDev &d = h.d;
     rt_free((void *)d.D); rt_free((void *)d.S2); rt_free(d.AP); rt_free(d.mat); rt_free(d.colPos);
     rt_free(d.atoms); rt_free(d.vec); rt_free(d.freeHandles); rt_free(d.binHead);
-    rt_free(d.bits0); rt_free(d.bits1); rt_free(d.bits2); rt_free(d.eraseList); rt_free(d.queue); rt_free(d.queueUnits);
+    rt_free(d.bits0); rt_free(d.bits1); rt_free(d.bits2); rt_free(d.eraseList); rt_free(d.queue); rt_free(d.queueUnits); rt_free(d.partials);
     rt_free(d.rowStamp); rt_free(d.atomStamp); rt_free(d.gapStamp); rt_free(d.inlineStamp); rt_free(d.atomDest);
     rt_free(d.gs); rt_free(d.trace); rt_free(d.traceBatchNproc); rt_free(d.traceBatchQlen);
     rt_free(h.Sraw); rt_free(h.seeds); rt_free_host(h.hSeeds); rt_free(h.partial);
@@ -227,7 +227,7 @@ static void build_sampler(cogaps_session *s, HostSampler &h, char name, const fl
     d.nWords0 = (uint32_t)((nBins + 63) / 64); d.nWords1 = (d.nWords0 + 63) / 64; d.nWords2 = (d.nWords1 + 63) / 64;
     d.bits0 = dalloc<unsigned long long>(d.nWords0); d.bits1 = dalloc<unsigned long long>(d.nWords1); d.bits2 = dalloc<unsigned long long>(d.nWords2);
     d.queueCap = d.M + 8; d.eraseCap = d.queueCap;
-    d.eraseList = dalloc<uint32_t>(d.eraseCap); d.queue = dalloc<PropRec>(d.queueCap); d.queueUnits = dalloc<uint32_t>(d.queueCap);
+    d.eraseList = dalloc<uint32_t>(d.eraseCap); d.queue = dalloc<PropRec>(d.queueCap); d.queueUnits = dalloc<uint32_t>(d.queueCap); d.partials = dalloc<float>((size_t)d.queueCap * 64);
     d.rowStamp = dalloc<unsigned long long>(d.M);
     d.atomStamp = dalloc<unsigned long long>(d.atomCap); d.gapStamp = dalloc<unsigned long long>((size_t)d.atomCap + 1);
     d.inlineStamp = dalloc<unsigned long long>(d.atomCap); d.atomDest = dalloc<uint64_t>(d.atomCap);
@@ -303,9 +303,21 @@ static void launch_gen(cogaps_session *s, HostSampler &h)
 }
 static void launch_eval(cogaps_session *s, HostSampler &h)
 {
-    const uint32_t grid = std::min<uint32_t>(h.d.queueCap, h.d.redW >= 512 ? 256u : 512u);
     const int slot = timing_slot(s, h, 1, h.evalLaunches);
-    LAUNCH_V(eval_kernel, h.d.redW, grid, s->stream, h.d);
+    if (h.d.redW <= 1024u) {
+        // one workgroup of W threads per proposal
+        const uint32_t grid = std::min<uint32_t>(h.d.queueCap, 512u);
+        RT_LAUNCH(eval_kernel<EVAL_FUSED>, grid, h.d.redW, s->stream, h.d, 1u);
+    } else {
+        // long data vectors: `slices` workgroups of `bs` threads per proposal, alpha kernel then apply kernel
+        // (512 threads fill the machine a little better than 1024; at most 16 slices fit the partials record)
+        const uint32_t bs = std::max<uint32_t>(512u, h.d.redW / 16u);
+        const uint32_t slices = std::min<uint32_t>(h.d.redW / bs, ((h.d.Npad >> 2) + bs - 1u) / bs);
+        const uint32_t perWave = std::max<uint32_t>(1u, (512u * (1024u / bs)) / slices);   // two resident 1024-thread workgroups per compute unit
+        const uint32_t grid = std::min<uint32_t>(h.d.queueCap, perWave) * slices;
+        RT_LAUNCH(eval_kernel<EVAL_ALPHA>, grid, bs, s->stream, h.d, slices);
+        RT_LAUNCH(eval_kernel<EVAL_APPLY>, grid, bs, s->stream, h.d, slices);
+    }
     if (slot >= 0) rt_event_stop(s->evPool[slot], s->stream);
     h.evalLaunches++;
 }
@@ -705,7 +717,7 @@ int cogaps_session_debug_prof(cogaps_session *s, char which, uint64_t *out16)
     for (int i = 0; i < 16; ++i) out16[i] = s->hGs->prof[i];
     SESSION_END
 }
-#if defined(GEN_PROFILE)
+#if defined(GEN_TIMELINE)
 extern "C" int cogaps_debug_timeline(unsigned long long *out, int n)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * (size_t)n);

@@ -43,6 +43,24 @@ struct EvalAcc { float s, m; };
 #define EVAL_MODE_CH 1       // ... with the change ch*v added to AP (death)
 #define EVAL_MODE_SAME 2     // v = other[:,c1] - other[:,c2], one row (DenseNormalModel.cpp:200-212)
 
+#if defined(GEN_TIMELINE) && !defined(COGAPS_EMUL)
+// dev: timestamps of the first 16 workgroups of a launch (lane 0 of the first and of the last wave)
+__device__ unsigned long long g_eval_timeline[2 * 16 * 2 * 12];     // [narrow | wide workgroups]
+#define EVAL_TS(id) do { if ((t & 63u) == 0u && ets_n < 11u) { ets[ets_n++] = ((unsigned long long)cg_clock() << 8) | (unsigned long long)(id); } } while (0)
+#define EVAL_TS_DUMP(ty) do { const uint32_t lastW_ = (cg_bdim() - 1u) >> 6; if (cg_bid() < 16u && (t & 63u) == 0u && ((t >> 6) == 0u || (t >> 6) == lastW_) && qlen >= 40u) { \
+    unsigned long long *o_ = &g_eval_timeline[((PHASE != EVAL_FUSED ? 16u : 0u) * 2u + cg_bid() * 2u + ((t >> 6) ? 1u : 0u)) * 12u]; o_[0] = (unsigned long long)(ty); for (uint32_t i_ = 0; i_ < 11u; ++i_) o_[1 + i_] = i_ < ets_n ? ets[i_] : 0ull; } } while (0)
+#define EVAL_PIN(x) asm volatile("" : "+v"(x) :: "memory")
+#define EVAL_TS_PARAMS , unsigned long long (&ets)[11], uint32_t &ets_n
+#define EVAL_TS_ARGS , ets, ets_n
+#else
+#define EVAL_TS(id) do { } while (0)
+#define EVAL_TS_DUMP(ty) do { } while (0)
+#define EVAL_PIN(x) do { } while (0)
+#define EVAL_TS_PARAMS
+#define EVAL_TS_ARGS
+#endif
+
+// G: virtual lanes whose chunks are in flight together (registers: 16*G*NR floats per thread)
 // lane-order sum of the NC components whose per-wave, per-slot partials sit in lds[wave][NC][V] (after a
 // barrier): wave 0 folds them, lane i < NC*V over the waves (bits 6.. of the virtual lane index), then the
 // thread-slot bits across lanes.  Totals are returned in wave 0.
@@ -74,95 +92,82 @@ CG_DEVICE void eval_vpark(float x, int j, float *lds, float (&tot)[1])
     else tot[0] = x;
 }
 
-// Alpha parameters of NR rows (NR = 2: the two rows of a move / exchange across rows, loaded together), summed
-// in lane order; tot = {s, s_mu} per row, valid in wave 0 (in every lane of a one-wave workgroup).  The slots
-// are processed G at a time: their chunks are loaded before any is consumed (4*G*NR independent float4 loads
-// in flight), reduced over the wave and parked in LDS, so a thread never holds more than G slots.  A chunk
-// index past the row reads nothing and contributes (v=0, S2=1, D=AP=0) -> +0 to both sums, which leaves them
-// bit-unchanged.  lds: [16][2*NR][V].
-template <int V, int G, int NR, int MODE>
-CG_DEVICE void eval_alpha(const SamplerDev &S, const uint32_t (&row)[NR], const uint32_t (&col)[NR], uint32_t col2, float ch, float *lds, float (&tot)[2 * NR])
+// Alpha parameters of NR rows (NR = 2: the two rows of a move / exchange across rows, loaded together) over the
+// chunks chunk0 + t, + stride, + 2*stride ...: thread t accumulates them in increasing order from +0 (one chunk
+// unless the vector is longer than 4*W), the workgroup folds its BS partials by an ascending xor butterfly.
+// tot = {s, s_mu} per row, valid in wave 0 (in every lane of a one-wave workgroup).  A chunk index past the
+// row reads nothing and contributes (v=0, S2=1, D=AP=0) -> +0 to both sums, which leaves them bit-unchanged.
+// lds: [16][2*NR].
+template <int NR, int MODE>
+CG_DEVICE void eval_alpha(const SamplerDev &S, const uint32_t (&row)[NR], const uint32_t (&col)[NR], uint32_t col2, float ch, uint32_t chunk0, uint32_t stride, float *lds, float (&tot)[2 * NR] EVAL_TS_PARAMS)
 {
-    constexpr int NC = 2 * NR, NV = NC * V;
-    const uint32_t nq = S.Npad >> 2, BS = cg_bdim(), t = cg_tid(), W = (uint32_t)V * BS, nw = BS >> 6;
-#pragma unroll 1
-    for (int g0 = 0; g0 < V; g0 += G) {
-        float ps[NR][G], pm[NR][G];
-        for (int r = 0; r < NR; ++r) for (int u = 0; u < G; ++u) { ps[r][u] = 0.f; pm[r][u] = 0.f; }
+    constexpr int NC = 2 * NR;
+    const uint32_t nq = S.Npad >> 2, BS = cg_bdim(), t = cg_tid(), nw = BS >> 6;
+    float ps[NR], pm[NR];
+    for (int r = 0; r < NR; ++r) { ps[r] = 0.f; pm[r] = 0.f; }
 #if defined(GEN_PROFILE)
-        if (!(S.dbg & 4u))
+    if (!(S.dbg & 4u))
 #endif
-        for (uint32_t base = (uint32_t)g0 * BS; base < nq; base += W) {
-            cg_f4 v[NR][G], w2[G], d[NR][G], s[NR][G], p[NR][G];
+    for (uint32_t j = chunk0 + t; j < nq; j += stride) {
+        cg_f4 v[NR], w2, d[NR], s[NR], p[NR];
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const float *Dr = S.D + (size_t)row[r] * S.Npad, *Sr = S.S2 + (size_t)row[r] * S.Npad, *Ar = S.AP + (size_t)row[r] * S.Npad;
-                const float *Vr = S.other + (size_t)col[r] * S.Npad, *V2 = S.other + (size_t)col2 * S.Npad;
-#pragma unroll
-                for (int u = 0; u < G; ++u) {
-                    const uint32_t j = base + (uint32_t)u * BS + t;
-                    if (j < nq) { v[r][u] = ld4(Vr, j); d[r][u] = ld4(Dr, j); s[r][u] = ld4(Sr, j); p[r][u] = ld4(Ar, j); if (MODE == EVAL_MODE_SAME) w2[u] = ld4(V2, j); }
-                    else { v[r][u] = f4_zero(); d[r][u] = f4_zero(); s[r][u] = f4_one(); p[r][u] = f4_zero(); if (MODE == EVAL_MODE_SAME) w2[u] = f4_zero(); }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < NR; ++r) {
-#pragma unroll
-                for (int u = 0; u < G; ++u) {
-                    EvalAcc a; a.s = ps[r][u]; a.m = pm[r][u];
-                    if (MODE == EVAL_MODE_CH) { EVAL_ELEM_CH(v[r][u].x, d[r][u].x, s[r][u].x, p[r][u].x) EVAL_ELEM_CH(v[r][u].y, d[r][u].y, s[r][u].y, p[r][u].y) EVAL_ELEM_CH(v[r][u].z, d[r][u].z, s[r][u].z, p[r][u].z) EVAL_ELEM_CH(v[r][u].w, d[r][u].w, s[r][u].w, p[r][u].w) }
-                    else if (MODE == EVAL_MODE_SAME) {
-                        { float x = v[r][u].x - w2[u].x; EVAL_ELEM(x, d[r][u].x, s[r][u].x, p[r][u].x) }
-                        { float x = v[r][u].y - w2[u].y; EVAL_ELEM(x, d[r][u].y, s[r][u].y, p[r][u].y) }
-                        { float x = v[r][u].z - w2[u].z; EVAL_ELEM(x, d[r][u].z, s[r][u].z, p[r][u].z) }
-                        { float x = v[r][u].w - w2[u].w; EVAL_ELEM(x, d[r][u].w, s[r][u].w, p[r][u].w) }
-                    } else { EVAL_ELEM(v[r][u].x, d[r][u].x, s[r][u].x, p[r][u].x) EVAL_ELEM(v[r][u].y, d[r][u].y, s[r][u].y, p[r][u].y) EVAL_ELEM(v[r][u].z, d[r][u].z, s[r][u].z, p[r][u].z) EVAL_ELEM(v[r][u].w, d[r][u].w, s[r][u].w, p[r][u].w) }
-                    ps[r][u] = a.s; pm[r][u] = a.m;
-                }
-            }
+        for (int r = 0; r < NR; ++r) {
+            const float *Dr = S.D + (size_t)row[r] * S.Npad, *Sr = S.S2 + (size_t)row[r] * S.Npad, *Ar = S.AP + (size_t)row[r] * S.Npad;
+            const float *Vr = S.other + (size_t)col[r] * S.Npad, *V2 = S.other + (size_t)col2 * S.Npad;
+            v[r] = ld4(Vr, j); d[r] = ld4(Dr, j); s[r] = ld4(Sr, j); p[r] = ld4(Ar, j); if (MODE == EVAL_MODE_SAME) w2 = ld4(V2, j);
         }
-        // bits 0-5 of the virtual lane index: the wave butterfly
-        for (int off = 1; off < 64; off <<= 1) {
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-#pragma unroll
-                for (int u = 0; u < G; ++u) { ps[r][u] = ps[r][u] + cg_shfl_xor_f32(ps[r][u], off); pm[r][u] = pm[r][u] + cg_shfl_xor_f32(pm[r][u], off); }
-            }
-        }
-        if (nw > 1) {
-            if ((t & 63u) == 0) {
-#pragma unroll
-                for (int r = 0; r < NR; ++r) {
-#pragma unroll
-                    for (int u = 0; u < G; ++u) { lds[(t >> 6) * NV + (2 * r) * V + g0 + u] = ps[r][u]; lds[(t >> 6) * NV + (2 * r + 1) * V + g0 + u] = pm[r][u]; }
-                }
-            }
-        } else {
-            // one wave: V == 1, the butterfly left the totals in every lane
-#pragma unroll
-            for (int r = 0; r < NR; ++r) { tot[2 * r] = ps[r][0]; tot[2 * r + 1] = pm[r][0]; }
+        for (int r = 0; r < NR; ++r) {
+            EvalAcc a; a.s = ps[r]; a.m = pm[r];
+            if (MODE == EVAL_MODE_CH) { EVAL_ELEM_CH(v[r].x, d[r].x, s[r].x, p[r].x) EVAL_ELEM_CH(v[r].y, d[r].y, s[r].y, p[r].y) EVAL_ELEM_CH(v[r].z, d[r].z, s[r].z, p[r].z) EVAL_ELEM_CH(v[r].w, d[r].w, s[r].w, p[r].w) }
+            else if (MODE == EVAL_MODE_SAME) {
+                { float x = v[r].x - w2.x; EVAL_ELEM(x, d[r].x, s[r].x, p[r].x) }
+                { float x = v[r].y - w2.y; EVAL_ELEM(x, d[r].y, s[r].y, p[r].y) }
+                { float x = v[r].z - w2.z; EVAL_ELEM(x, d[r].z, s[r].z, p[r].z) }
+                { float x = v[r].w - w2.w; EVAL_ELEM(x, d[r].w, s[r].w, p[r].w) }
+            } else { EVAL_ELEM(v[r].x, d[r].x, s[r].x, p[r].x) EVAL_ELEM(v[r].y, d[r].y, s[r].y, p[r].y) EVAL_ELEM(v[r].z, d[r].z, s[r].z, p[r].z) EVAL_ELEM(v[r].w, d[r].w, s[r].w, p[r].w) }
+            ps[r] = a.s; pm[r] = a.m;
         }
     }
-    if (nw > 1) { cg_sync(); eval_vfinish<NC, V>(lds, tot); }
+    { float z_ = ps[0]; EVAL_PIN(z_); ps[0] = z_; } EVAL_TS(10);
+    // bits 0-5 of the lane index: the wave butterfly
+    for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) { ps[r] = ps[r] + cg_shfl_xor_f32(ps[r], off); pm[r] = pm[r] + cg_shfl_xor_f32(pm[r], off); }
+    }
+    if (nw > 1) {
+        if ((t & 63u) == 0) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) { lds[(t >> 6) * NC + 2 * r] = ps[r]; lds[(t >> 6) * NC + 2 * r + 1] = pm[r]; }
+        }
+        EVAL_TS(11);
+        cg_sync();
+        EVAL_TS(12);
+        eval_vfinish<NC, 1>(lds, tot);
+    } else {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) { tot[2 * r] = ps[r]; tot[2 * r + 1] = pm[r]; }
+    }
 }
 
 // DenseNormalModel.cpp:243-258: AP[:,row] += delta * other[:,col]
-template <int UN>
-CG_DEVICE void eval_update_ap(const SamplerDev &S, uint32_t row, uint32_t col, float delta)
+// over the chunks chunk0 + t, + stride, ... (a whole row in the fused kernel, one slice in the split one)
+CG_DEVICE void eval_update_ap(const SamplerDev &S, uint32_t row, uint32_t col, float delta, uint32_t chunk0, uint32_t stride)
 {
-    const uint32_t nq = S.Npad >> 2, BS = cg_bdim(), t = cg_tid();
+    constexpr int UN = 4;
+    const uint32_t nq = S.Npad >> 2, t = cg_tid();
     float *AP = S.AP + (size_t)row * S.Npad;
     const float *Vc = S.other + (size_t)col * S.Npad;
 #if defined(GEN_PROFILE)
     if (S.dbg & 2u) return;
 #endif
-    for (uint32_t j0 = t; j0 < nq; j0 += UN * BS) {
+    for (uint32_t j0 = chunk0 + t; j0 < nq; j0 += UN * stride) {
         cg_f4 v[UN], p[UN];
 #pragma unroll
-        for (int u = 0; u < UN; ++u) { const uint32_t j = j0 + (uint32_t)u * BS; if (j < nq) { v[u] = ld4(Vc, j); p[u] = ld4(AP, j); } else { v[u] = f4_zero(); p[u] = f4_zero(); } }
+        for (int u = 0; u < UN; ++u) { const uint32_t j = j0 + (uint32_t)u * stride; if (j < nq) { v[u] = ld4(Vc, j); p[u] = ld4(AP, j); } else { v[u] = f4_zero(); p[u] = f4_zero(); } }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const uint32_t j = j0 + (uint32_t)u * BS;
+            const uint32_t j = j0 + (uint32_t)u * stride;
             if (j < nq) {
                 cg_f4 q = p[u];
                 q.x = q.x + delta * v[u].x; q.y = q.y + delta * v[u].y; q.z = q.z + delta * v[u].z; q.w = q.w + delta * v[u].w;
@@ -204,38 +209,35 @@ CG_DEVICE void eval_domain_move(const SamplerDev &S, uint32_t h, uint64_t oldPos
 #define EVAL_PROF(i) do { } while (0)
 #endif
 
-#if defined(GEN_PROFILE) && !defined(COGAPS_EMUL)
-// dev: timestamps of the first 16 workgroups of a launch (lane 0 of the first and of the last wave)
-__device__ unsigned long long g_eval_timeline[2 * 16 * 2 * 12];     // [narrow | wide workgroups]
-#define EVAL_TS(id) do { if ((t & 63u) == 0u && ets_n < 11u) { ets[ets_n++] = ((unsigned long long)cg_clock() << 8) | (unsigned long long)(id); } } while (0)
-#define EVAL_TS_DUMP(ty) do { const uint32_t lastW_ = (cg_bdim() - 1u) >> 6; if (cg_bid() < 16u && (t & 63u) == 0u && ((t >> 6) == 0u || (t >> 6) == lastW_) && qlen >= 40u) { \
-    unsigned long long *o_ = &g_eval_timeline[((cg_bdim() > 256u ? 16u : 0u) * 2u + cg_bid() * 2u + ((t >> 6) ? 1u : 0u)) * 12u]; o_[0] = (unsigned long long)(ty); for (uint32_t i_ = 0; i_ < 11u; ++i_) o_[1 + i_] = i_ < ets_n ? ets[i_] : 0ull; } } while (0)
-#define EVAL_PIN(x) asm volatile("" : "+v"(x) :: "memory")
-#else
-#define EVAL_TS(id) do { } while (0)
-#define EVAL_TS_DUMP(ty) do { } while (0)
-#define EVAL_PIN(x) do { } while (0)
-#endif
+#define EVAL_FUSED 0     // one workgroup per proposal: alpha, decision, update
+#define EVAL_ALPHA 1     // split evaluation, first kernel: `slices` workgroups per proposal, per-slice alpha partials
+#define EVAL_APPLY 2     // split evaluation, second kernel: combine the partials, decide, update the slice
 
-// G: virtual lanes whose chunks are in flight together (registers: 16*G*NR floats per thread)
-template <int V, int NR> struct EvalGroup { static constexpr int G = (V < 4 / NR) ? V : 4 / NR; };
-
-template <int V>
-CG_DEVICE void eval_body(const SamplerDev &S)
+// The split form serves data vectors of more than 4096 elements (W > 1024 virtual lanes): one workgroup can pull a
+// row no faster than its compute unit's ~64 B/clk, so the row is cut into slices of 1024 chunks, one workgroup
+// each.  Slice j owns virtual lanes j*1024 .. j*1024+1023; the per-slice totals go through S.partials
+// ([queueCap][4][16]) and every workgroup of the second kernel folds them in the same ascending order (the top
+// bits of the butterfly), repeats the (deterministic) decision and updates its own slice of AP.
+template <int PHASE>
+CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices)
 {
-#if defined(GEN_PROFILE) && !defined(COGAPS_EMUL)
+#if defined(GEN_TIMELINE) && !defined(COGAPS_EMUL)
     unsigned long long ets[11]; uint32_t ets_n = 0;
 #endif
-    CG_SHARED float lds[16 * 4 * V];
+    CG_SHARED float lds[16 * 4];
     CG_SHARED float decf; CG_SHARED uint32_t deci;     // decision of wave 0, broadcast to the other waves
-    const uint32_t t = cg_tid();
+    const uint32_t t = cg_tid(), BS = cg_bdim();
     unsigned long long eprof_last = cg_clock(); (void)eprof_last;
     const float lambda = S.lambda;
     EVAL_TS(0);
-    const bool multiWave = cg_bdim() > 64u;
+    const bool multiWave = BS > 64u;
     const bool scalarLane = !multiWave || t < 64u;       // the per-proposal scalar math (LUTs, fp64 log) runs in wave 0 only
+    const uint32_t slice = (PHASE == EVAL_FUSED) ? 0u : cg_bid() % slices;
+    const uint32_t qStep = (PHASE == EVAL_FUSED) ? cg_gdim() : cg_gdim() / slices;
+    const uint32_t chunk0 = slice * BS, stride = (PHASE == EVAL_FUSED) ? BS : S.redW;
+    const bool writer = slice == 0u && t == 0u;          // the one thread that stores the proposal's scalar results
 #define EVAL_BCAST(F0, I0) do { if (multiWave) { if (t == 0) { decf = (F0); deci = (I0); } cg_sync(); (F0) = decf; (I0) = deci; } } while (0)
-    for (uint32_t q = cg_bid(); ; q += cg_gdim()) {
+    for (uint32_t q = (PHASE == EVAL_FUSED) ? cg_bid() : cg_bid() / slices; ; q += qStep) {
         // one trip: the record (slot q always exists: q < queueCap), the queue length, the annealing temperature
         const PropRec p = S.queue[q < S.queueCap ? q : 0u];
         const uint32_t qlen = S.gs->qlen;
@@ -253,33 +255,59 @@ CG_DEVICE void eval_body(const SamplerDev &S)
 #if defined(GEN_PROFILE)
         if (S.dbg & 1u) { if (p.type == 0xFFu || m1 == -1.f) S.queueUnits[q] = (uint32_t)old1; break; }   // record only
 #endif
-        const uint32_t rowA[1] = {p.r1}, colA[1] = {p.c1};
+        // ---------------------------------------------------------------- alpha parameters (DenseNormalModel.cpp:161-240)
+        // which reduction the step needs: birth with Gibbs, death, move, exchange with canUseGibbs(c1,c2)
+        const bool need = (p.type == 'B') ? gibbs1 : ((p.type == 'D' || p.type == 'M') ? true : (gibbs1 || gibbs2));
+        const bool diff = two && p.r1 != p.r2;
+        float s = 0.f, smu = 0.f;          // un-annealed sums, valid in wave 0
+        if (need) {
+            float tot[4] = {0.f, 0.f, 0.f, 0.f};
+            if (PHASE != EVAL_APPLY) {
+                const uint32_t rowA[1] = {p.r1}, colA[1] = {p.c1};
+                if (diff) {
+                    const uint32_t rowAB[2] = {p.r1, p.r2}, colAB[2] = {p.c1, p.c2};
+                    eval_alpha<2, EVAL_MODE_ONE>(S, rowAB, colAB, 0u, 0.f, chunk0, stride, lds, tot EVAL_TS_ARGS);
+                } else {
+                    float t2[2] = {0.f, 0.f};
+                    if (p.type == 'D') eval_alpha<1, EVAL_MODE_CH>(S, rowA, colA, 0u, -1.f * m1, chunk0, stride, lds, t2 EVAL_TS_ARGS);
+                    else if (two) eval_alpha<1, EVAL_MODE_SAME>(S, rowA, colA, p.c2, 0.f, chunk0, stride, lds, t2 EVAL_TS_ARGS);
+                    else eval_alpha<1, EVAL_MODE_ONE>(S, rowA, colA, 0u, 0.f, chunk0, stride, lds, t2 EVAL_TS_ARGS);
+                    tot[0] = t2[0]; tot[1] = t2[1];
+                }
+                if (PHASE == EVAL_ALPHA) { if (t == 0) { float *o = S.partials + (size_t)q * 64u + slice; o[0] = tot[0]; o[16] = tot[1]; o[32] = tot[2]; o[48] = tot[3]; } }
+            } else {
+                // fold the slices: the top bits of the butterfly (slots past the last slice hold +0, as the empty lanes
+                // do).  Wave 0 only: lane i holds element (component i / 16, slice i % 16) of the 64-float record.
+                if (t < 64u) {
+                    const uint32_t slots = S.redW / BS;
+                    float z = ((t & 15u) < slices) ? S.partials[(size_t)q * 64u + t] : 0.f;
+                    for (uint32_t st = 1; st < slots; st <<= 1) z = z + cg_shfl_xor_f32(z, (int)st);
+                    tot[0] = cg_shfl_f32(z, 0); tot[1] = cg_shfl_f32(z, 16); tot[2] = cg_shfl_f32(z, 32); tot[3] = cg_shfl_f32(z, 48);
+                }
+            }
+            s = diff ? tot[0] + tot[2] : tot[0]; smu = diff ? tot[1] - tot[3] : tot[1];        // AlphaParameters.cpp:11-14
+        }
+        EVAL_PIN(s); EVAL_TS(3);
+        if (PHASE == EVAL_ALPHA) { if (q + qStep >= qlen) break; cg_sync(); continue; }
+        s = s * T; smu = smu * T;
         if (p.type == 'B') {
             // ---------------------------------------------------------------- birth (:127-144)
-            OptF mass; mass.v = 0.f; mass.has = false;
             float bv = 0.f; uint32_t bhas = 0;
-            if (gibbs1) {
-                float tot[2] = {0.f, 0.f};
-                eval_alpha<V, EvalGroup<V, 1>::G, 1, EVAL_MODE_ONE>(S, rowA, colA, 0u, 0.f, lds, tot);
-                EVAL_PIN(tot[0]); EVAL_TS(3);
-                if (scalarLane) { OptF g = gm_gibbs_mass(tot[0] * T, tot[1] * T, 0.f, S.maxGibbsMass, rng, S.luts, true, lambda); bv = g.v; bhas = g.has ? 1u : 0u; }
-            } else if (scalarLane) { bv = pcg_exponential(rng, lambda); bhas = 1u; }
+            if (scalarLane) {
+                if (gibbs1) { OptF g = gm_gibbs_mass(s, smu, 0.f, S.maxGibbsMass, rng, S.luts, true, lambda); bv = g.v; bhas = g.has ? 1u : 0u; }
+                else { bv = pcg_exponential(rng, lambda); bhas = 1u; }
+            }
             EVAL_PIN(bv); EVAL_TS(4);
             EVAL_BCAST(bv, bhas);
             EVAL_TS(5);
-            mass.v = bv; mass.has = bhas != 0u;
-            if (mass.has && mass.v >= GAPS_EPSILON) {
-                eval_update_ap<(V >= 4 ? 4 : 8)>(S, p.r1, p.c1, mass.v); ++nUpd;                          // changeMatrix
-                if (t == 0) { S.atoms[p.h1].mass = mass.v; eval_store_matrix(S, p.r1, p.c1, old1, old1 + mass.v); }
-            } else if (t == 0) eval_cache_erase(S, p.h1);
+            if (bhas != 0u && bv >= GAPS_EPSILON) {
+                eval_update_ap(S, p.r1, p.c1, bv, chunk0, stride); ++nUpd;                          // changeMatrix
+                if (writer) { S.atoms[p.h1].mass = bv; eval_store_matrix(S, p.r1, p.c1, old1, old1 + bv); }
+            } else if (writer) eval_cache_erase(S, p.h1);
         } else if (p.type == 'D') {
             // ---------------------------------------------------------------- death / rebirth (:148-180)
             float rebirth = m1;
-            float tot[2] = {0.f, 0.f};
-            eval_alpha<V, EvalGroup<V, 1>::G, 1, EVAL_MODE_CH>(S, rowA, colA, 0u, -1.f * m1, lds, tot);
-            const float s = tot[0] * T, smu = tot[1] * T;
             EVAL_PROF(1);
-            EVAL_PIN(tot[0]); EVAL_TS(3);
             uint32_t acc = 0;
             if (scalarLane) {
                 if (gibbs1) {
@@ -292,92 +320,69 @@ CG_DEVICE void eval_body(const SamplerDev &S)
             EVAL_PIN(acc); EVAL_TS(4);
             EVAL_BCAST(rebirth, acc);
             EVAL_TS(5);
-            const bool accept = acc != 0u;
             EVAL_PROF(2);
-            if (accept) {
+            if (acc != 0u) {
                 if (rebirth != m1) {
                     const float nv = gm_max(old1 + (rebirth - m1), 0.f);            // safelyChangeMatrix
-                    eval_update_ap<(V >= 4 ? 4 : 8)>(S, p.r1, p.c1, nv - old1); ++nUpd;
-                    if (t == 0) { eval_store_matrix(S, p.r1, p.c1, old1, nv); S.atoms[p.h1].mass = rebirth; }
+                    eval_update_ap(S, p.r1, p.c1, nv - old1, chunk0, stride); ++nUpd;
+                    if (writer) { eval_store_matrix(S, p.r1, p.c1, old1, nv); S.atoms[p.h1].mass = rebirth; }
                 }
             } else {
                 const float nv = gm_max(old1 + (-1.f * m1), 0.f);
-                eval_update_ap<(V >= 4 ? 4 : 8)>(S, p.r1, p.c1, nv - old1); ++nUpd;
-                if (t == 0) { eval_store_matrix(S, p.r1, p.c1, old1, nv); eval_cache_erase(S, p.h1); }
+                eval_update_ap(S, p.r1, p.c1, nv - old1, chunk0, stride); ++nUpd;
+                if (writer) { eval_store_matrix(S, p.r1, p.c1, old1, nv); eval_cache_erase(S, p.h1); }
             }
             EVAL_PROF(3);
-        } else {
-            // ---------------------------------------------------------------- 2-site alpha (:186-214)
-            float s = 0.f, smu = 0.f;
-            const bool need = (p.type == 'M') || gibbs1 || gibbs2;                  // exchange: canUseGibbs(c1,c2)
-            if (need) {
-                if (p.r1 == p.r2) {
-                    float tot[2] = {0.f, 0.f};
-                    eval_alpha<V, EvalGroup<V, 1>::G, 1, EVAL_MODE_SAME>(S, rowA, colA, p.c2, 0.f, lds, tot);
-                    s = tot[0]; smu = tot[1];
-                } else {
-                    const uint32_t rowAB[2] = {p.r1, p.r2}, colAB[2] = {p.c1, p.c2};
-                    float tot[4] = {0.f, 0.f, 0.f, 0.f};
-                    eval_alpha<V, EvalGroup<V, 2>::G, 2, EVAL_MODE_ONE>(S, rowAB, colAB, 0u, 0.f, lds, tot);
-                    s = tot[0] + tot[2]; smu = tot[1] - tot[3];                     // AlphaParameters.cpp:11-14
+        } else if (p.type == 'M') {
+            // ---------------------------------------------------------------- move (:184-196)
+            uint32_t acc = 0; float unused = 0.f;
+            if (scalarLane) { const float deltaLL = -1.f * m1 * (smu + s * m1 / 2.f); acc = (gm_logf(pcg_uniform(rng)) < deltaLL) ? 1u : 0u; }
+            EVAL_PIN(acc); EVAL_TS(4);
+            EVAL_BCAST(unused, acc);
+            EVAL_TS(5);
+            if (acc) {
+                const float nv1 = gm_max(old1 + (-m1), 0.f);                    // safelyChangeMatrix(r1,c1,-m)
+                eval_update_ap(S, p.r1, p.c1, nv1 - old1, chunk0, stride); ++nUpd;
+                eval_update_ap(S, p.r2, p.c2, m1, chunk0, stride); ++nUpd;              // changeMatrix(r2,c2,+m); same thread owns the same elements
+                if (writer) {
+                    eval_domain_move(S, p.h1, curPos, p.pos);
+                    eval_store_matrix(S, p.r1, p.c1, old1, nv1);
+                    eval_store_matrix(S, p.r2, p.c2, old2, old2 + m1);
                 }
-                s = s * T; smu = smu * T;
             }
-            EVAL_PIN(s); EVAL_TS(3);
-            if (p.type == 'M') {
-                // ------------------------------------------------------------ move (:184-196)
-                uint32_t acc = 0; float unused = 0.f;
-                if (scalarLane) { const float deltaLL = -1.f * m1 * (smu + s * m1 / 2.f); acc = (gm_logf(pcg_uniform(rng)) < deltaLL) ? 1u : 0u; }
-                EVAL_PIN(acc); EVAL_TS(4);
-                EVAL_BCAST(unused, acc);
-                EVAL_TS(5);
-                if (acc) {
-                    const float nv1 = gm_max(old1 + (-m1), 0.f);                    // safelyChangeMatrix(r1,c1,-m)
-                    eval_update_ap<(V >= 4 ? 4 : 8)>(S, p.r1, p.c1, nv1 - old1); ++nUpd;
-                    eval_update_ap<(V >= 4 ? 4 : 8)>(S, p.r2, p.c2, m1); ++nUpd;                          // changeMatrix(r2,c2,+m); same lane owns the same elements
-                    if (t == 0) {
-                        eval_domain_move(S, p.h1, curPos, p.pos);
-                        eval_store_matrix(S, p.r1, p.c1, old1, nv1);
-                        eval_store_matrix(S, p.r2, p.c2, old2, old2 + m1);
-                    }
-                }
-            } else if (need) {
-                // ------------------------------------------------------------ exchange (:201-219)
-                OptF g; g.v = 0.f; g.has = false;
-                { float gv = 0.f; uint32_t gh = 0;
-                  if (scalarLane) { OptF g0 = gm_gibbs_mass(s, smu, -m1, m2, rng, S.luts, false, 0.f); gv = g0.v; gh = g0.has ? 1u : 0u; }
-                  EVAL_PIN(gv); EVAL_TS(4);
-                  EVAL_BCAST(gv, gh); g.v = gv; g.has = gh != 0u; }
-                EVAL_TS(5);
-                const float n1 = m1 + g.v, n2 = m2 - g.v;
-                if (g.has && n1 > GAPS_EPSILON && n2 > GAPS_EPSILON) {
-                    const float nv1 = gm_max(old1 + (n1 - m1), 0.f);
-                    eval_update_ap<(V >= 4 ? 4 : 8)>(S, p.r1, p.c1, nv1 - old1); ++nUpd;
-                    const float nv2 = gm_max(old2 + (n2 - m2), 0.f);
-                    eval_update_ap<(V >= 4 ? 4 : 8)>(S, p.r2, p.c2, nv2 - old2); ++nUpd;
-                    if (t == 0) {
-                        eval_store_matrix(S, p.r1, p.c1, old1, nv1);
-                        eval_store_matrix(S, p.r2, p.c2, old2, nv2);
-                        S.atoms[p.h1].mass = n1; S.atoms[p.h2].mass = n2;
-                    }
+        } else if (need) {
+            // ---------------------------------------------------------------- exchange (:201-219)
+            float gv = 0.f; uint32_t gh = 0;
+            if (scalarLane) { OptF g0 = gm_gibbs_mass(s, smu, -m1, m2, rng, S.luts, false, 0.f); gv = g0.v; gh = g0.has ? 1u : 0u; }
+            EVAL_PIN(gv); EVAL_TS(4);
+            EVAL_BCAST(gv, gh);
+            EVAL_TS(5);
+            const float n1 = m1 + gv, n2 = m2 - gv;
+            if (gh != 0u && n1 > GAPS_EPSILON && n2 > GAPS_EPSILON) {
+                const float nv1 = gm_max(old1 + (n1 - m1), 0.f);
+                eval_update_ap(S, p.r1, p.c1, nv1 - old1, chunk0, stride); ++nUpd;
+                const float nv2 = gm_max(old2 + (n2 - m2), 0.f);
+                eval_update_ap(S, p.r2, p.c2, nv2 - old2, chunk0, stride); ++nUpd;
+                if (writer) {
+                    eval_store_matrix(S, p.r1, p.c1, old1, nv1);
+                    eval_store_matrix(S, p.r2, p.c2, old2, nv2);
+                    S.atoms[p.h1].mass = n1; S.atoms[p.h2].mass = n2;
                 }
             }
         }
         EVAL_TS(6);
         EVAL_TS_DUMP(p.type | (nUpd << 8) | ((p.r1 == p.r2 ? 1u : 0u) << 16));
-        if (t == 0) {   // roofline bookkeeping: algorithmic traffic of this proposal in units of 4N bytes
+        if (writer) {   // roofline bookkeeping: algorithmic traffic of this proposal in units of 4N bytes
             // (alpha: 4 one-site, 5 two-site same row, 8 different rows; 3 per AP update); the generator sums the slots
             uint32_t units = nUpd * 3u;
-            if (p.type == 'B') units += gibbs1 ? 4u : 0u;
-            else if (p.type == 'D') units += 4u;
-            else if (p.type == 'M' || gibbs1 || gibbs2) units += (p.r1 == p.r2) ? 5u : 8u;
+            if (need) units += !two ? 4u : (diff ? 8u : 5u);
             S.queueUnits[q] = units;
         }
-        if (q + cg_gdim() >= qlen) break;   // last proposal of this workgroup
+        if (q + qStep >= qlen) break;   // last proposal of this workgroup
         cg_sync();   // the LDS scratch is reused by the next proposal
     }
 }
 
-// V = virtual lanes per thread: workgroups of BS = W / V <= 1024 threads
-template <int V>
-CG_KERNEL void CG_LAUNCH_BOUNDS(1024) eval_kernel(SamplerDev S) { eval_body<V>(S); }
+// the split kernels are built for two resident 1024-thread workgroups per compute unit (<= 64 VGPRs)
+template <int PHASE>
+CG_KERNEL void CG_LAUNCH_BOUNDS2(1024, (PHASE == EVAL_FUSED ? 4 : 8)) eval_kernel(SamplerDev S, uint32_t slices) { eval_body<PHASE>(S, slices); }

@@ -97,6 +97,7 @@ struct SamplerDev {
     uint32_t eraseCap;
     // ---- ProposalQueue -------------------------------------------------------------------------
     PropRec *queue;    // [queueCap]
+    float *partials;      // [queueCap][4][16] per-slice alpha totals of the split evaluation (eval_kernel.h)
     uint32_t *queueUnits; // [queueCap] algorithmic traffic of each evaluated proposal, in units of 4N bytes
     uint32_t queueCap;
     const uint64_t *seeds;  // seeder outputs for this update(): candidate k of the update uses seeds[k]

@@ -30,7 +30,7 @@
 #define GEN_PROF(i) do { } while (0)
 #define GEN_PROF_FLUSH() do { } while (0)
 #endif
-#if defined(GEN_PROFILE) && !defined(COGAPS_EMUL)
+#if defined(GEN_TIMELINE) && !defined(COGAPS_EMUL)
 // per-wave timeline of one typical launch (lane 0 of every wave records (clock << 8 | id)); dev tool only
 __device__ unsigned long long g_timeline[(GEN_WIN / 64) * 64];
 #define GEN_TS(id) do { if ((t & 63u) == 0u && ts_n < 64u) { sh.ts[(t & ~63u) + ts_n] = ((unsigned long long)cg_clock() << 8) | (unsigned long long)(id); ++ts_n; } } while (0)
@@ -96,7 +96,7 @@ struct GenShared {
     // vector and the net writes of the swap-with-last replay
     uint64_t fpos[FLUSH_MAX]; uint32_t fh[FLUSH_MAX], fl[FLUSH_MAX], fr[FLUSH_MAX], fidx[FLUSH_MAX], fbin[FLUSH_MAX], vt[FLUSH_MAX], lowSlot[FLUSH_MAX], lowH[FLUSH_MAX];
     uint32_t nLow, newFront, flushM, flushBase, unitSum;
-#if defined(GEN_PROFILE)
+#if defined(GEN_TIMELINE)
     unsigned long long ts[(WIN / 64) * 64]; uint32_t tsn[WIN / 64];
 #endif
     alignas(16) uint32_t bkey[4 * GEN_TAB_NB];      // conflict sets of round 1: keys, bucket-major

@@ -19,6 +19,7 @@
 #define CG_KERNEL __global__
 #define CG_SHARED __shared__
 #define CG_LAUNCH_BOUNDS(n) __launch_bounds__(n)
+#define CG_LAUNCH_BOUNDS2(n, wavesPerSimd) __launch_bounds__(n, wavesPerSimd)
 
 CG_DEVICE unsigned cg_tid() { return threadIdx.x; }
 CG_DEVICE unsigned cg_bid() { return blockIdx.x; }

@@ -11,6 +11,7 @@
 #define CG_KERNEL
 #define CG_SHARED static
 #define CG_LAUNCH_BOUNDS(n)
+#define CG_LAUNCH_BOUNDS2(n, w)
 
 namespace cgemu {
 struct LaneCtx { unsigned tid, bid, bdim, gdim; };

@@ -26,7 +26,7 @@ def test_library_builds_loads_and_exports_header_symbols():
     assert set(_capi.EXPORTS) <= declared
     assert b"gfx950" in lib.cogaps_build_report()
     assert lib.cogaps_checkpoints_enabled() == 0 and lib.cogaps_compiled_with_openmp() == 0
-    assert [lib.cogaps_reduction_width(n) for n in (9, 2000, 2049, 4100, 20000, 50000)] == [64, 64, 128, 256, 1024, 1024]
+    assert [lib.cogaps_reduction_width(n) for n in (9, 256, 257, 2000, 2049, 20000, 70000)] == [64, 64, 128, 512, 1024, 8192, 16384]
 
 
 def test_struct_layouts_match_header():

@@ -27,9 +27,19 @@ def test_tiny_domain_hazards(emul_lib):
 
 
 def test_multiwave_evaluation(emul_lib):
-    """P-side data vectors of 4100 elements -> 256-lane evaluation workgroups (cross-wave butterfly)"""
-    data = pu.synthetic(4100, 12)
-    pu.run_stepwise(emul_lib(256), data, 5, trace=False, nPatterns=3, seed=123, total_iter=10)
+    """P-side data vectors of 2600 elements -> 1024 virtual lanes, one 1024-thread workgroup per proposal
+    (cross-wave butterfly in LDS)"""
+    data = pu.synthetic(2600, 12)
+    pu.run_stepwise(emul_lib(256), data, 6, trace=False, nPatterns=3, seed=123, total_iter=10)
+
+
+@pytest.mark.parametrize("genes,iters", [(6000, 8), (20000, 4), (70000, 3)])
+def test_split_evaluation(emul_lib, genes, iters):
+    """P-side data vectors longer than 4096 elements: W = 2048 / 8192 / 16384 virtual lanes, several workgroups
+    per proposal (alpha kernel + apply kernel, per-slice partials folded in butterfly order); 70000 elements
+    also gives every virtual lane more than one chunk"""
+    data = pu.synthetic(genes, 8, seed=genes)
+    pu.run_stepwise(emul_lib(256), data, iters, trace=False, nPatterns=3, seed=7, total_iter=10)
 
 
 def test_transposed_and_uncertainty(emul_lib, modsim):

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cogaps_amd import _capi
 from bench import synthetic_dense
 import ctypes
-PL = _capi.bind(ctypes.CDLL(os.path.join(os.path.dirname(_capi.LIB_PATH), 'libcogaps_hip_PROFILE_DEV.so')))
+PL = _capi.bind(ctypes.CDLL(os.path.join(os.path.dirname(_capi.LIB_PATH), 'libcogaps_hip_REPLAY_DEV.so')))
 warm = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 for which in 'AP':
     for flags, name in [(0, 'full'), (2, 'no AP update'), (6, 'no row loads, no update'), (1, 'record+scalars only')]:

@@ -35,7 +35,7 @@ ebuf = (ctypes.c_uint64 * (2 * 16 * 2 * 12))()
 PL.cogaps_debug_eval_timeline.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert PL.cogaps_debug_eval_timeline(ebuf, 2 * 16 * 2 * 12) == 0
 ea = np.array(ebuf).reshape(2, 16, 2, 12)
-en = {0: 'entry', 1: 'record', 2: 'scalars', 3: 'rows+reduce', 4: 'scalar math', 5: 'broadcast', 6: 'AP update'}
+en = {0: 'entry', 1: 'record', 2: 'scalars', 3: 'reduced', 4: 'scalar math', 5: 'broadcast', 6: 'AP update', 10: 'partials', 11: 'parked', 12: 'barrier'}
 for which, e in (('narrow workgroups (A sampler)', ea[0]), ('wide workgroups (P sampler)', ea[1])):
     print()
     print('evaluation kernel, %s, cycles since workgroup entry:' % which)
@@ -44,6 +44,6 @@ for which, e in (('narrow workgroups (A sampler)', ea[0]), ('wide workgroups (P 
         ty = int(e[b, 0, 0])
         for w in range(2):
             ts = [(int(x) & 0xFF, int(x) >> 8) for x in e[b, w, 1:] if x]
-            if not ts or (w == 1 and which.startswith('narrow')): continue
+            if not ts: continue
             t0 = ts[0][1]
             print('  wg %2d %s nUpd %d sameRow %d wave %s: ' % (b, chr(ty & 0xFF), (ty >> 8) & 0xFF, ty >> 16, 'first' if w == 0 else 'last ') + '  '.join('%s %d' % (en.get(i, str(i)), c - t0) for i, c in ts[1:]))

@@ -27,8 +27,8 @@ SURVEY_8C = {
 
 
 def red_width(n):   # cogaps_reduction_width (cogaps_hip.cpp)
-    need, w = (n + 31) // 32, 64
-    while w < need and w < 1024:
+    need, w = (n + 3) // 4, 64
+    while w < need and w < 16384:
         w <<= 1
     return w
 
