@@ -121,7 +121,7 @@ def main():
         return upd
 
     run_steps(0, W)
-    perf0 = S.perf()
+    perf0 = {w: S.perf(w) for w in "AP"}
     S.set_timing(True)
     torch.cuda.synchronize()
     if dist is not None:
@@ -138,7 +138,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     S.set_timing(False)
-    perf1 = S.perf()
+    perf1 = {w: S.perf(w) for w in "AP"}
 
     tot_updates, max_dt = float(updates), dt
     if dist is not None:
@@ -150,22 +150,27 @@ def main():
         tot_updates, max_dt = float(u[0].item()), float(m[1].item())
 
     if rank == 0:
-        ev_bytes = perf1["evalBytes"] - perf0["evalBytes"]
-        ev_launch = perf1["evalLaunches"] - perf0["evalLaunches"]
-        batches = perf1["batches"] - perf0["batches"]
-        # HIP events bracket a sample of the launches on the kernels' stream.  A bracket also contains the
-        # fixed launch overhead; the launches enqueued past the end of an update (empty queue) measure exactly
-        # that overhead, so kernel time = (mean over batch-processing launches) - (mean over empty launches).
-        n_noop = perf1["evalNoopTimed"] - perf0["evalNoopTimed"]
-        noop_us = 1e3 * (perf1["evalNoopMs"] - perf0["evalNoopMs"]) / n_noop if n_noop else 0.0
-        g_noop = perf1["genNoopTimed"] - perf0["genNoopTimed"]
-        gnoop_us = 1e3 * (perf1["genNoopMs"] - perf0["genNoopMs"]) / g_noop if g_noop else 0.0
-        ev_raw_us = 1e3 * (perf1["evalMs"] - perf0["evalMs"]) / max(1, batches)
-        gen_raw_us = 1e3 * (perf1["genMs"] - perf0["genMs"]) / max(1, batches)
-        ev_us, gen_us = max(ev_raw_us - noop_us, 1e-3), max(gen_raw_us - gnoop_us, 1e-3)
-        ev_ms, gen_ms = ev_us * batches / 1e3, gen_us * batches / 1e3
-        ev_launch = batches
-        achieved = (ev_bytes / 1e9) / (ev_ms / 1e3) if ev_ms > 0 else 0.0
+        def kernel_times(w):
+            """HIP start/stop events ride on the dispatch packets of a sample of the launches (hipExtLaunchKernelGGL on
+            the kernels' stream): begin-to-end time of the dispatch, the quantity rocprofv3 --kernel-trace reports.
+            Launches enqueued past the end of an update (empty queue) are kept out of the average."""
+            d = {k: perf1[w][k] - perf0[w][k] for k in perf1[w]}
+            nb = max(1, d["batches"])
+            ev_noop = 1e3 * d["evalNoopMs"] / d["evalNoopTimed"] if d["evalNoopTimed"] else 0.0
+            return dict(batches=d["batches"], bytes=d["evalBytes"], eval_us=1e3 * d["evalMs"] / nb, gen_us=1e3 * d["genMs"] / nb,
+                        eval_empty_us=ev_noop, launches=d["evalLaunches"] + d["genLaunches"])
+        kt = {w: kernel_times(w) for w in "AP"}
+        batches = kt["A"]["batches"] + kt["P"]["batches"]
+        # the roofline kernel: the fused evaluation kernel, which serves the sampler whose data vectors have at most
+        # 4096 elements (A in the headline workload: one workgroup of 512 threads per proposal); the other sampler's
+        # long vectors go through the split alpha/apply kernels, reported alongside
+        roof = "A" if S.dims("A")[1] <= 4096 else "P"
+        rk = kt[roof]
+        achieved = (rk["bytes"] / 1e9) / (rk["eval_us"] * rk["batches"] / 1e6) if rk["batches"] else 0.0
+        gen_ms = sum(kt[w]["gen_us"] * kt[w]["batches"] for w in "AP") / 1e3
+        ev_ms = sum(kt[w]["eval_us"] * kt[w]["batches"] for w in "AP") / 1e3
+        other = "P" if roof == "A" else "A"
+        ok = kt[other]
         out = {
             "metric": METRIC, "value": tot_updates / max_dt, "unit": "proposals/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * max_dt / K,
@@ -177,12 +182,15 @@ def main():
                        "avg_queue_A": S.avg_queue("A"), "avg_queue_P": S.avg_queue("P"),
                        "atoms_A": S.natoms("A"), "atoms_P": S.natoms("P"),
                        "gen_kernel_ms_rank0": gen_ms, "eval_kernel_ms_rank0": ev_ms,
-                       "launches_per_batch": (perf1["evalLaunches"] + perf1["genLaunches"] - perf0["evalLaunches"] - perf0["genLaunches"]) / max(1, batches)},
-            "roofline": {"bound": "hbm", "kernel": "eval_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "launches_per_batch": (kt["A"]["launches"] + kt["P"]["launches"]) / max(1, batches)},
+            "roofline": {"bound": "hbm", "kernel": "eval_kernel<EVAL_FUSED> (sampler %s)" % roof, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "bytes_per_launch": ev_bytes / max(1, ev_launch), "avg_launch_us": ev_us,
-                         "event_bracket_us": ev_raw_us, "empty_launch_us": noop_us,
-                         "note": "one launch = one batch; avg over launches that processed a batch (A and P samplers together)"},
+                         "bytes_per_launch": rk["bytes"] / max(1, rk["batches"]), "avg_launch_us": rk["eval_us"],
+                         "empty_queue_launch_us": rk["eval_empty_us"], "launches": int(rk["batches"]),
+                         "note": "one launch = one batch of sampler %s" % roof,
+                         "other_sampler": {"kernels": "eval_kernel<EVAL_ALPHA> + eval_kernel<EVAL_APPLY> (sampler %s, two launches per batch)" % other,
+                                           "bytes_per_batch": ok["bytes"] / max(1, ok["batches"]), "avg_batch_us": ok["eval_us"], "batches": int(ok["batches"]),
+                                           "achieved": (ok["bytes"] / 1e9) / (ok["eval_us"] * ok["batches"] / 1e6) if ok["batches"] else 0.0}},
         }
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(data, params, args.cpu_seconds)

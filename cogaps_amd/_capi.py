@@ -69,7 +69,7 @@ EXPORTS = [
     "cogaps_session_chisq", "cogaps_session_get_matrix", "cogaps_session_get_ap",
     "cogaps_session_get_atoms", "cogaps_session_dims", "cogaps_session_avg_queue",
     "cogaps_session_finish", "cogaps_session_set_timing", "cogaps_session_perf",
-    "cogaps_reduction_width", "cogaps_session_debug_prof", "cogaps_session_debug_replay",
+    "cogaps_session_perf_sampler", "cogaps_reduction_width", "cogaps_session_debug_prof", "cogaps_session_debug_replay",
 ]
 
 
@@ -103,6 +103,7 @@ def bind(L):
     L.cogaps_session_finish.argtypes = [vp, C.POINTER(CogapsResultC)]
     L.cogaps_session_set_timing.argtypes = [vp, C.c_int]
     L.cogaps_session_perf.argtypes = [vp, C.POINTER(CogapsPerfC)]
+    L.cogaps_session_perf_sampler.argtypes = [vp, C.c_char, C.POINTER(CogapsPerfC)]
     L.cogaps_session_debug_prof.argtypes = [vp, C.c_char, C.POINTER(C.c_uint64)]
     L.cogaps_session_debug_replay.argtypes = [vp, C.c_char, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
     L.cogaps_reduction_width.restype = C.c_uint32
@@ -297,9 +298,12 @@ class Session:
     def set_timing(self, on):
         self._ck(self.L.cogaps_session_set_timing(self.h, int(on)))
 
-    def perf(self):
+    def perf(self, which=None):
         p = CogapsPerfC()
-        self._ck(self.L.cogaps_session_perf(self.h, C.byref(p)))
+        if which is None:
+            self._ck(self.L.cogaps_session_perf(self.h, C.byref(p)))
+        else:
+            self._ck(self.L.cogaps_session_perf_sampler(self.h, which.encode(), C.byref(p)))
         return {f[0]: getattr(p, f[0]) for f in CogapsPerfC._fields_}
 
     def debug_replay(self, which, kind, n, flags=0):

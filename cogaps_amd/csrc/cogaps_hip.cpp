@@ -272,14 +272,15 @@ static void grow_atoms(cogaps_session *s, HostSampler &h, uint32_t need)
     d.atomCap = cap;
 }
 
-// HIP-event timing of a sample of the launches (every 8th), on the stream the kernels run on; the
-// events are resolved after the chunk's synchronisation so that timing never stalls the queue
+// HIP-event timing of a sample of the launches (every 8th): the start / stop events are attached to the kernel's
+// own dispatch packet (hipExtLaunchKernelGGL), so their difference is the dispatch's begin-to-end time, the
+// figure rocprofv3 --kernel-trace reports; no extra packets enter the stream.  Events are resolved after the
+// chunk's synchronisation so that timing never stalls the queue.
 static int timing_slot(cogaps_session *s, HostSampler &h, int kind, uint64_t ordinal)
 {
     if (!s->timing || (ordinal % 8) != 0 || s->evUsed >= s->evPool.size()) return -1;
     const int i = (int)s->evUsed++;
     s->evKind[i] = kind; s->evOwner[i] = &h; s->evOrd[i] = h.updLaunches;
-    rt_event_start(s->evPool[i], s->stream);
     return i;
 }
 // `realBatches` = batches the current update has generated so far: pair number k processed a batch iff k < realBatches
@@ -290,15 +291,16 @@ static void timing_resolve(cogaps_session *s, uint64_t realBatches)
         HostSampler *h = s->evOwner[i];
         const bool real = s->evOrd[i] < realBatches;
         if (s->evKind[i] == 0) { if (real) { h->genMs += ms; h->genTimed++; } else { h->genNoopMs += ms; h->genNoopTimed++; } }
-        else { if (real) { h->evalMs += ms; h->evalTimed++; } else { h->evalNoopMs += ms; h->evalNoopTimed++; } }
+        else if (s->evKind[i] == 1) { if (real) { h->evalMs += ms; h->evalTimed++; } else { h->evalNoopMs += ms; h->evalNoopTimed++; } }
+        else { if (real) h->evalMs += ms; else h->evalNoopMs += ms; }      // second kernel of a split evaluation: same sample as the first
     }
     s->evUsed = 0;
 }
+#define LAUNCH_MAYBE_TIMED(slot, KERNEL, grid, block, ...) do { if ((slot) >= 0) RT_LAUNCH_TIMED(KERNEL, grid, block, s->stream, s->evPool[slot], __VA_ARGS__); else RT_LAUNCH(KERNEL, grid, block, s->stream, __VA_ARGS__); } while (0)
 static void launch_gen(cogaps_session *s, HostSampler &h)
 {
     const int slot = timing_slot(s, h, 0, h.genLaunches);
-    RT_LAUNCH(gen_kernel<GEN_WIN>, 1, GEN_WIN, s->stream, h.d);
-    if (slot >= 0) rt_event_stop(s->evPool[slot], s->stream);
+    LAUNCH_MAYBE_TIMED(slot, gen_kernel<GEN_WIN>, 1, GEN_WIN, h.d);
     h.genLaunches++;
 }
 static void launch_eval(cogaps_session *s, HostSampler &h)
@@ -307,7 +309,7 @@ static void launch_eval(cogaps_session *s, HostSampler &h)
     if (h.d.redW <= 1024u) {
         // one workgroup of W threads per proposal
         const uint32_t grid = std::min<uint32_t>(h.d.queueCap, 512u);
-        RT_LAUNCH(eval_kernel<EVAL_FUSED>, grid, h.d.redW, s->stream, h.d, 1u);
+        LAUNCH_MAYBE_TIMED(slot, eval_kernel<EVAL_FUSED>, grid, h.d.redW, h.d, 1u);
     } else {
         // long data vectors: `slices` workgroups of `bs` threads per proposal, alpha kernel then apply kernel
         // (512 threads fill the machine a little better than 1024; at most 16 slices fit the partials record)
@@ -315,10 +317,11 @@ static void launch_eval(cogaps_session *s, HostSampler &h)
         const uint32_t slices = std::min<uint32_t>(h.d.redW / bs, ((h.d.Npad >> 2) + bs - 1u) / bs);
         const uint32_t perWave = std::max<uint32_t>(1u, (512u * (1024u / bs)) / slices);   // two resident 1024-thread workgroups per compute unit
         const uint32_t grid = std::min<uint32_t>(h.d.queueCap, perWave) * slices;
-        RT_LAUNCH(eval_kernel<EVAL_ALPHA>, grid, bs, s->stream, h.d, slices);
-        RT_LAUNCH(eval_kernel<EVAL_APPLY>, grid, bs, s->stream, h.d, slices);
+        int slot2 = -1;
+        if (slot >= 0 && s->evUsed < s->evPool.size()) { slot2 = (int)s->evUsed++; s->evKind[slot2] = 3; s->evOwner[slot2] = &h; s->evOrd[slot2] = h.updLaunches; }
+        LAUNCH_MAYBE_TIMED(slot, eval_kernel<EVAL_ALPHA>, grid, bs, h.d, slices);
+        LAUNCH_MAYBE_TIMED(slot2, eval_kernel<EVAL_APPLY>, grid, bs, h.d, slices);
     }
-    if (slot >= 0) rt_event_stop(s->evPool[slot], s->stream);
     h.evalLaunches++;
 }
 
@@ -738,22 +741,30 @@ int cogaps_session_set_timing(cogaps_session *s, int on)
     s->timing = on != 0;
     SESSION_END
 }
+static void add_perf(cogaps_session *s, HostSampler *h, cogaps_perf *out)
+{
+    read_gs(s, *h);
+    out->evalBytes += s->hGs->evalBytes; out->proposalsQueued += s->hGs->evalProps;
+    out->evalLaunches += h->evalLaunches; out->genLaunches += h->genLaunches; out->batches += h->batches;
+    // sampled event timing scaled to the launches that processed a batch
+    if (h->evalTimed) out->evalMs += h->evalMs * (double)h->batches / (double)h->evalTimed;
+    if (h->genTimed) out->genMs += h->genMs * (double)h->batches / (double)h->genTimed;
+    out->evalNoopMs += h->evalNoopMs; out->evalNoopTimed += h->evalNoopTimed;
+    out->genNoopMs += h->genNoopMs; out->genNoopTimed += h->genNoopTimed;
+}
 int cogaps_session_perf(cogaps_session *s, cogaps_perf *out)
 {
     SESSION_TRY
     memset(out, 0, sizeof(*out));
-    for (HostSampler *h : {&s->A, &s->P}) {
-        read_gs(s, *h);
-        out->evalBytes += s->hGs->evalBytes; out->proposalsQueued += s->hGs->evalProps;
-        out->evalLaunches += h->evalLaunches; out->genLaunches += h->genLaunches; out->batches += h->batches;
-        // sampled event timing (every 8th launch) scaled to all launches
-        // sampled event timing (every 8th launch) scaled to the launches that processed a batch
-        if (h->evalTimed) out->evalMs += h->evalMs * (double)h->batches / (double)h->evalTimed;
-        if (h->genTimed) out->genMs += h->genMs * (double)h->batches / (double)h->genTimed;
-        out->evalNoopMs += h->evalNoopMs; out->evalNoopTimed += h->evalNoopTimed;
-        out->genNoopMs += h->genNoopMs; out->genNoopTimed += h->genNoopTimed;
-    }
+    for (HostSampler *h : {&s->A, &s->P}) add_perf(s, h, out);
     out->syncMs = s->syncMs;
+    SESSION_END
+}
+int cogaps_session_perf_sampler(cogaps_session *s, char which, cogaps_perf *out)
+{
+    SESSION_TRY
+    memset(out, 0, sizeof(*out));
+    add_perf(s, &pick(s, which), out);
     SESSION_END
 }
 

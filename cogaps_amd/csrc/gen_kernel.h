@@ -76,6 +76,8 @@ __device__ unsigned long long g_timeline[(GEN_WIN / 64) * 64];
 #define GEN_K_ATOM 1u
 #define GEN_K_GAP 2u
 #define GEN_K_INL 3u
+#define GEN_GS_WORDS ((uint32_t)(offsetof(GenScalars, evalProps) / 4u + 2u))      // words [0, GEN_GS_WORDS) of GenScalars are written back by the generator
+#define GEN_GS_ERROR_WORD ((uint32_t)(offsetof(GenScalars, error) / 4u))
 #define FLUSH_MAX 64                 // erase caches up to this size are flushed in parallel
 #define CG_KEEP 0xFFFFFFFEu          // "front unchanged" marker
 
@@ -95,7 +97,7 @@ struct GenShared {
     // flush: erase cache sorted by position (handles, links, vector indices, bins), the tail of the unsorted
     // vector and the net writes of the swap-with-last replay
     uint64_t fpos[FLUSH_MAX]; uint32_t fh[FLUSH_MAX], fl[FLUSH_MAX], fr[FLUSH_MAX], fidx[FLUSH_MAX], fbin[FLUSH_MAX], vt[FLUSH_MAX], lowSlot[FLUSH_MAX], lowH[FLUSH_MAX];
-    uint32_t nLow, newFront, flushM, flushBase, unitSum;
+    uint32_t nLow, newFront, flushM, flushBase, unitSum, endBatch;
 #if defined(GEN_TIMELINE)
     unsigned long long ts[(WIN / 64) * 64]; uint32_t tsn[WIN / 64];
 #endif

@@ -126,23 +126,32 @@ CG_DEVICE void gen_body(const SamplerDev &S)
         for (uint32_t q = t + WIN; q < e_prevQ; q += WIN) units += S.queueUnits[q];
         if (units) cg_atomic_add_u32(&sh.unitSum, units);
     }
+    // set-up of the first round, issued before the flush so that it runs under the flush's memory trips: after the
+    // flush the domain holds e_n - e_m atoms
+    const bool updateDone = e_nDone >= e_nSteps;
+    {
+        const uint32_t n0 = e_n - e_m;
+        // death probability (ProposalQueue::deathProb) for every atom count an attempt of this window can see:
+        // lane t fills the entries for t births / t deaths ahead of it
+        sh.dpHi[t] = gm_death_prob((double)((uint64_t)n0 + t), S.domainLenD, S.alphaD, S.numBins);
+        sh.dpLo[t] = (n0 >= t) ? gm_death_prob((double)(uint64_t)(n0 - t), S.domainLenD, S.alphaD, S.numBins) : 0.f;
+        if (t < (unsigned)(WIN / 64)) { sh.mq[t] = 0ull; sh.mb[t] = 0ull; sh.md[t] = 0ull; }
+        if (t == 0) {
+            sh.batchEpoch = sh.g.batchEpoch + 1;
+            sh.roundNo = 1; sh.stopKey = 0xFFFFFFFFu;
+            sh.qrngRound = sh.g.qrng;
+            sh.nR = n0; sh.minAtoms = n0;
+            sh.processed = 0; sh.qlen = 0; sh.skip = sh.g.useCached ? 1u : 0u;
+            sh.remaining = e_nSteps - e_nDone;
+            sh.u1c = sh.g.u1; sh.u2c = sh.g.u2; sh.updBase = e_nDone;
+        }
+    }
     gen_flush_parallel<WIN>(S, sh, e_m, e_n, e_fc, specH);
     GEN_PROF(0);
     GEN_TS(2);
-
-    if (t == 0) {
-        sh.done = (sh.g.nDone >= sh.g.nSteps) ? 1u : 0u;
-        sh.batchEpoch = sh.g.batchEpoch + 1;
-        sh.roundNo = 0;
-        sh.qrngRound = sh.g.qrng;
-        const uint32_t n = sh.g.nAtoms;
-        sh.nR = n; sh.minAtoms = n;
-        sh.processed = 0; sh.qlen = 0; sh.skip = sh.g.useCached ? 1u : 0u;
-        sh.remaining = sh.g.nSteps - sh.g.nDone;
-        sh.u1c = sh.g.u1; sh.u2c = sh.g.u2; sh.updBase = sh.g.nDone;
-    }
-    cg_sync();
-    if (sh.done) {
+    if (t == 0) sh.newFront = CG_NONE;        // (the commit phase's marker; barriers follow before it is used)
+    if (e_m == 0) cg_sync();                   // the flush ended with a barrier otherwise
+    if (updateDone) {
         if (t == 0) { gs->nAtoms = sh.g.nAtoms; gs->front = sh.g.front; gs->freeCount = sh.g.freeCount; gs->eraseCount = 0; gs->qlen = 0; gs->batchNproc = 0; gs->updateFlushed = 1;
                       gs->evalBytes = sh.g.evalBytes + (unsigned long long)sh.unitSum * 4ull * S.N; gs->evalProps = sh.g.evalProps + e_prevQ; }
         GEN_PROF_FLUSH();
@@ -150,21 +159,10 @@ CG_DEVICE void gen_body(const SamplerDev &S)
     }
 
     const uint64_t batchEpoch = sh.batchEpoch;
-    const uint32_t updBase = sh.updBase;        // attempts consumed by earlier batches of this update
+    const uint32_t updBase = e_nDone;           // attempts consumed by earlier batches of this update
     const uint32_t K = S.K;
 
     for (;;) {
-        // ------------------------------------------------------------------ round set-up
-        if (t == 0) { sh.roundNo += 1; sh.stopKey = 0xFFFFFFFFu; sh.newFront = CG_NONE; if (sh.roundNo >= 4094u) gs->error = GAPS_ERR_SPIN; }
-        if (t < (unsigned)(WIN / 64)) { sh.mq[t] = 0ull; sh.mb[t] = 0ull; sh.md[t] = 0ull; }
-        {   // death probability (ProposalQueue::deathProb) for every atom count an attempt of this window can
-            // see: lane t fills the entries for t births / t deaths ahead of it (sh.nR / sh.minAtoms were
-            // published before the previous barrier)
-            const uint32_t n0 = sh.nR, m0 = sh.minAtoms;
-            sh.dpHi[t] = gm_death_prob((double)((uint64_t)n0 + t), S.domainLenD, S.alphaD, S.numBins);
-            sh.dpLo[t] = (m0 >= t) ? gm_death_prob((double)(uint64_t)(m0 - t), S.domainLenD, S.alphaD, S.numBins) : 0.f;
-        }
-        cg_sync();
         GEN_TS(4);
         const uint32_t roundNo = sh.roundNo;
         const uint32_t nR = sh.nR, minR = sh.minAtoms, skip = sh.skip, processed = sh.processed;
@@ -634,20 +632,17 @@ CG_DEVICE void gen_body(const SamplerDev &S)
 #if defined(GEN_PROFILE)
             prof_acc[15] += 1ull;
 #endif
-        }
-        cg_sync();
-        GEN_PROF_R(7, 12);
-        GEN_TS(23);
-        const bool endBatch = sh.stopFail || (sh.processed >= sh.remaining);
-        if (endBatch) {
-            if (t == 0) {
+            const bool endB = stopFail || (processed + stopT >= sh.remaining);
+            sh.endBatch = endB ? 1u : 0u;
+            if (endB) {
+                // final values of the scalars the generator owns, in the LDS copy; the lanes write it back below
                 GenScalars &g = sh.g;
                 g.qrng = sh.qrngRound;
-                if (sh.stopFail) { g.useCached = 1; g.u1 = sh.u1[sh.stopT]; g.u2 = sh.u2[sh.stopT]; }
+                if (stopFail) { g.useCached = 1; g.u1 = sh.u1[stopT]; g.u2 = sh.u2[stopT]; }
                 else g.useCached = 0;
-                const uint32_t nDone = updBase + sh.processed;
+                const uint32_t nDone = updBase + processed + stopT;
                 g.nDone = nDone;
-                g.qlen = sh.qlen; g.batchNproc = sh.processed;
+                g.qlen = sh.qlen; g.batchNproc = processed + stopT;
                 g.batchEpoch = batchEpoch; g.eraseCount = 0;
                 if (nDone < g.nSteps) {           // n < nSteps: AsynchronousGibbsSampler.h:97-102
                     const float ns = g.nQueueSamples + 1.f;
@@ -658,18 +653,20 @@ CG_DEVICE void gen_body(const SamplerDev &S)
                 }
                 if (g.traceOn) {
                     const uint32_t bi = g.traceBatchCount;
-                    if (bi < g.traceCap) { S.traceBatchNproc[bi] = sh.processed; S.traceBatchQlen[bi] = sh.qlen; }
+                    if (bi < g.traceCap) { S.traceBatchNproc[bi] = processed + stopT; S.traceBatchQlen[bi] = sh.qlen; }
                     g.traceBatchCount = bi + 1; g.traceCount += sh.qlen;
                 }
                 g.nBatches += 1;
-                // write back everything the generator owns (error / evalBytes / evalProps / prof are updated in place)
-                gs->qrng = g.qrng; gs->batchEpoch = g.batchEpoch; gs->nAtoms = g.nAtoms; gs->front = g.front;
-                gs->freeCount = g.freeCount; gs->handleHi = g.handleHi; gs->nDone = g.nDone; gs->qlen = g.qlen;
-                gs->batchNproc = g.batchNproc; gs->eraseCount = 0; gs->useCached = g.useCached; gs->u1 = g.u1; gs->u2 = g.u2;
-                gs->avgQueue = g.avgQueue; gs->nQueueSamples = g.nQueueSamples; gs->nBatches = g.nBatches;
-                gs->traceCount = g.traceCount; gs->traceBatchCount = g.traceBatchCount;
-                gs->evalBytes = g.evalBytes + (unsigned long long)sh.unitSum * 4ull * S.N; gs->evalProps = g.evalProps + e_prevQ;
+                g.evalBytes = g.evalBytes + (unsigned long long)sh.unitSum * 4ull * S.N; g.evalProps = g.evalProps + e_prevQ;
             }
+        }
+        cg_sync();
+        GEN_PROF_R(7, 12);
+        GEN_TS(23);
+        if (sh.endBatch) {
+            // write back the leading words of GenScalars (everything the generator owns) one lane per word; the
+            // sticky error word is only ever written in place
+            if (t < GEN_GS_WORDS && t != GEN_GS_ERROR_WORD) reinterpret_cast<uint32_t *>(gs)[t] = reinterpret_cast<const uint32_t *>(&sh.g)[t];
             GEN_TS(24);
             cg_sync();
             GEN_TS_DUMP();
@@ -677,6 +674,15 @@ CG_DEVICE void gen_body(const SamplerDev &S)
             GEN_PROF_FLUSH();
             return;
         }
+        // ------------------------------------------------------------------ set-up of the next round of this batch
+        if (t == 0) { sh.roundNo += 1; sh.stopKey = 0xFFFFFFFFu; sh.newFront = CG_NONE; if (sh.roundNo >= 4094u) gs->error = GAPS_ERR_SPIN; }
+        if (t < (unsigned)(WIN / 64)) { sh.mq[t] = 0ull; sh.mb[t] = 0ull; sh.md[t] = 0ull; }
+        {   // sh.nR / sh.minAtoms were published before the barrier above
+            const uint32_t n0 = sh.nR, m0 = sh.minAtoms;
+            sh.dpHi[t] = gm_death_prob((double)((uint64_t)n0 + t), S.domainLenD, S.alphaD, S.numBins);
+            sh.dpLo[t] = (m0 >= t) ? gm_death_prob((double)(uint64_t)(m0 - t), S.domainLenD, S.alphaD, S.numBins) : 0.f;
+        }
+        cg_sync();
     }
 }
 

@@ -2,6 +2,9 @@
 // host memory + the fiber emulator in the test-only COGAPS_EMUL build (tests/emul).
 #pragma once
 #include "platform.h"
+#if !defined(COGAPS_EMUL)
+#include <hip/hip_ext.h>
+#endif
 #include <stdlib.h>
 #include <string.h>
 #include <string>
@@ -24,6 +27,7 @@ inline rt_stream_t rt_stream_create() { return 0; }
 inline void rt_stream_destroy(rt_stream_t) {}
 #define RT_LAUNCH(kernel, grid, block, stream, ...) cgemu::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })
 struct rt_event_pair { };
+#define RT_LAUNCH_TIMED(kernel, grid, block, stream, ev, ...) RT_LAUNCH(kernel, grid, block, stream, __VA_ARGS__)
 inline void rt_event_create(rt_event_pair &) {}
 inline void rt_event_destroy(rt_event_pair &) {}
 inline void rt_event_start(rt_event_pair &, rt_stream_t) {}
@@ -55,6 +59,8 @@ inline rt_stream_t rt_stream_create() { hipStream_t s; RT_CHECK(hipStreamCreateW
 inline void rt_stream_destroy(rt_stream_t s) { (void)hipStreamDestroy(s); }
 #define RT_LAUNCH(kernel, grid, block, stream, ...) do { hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (stream), __VA_ARGS__); RT_CHECK(hipGetLastError()); } while (0)
 struct rt_event_pair { hipEvent_t a, b; };
+// start / stop events carried by the kernel's own dispatch packet
+#define RT_LAUNCH_TIMED(kernel, grid, block, stream, ev, ...) do { hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (stream), (ev).a, (ev).b, 0, __VA_ARGS__); RT_CHECK(hipGetLastError()); } while (0)
 inline void rt_event_create(rt_event_pair &e) { RT_CHECK(hipEventCreate(&e.a)); RT_CHECK(hipEventCreate(&e.b)); }
 inline void rt_event_destroy(rt_event_pair &e) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 inline void rt_event_start(rt_event_pair &e, rt_stream_t s) { RT_CHECK(hipEventRecord(e.a, s)); }

@@ -134,12 +134,13 @@ int cogaps_session_finish(cogaps_session *s, cogaps_result *out);
 typedef struct cogaps_perf {
     uint64_t evalBytes;       /* sum over evaluated proposals of 16N/20N/32N + 12N per AP update */
     uint64_t evalLaunches, genLaunches, batches, proposalsQueued;
-    double evalMs, genMs, syncMs;   /* HIP-event time of the launches that processed a batch (sampled, scaled to `batches`) */
-    double evalNoopMs, genNoopMs;   /* summed HIP-event time of sampled launches past the end of an update (launch overhead only) */
+    double evalMs, genMs, syncMs;   /* HIP-event time (dispatch begin to end) of the launches that processed a batch (sampled, scaled to `batches`) */
+    double evalNoopMs, genNoopMs;   /* summed HIP-event time of sampled launches past the end of an update (empty queue) */
     uint64_t evalNoopTimed, genNoopTimed; /* ... and how many were sampled */
 } cogaps_perf;
 int cogaps_session_set_timing(cogaps_session *s, int on);
-int cogaps_session_perf(cogaps_session *s, cogaps_perf *out);
+int cogaps_session_perf(cogaps_session *s, cogaps_perf *out);                      /* both samplers */
+int cogaps_session_perf_sampler(cogaps_session *s, char which, cogaps_perf *out);   /* the 'A' or the 'P' sampler alone */
 
 /* development aid: per-phase cycle counters of the generator kernel (all zero unless built with -DGEN_PROFILE) */
 int cogaps_session_debug_prof(cogaps_session *s, char which, uint64_t *out16);

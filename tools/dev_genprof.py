@@ -6,7 +6,7 @@ from bench import synthetic_dense
 import torch
 d = synthetic_dense(20000, 2000)
 import ctypes
-PL = _capi.bind(ctypes.CDLL(os.path.join(os.path.dirname(_capi.LIB_PATH), 'libcogaps_hip_PROFILE_DEV.so')))
+PL = _capi.bind(ctypes.CDLL(os.path.join(os.path.dirname(_capi.LIB_PATH), 'libcogaps_hip_REPLAY_DEV.so')))
 S = _capi.Session(d, lib=PL, nPatterns=50, nIterations=100, seed=42)
 warm = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 S.run_iterations(1, 0, warm)
@@ -32,7 +32,4 @@ for w in 'AP':
     print(w, 'rounds', pr[15], 'total Mcycles %.1f' % (tot / 1e6), 'prologue cycles/round %.0f' % (pr[14] / max(1, pr[15])))
     for i, n in enumerate(names):
         print('   %-28s %6.1f%%  %8.0f cycles/round' % (n, 100 * pr[i] / tot, pr[i] / max(1, pr[15])))
-    n2 = pr[14] >> 40; pr[14] &= (1 << 40) - 1
-    if n2: print('   rounds>=2: %d; cycles/round there: A1 %.0f A2 %.0f B1 %.0f commit %.0f bookkeeping %.0f   (round-1 marks above are then per ALL rounds: scale by %.3f)' % ((n2,) + tuple(x / n2 for x in sub) + (pr[15] / max(1, pr[15] - n2),)))
-    print('   sub-marks (cycles/round): B2 lookups %.0f | A2: stage1 rng+addr %.0f, vec/bits0 trip %.0f, atoms/binHead trip %.0f, neighbour trip %.0f' % tuple(x / max(1, pr[15]) for x in sub))
 print('rounds per batch: %.3f; generator cycles per batch %.0f' % (sum(S.debug_prof(w)[15] - q0[w][15] for w in 'AP') / nb, allc / nb))
