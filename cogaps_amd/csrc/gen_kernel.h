@@ -282,7 +282,7 @@ CG_DEVICE void gen_count3(uint32_t (*w)[WIN / 64], unsigned t, bool a, bool b, b
     const unsigned long long ma = cg_ballot(a), mb = cg_ballot(b), mc = cg_ballot(c);
     const unsigned long long lt = (1ull << lane) - 1ull;
     if (lane == 0) { w[0][wave] = (uint32_t)cg_popc64(ma); w[1][wave] = (uint32_t)cg_popc64(mb); w[2][wave] = (uint32_t)cg_popc64(mc); }
-    cg_sync();
+    cg_sync_lds();
     ea = (uint32_t)cg_popc64(ma & lt); eb = (uint32_t)cg_popc64(mb & lt); ec = (uint32_t)cg_popc64(mc & lt); ta = 0; tb = 0; tc = 0;
     for (unsigned k = 0; k < (unsigned)(WIN / 64); ++k) {
         const uint32_t xa = w[0][k], xb = w[1][k], xc = w[2][k];

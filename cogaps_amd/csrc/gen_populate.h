@@ -36,14 +36,14 @@ CG_DEVICE void gen_flush_parallel(const SamplerDev &S, GenShared<WIN> &sh, const
     // 1. fetch the erased atoms and the tail of the unsorted vector
     uint32_t myH = 0; AtomRec rec; rec.pos = 0; rec.left = CG_NONE; rec.right = CG_NONE; rec.mass = 0.f; rec.idx = 0;
     if (t < m) { myH = specH; rec = S.atoms[myH]; sh.fpos[t] = rec.pos; sh.vt[t] = S.vec[n - m + t]; }
-    cg_sync();
+    cg_sync_lds();
     // 2. rank sort by position (positions are unique)
     if (t < m) {
         uint32_t r = 0;
         for (uint32_t j = 0; j < m; ++j) r += (sh.fpos[j] < rec.pos) ? 1u : 0u;
         sh.fh[r] = myH; sh.fl[r] = rec.left; sh.fr[r] = rec.right; sh.fidx[r] = rec.idx; sh.fbin[r] = gen_bin_of(S, rec.pos);
     }
-    cg_sync();
+    cg_sync_lds();
     // 3. list surgery + bin heads (reads the pre-flush links only)
     if (t < m) {
         const uint32_t k = t, h = sh.fh[k];
@@ -83,7 +83,7 @@ CG_DEVICE void gen_flush_parallel(const SamplerDev &S, GenShared<WIN> &sh, const
         sh.nLow = nl; sh.flushM = m;
         g.nAtoms = n - m; g.freeCount += m; g.eraseCount = 0;
     }
-    cg_sync();
+    cg_sync_lds();
     if (t < sh.nLow) { const uint32_t slot = sh.lowSlot[t], h = sh.lowH[t]; S.vec[slot] = h; S.atoms[h].idx = slot; }
     if (t == 0 && sh.newFront != CG_KEEP) { g.front = sh.newFront; }
     cg_sync();
@@ -115,7 +115,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
     }
     if (t == 0) { sh.jmul[WIN] = S.lcgMul[2 * WIN]; sh.jinc[WIN] = S.lcgInc[2 * WIN]; }
     sh.jmul[t] = jm0; sh.jinc[t] = ji0;        // even-step PCG jumps, for the round bookkeeping
-    cg_sync();
+    cg_sync_lds();
     GEN_PROF(14);
     GEN_TS(1);
     // second trip (addresses from the first), in flight while the flush runs: this round's seeds
@@ -150,7 +150,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
     GEN_PROF(0);
     GEN_TS(2);
     if (t == 0) sh.newFront = CG_NONE;        // (the commit phase's marker; barriers follow before it is used)
-    if (e_m == 0) cg_sync();                   // the flush ended with a barrier otherwise
+    if (e_m == 0) cg_sync_lds();                   // the flush ended with a barrier otherwise
     if (updateDone) {
         if (t == 0) { gs->nAtoms = sh.g.nAtoms; gs->front = sh.g.front; gs->freeCount = sh.g.freeCount; gs->eraseCount = 0; gs->qlen = 0; gs->batchNproc = 0; gs->updateFlushed = 1;
                       gs->evalBytes = sh.g.evalBytes + (unsigned long long)sh.unitSum * 4ull * S.N; gs->evalProps = sh.g.evalProps + e_prevQ; }
@@ -212,7 +212,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
             GEN_TS(8);
             if (t == 0) sh.nWork = T0 + T1 + T2;
         }
-        cg_sync();
+        cg_sync_lds();
         GEN_PROF_R(1, 8);
         GEN_TS(9);
 
@@ -409,7 +409,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
             for (int k = 0; k < nk; ++k) cg_atomic_max_u64(gen_stamp_ptr(S, rk[k], rid[k]), st);
         }
         GEN_TS(15);
-        cg_sync();
+        if (ldsRound) cg_sync_lds(); else cg_sync();
         if (ldsRound) {
             if (live) {
                 uint32_t *words = &sh.bval[0].used;       // word 0 = used, 1 = gap, 2 = inl
@@ -417,7 +417,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
                 cg_atomic_min_u32(&words[4u * rs1 + rf1], ct);
                 cg_atomic_min_u32(&words[4u * rs2 + rf2], ct);
             }
-            cg_sync();
+            cg_sync_lds();
         }
         GEN_PROF_R(3, 10);
         GEN_TS(16);
@@ -538,7 +538,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
         }
         GEN_TS(18);
         if (go && (flags & (GEN_F_HAZARD | GEN_F_FAIL))) cg_atomic_min_u32(&sh.stopKey, 2u * ct + ((flags & GEN_F_HAZARD) ? 0u : 1u));
-        cg_sync();
+        if (ldsRound) cg_sync_lds(); else cg_sync();
         GEN_PROF(4);
         GEN_TS(19);
 
@@ -554,7 +554,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
             if (type == 'B') cg_atomic_or_u64(&sh.mb[ct >> 6], bit);
             if (type == 'D') cg_atomic_or_u64(&sh.md[ct >> 6], bit);
         }
-        cg_sync();
+        cg_sync_lds();
         GEN_PROF(5);
         GEN_TS(20);
         if (commit) {
@@ -612,7 +612,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
             }
         }
         GEN_TS(21);
-        cg_sync();
+        cg_sync_lds();
         GEN_PROF_R(6, 11);
         GEN_TS(22);
         // ------------------------------------------------------------------ round bookkeeping
@@ -660,7 +660,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
                 g.evalBytes = g.evalBytes + (unsigned long long)sh.unitSum * 4ull * S.N; g.evalProps = g.evalProps + e_prevQ;
             }
         }
-        cg_sync();
+        cg_sync_lds();
         GEN_PROF_R(7, 12);
         GEN_TS(23);
         if (sh.endBatch) {
@@ -668,7 +668,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
             // sticky error word is only ever written in place
             if (t < GEN_GS_WORDS && t != GEN_GS_ERROR_WORD) reinterpret_cast<uint32_t *>(gs)[t] = reinterpret_cast<const uint32_t *>(&sh.g)[t];
             GEN_TS(24);
-            cg_sync();
+            cg_sync_lds();
             GEN_TS_DUMP();
             GEN_PROF(13);
             GEN_PROF_FLUSH();

@@ -26,6 +26,9 @@ CG_DEVICE unsigned cg_bid() { return blockIdx.x; }
 CG_DEVICE unsigned cg_bdim() { return blockDim.x; }
 CG_DEVICE unsigned cg_gdim() { return gridDim.x; }
 CG_DEVICE void cg_sync() { __syncthreads(); }
+// workgroup barrier that orders LDS traffic only: outstanding global loads / stores stay in flight across it
+// (__syncthreads waits for vmcnt(0) as well).  Only where the lanes exchange nothing through global memory.
+CG_DEVICE void cg_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // global-memory atomics (device scope)
 CG_DEVICE uint32_t cg_atomic_add_u32(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }

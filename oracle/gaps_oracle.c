@@ -815,6 +815,15 @@ typedef struct go_sampler {
     uint32_t redW, redG;
     go_domain dom; go_queue queue;
     float avgQueue, nQueueSamples;
+    /* ---- SparseNormalModel (SparseNormalModel.h:56-64): D as bit flags + packed non-zeros per vector, mMatrix as a
+     * HybridMatrix = row copy `rows` [M][K] + column copy `mat` [K][M] with bit flags `mflags` [K][Mw] ---- */
+    int sparse;
+    uint64_t *dflags; uint32_t Wn;      /* [M][Wn], Wn = N/64 + 1 (SparseVector.cpp:14-18) */
+    uint32_t *dptr; float *dvals;       /* packed values of vector r: dvals[dptr[r] .. dptr[r+1]) */
+    float *rows; uint64_t *mflags; uint32_t Mw;
+    const struct go_sampler *oth;       /* mOtherMatrix */
+    float *Z1, *Z2;                     /* lookup tables, Z2 column-major K x K */
+    float beta;
 } go_sampler;
 
 /* lane-strided reduction (generalises SIMD.h PackedFloat: SIMD_INC lanes, here W lanes with G
@@ -837,8 +846,11 @@ static void lanes_finish(lane_acc *a, uint32_t W, float *s, float *smu)
 }
 
 /* DenseNormalModel.cpp:162-183 (ch == NULL) and :217-240 (with change) */
+static void sp_alpha_one(const go_sampler *sm, uint32_t row, uint32_t col, const float *ch, float *s_out, float *smu_out);
+static void sp_alpha_two(const go_sampler *sm, uint32_t r1, uint32_t c1, uint32_t r2, uint32_t c2, float *s_out, float *smu_out);
 static void alpha_one(const go_sampler *sm, uint32_t row, uint32_t col, const float *ch, float *s_out, float *smu_out)
 {
+    if (sm->sparse) { sp_alpha_one(sm, row, col, ch, s_out, smu_out); return; }
     const uint32_t N = sm->N;
     const float *D = sm->D + (size_t)row * N, *S = sm->S + (size_t)row * N, *AP = sm->AP + (size_t)row * N;
     const float *mat = sm->other + (size_t)col * N;
@@ -861,6 +873,7 @@ static void alpha_one(const go_sampler *sm, uint32_t row, uint32_t col, const fl
 /* DenseNormalModel.cpp:186-214 */
 static void alpha_two(const go_sampler *sm, uint32_t r1, uint32_t c1, uint32_t r2, uint32_t c2, float *s_out, float *smu_out)
 {
+    if (sm->sparse) { sp_alpha_two(sm, r1, c1, r2, c2, s_out, smu_out); return; }
     if (r1 == r2) {
         const uint32_t N = sm->N;
         const float *D = sm->D + (size_t)r1 * N, *S = sm->S + (size_t)r1 * N, *AP = sm->AP + (size_t)r1 * N;
@@ -885,6 +898,227 @@ static void alpha_two(const go_sampler *sm, uint32_t r1, uint32_t c1, uint32_t r
     alpha_one(sm, r2, c2, NULL, &sb, &mb);
     *s_out = sa + sb; *smu_out = ma - mb; /* AlphaParameters.cpp:11-14 "minus sign not a typo" */
 }
+/* ======================================================================================
+ * SparseNormalModel
+ * ====================================================================================== */
+
+/* gaps::dot in the scalar build (VectorMath.h:41-134, SIMD_INC = 1): for size <= 25 the fall-through switch adds
+ * element size-1 first and element 0 last; longer vectors are added front to back */
+static float sp_dot(const float *a, const float *b, uint32_t n)
+{
+    float d = 0.f;
+    if (n <= 25) { for (uint32_t i = n; i-- > 0;) d = d + a[i] * b[i]; }
+    else { for (uint32_t i = 0; i < n; ++i) d = d + a[i] * b[i]; }
+    return d;
+}
+/* VectorMath.h:137-155 */
+static float sp_dot_diff(const float *a, const float *b, const float *c, uint32_t n)
+{
+    float d = 0.f;
+    for (uint32_t i = 0; i < n; ++i) d += a[i] * (b[i] - c[i]);
+    return d;
+}
+/* virtual lanes of the sparse reductions in lane mode: one per 64-bit flag word up to 256 */
+static uint32_t sp_width(uint32_t N)
+{
+    uint32_t need = N / 64 + 1, w = 64;
+    while (w < need && w < 256) w <<= 1;
+    return w;
+}
+/* HybridVector::add / set (HybridVector.cpp:55-86) on column `col` of the column copy */
+static void hv_add(go_sampler *sm, uint32_t row, uint32_t col, float v)
+{
+    float *e = &sm->mat[(size_t)col * sm->M + row];
+    uint64_t *f = &sm->mflags[(size_t)col * sm->Mw + row / 64];
+    if (*e + v < GO_EPSILON) {
+#pragma omp atomic
+        *f &= ~(1ull << (row % 64));
+        *e = 0.f;
+    } else {
+#pragma omp atomic
+        *f |= (1ull << (row % 64));
+        *e += v;
+    }
+}
+static void hv_set(go_sampler *sm, uint32_t row, uint32_t col, float v)
+{
+    float *e = &sm->mat[(size_t)col * sm->M + row];
+    uint64_t *f = &sm->mflags[(size_t)col * sm->Mw + row / 64];
+    if (v < GO_EPSILON) {
+#pragma omp atomic
+        *f &= ~(1ull << (row % 64));
+        *e = 0.f;
+    } else {
+#pragma omp atomic
+        *f |= (1ull << (row % 64));
+        *e = v;
+    }
+}
+/* SparseNormalModel.cpp:153-193 (ch == NULL) and :196-239.  Lane mode: virtual lane L of sp_width(N) takes the flag
+ * words w = L, L+W, ... in increasing w (bits in increasing order) and accumulates its terms from +0; the lanes are
+ * folded by the ascending xor butterfly and the total is added to the table terms once. */
+static void sp_alpha_one(const go_sampler *sm, uint32_t row, uint32_t col, const float *ch, float *s_out, float *smu_out)
+{
+    const go_sampler *ot = sm->oth;
+    const uint32_t K = sm->K;
+    const uint64_t *fD = sm->dflags + (size_t)row * sm->Wn, *fV = ot->mflags + (size_t)col * ot->Mw;
+    const float *data = sm->dvals + sm->dptr[row];
+    const float *V = ot->mat + (size_t)col * ot->M;
+    const float *arow = sm->rows + (size_t)row * K;
+    float s = sm->Z1[col];
+    float s_mu = -1.f * sp_dot(arow, sm->Z2 + (size_t)col * K, K);
+    if (ch) s_mu -= *ch * sm->Z2[(size_t)col * K + col];
+    const int lanes = sm->redW > 1;
+    const uint32_t W = sp_width(sm->N);
+    lane_acc a;
+    if (lanes) for (uint32_t L = 0; L < W; ++L) { a.s[L] = 0.f; a.m[L] = 0.f; }
+    unsigned sparseIndex = 0;
+    for (uint32_t i = 0; i < sm->Wn; ++i) {
+        uint64_t d_flags = fD[i];
+        uint64_t common = d_flags & fV[i];
+        float *ps = lanes ? &a.s[i % W] : &s, *pm = lanes ? &a.m[i % W] : &s_mu;
+        while (common != 0u) {
+            unsigned index = (unsigned)__builtin_ffsll((long long)common) - 1;
+            sparseIndex += (unsigned)__builtin_popcountll(d_flags & ((1ull << index) - 1ull));
+            d_flags = (index == 63) ? 0 : d_flags & ~((1ull << (index + 1ull)) - 1ull);
+            common &= d_flags;
+            unsigned v_ndx = 64 * i + index;
+            float v_val = V[v_ndx];
+            float d_val = data[sparseIndex++];
+            float term1 = v_val / d_val;
+            float term2 = v_val - term1 / d_val;
+            *ps += term1 * term1 - v_val * v_val;
+            *pm += term1 + term2 * sp_dot(arow, ot->rows + (size_t)v_ndx * K, K);
+            if (ch) *pm += term2 * ot->rows[(size_t)v_ndx * K + col] * *ch;
+        }
+        sparseIndex += (unsigned)__builtin_popcountll(d_flags);
+    }
+    if (lanes) { float ts, tm; lanes_finish(&a, W, &ts, &tm); s += ts; s_mu += tm; }
+    *s_out = s * sm->beta; *smu_out = s_mu * sm->beta;
+}
+/* SparseNormalModel.cpp:242-292 */
+static void sp_alpha_two(const go_sampler *sm, uint32_t r1, uint32_t c1, uint32_t r2, uint32_t c2, float *s_out, float *smu_out)
+{
+    if (r1 == r2) {
+        const go_sampler *ot = sm->oth;
+        const uint32_t K = sm->K;
+        const uint64_t *fD = sm->dflags + (size_t)r1 * sm->Wn, *fV1 = ot->mflags + (size_t)c1 * ot->Mw, *fV2 = ot->mflags + (size_t)c2 * ot->Mw;
+        const float *data = sm->dvals + sm->dptr[r1];
+        const float *V1 = ot->mat + (size_t)c1 * ot->M, *V2 = ot->mat + (size_t)c2 * ot->M;
+        const float *arow = sm->rows + (size_t)r1 * K;
+        float s = sm->Z1[c1] - 2.f * sm->Z2[(size_t)c2 * K + c1] + sm->Z1[c2];
+        float s_mu = -1.f * sp_dot_diff(arow, sm->Z2 + (size_t)c1 * K, sm->Z2 + (size_t)c2 * K, K);
+        const int lanes = sm->redW > 1;
+        const uint32_t W = sp_width(sm->N);
+        lane_acc a;
+        if (lanes) for (uint32_t L = 0; L < W; ++L) { a.s[L] = 0.f; a.m[L] = 0.f; }
+        unsigned sparseIndex = 0;
+        for (uint32_t i = 0; i < sm->Wn; ++i) {
+            uint64_t d_flags = fD[i];
+            uint64_t common = d_flags & (fV1[i] | fV2[i]);
+            float *ps = lanes ? &a.s[i % W] : &s, *pm = lanes ? &a.m[i % W] : &s_mu;
+            while (common != 0u) {
+                unsigned index = (unsigned)__builtin_ffsll((long long)common) - 1;
+                sparseIndex += (unsigned)__builtin_popcountll(d_flags & ((1ull << index) - 1ull));
+                d_flags = (index == 63) ? 0 : d_flags & ~((1ull << (index + 1ull)) - 1ull);
+                common &= d_flags;
+                unsigned v_ndx = 64 * i + index;
+                float v1_val = V1[v_ndx], v2_val = V2[v_ndx];
+                float d_val = data[sparseIndex++];
+                float d_recip = 1.f / d_val;
+                float term1 = 1.f - d_recip * d_recip;
+                float v_diff = v1_val - v2_val;
+                float ap = sp_dot(arow, ot->rows + (size_t)v_ndx * K, K);
+                *ps -= v_diff * v_diff * term1;
+                *pm += v_diff * (ap * term1 + d_recip);
+            }
+            sparseIndex += (unsigned)__builtin_popcountll(d_flags);
+        }
+        if (lanes) { float ts, tm; lanes_finish(&a, W, &ts, &tm); s += ts; s_mu += tm; }
+        *s_out = s * sm->beta; *smu_out = s_mu * sm->beta;
+        return;
+    }
+    float sa, ma, sb, mb;
+    sp_alpha_one(sm, r1, c1, NULL, &sa, &ma);
+    sp_alpha_one(sm, r2, c2, NULL, &sb, &mb);
+    *s_out = sa + sb; *smu_out = ma - mb;
+}
+/* SparseNormalModel::generateLookupTables (SparseNormalModel.cpp:294-311).  Z1 reads the other matrix through
+ * operator() = its row copy, Z2 through the column copies.  Lane mode: the dense lane order over the N elements. */
+static void sp_tables(go_sampler *sm)
+{
+    const go_sampler *ot = sm->oth;
+    const uint32_t K = sm->K, N = ot->M;
+    for (uint32_t i = 0; i < K; ++i) {
+        if (sm->redW <= 1) {
+            float z = 0.f;
+            for (uint32_t k = 0; k < N; ++k) { float v = ot->rows[(size_t)k * K + i]; z += v * v; }
+            sm->Z1[i] = z;
+        } else {
+            lane_acc a; const uint32_t W = sm->redW, G = sm->redG;
+            for (uint32_t L = 0; L < W; ++L) { a.s[L] = 0.f; a.m[L] = 0.f; }
+            for (uint32_t k = 0; k < N; ++k) { float v = ot->rows[(size_t)k * K + i]; a.s[(k / G) % W] += v * v; }
+            float ts, tm; lanes_finish(&a, W, &ts, &tm); sm->Z1[i] = ts;
+        }
+        for (uint32_t j = i; j < K; ++j) {
+            const float *ci = ot->mat + (size_t)i * N, *cj = ot->mat + (size_t)j * N;
+            float d;
+            if (sm->redW <= 1) d = sp_dot(ci, cj, N);
+            else {
+                lane_acc a; const uint32_t W = sm->redW, G = sm->redG;
+                for (uint32_t L = 0; L < W; ++L) { a.s[L] = 0.f; a.m[L] = 0.f; }
+                for (uint32_t k = 0; k < N; ++k) a.s[(k / G) % W] += ci[k] * cj[k];
+                float tm; lanes_finish(&a, W, &d, &tm);
+            }
+            sm->Z2[(size_t)j * K + i] = d; sm->Z2[(size_t)i * K + j] = d;
+        }
+    }
+}
+/* SparseNormalModel::chiSq (SparseNormalModel.cpp:40-62).  Lane mode: per vector j, lane (i/G)%W takes element i
+ * (the dense term, then the non-zero correction of the same element), butterfly, vectors added in order. */
+static float sp_chisq(const go_sampler *sm)
+{
+    const go_sampler *ot = sm->oth;
+    const uint32_t K = sm->K;
+    float chisq = 0.f;
+    for (uint32_t j = 0; j < sm->M; ++j) {
+        const float *arow = sm->rows + (size_t)j * K;
+        const uint64_t *fD = sm->dflags + (size_t)j * sm->Wn;
+        const float *data = sm->dvals + sm->dptr[j];
+        if (sm->redW <= 1) {
+            for (uint32_t i = 0; i < sm->N; ++i) { float dot = sp_dot(arow, ot->rows + (size_t)i * K, K); chisq += dot * dot; }
+            unsigned si = 0;
+            for (uint32_t w = 0; w < sm->Wn; ++w) {
+                uint64_t fl = fD[w];
+                while (fl) {
+                    unsigned b = (unsigned)__builtin_ffsll((long long)fl) - 1; fl &= fl - 1;
+                    float d = data[si++];
+                    float dot = sp_dot(arow, ot->rows + (size_t)(64 * w + b) * K, K);
+                    float dsq = d * d;
+                    chisq += 1 + dot * (dot - 2 * d - dsq * dot) / dsq;
+                }
+            }
+        } else {
+            lane_acc a; const uint32_t W = sm->redW, G = sm->redG;
+            for (uint32_t L = 0; L < W; ++L) { a.s[L] = 0.f; a.m[L] = 0.f; }
+            unsigned si = 0;
+            for (uint32_t i = 0; i < sm->N; ++i) {
+                float dot = sp_dot(arow, ot->rows + (size_t)i * K, K);
+                float *acc = &a.s[(i / G) % W];
+                *acc += dot * dot;
+                if ((fD[i / 64] >> (i % 64)) & 1ull) {
+                    float d = data[si++];
+                    float dsq = d * d;
+                    *acc += 1 + dot * (dot - 2 * d - dsq * dot) / dsq;
+                }
+            }
+            float ps, pm; lanes_finish(&a, W, &ps, &pm);
+            chisq += ps;
+        }
+    }
+    return chisq * sm->beta;
+}
+
 /* DenseNormalModel.cpp:243-258 */
 static void update_ap(go_sampler *sm, uint32_t row, uint32_t col, float delta)
 {
@@ -895,12 +1129,17 @@ static void update_ap(go_sampler *sm, uint32_t row, uint32_t col, float delta)
 /* DenseNormalModel.cpp:110-115 */
 static void change_matrix(go_sampler *sm, uint32_t row, uint32_t col, float delta)
 {
+    if (sm->sparse) { sm->rows[(size_t)row * sm->K + col] += delta; hv_add(sm, row, col, delta); return; }   /* HybridMatrix::add, HybridMatrix.cpp:25-31 */
     sm->mat[(size_t)col * sm->M + row] += delta;
     update_ap(sm, row, col, delta);
 }
 /* DenseNormalModel.cpp:117-123 */
 static void safely_change_matrix(go_sampler *sm, uint32_t row, uint32_t col, float delta)
 {
+    if (sm->sparse) {   /* SparseNormalModel.cpp:117-122: mMatrix(row,col) is the row copy; HybridMatrix::set */
+        float newVal = fmax_ref(sm->rows[(size_t)row * sm->K + col] + delta, 0.f);
+        sm->rows[(size_t)row * sm->K + col] = newVal; hv_set(sm, row, col, newVal); return;
+    }
     float *e = &sm->mat[(size_t)col * sm->M + row];
     float newVal = fmax_ref(*e + delta, 0.f);
     update_ap(sm, row, col, newVal - *e);
@@ -909,6 +1148,11 @@ static void safely_change_matrix(go_sampler *sm, uint32_t row, uint32_t col, flo
 /* DenseNormalModel.cpp:100-108, VectorMath.cpp:113-123 */
 static int can_use_gibbs(const go_sampler *sm, uint32_t col)
 {
+    if (sm->sparse) {   /* isVectorZero(HybridVector) = empty(): no flag set (VectorMath.cpp:125-128) */
+        const uint64_t *f = sm->oth->mflags + (size_t)col * sm->oth->Mw;
+        for (uint32_t i = 0; i < sm->oth->Mw; ++i) if (f[i]) return 1;
+        return 0;
+    }
     const float *v = sm->other + (size_t)col * sm->N;
     for (uint32_t i = 0; i < sm->N; ++i) if (v[i] > 0.f) return 1;
     return 0;
@@ -1057,9 +1301,10 @@ static void sampler_update(go_sampler *sm, unsigned nSteps, unsigned nThreads, g
  * D[vector j][element i], then DenseNormalModel ctor (DenseNormalModel.h:66-88) ---- */
 static void sampler_init(go_sampler *sm, const float *data, uint32_t nrow, uint32_t ncol, const float *unc,
                          int genesInCols, int subsetGenes, const uint32_t *indices, uint32_t nIdx,
-                         uint32_t K, float alpha, float maxGibbsMass, go_randstate *rs, uint32_t redW, uint32_t redG)
+                         uint32_t K, float alpha, float maxGibbsMass, go_randstate *rs, uint32_t redW, uint32_t redG, int sparse)
 {
     memset(sm, 0, sizeof(*sm));
+    sm->sparse = sparse; sm->beta = 100.f;
     int subsetData = nIdx != 0;
     uint32_t nGenes = (subsetData && subsetGenes) ? nIdx : (genesInCols ? ncol : nrow);
     uint32_t nSamples = (subsetData && !subsetGenes) ? nIdx : (genesInCols ? nrow : ncol);
@@ -1075,10 +1320,32 @@ static void sampler_init(go_sampler *sm, const float *data, uint32_t nrow, uint3
             uint32_t dataRow = (subsetData && (subsetGenes != genesInCols)) ? indices[genesInCols ? j : i] - 1 : (genesInCols ? j : i);
             uint32_t dataCol = (subsetData && (subsetGenes == genesInCols)) ? indices[genesInCols ? i : j] - 1 : (genesInCols ? i : j);
             sm->D[(size_t)j * sm->N + i] = data[(size_t)dataRow * ncol + dataCol];
-            if (unc) sm->S[(size_t)j * sm->N + i] = unc[(size_t)dataRow * ncol + dataCol];
+            if (unc && !sparse) sm->S[(size_t)j * sm->N + i] = unc[(size_t)dataRow * ncol + dataCol];
         }
     }
-    if (!unc) { /* gaps::pmax(mDMatrix, 0.1f), MatrixMath.cpp:74-84 */
+    if (sparse) {
+        /* SparseMatrix(mat, ...) (SparseMatrix.cpp:10-47): SparseVector keeps v > 0 only (SparseVector.cpp:20-33);
+         * the uncertainty is always the default one (SparseNormalModel.h:90-96) */
+        sm->Wn = sm->N / 64 + 1; sm->Mw = sm->M / 64 + 1;
+        sm->dflags = (uint64_t *)calloc((size_t)sm->M * sm->Wn, 8);
+        sm->dptr = (uint32_t *)calloc((size_t)sm->M + 1, 4);
+        size_t nz = 0;
+        for (size_t t = 0; t < tot; ++t) { if (!(sm->D[t] > 0.f)) sm->D[t] = 0.f; else ++nz; }
+        sm->dvals = (float *)malloc((nz ? nz : 1) * 4);
+        nz = 0;
+        for (uint32_t j = 0; j < sm->M; ++j) {
+            sm->dptr[j] = (uint32_t)nz;
+            for (uint32_t i = 0; i < sm->N; ++i) {
+                float v = sm->D[(size_t)j * sm->N + i];
+                if (v > 0.f) { sm->dvals[nz++] = v; sm->dflags[(size_t)j * sm->Wn + i / 64] |= 1ull << (i % 64); }
+            }
+        }
+        sm->dptr[sm->M] = (uint32_t)nz;
+        sm->rows = (float *)calloc((size_t)sm->M * K, 4);
+        sm->mflags = (uint64_t *)calloc((size_t)K * sm->Mw, 8);
+        sm->Z1 = (float *)calloc(K, 4); sm->Z2 = (float *)calloc((size_t)K * K, 4);
+    }
+    if (!unc || sparse) { /* gaps::pmax(mDMatrix, 0.1f), MatrixMath.cpp:74-84 */
         for (size_t t = 0; t < tot; ++t) sm->S[t] = fmax_ref(sm->D[t] * 0.1f, 0.1f);
     }
     /* gaps::nonZeroMean, MatrixMath.cpp:39-55: column-major sequential sum */
@@ -1099,11 +1366,13 @@ static void sampler_init(go_sampler *sm, const float *data, uint32_t nrow, uint3
 static void sampler_free(go_sampler *sm)
 {
     free(sm->D); free(sm->S); free(sm->AP); free(sm->mat);
+    free(sm->dflags); free(sm->dptr); free(sm->dvals); free(sm->rows); free(sm->mflags); free(sm->Z1); free(sm->Z2);
     dom_free(&sm->dom); queue_free(&sm->queue);
 }
 /* DenseNormalModel.cpp:20-36 */
 static void sampler_sync(go_sampler *dst, const go_sampler *src)
 {
+    if (dst->sparse) { dst->oth = src; dst->other = src->mat; sp_tables(dst); return; }   /* SparseNormalModel.cpp:27-31 */
     const uint32_t nc = src->M, nr = src->N; /* src AP: nr x nc; vector j of src has nr elements */
 #pragma omp parallel for schedule(static)
     for (int64_t j = 0; j < (int64_t)nc; ++j)
@@ -1114,6 +1383,7 @@ static void sampler_sync(go_sampler *dst, const go_sampler *src)
 /* DenseNormalModel.cpp:38-54 */
 static void sampler_extra_init(go_sampler *sm)
 {
+    if (sm->sparse) return;    /* SparseNormalModel.cpp:34-37 */
     for (uint32_t j = 0; j < sm->M; ++j)
         for (uint32_t i = 0; i < sm->N; ++i) {
             float acc = 0.f;
@@ -1124,6 +1394,7 @@ static void sampler_extra_init(go_sampler *sm)
 /* DenseNormalModel.cpp:56-68: i over rows (element index) outer, j over columns (vectors) inner */
 static float sampler_chisq(const go_sampler *sm)
 {
+    if (sm->sparse) return sp_chisq(sm);
     float chisq = 0.f;
     if (sm->redW <= 1) {
         for (uint32_t i = 0; i < sm->N; ++i)
@@ -1184,15 +1455,18 @@ go_session *go_create(const float *data, uint32_t nrow, uint32_t ncol, const go_
     uint32_t nIdx = p->subsetData ? p->nSubset : 0;
     /* GapsRunner.cpp:402-406: A sampler on the transposed data, flags flipped */
     sampler_init(&s->A, data, nrow, ncol, unc, !p->transposeData, !p->subsetGenes, idx, nIdx, p->nPatterns,
-                 p->alphaA, p->maxGibbsMassA, s->rs, p->redW_A, p->redG);
+                 p->alphaA, p->maxGibbsMassA, s->rs, p->redW_A, p->redG, p->useSparseOptimization);
     sampler_init(&s->P, data, nrow, ncol, unc, p->transposeData, p->subsetGenes, idx, nIdx, p->nPatterns,
-                 p->alphaP, p->maxGibbsMassP, s->rs, p->redW_P, p->redG);
+                 p->alphaP, p->maxGibbsMassP, s->rs, p->redW_P, p->redG, p->useSparseOptimization);
     s->nGenes = s->A.M; s->nSamples = s->P.M; s->K = p->nPatterns;
     /* processFixedMatrix, GapsRunner.cpp:329-350 */
-    if (p->whichMatrixFixed == 'A' && p->fixedPatterns) {
-        for (uint32_t r = 0; r < s->A.M; ++r) for (uint32_t k = 0; k < s->K; ++k) s->A.mat[(size_t)k * s->A.M + r] = p->fixedPatterns[(size_t)r * s->K + k];
-    } else if (p->whichMatrixFixed == 'P' && p->fixedPatterns) {
-        for (uint32_t r = 0; r < s->P.M; ++r) for (uint32_t k = 0; k < s->K; ++k) s->P.mat[(size_t)k * s->P.M + r] = p->fixedPatterns[(size_t)r * s->K + k];
+    if ((p->whichMatrixFixed == 'A' || p->whichMatrixFixed == 'P') && p->fixedPatterns) {
+        go_sampler *fx = p->whichMatrixFixed == 'A' ? &s->A : &s->P;
+        for (uint32_t r = 0; r < fx->M; ++r) for (uint32_t k = 0; k < s->K; ++k) {
+            const float v = p->fixedPatterns[(size_t)r * s->K + k];
+            if (fx->sparse) { fx->rows[(size_t)r * s->K + k] = v; hv_add(fx, r, k, -1.f * fx->mat[(size_t)k * fx->M + r]); hv_add(fx, r, k, v); }   /* HybridMatrix::operator=(Matrix), HybridMatrix.cpp:70-84 */
+            else fx->mat[(size_t)k * fx->M + r] = v;
+        }
     }
     size_t na = (size_t)s->nGenes * s->K, np = (size_t)s->nSamples * s->K;
     s->Amean = (float *)calloc(na, 4); s->Astd = (float *)calloc(na, 4);
@@ -1253,6 +1527,29 @@ void go_get_matrix(const go_session *s, char which, float *out)
     const go_sampler *sm = pickc(s, which);
     for (uint32_t r = 0; r < sm->M; ++r) for (uint32_t k = 0; k < sm->K; ++k) out[(size_t)r * sm->K + k] = sm->mat[(size_t)k * sm->M + r];
 }
+/* test hooks: load both factor matrices (row-major [rows][K]) as setMatrix would and rebuild what depends on them;
+ * evaluate the alpha parameters of one (mode 0), one with change (mode 1) or two (mode 2) matrix entries */
+void go_debug_set_matrices(go_session *s, const float *A, const float *P)
+{
+    for (int w = 0; w < 2; ++w) {
+        go_sampler *sm = w ? &s->P : &s->A; const float *src = w ? P : A;
+        for (uint32_t r = 0; r < sm->M; ++r) for (uint32_t k = 0; k < sm->K; ++k) {
+            const float v = src[(size_t)r * sm->K + k];
+            if (sm->sparse) { sm->rows[(size_t)r * sm->K + k] = v; hv_add(sm, r, k, -1.f * sm->mat[(size_t)k * sm->M + r]); hv_add(sm, r, k, v); }
+            else sm->mat[(size_t)k * sm->M + r] = v;
+        }
+    }
+    sampler_sync(&s->A, &s->P); sampler_sync(&s->P, &s->A);
+    sampler_extra_init(&s->A); sampler_extra_init(&s->P);
+}
+void go_debug_alpha(const go_session *s, char which, int mode, uint32_t r1, uint32_t c1, uint32_t r2, uint32_t c2, float ch, float *out2)
+{
+    const go_sampler *sm = pickc(s, which);
+    if (mode == 0) alpha_one(sm, r1, c1, NULL, &out2[0], &out2[1]);
+    else if (mode == 1) alpha_one(sm, r1, c1, &ch, &out2[0], &out2[1]);
+    else alpha_two(sm, r1, c1, r2, c2, &out2[0], &out2[1]);
+}
+void go_get_rows(const go_session *s, char which, float *out) { const go_sampler *sm = pickc(s, which); if (sm->sparse) memcpy(out, sm->rows, (size_t)sm->M * sm->K * 4); else go_get_matrix(s, which, out); }
 void go_get_ap(const go_session *s, char which, float *out) { const go_sampler *sm = pickc(s, which); memcpy(out, sm->AP, (size_t)sm->M * sm->N * 4); }
 void go_get_atoms(const go_session *s, char which, uint64_t *pos, float *mass, uint32_t *left, uint32_t *right)
 {

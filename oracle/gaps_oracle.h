@@ -42,6 +42,7 @@ typedef struct go_params {
     int32_t math_mode;         /* GO_MATH_* */
     uint32_t redW_A, redW_P;   /* reduction lanes for A / P sampler; 0 or 1 = sequential (reference scalar order) */
     uint32_t redG;             /* lane granularity in elements (1 = reference PackedFloat pattern, 4 = float4) */
+    int32_t useSparseOptimization; /* SparseNormalModel instead of DenseNormalModel (GapsRunner.cpp:65-91) */
 } go_params;
 
 typedef struct go_result {
@@ -102,6 +103,9 @@ void go_stats_update(go_session *s);
 float go_chisq(const go_session *s, char which);
 /* copy-outs: matrix is row-major [rows][K]; AP is [M][N] (one contiguous vector per factor row) */
 void go_get_matrix(const go_session *s, char which, float *out);
+void go_debug_set_matrices(go_session *s, const float *A, const float *P);
+void go_debug_alpha(const go_session *s, char which, int mode, uint32_t r1, uint32_t c1, uint32_t r2, uint32_t c2, float ch, float *out2);
+void go_get_rows(const go_session *s, char which, float *out); /* HybridMatrix row copy (sparse model); = go_get_matrix for the dense model */
 void go_get_ap(const go_session *s, char which, float *out);
 void go_get_atoms(const go_session *s, char which, uint64_t *pos, float *mass,
                   uint32_t *left, uint32_t *right); /* in mAtoms order; neighbours as indices */

@@ -26,6 +26,7 @@ class GoParams(C.Structure):
         ("whichMatrixFixed", C.c_char), ("fixedPatterns", C.POINTER(C.c_float)),
         ("fixedRows", C.c_uint32), ("math_mode", C.c_int32),
         ("redW_A", C.c_uint32), ("redW_P", C.c_uint32), ("redG", C.c_uint32),
+        ("useSparseOptimization", C.c_int32),
     ]
 
 
@@ -104,6 +105,9 @@ def lib(omp=False):
     L.go_chisq.argtypes = [C.c_void_p, C.c_char]
     L.go_get_matrix.argtypes = [C.c_void_p, C.c_char, fp]
     L.go_get_ap.argtypes = [C.c_void_p, C.c_char, fp]
+    L.go_get_rows.argtypes = [C.c_void_p, C.c_char, fp]
+    L.go_debug_set_matrices.argtypes = [C.c_void_p, fp, fp]
+    L.go_debug_alpha.argtypes = [C.c_void_p, C.c_char, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, fp]
     L.go_get_atoms.argtypes = [C.c_void_p, C.c_char, C.POINTER(C.c_uint64), fp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.go_get_dims.argtypes = [C.c_void_p, C.c_char] + [C.POINTER(C.c_uint32)] * 3
     for n in ("go_lambda", "go_max_gibbs_mass", "go_avg_queue"):
@@ -134,7 +138,7 @@ def make_params(nPatterns=3, nIterations=1000, seed=0, outputFrequency=500, maxT
                 alphaA=0.01, alphaP=0.01, maxGibbsMassA=100.0, maxGibbsMassP=100.0,
                 transposeData=False, subsetIndices=None, subsetDim=0,
                 whichMatrixFixed="N", fixedPatterns=None, math_mode=MATH_LIBM,
-                redW_A=1, redW_P=1, redG=1):
+                redW_A=1, redW_P=1, redG=1, sparseOptimization=False):
     p = GoParams()
     lib().go_default_params(C.byref(p))
     p.nPatterns, p.nIterations, p.seed = nPatterns, nIterations, seed
@@ -157,6 +161,7 @@ def make_params(nPatterns=3, nIterations=1000, seed=0, outputFrequency=500, maxT
         p.fixedRows = fx.shape[0]
     p.math_mode = math_mode
     p.redW_A, p.redW_P, p.redG = redW_A, redW_P, redG
+    p.useSparseOptimization = int(bool(sparseOptimization))
     p._keep = keep
     return p
 
@@ -263,6 +268,22 @@ class Session:
         m, n, k = self.dims(which)
         out = np.zeros((m, k), dtype=np.float32)
         self.L.go_get_matrix(self.h, which.encode(), _fp(out))
+        return out
+
+    def debug_set_matrices(self, A, P):
+        a = np.ascontiguousarray(A, dtype=np.float32); b = np.ascontiguousarray(P, dtype=np.float32)
+        self.L.go_debug_set_matrices(self.h, _fp(a), _fp(b))
+
+    def debug_alpha(self, which, mode, r1, c1, r2=0, c2=0, ch=0.0):
+        out = np.zeros(2, dtype=np.float32)
+        self.L.go_debug_alpha(self.h, which.encode(), mode, r1, c1, r2, c2, ch, _fp(out))
+        return float(out[0]), float(out[1])
+
+    def rows(self, which):
+        """HybridMatrix row copy (sparse model); the matrix itself for the dense model"""
+        m, n, k = self.dims(which)
+        out = np.zeros((m, k), dtype=np.float32)
+        self.L.go_get_rows(self.h, which.encode(), _fp(out))
         return out
 
     def ap(self, which):
