@@ -69,7 +69,7 @@ EXPORTS = [
     "cogaps_session_chisq", "cogaps_session_get_matrix", "cogaps_session_get_ap",
     "cogaps_session_get_atoms", "cogaps_session_dims", "cogaps_session_avg_queue",
     "cogaps_session_finish", "cogaps_session_set_timing", "cogaps_session_perf",
-    "cogaps_session_perf_sampler", "cogaps_reduction_width", "cogaps_session_debug_prof", "cogaps_session_debug_replay",
+    "cogaps_session_perf_sampler", "cogaps_session_get_rows", "cogaps_sparse_width", "cogaps_reduction_width", "cogaps_session_debug_prof", "cogaps_session_debug_replay",
 ]
 
 
@@ -107,6 +107,9 @@ def bind(L):
     L.cogaps_session_debug_prof.argtypes = [vp, C.c_char, C.POINTER(C.c_uint64)]
     L.cogaps_session_debug_replay.argtypes = [vp, C.c_char, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
     L.cogaps_reduction_width.restype = C.c_uint32
+    L.cogaps_sparse_width.restype = C.c_uint32
+    L.cogaps_sparse_width.argtypes = [C.c_uint32]
+    L.cogaps_session_get_rows.argtypes = [vp, C.c_char, fp]
     L.cogaps_reduction_width.argtypes = [C.c_uint32]
     return L
 
@@ -268,6 +271,12 @@ class Session:
         m, n, k = self.dims(which)
         out = np.zeros((m, k), dtype=np.float32)
         self._ck(self.L.cogaps_session_get_matrix(self.h, which.encode(), _fp(out)))
+        return out
+
+    def rows(self, which):
+        m, n, k = self.dims(which)
+        out = np.zeros((m, k), dtype=np.float32)
+        self._ck(self.L.cogaps_session_get_rows(self.h, which.encode(), _fp(out)))
         return out
 
     def ap(self, which):

@@ -11,6 +11,7 @@
 #include "gen_kernel.h"
 #include "eval_kernel.h"
 #include "aux_kernels.h"
+#include "sparse_kernels.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -119,6 +120,13 @@ extern "C" uint32_t cogaps_reduction_width(uint32_t N)
     while (w < need && w < 16384u) w <<= 1;
     return w;
 }
+// threads (= virtual lanes) of the sparse evaluation: one per 64-bit flag word of a data vector, 64..256 (sparse_kernels.h)
+extern "C" uint32_t cogaps_sparse_width(uint32_t N)
+{
+    uint32_t need = N / 64u + 1u, w = 64;
+    while (w < need && w < 256u) w <<= 1;
+    return w;
+}
 // launch a kernel template<int V> with V = W / threads virtual lanes per thread
 #define LAUNCH_V(KERNEL, W, grid, stream, ...) do { const uint32_t bs_ = (W) < 1024u ? (W) : 1024u; \
     switch ((W) / bs_) { case 1: RT_LAUNCH(KERNEL<1>, grid, bs_, stream, __VA_ARGS__); break; case 2: RT_LAUNCH(KERNEL<2>, grid, bs_, stream, __VA_ARGS__); break; \
@@ -177,6 +185,7 @@ static void free_sampler(HostSampler &h)
     rt_free(d.rowStamp); rt_free(d.atomStamp); rt_free(d.gapStamp); rt_free(d.inlineStamp); rt_free(d.atomDest);
     rt_free(d.gs); rt_free(d.trace); rt_free(d.traceBatchNproc); rt_free(d.traceBatchQlen);
     rt_free(h.Sraw); rt_free(h.seeds); rt_free_host(h.hSeeds); rt_free(h.partial);
+    rt_free((void *)d.dflags); rt_free((void *)d.dprefix); rt_free((void *)d.dptr); rt_free((void *)d.dvals); rt_free(d.rows); rt_free(d.mflags); rt_free(d.Z1); rt_free(d.Z2);
 }
 
 // Matrix(mat, genesInCols, subsetGenes, indices) (data_structures/Matrix.cpp:30-69) laid out as
@@ -190,6 +199,7 @@ static void build_sampler(cogaps_session *s, HostSampler &h, char name, const fl
     const uint32_t nG = (subsetData && subsetGenes) ? nIdx : (genesInCols ? ncol : nrow);
     const uint32_t nS = (subsetData && !subsetGenes) ? nIdx : (genesInCols ? nrow : ncol);
     SamplerDev &d = h.d; memset(&d, 0, sizeof(d)); h.name = name;
+    const bool sparse = p.useSparseOptimization != 0;
     d.N = nG; d.M = nS; d.K = p.nPatterns;
     d.Npad = (d.N + 3u) & ~3u; d.Mpad = (d.M + 3u) & ~3u;
     d.redW = cogaps_reduction_width(d.N);
@@ -200,10 +210,11 @@ static void build_sampler(cogaps_session *s, HostSampler &h, char name, const fl
         for (uint32_t i = 0; i < nG; ++i) {
             const uint32_t dataRow = (subsetData && (subsetGenes != genesInCols)) ? indices[genesInCols ? j : i] - 1 : (genesInCols ? j : i);
             const uint32_t dataCol = (subsetData && (subsetGenes == genesInCols)) ? indices[genesInCols ? i : j] - 1 : (genesInCols ? i : j);
-            const float v = data[(size_t)dataRow * ncol + dataCol];
+            float v = data[(size_t)dataRow * ncol + dataCol];
+            if (sparse && !(v > 0.f)) v = 0.f;                                // SparseVector keeps v > 0 only (SparseVector.cpp:20-33)
             const size_t o = (size_t)j * d.Npad + i;
             D[o] = v;
-            const float sd = unc ? unc[(size_t)dataRow * ncol + dataCol] : gm_max(v * 0.1f, 0.1f);   // gaps::pmax, MatrixMath.cpp:74-84
+            const float sd = (unc && !sparse) ? unc[(size_t)dataRow * ncol + dataCol] : gm_max(v * 0.1f, 0.1f);   // gaps::pmax, MatrixMath.cpp:74-84; the sparse model always assumes the default (SparseNormalModel.h:90-96)
             SR[o] = sd; S2[o] = sd * sd;
             sum += v; if (v > 0.f) ++nnz;                                    // gaps::nonZeroMean, MatrixMath.cpp:39-55
         }
@@ -215,7 +226,31 @@ static void build_sampler(cogaps_session *s, HostSampler &h, char name, const fl
     rt_h2d(dD, D.data(), tot * 4, s->stream); rt_h2d(dS2, S2.data(), tot * 4, s->stream); rt_h2d(h.Sraw, SR.data(), tot * 4, s->stream);
     rt_sync(s->stream);
     d.D = dD; d.S2 = dS2;
-    d.AP = dalloc<float>(tot);
+    d.unitBytes = 4u * d.N;
+    if (!sparse) d.AP = dalloc<float>(tot);
+    else {
+        // SparseMatrix (flag words + packed values per vector) and the HybridMatrix copies; D / Sraw stay for meanChiSq
+        if (d.K > SP_KMAX) throw std::runtime_error("useSparseOptimization supports at most 512 patterns");
+        d.sparse = 1; d.beta = 100.f; d.unitBytes = 1u;
+        d.Wn = d.N / 64u + 1u; d.Mw = d.M / 64u + 1u; d.Kpad = (d.K + 3u) & ~3u;
+        std::vector<unsigned long long> fl((size_t)d.M * d.Wn, 0ull); std::vector<uint32_t> pre((size_t)d.M * d.Wn, 0u), ptr((size_t)d.M + 1, 0u); std::vector<float> vals;
+        for (uint32_t j = 0; j < d.M; ++j) {
+            ptr[j] = (uint32_t)vals.size();
+            for (uint32_t w = 0; w < d.Wn; ++w) {
+                pre[(size_t)j * d.Wn + w] = (uint32_t)vals.size() - ptr[j];
+                for (uint32_t b = 0; b < 64u; ++b) { const uint32_t i = 64u * w + b; if (i < d.N && D[(size_t)j * d.Npad + i] > 0.f) { fl[(size_t)j * d.Wn + w] |= 1ull << b; vals.push_back(D[(size_t)j * d.Npad + i]); } }
+            }
+        }
+        ptr[d.M] = (uint32_t)vals.size();
+        unsigned long long *dfl = dalloc<unsigned long long>(fl.size()); uint32_t *dpre = dalloc<uint32_t>(pre.size()), *dptr = dalloc<uint32_t>(ptr.size()); float *dv = dalloc<float>(vals.size() + 1);
+        rt_h2d(dfl, fl.data(), fl.size() * 8, s->stream); rt_h2d(dpre, pre.data(), pre.size() * 4, s->stream); rt_h2d(dptr, ptr.data(), ptr.size() * 4, s->stream);
+        if (!vals.empty()) rt_h2d(dv, vals.data(), vals.size() * 4, s->stream);
+        rt_sync(s->stream);
+        d.dflags = dfl; d.dprefix = dpre; d.dptr = dptr; d.dvals = dv;
+        d.rows = dalloc<float>((size_t)d.M * d.Kpad);
+        d.mflags = dalloc<unsigned long long>((size_t)d.K * d.Mw);
+        d.Z1 = dalloc<float>(d.K); d.Z2 = dalloc<float>((size_t)d.K * d.K);
+    }
     d.mat = dalloc<float>((size_t)d.K * d.Mpad);
     d.colPos = dalloc<uint32_t>(d.K);
     d.luts.erf = s->dErf; d.luts.erfinv = s->dErfinv; d.luts.qgamma = s->dQgamma;
@@ -306,7 +341,10 @@ static void launch_gen(cogaps_session *s, HostSampler &h)
 static void launch_eval(cogaps_session *s, HostSampler &h)
 {
     const int slot = timing_slot(s, h, 1, h.evalLaunches);
-    if (h.d.redW <= 1024u) {
+    if (h.d.sparse) {
+        const uint32_t grid = std::min<uint32_t>(h.d.queueCap, 1024u);
+        LAUNCH_MAYBE_TIMED(slot, eval_sparse_kernel, grid, cogaps_sparse_width(h.d.N), h.d);
+    } else if (h.d.redW <= 1024u) {
         // one workgroup of W threads per proposal
         const uint32_t grid = std::min<uint32_t>(h.d.queueCap, 512u);
         LAUNCH_MAYBE_TIMED(slot, eval_kernel<EVAL_FUSED>, grid, h.d.redW, h.d, 1u);
@@ -406,18 +444,24 @@ static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool t
 
 static void do_sync(cogaps_session *s, HostSampler &dst, HostSampler &src)
 {
+    if (dst.d.sparse) {     // SparseNormalModel::sync = generateLookupTables (SparseNormalModel.cpp:27-31, 294-311)
+        const uint32_t K = dst.d.K;
+        LAUNCH_V(sparse_tables_kernel, dst.d.redW, K + K * (K + 1u) / 2u, s->stream, dst.d);
+        return;
+    }
     const uint32_t tilesX = (src.d.N + TR_TILE - 1) / TR_TILE, tilesY = (src.d.M + TR_TILE - 1) / TR_TILE;
     RT_LAUNCH(transpose_kernel, tilesX * tilesY, 256, s->stream, (const float *)src.d.AP, dst.d.AP, src.d.M, src.d.N, src.d.Npad, dst.d.Npad, tilesX);
 }
 
 static float chisq_of(cogaps_session *s, HostSampler &h)
 {
-    LAUNCH_V(chisq_rows_kernel_s, h.d.redW, h.d.M, s->stream, h.d, (const float *)h.Sraw, h.partial);
+    if (h.d.sparse) LAUNCH_V(chisq_sparse_kernel, h.d.redW, h.d.M, s->stream, h.d, h.partial);
+    else LAUNCH_V(chisq_rows_kernel_s, h.d.redW, h.d.M, s->stream, h.d, (const float *)h.Sraw, h.partial);
     std::vector<float> part(h.d.M);
     rt_d2h(part.data(), h.partial, (size_t)h.d.M * 4, s->stream); rt_sync(s->stream);
     float c = 0.f;
     for (uint32_t j = 0; j < h.d.M; ++j) c += part[j];
-    return c;
+    return h.d.sparse ? c * h.d.beta : c;
 }
 
 extern "C" {
@@ -446,7 +490,6 @@ cogaps_session *cogaps_session_create(const float *data, uint32_t nrow, uint32_t
     cogaps_session *s = nullptr;
     try {
         const cogaps_params &p = *params;
-        if (p.useSparseOptimization) { fail("useSparseOptimization (SparseNormalModel) is not available in this build"); return nullptr; }
         if (!p.asynchronousUpdates) { fail("asynchronousUpdates=FALSE (SingleThreadedGibbsSampler) is not part of this library"); return nullptr; }
         if (p.nPatterns == 0 || nrow == 0 || ncol == 0) { fail("empty problem"); return nullptr; }
         if (p.whichMatrixFixed != 'N' && p.whichMatrixFixed != 'A' && p.whichMatrixFixed != 'P') { fail("whichMatrixFixed must be 'N', 'A' or 'P'"); return nullptr; }
@@ -480,21 +523,40 @@ cogaps_session *cogaps_session_create(const float *data, uint32_t nrow, uint32_t
         if (s->A.d.N != s->P.d.M || s->P.d.N != s->A.d.M) throw std::runtime_error("internal: sampler dimensions do not mirror");
         s->A.d.other = s->P.d.mat; s->A.d.otherColPos = s->P.d.colPos;
         s->P.d.other = s->A.d.mat; s->P.d.otherColPos = s->A.d.colPos;
+        if (p.useSparseOptimization) {
+            s->A.d.orows = s->P.d.rows; s->A.d.oflags = s->P.d.mflags; s->A.d.oMw = s->P.d.Mw; s->A.d.oKpad = s->P.d.Kpad;
+            s->P.d.orows = s->A.d.rows; s->P.d.oflags = s->A.d.mflags; s->P.d.oMw = s->A.d.Mw; s->P.d.oKpad = s->A.d.Kpad;
+        }
         // processFixedMatrix (GapsRunner.cpp:329-350)
         if (p.whichMatrixFixed != 'N') {
             HostSampler &f = (p.whichMatrixFixed == 'A') ? s->A : s->P;
             if (!p.fixedPatterns || p.fixedRows != f.d.M) throw std::runtime_error("fixedPatterns must have one row per row of the fixed matrix");
             std::vector<float> m((size_t)f.d.K * f.d.Mpad, 0.f);
             for (uint32_t r = 0; r < f.d.M; ++r) for (uint32_t k = 0; k < f.d.K; ++k) m[(size_t)k * f.d.Mpad + r] = p.fixedPatterns[(size_t)r * f.d.K + k];
+            if (f.d.sparse) {
+                // HybridMatrix::operator=(Matrix) (HybridMatrix.cpp:70-84): the row copy takes the value, the column copy
+                // takes it through add(): entries below epsilon are held at zero and unflagged
+                std::vector<float> rw((size_t)f.d.M * f.d.Kpad, 0.f); std::vector<unsigned long long> fl((size_t)f.d.K * f.d.Mw, 0ull); std::vector<uint32_t> cnt(f.d.K, 0u);
+                for (uint32_t r = 0; r < f.d.M; ++r) for (uint32_t k = 0; k < f.d.K; ++k) {
+                    const float v = p.fixedPatterns[(size_t)r * f.d.K + k];
+                    rw[(size_t)r * f.d.Kpad + k] = v;
+                    if (0.f + v < GAPS_EPSILON) m[(size_t)k * f.d.Mpad + r] = 0.f;
+                    else { fl[(size_t)k * f.d.Mw + (r >> 6)] |= 1ull << (r & 63u); ++cnt[k]; }
+                }
+                rt_h2d(f.d.rows, rw.data(), rw.size() * 4, s->stream); rt_h2d(f.d.mflags, fl.data(), fl.size() * 8, s->stream); rt_h2d(f.d.colPos, cnt.data(), cnt.size() * 4, s->stream);
+            }
             rt_h2d(f.d.mat, m.data(), m.size() * 4, s->stream); rt_sync(s->stream);
-            RT_LAUNCH(count_pos_kernel, f.d.K, 256, s->stream, f.d);
+            if (!f.d.sparse) RT_LAUNCH(count_pos_kernel, f.d.K, 256, s->stream, f.d);
         }
         s->Asum = dalloc<float>((size_t)s->K * s->A.d.Mpad); s->Asq = dalloc<float>((size_t)s->K * s->A.d.Mpad);
         s->Psum = dalloc<float>((size_t)s->K * s->P.d.Mpad); s->Psq = dalloc<float>((size_t)s->K * s->P.d.Mpad);
         s->runnerRng = pcg_from_seed(s->seeder.next());
         // ASampler.sync(PSampler); PSampler.sync(ASampler); extraInitialization x2 (GapsRunner.cpp:444-447)
-        RT_LAUNCH(init_ap_kernel, (s->A.d.N + 255) / 256, 256, s->stream, s->A.d);
-        RT_LAUNCH(init_ap_kernel, (s->P.d.N + 255) / 256, 256, s->stream, s->P.d);
+        if (p.useSparseOptimization) { do_sync(s, s->A, s->P); do_sync(s, s->P, s->A); }     // the lookup tables; extraInitialization is a no-op (SparseNormalModel.cpp:34-37)
+        else {
+            RT_LAUNCH(init_ap_kernel, (s->A.d.N + 255) / 256, 256, s->stream, s->A.d);
+            RT_LAUNCH(init_ap_kernel, (s->P.d.N + 255) / 256, 256, s->stream, s->P.d);
+        }
         rt_sync(s->stream);
         return s;
     } catch (const std::exception &e) {
@@ -620,10 +682,21 @@ int cogaps_session_get_matrix(cogaps_session *s, char which, float *out)
     for (uint32_t r = 0; r < h.d.M; ++r) for (uint32_t k = 0; k < h.d.K; ++k) out[(size_t)r * h.d.K + k] = m[(size_t)k * h.d.Mpad + r];
     SESSION_END
 }
+int cogaps_session_get_rows(cogaps_session *s, char which, float *out)
+{
+    SESSION_TRY
+    HostSampler &h = pick(s, which);
+    if (!h.d.sparse) return cogaps_session_get_matrix(s, which, out);
+    std::vector<float> m((size_t)h.d.M * h.d.Kpad);
+    rt_d2h(m.data(), h.d.rows, m.size() * 4, s->stream); rt_sync(s->stream);
+    for (uint32_t r = 0; r < h.d.M; ++r) memcpy(out + (size_t)r * h.d.K, m.data() + (size_t)r * h.d.Kpad, (size_t)h.d.K * 4);
+    SESSION_END
+}
 int cogaps_session_get_ap(cogaps_session *s, char which, float *out)
 {
     SESSION_TRY
     HostSampler &h = pick(s, which);
+    if (h.d.sparse) { memset(out, 0, (size_t)h.d.M * h.d.N * 4); return 0; }     // the sparse model keeps no A*P cache
     std::vector<float> m((size_t)h.d.M * h.d.Npad);
     rt_d2h(m.data(), h.d.AP, m.size() * 4, s->stream); rt_sync(s->stream);
     for (uint32_t r = 0; r < h.d.M; ++r) memcpy(out + (size_t)r * h.d.N, m.data() + (size_t)r * h.d.Npad, (size_t)h.d.N * 4);

@@ -118,6 +118,18 @@ struct SamplerDev {
     double invK;           // 1.0 / nPatterns (gen_div_k)
     uint64_t rboundNone;   // static_cast<uint64_t>(mDomainLength), ProposalQueue.cpp:216
     uint64_t iPartL, limitL; // uniform64(1, domainLenU): iPart = UINT64_MAX / L, limit = L * iPart (Random.cpp:112-117)
+    // ---- SparseNormalModel (sparse_kernels.h); unused (null / 0) with the dense model -------------------------------
+    uint32_t sparse;       // 1: useSparseOptimization
+    uint32_t Wn, Mw, oMw;  // flag words per data vector (N/64+1), per column of this matrix (M/64+1) and of the other one
+    uint32_t Kpad, oKpad;  // row stride of the row copies
+    const unsigned long long *dflags; const uint32_t *dprefix, *dptr; const float *dvals;
+    float *rows;           // [M][Kpad] HybridMatrix row copy (mMatrix(r,c))
+    unsigned long long *mflags;        // [K][Mw] flags of the column copy `mat`
+    const float *orows;    // the other sampler's rows
+    const unsigned long long *oflags;  // ... and mflags
+    float *Z1, *Z2;        // [K], column-major [K][K]
+    float beta;
+    uint32_t unitBytes;    // bytes per unit of queueUnits (4N with the dense model, 1 with the sparse one)
     GenScalars *gs;
     // ---- optional trace (parity tests) -------------------------------------------------------
     PropRec *trace;        // [traceCap] copies of queued proposals

@@ -153,7 +153,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
     if (e_m == 0) cg_sync_lds();                   // the flush ended with a barrier otherwise
     if (updateDone) {
         if (t == 0) { gs->nAtoms = sh.g.nAtoms; gs->front = sh.g.front; gs->freeCount = sh.g.freeCount; gs->eraseCount = 0; gs->qlen = 0; gs->batchNproc = 0; gs->updateFlushed = 1;
-                      gs->evalBytes = sh.g.evalBytes + (unsigned long long)sh.unitSum * 4ull * S.N; gs->evalProps = sh.g.evalProps + e_prevQ; }
+                      gs->evalBytes = sh.g.evalBytes + (unsigned long long)sh.unitSum * S.unitBytes; gs->evalProps = sh.g.evalProps + e_prevQ; }
         GEN_PROF_FLUSH();
         return;
     }
@@ -293,7 +293,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
 #endif
         // the scalars the evaluation starts from travel in the queue record (consumed at commit)
         float old1 = 0.f, old2 = 0.f; uint32_t gib1 = 0, gib2 = 0;
-        if (isB || pick) { old1 = S.mat[(size_t)c1 * S.Mpad + r1]; gib1 = S.otherColPos[c1]; }
+        if (isB || pick) { old1 = S.sparse ? S.rows[(size_t)r1 * S.Kpad + c1] : S.mat[(size_t)c1 * S.Mpad + r1]; gib1 = S.otherColPos[c1]; }
         GEN_PIN(b3.pos); GEN_PIN(lp); GEN_PIN(rp);
         GEN_TS(13);
         GEN_SUBS(12);
@@ -315,7 +315,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
                 flags &= ~(GEN_F_BINEMPTY | GEN_F_WORDZERO | GEN_F_NEWHEAD);
                 if (nh) flags |= GEN_F_NEWHEAD;
                 if (S.binHead[bin] == CG_NONE) { flags |= GEN_F_BINEMPTY; if (S.bits0[bin >> 6] == 0ull) flags |= GEN_F_WORDZERO; }
-                old1 = S.mat[(size_t)c1 * S.Mpad + r1]; gib1 = S.otherColPos[c1];      // the retry may have moved the birth to another bin
+                old1 = S.sparse ? S.rows[(size_t)r1 * S.Kpad + c1] : S.mat[(size_t)c1 * S.Mpad + r1]; gib1 = S.otherColPos[c1];      // the retry may have moved the birth to another bin
             }
         } else if (pick) {
             if (type == 'M') {
@@ -339,7 +339,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
                 }
             }
         }
-        if (pick && (type == 'M' || type == 'E')) { old2 = S.mat[(size_t)c2 * S.Mpad + r2]; gib2 = S.otherColPos[c2]; }
+        if (pick && (type == 'M' || type == 'E')) { old2 = S.sparse ? S.rows[(size_t)r2 * S.Kpad + c2] : S.mat[(size_t)c2 * S.Mpad + r2]; gib2 = S.otherColPos[c2]; }
         GEN_PIN(pos); GEN_PIN(flags); GEN_PIN(r2); GEN_PIN(c2); GEN_PIN(rbpos); GEN_PIN(nm1);
         GEN_TS(14);
         GEN_PROF_R(2, 9);
@@ -657,7 +657,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
                     g.traceBatchCount = bi + 1; g.traceCount += sh.qlen;
                 }
                 g.nBatches += 1;
-                g.evalBytes = g.evalBytes + (unsigned long long)sh.unitSum * 4ull * S.N; g.evalProps = g.evalProps + e_prevQ;
+                g.evalBytes = g.evalBytes + (unsigned long long)sh.unitSum * S.unitBytes; g.evalProps = g.evalProps + e_prevQ;
             }
         }
         cg_sync_lds();

@@ -1,0 +1,299 @@
+// sparse_kernels.h -- SparseNormalModel (reference src/gibbs_sampler/SparseNormalModel.cpp) on the device.
+//
+// Data: vector r of the data matrix is a SparseVector (SparseVector.cpp:20-33): 64-bit flag words `dflags[r][*]`
+// and the packed positive values `dvals[dptr[r] ..)`; `dprefix[r][w]` = number of values before word w.  The
+// sampler's matrix is a HybridMatrix (HybridMatrix.cpp:25-39): a row copy `rows [M][Kpad]`, a column copy `mat
+// [K][Mpad]` whose entries below epsilon are held at zero, and the column copy's flag words `mflags [K][Mw]`.  The two
+// copies can disagree by less than epsilon and the reference reads both -- so does this file.
+// No A*P cache exists in this model; an accepted proposal only changes matrix entries.
+//
+// Alpha parameters (SparseNormalModel.cpp:153-292): table terms Z1 / Z2 plus one term per index that is non-zero in
+// both the data vector and the other matrix's column; every such term needs the K-length dot product of this
+// sampler's matrix row with the other matrix's row at that index (gaps::dot in the scalar build's order).
+// Lane order (the parity contract with the oracle): W = cogaps_sparse_width(N) virtual lanes = threads; lane L takes
+// the flag words L, L+W, ... in increasing order, bits in increasing order, and accumulates its terms from +0; the
+// lanes are folded by the ascending xor butterfly; the total is added to the table terms once; then beta.
+#pragma once
+#include "eval_kernel.h"
+
+#define SP_KMAX 512      // nPatterns limit of the sparse kernels (matrix rows staged in LDS)
+
+// gaps::dot, scalar build (VectorMath.h:41-134): up to 25 elements are added last-to-first, more first-to-last
+CG_DEVICE float sp_dot(const float *a, const float *b, uint32_t n)
+{
+    float d = 0.f;
+    if (n <= 25u) { for (uint32_t i = n; i-- > 0u;) d = d + a[i] * b[i]; }
+    else { for (uint32_t i = 0; i < n; ++i) d = d + a[i] * b[i]; }
+    return d;
+}
+
+#define SP_MODE_ONE 0
+#define SP_MODE_CH 1
+#define SP_MODE_SAME 2
+
+// per-lane partial sums of one alpha evaluation over this thread's flag words
+template <int MODE>
+CG_DEVICE void sp_partial(const SamplerDev &S, uint32_t row, uint32_t col, uint32_t col2, float ch, const float *arow, float &ps, float &pm)
+{
+    const uint32_t BS = cg_bdim(), t = cg_tid(), K = S.K;
+    const unsigned long long *fD = S.dflags + (size_t)row * S.Wn;
+    const unsigned long long *fV = S.oflags + (size_t)col * S.oMw, *fV2 = S.oflags + (size_t)col2 * S.oMw;
+    const uint32_t *pre = S.dprefix + (size_t)row * S.Wn;
+    const float *data = S.dvals + S.dptr[row];
+    const float *V = S.other + (size_t)col * S.Npad, *V2 = S.other + (size_t)col2 * S.Npad;
+    ps = 0.f; pm = 0.f;
+    for (uint32_t w = t; w < S.Wn; w += BS) {
+        const unsigned long long dfl = fD[w];
+        unsigned long long common = dfl & (MODE == SP_MODE_SAME ? (fV[w] | fV2[w]) : fV[w]);
+        const uint32_t base = pre[w];
+        while (common != 0ull) {
+            const uint32_t bit = (uint32_t)cg_ctz64(common);
+            common &= common - 1ull;
+            const uint32_t idx = 64u * w + bit;
+            const float d_val = data[base + (uint32_t)cg_popc64(dfl & ((1ull << bit) - 1ull))];
+            const float ap = sp_dot(arow, S.orows + (size_t)idx * S.oKpad, K);
+            if (MODE == SP_MODE_SAME) {
+                const float d_recip = 1.f / d_val;
+                const float term1 = 1.f - d_recip * d_recip;
+                const float v_diff = V[idx] - V2[idx];
+                ps = ps - v_diff * v_diff * term1;
+                pm = pm + v_diff * (ap * term1 + d_recip);
+            } else {
+                const float v_val = V[idx];
+                const float term1 = v_val / d_val;
+                const float term2 = v_val - term1 / d_val;
+                ps = ps + (term1 * term1 - v_val * v_val);
+                pm = pm + (term1 + term2 * ap);
+                if (MODE == SP_MODE_CH) pm = pm + term2 * S.orows[(size_t)idx * S.oKpad + col] * ch;
+            }
+        }
+    }
+}
+
+// HybridMatrix::add (HybridMatrix.cpp:25-31) / set (:33-39) on entry (row, col): the row copy, the column copy with
+// its epsilon rule (HybridVector.cpp:55-86) and flag word, and the count of flagged entries per column (canUseGibbs =
+// "the column has a flagged entry", VectorMath.cpp:125-128).  One thread per entry; rows are proposal-exclusive.
+CG_DEVICE void sp_store_col(const SamplerDev &S, uint32_t row, uint32_t col, float newCol, bool zero)
+{
+    unsigned long long *f = S.mflags + (size_t)col * S.Mw + (row >> 6);
+    const unsigned long long bit = 1ull << (row & 63u);
+    if (zero) {
+        const unsigned long long old = cg_atomic_and_u64(f, ~bit);
+        S.mat[(size_t)col * S.Mpad + row] = 0.f;
+        if (old & bit) cg_atomic_sub_u32(&S.colPos[col], 1u);
+    } else {
+        const unsigned long long old = cg_atomic_or_u64(f, bit);
+        S.mat[(size_t)col * S.Mpad + row] = newCol;
+        if (!(old & bit)) cg_atomic_add_u32(&S.colPos[col], 1u);
+    }
+}
+CG_DEVICE void sp_change_matrix(const SamplerDev &S, uint32_t row, uint32_t col, float oldRow, float delta)     // SparseNormalModel.cpp:110-114
+{
+    S.rows[(size_t)row * S.Kpad + col] = oldRow + delta;
+    const float c = S.mat[(size_t)col * S.Mpad + row];
+    const bool zero = c + delta < GAPS_EPSILON;
+    sp_store_col(S, row, col, c + delta, zero);
+}
+CG_DEVICE void sp_safely_change_matrix(const SamplerDev &S, uint32_t row, uint32_t col, float oldRow, float delta)   // :116-122
+{
+    const float newVal = gm_max(oldRow + delta, 0.f);
+    S.rows[(size_t)row * S.Kpad + col] = newVal;
+    sp_store_col(S, row, col, newVal, newVal < GAPS_EPSILON);
+}
+
+// One workgroup of W = cogaps_sparse_width(N) threads per queued proposal (AsynchronousGibbsSampler.h:127-219 over the
+// sparse model).
+CG_DEVICE void eval_sparse_body(const SamplerDev &S)
+{
+    CG_SHARED float lds[16 * 4];
+    CG_SHARED float arowA[SP_KMAX], arowB[SP_KMAX];
+    CG_SHARED float decf; CG_SHARED uint32_t deci;
+    const uint32_t t = cg_tid(), BS = cg_bdim(), K = S.K;
+    const float lambda = S.lambda, beta = S.beta;
+    const bool multiWave = BS > 64u;
+    const bool scalarLane = !multiWave || t < 64u;
+    for (uint32_t q = cg_bid(); ; q += cg_gdim()) {
+        const PropRec p = S.queue[q < S.queueCap ? q : 0u];
+        const uint32_t qlen = S.gs->qlen;
+        const float T = S.gs->annealTemp;
+        if (q >= qlen) break;
+        uint64_t rng = p.rng;
+        const bool two = (p.type == 'M' || p.type == 'E');
+        const float m1 = p.m1, m2 = p.m2, old1 = p.old1, old2 = p.old2;     // old1/old2: the ROW copy (mMatrix(r,c))
+        const uint64_t curPos = p.curPos;
+        const bool gibbs1 = (p.gibbs & 1u) != 0u, gibbs2 = (p.gibbs & 2u) != 0u;
+        const bool need = (p.type == 'B') ? gibbs1 : ((p.type == 'D' || p.type == 'M') ? true : (gibbs1 || gibbs2));
+        const bool diff = two && p.r1 != p.r2;
+        float s = 0.f, smu = 0.f;
+        uint32_t nz = 0;          // common non-zeros visited (roofline bookkeeping)
+        if (need) {
+            // this sampler's matrix row(s), read by every lane for the K-length dots
+            for (uint32_t k = t; k < K; k += BS) { arowA[k] = S.rows[(size_t)p.r1 * S.Kpad + k]; if (diff) arowB[k] = S.rows[(size_t)p.r2 * S.Kpad + k]; }
+            cg_sync();
+            float x[4] = {0.f, 0.f, 0.f, 0.f};
+            if (diff) { sp_partial<SP_MODE_ONE>(S, p.r1, p.c1, 0u, 0.f, arowA, x[0], x[1]); sp_partial<SP_MODE_ONE>(S, p.r2, p.c2, 0u, 0.f, arowB, x[2], x[3]); }
+            else if (p.type == 'D') sp_partial<SP_MODE_CH>(S, p.r1, p.c1, 0u, -1.f * m1, arowA, x[0], x[1]);
+            else if (two) sp_partial<SP_MODE_SAME>(S, p.r1, p.c1, p.c2, 0.f, arowA, x[0], x[1]);
+            else sp_partial<SP_MODE_ONE>(S, p.r1, p.c1, 0u, 0.f, arowA, x[0], x[1]);
+            for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) x[c] = x[c] + cg_shfl_xor_f32(x[c], off);
+            }
+            float tot[4] = {x[0], x[1], x[2], x[3]};
+            if (multiWave) {
+                if ((t & 63u) == 0) { for (int c = 0; c < 4; ++c) lds[(t >> 6) * 4 + c] = x[c]; }
+                cg_sync();
+                eval_vfinish<4, 1>(lds, tot);
+            }
+            if (scalarLane) {
+                // table terms (SparseNormalModel.cpp:160-161, 205-207, 256-258), then beta
+                if (diff) {
+                    const float sa = (S.Z1[p.c1] + tot[0]) * beta, ma = (-1.f * sp_dot(arowA, S.Z2 + (size_t)p.c1 * K, K) + tot[1]) * beta;
+                    const float sb = (S.Z1[p.c2] + tot[2]) * beta, mb = (-1.f * sp_dot(arowB, S.Z2 + (size_t)p.c2 * K, K) + tot[3]) * beta;
+                    s = sa + sb; smu = ma - mb;                                    // AlphaParameters.cpp:11-14
+                } else if (two) {
+                    float s0 = S.Z1[p.c1] - 2.f * S.Z2[(size_t)p.c2 * K + p.c1] + S.Z1[p.c2];
+                    float d0 = 0.f;
+                    for (uint32_t k = 0; k < K; ++k) d0 += arowA[k] * (S.Z2[(size_t)p.c1 * K + k] - S.Z2[(size_t)p.c2 * K + k]);   // dot_diff, VectorMath.h:137-155
+                    float m0 = -1.f * d0;
+                    s = (s0 + tot[0]) * beta; smu = (m0 + tot[1]) * beta;
+                } else {
+                    float m0 = -1.f * sp_dot(arowA, S.Z2 + (size_t)p.c1 * K, K);
+                    if (p.type == 'D') m0 -= (-1.f * m1) * S.Z2[(size_t)p.c1 * K + p.c1];
+                    s = (S.Z1[p.c1] + tot[0]) * beta; smu = (m0 + tot[1]) * beta;
+                }
+            }
+        }
+        s = s * T; smu = smu * T;
+        const bool writer = t == 0u;
+#define SP_BCAST(F0, I0) do { if (multiWave) { if (t == 0) { decf = (F0); deci = (I0); } cg_sync(); (F0) = decf; (I0) = deci; } } while (0)
+        if (p.type == 'B') {
+            float bv = 0.f; uint32_t bhas = 0;
+            if (scalarLane) {
+                if (gibbs1) { OptF g = gm_gibbs_mass(s, smu, 0.f, S.maxGibbsMass, rng, S.luts, true, lambda); bv = g.v; bhas = g.has ? 1u : 0u; }
+                else { bv = pcg_exponential(rng, lambda); bhas = 1u; }
+            }
+            SP_BCAST(bv, bhas);
+            if (bhas != 0u && bv >= GAPS_EPSILON) {
+                if (writer) { S.atoms[p.h1].mass = bv; sp_change_matrix(S, p.r1, p.c1, old1, bv); }
+            } else if (writer) eval_cache_erase(S, p.h1);
+        } else if (p.type == 'D') {
+            float rebirth = m1; uint32_t acc = 0;
+            if (scalarLane) {
+                if (gibbs1) { OptF g = gm_gibbs_mass(s, smu, 0.f, S.maxGibbsMass, rng, S.luts, true, lambda); if (g.has) rebirth = g.v; }
+                const float deltaLL = rebirth * (smu - s * rebirth / 2.f);
+                acc = (gm_logf(pcg_uniform(rng)) < deltaLL) ? 1u : 0u;
+            }
+            SP_BCAST(rebirth, acc);
+            if (writer) {
+                if (acc != 0u) { if (rebirth != m1) { sp_safely_change_matrix(S, p.r1, p.c1, old1, rebirth - m1); S.atoms[p.h1].mass = rebirth; } }
+                else { sp_safely_change_matrix(S, p.r1, p.c1, old1, -1.f * m1); eval_cache_erase(S, p.h1); }
+            }
+        } else if (p.type == 'M') {
+            uint32_t acc = 0; float unused = 0.f;
+            if (scalarLane) { const float deltaLL = -1.f * m1 * (smu + s * m1 / 2.f); acc = (gm_logf(pcg_uniform(rng)) < deltaLL) ? 1u : 0u; }
+            SP_BCAST(unused, acc);
+            if (acc && writer) {
+                eval_domain_move(S, p.h1, curPos, p.pos);
+                sp_safely_change_matrix(S, p.r1, p.c1, old1, -m1);
+                sp_change_matrix(S, p.r2, p.c2, old2, m1);
+            }
+        } else if (need) {
+            float gv = 0.f; uint32_t gh = 0;
+            if (scalarLane) { OptF g0 = gm_gibbs_mass(s, smu, -m1, m2, rng, S.luts, false, 0.f); gv = g0.v; gh = g0.has ? 1u : 0u; }
+            SP_BCAST(gv, gh);
+            const float n1 = m1 + gv, n2 = m2 - gv;
+            if (gh != 0u && n1 > GAPS_EPSILON && n2 > GAPS_EPSILON && writer) {
+                sp_safely_change_matrix(S, p.r1, p.c1, old1, n1 - m1);
+                sp_safely_change_matrix(S, p.r2, p.c2, old2, n2 - m2);
+                S.atoms[p.h1].mass = n1; S.atoms[p.h2].mass = n2;
+            }
+        }
+        (void)nz;
+        if (writer) {
+            // roofline bookkeeping in bytes (sparse): flag words of the data vector and the column(s) per alpha
+            // call + the matrix row + a Z2 column; the per-non-zero gathers are data dependent and are not counted
+            uint32_t bytes = 0;
+            if (need) bytes = (diff ? 2u : 1u) * (16u * S.Wn + 8u * K) + ((two && !diff) ? 8u * S.Wn : 0u);
+            S.queueUnits[q] = bytes;
+        }
+        if (q + cg_gdim() >= qlen) break;
+        cg_sync();
+    }
+}
+CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_kernel(SamplerDev S) { eval_sparse_body(S); }
+
+// SparseNormalModel::generateLookupTables (SparseNormalModel.cpp:294-311): Z1[i] = sum_k other(k,i)^2 through the
+// other matrix's ROW copy, Z2(i,j) = dot of its column copies.  One workgroup per (i, j >= i) pair plus one per i;
+// lane order of the dense reductions over the N elements (float4 chunks, V slots per thread).
+template <int V>
+CG_KERNEL void CG_LAUNCH_BOUNDS(1024) sparse_tables_kernel(SamplerDev S)
+{
+    CG_SHARED float lds[16 * V];
+    const uint32_t K = S.K, t = cg_tid(), BS = cg_bdim(), W = (uint32_t)V * BS, nq = S.Npad >> 2, b = cg_bid();
+    float tot[1] = {0.f};
+    if (b < K) {
+        const uint32_t i = b;
+        for (int j = 0; j < V; ++j) {
+            float acc = 0.f;
+            for (uint32_t c = (uint32_t)j * BS + t; c < nq; c += W) {
+                for (uint32_t e = 0; e < 4u; ++e) { const uint32_t k = 4u * c + e; if (k < S.N) { const float v = S.orows[(size_t)k * S.oKpad + i]; acc = acc + v * v; } }
+            }
+            eval_vpark<V>(acc, j, lds, tot);
+        }
+        if (BS > 64u) { cg_sync(); eval_vfinish<1, V>(lds, tot); }
+        if (t == 0) S.Z1[i] = tot[0];
+    } else {
+        // pair index -> (i, j >= i)
+        uint32_t r = b - K, i = 0;
+        while (r >= K - i) { r -= K - i; ++i; }
+        const uint32_t j2 = i + r;
+        const float *ci = S.other + (size_t)i * S.Npad, *cj = S.other + (size_t)j2 * S.Npad;
+        for (int j = 0; j < V; ++j) {
+            float acc = 0.f;
+            for (uint32_t c = (uint32_t)j * BS + t; c < nq; c += W) {
+                const cg_f4 a = ld4(ci, c), bb = ld4(cj, c);
+                acc = acc + a.x * bb.x; acc = acc + a.y * bb.y; acc = acc + a.z * bb.z; acc = acc + a.w * bb.w;
+            }
+            eval_vpark<V>(acc, j, lds, tot);
+        }
+        if (BS > 64u) { cg_sync(); eval_vfinish<1, V>(lds, tot); }
+        if (t == 0) { S.Z2[(size_t)j2 * K + i] = tot[0]; S.Z2[(size_t)i * K + j2] = tot[0]; }
+    }
+}
+
+// SparseNormalModel::chiSq (SparseNormalModel.cpp:40-62), per-vector partial in the dense lane order over the elements
+template <int V>
+CG_KERNEL void CG_LAUNCH_BOUNDS(1024) chisq_sparse_kernel(SamplerDev S, float *partial)
+{
+    CG_SHARED float lds[16 * V];
+    CG_SHARED float arow[SP_KMAX];
+    const uint32_t row = cg_bid(), t = cg_tid(), BS = cg_bdim(), W = (uint32_t)V * BS, nq = S.Npad >> 2, K = S.K;
+    for (uint32_t k = t; k < K; k += BS) arow[k] = S.rows[(size_t)row * S.Kpad + k];
+    cg_sync();
+    const unsigned long long *fD = S.dflags + (size_t)row * S.Wn;
+    const uint32_t *pre = S.dprefix + (size_t)row * S.Wn;
+    const float *data = S.dvals + S.dptr[row];
+    float tot[1] = {0.f};
+    for (int j = 0; j < V; ++j) {
+        float acc = 0.f;
+        for (uint32_t c = (uint32_t)j * BS + t; c < nq; c += W) {
+            for (uint32_t e = 0; e < 4u; ++e) {
+                const uint32_t i = 4u * c + e;
+                if (i < S.N) {
+                    const float dot = sp_dot(arow, S.orows + (size_t)i * S.oKpad, K);
+                    acc = acc + dot * dot;
+                    const unsigned long long fl = fD[i >> 6];
+                    if ((fl >> (i & 63u)) & 1ull) {
+                        const float d = data[pre[i >> 6] + (uint32_t)cg_popc64(fl & ((1ull << (i & 63u)) - 1ull))];
+                        const float dsq = d * d;
+                        acc = acc + (1 + dot * (dot - 2 * d - dsq * dot) / dsq);
+                    }
+                }
+            }
+        }
+        eval_vpark<V>(acc, j, lds, tot);
+    }
+    if (BS > 64u) { cg_sync(); eval_vfinish<1, V>(lds, tot); }
+    if (t == 0) partial[row] = tot[0];
+}

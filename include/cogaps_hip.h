@@ -123,6 +123,7 @@ int cogaps_session_natoms(cogaps_session *s, char which, uint32_t *n);
 int cogaps_session_chisq(cogaps_session *s, char which, float *chisq);
 /* copy-outs (host buffers): matrix row-major [M][K]; AP [M][N]; atoms in vector order */
 int cogaps_session_get_matrix(cogaps_session *s, char which, float *out);
+int cogaps_session_get_rows(cogaps_session *s, char which, float *out);   /* sparse model: the HybridMatrix row copy, row-major [rows][nPatterns]; dense model: = get_matrix */
 int cogaps_session_get_ap(cogaps_session *s, char which, float *out);
 int cogaps_session_get_atoms(cogaps_session *s, char which, uint64_t *pos, float *mass,
                              uint32_t *left, uint32_t *right);
@@ -148,6 +149,8 @@ int cogaps_session_debug_replay(cogaps_session *s, char which, int kind, uint32_
 
 /* lanes of the evaluation workgroup for data vectors of length N (the reduction-order contract) */
 uint32_t cogaps_reduction_width(uint32_t N);
+/* threads (= virtual lanes) of the sparse model's evaluation workgroup: one per 64-bit flag word of a data vector, 64..256 */
+uint32_t cogaps_sparse_width(uint32_t N);
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,7 @@ def assert_state_equal(S, O, tag, chisq=True):
         for f in ("pos", "mass", "left", "right"):
             assert np.array_equal(a[f], b[f]), "%s %s: atom %s differs" % (tag, w, f)
         assert np.array_equal(S.matrix(w), O.matrix(w)), "%s %s: factor matrix differs" % (tag, w)
+        assert np.array_equal(S.rows(w), O.rows(w)), "%s %s: factor matrix (HybridMatrix row copy) differs" % (tag, w)
         assert np.array_equal(S.ap(w), O.ap(w)), "%s %s: AP cache differs" % (tag, w)
         assert S.avg_queue(w) == O.avg_queue(w), "%s %s: average queue length differs" % (tag, w)
         if chisq:
@@ -74,3 +75,13 @@ def synthetic(genes, samples, rank=3, seed=7):
     a0 = rng.gamma(2.0, 0.5, (genes, rank)) * (rng.random((genes, rank)) > 0.5)
     p0 = rng.gamma(2.0, 0.5, (samples, rank)) * (rng.random((samples, rank)) > 0.3)
     return ((a0 @ p0.T) * (0.9 + 0.2 * rng.random((genes, samples))) + 0.01).astype(np.float32)
+
+
+def synthetic_counts(genes, samples, zeros=0.85, rank=4, seed=7):
+    """count-like data (positive entries >= 1, `zeros` of the entries 0): the regime the sparse model's fixed
+    uncertainty (0.1 on zeros, 0.1*d elsewhere) coincides with the default max(0.1*d, 0.1)"""
+    rng = np.random.default_rng(seed)
+    a0 = rng.gamma(2.0, 0.5, (genes, rank)) * (rng.random((genes, rank)) > 0.5)
+    p0 = rng.gamma(2.0, 0.5, (samples, rank)) * (rng.random((samples, rank)) > 0.4)
+    d = np.ceil((a0 @ p0.T) * (0.9 + 0.2 * rng.random((genes, samples)))) * (rng.random((genes, samples)) > zeros)
+    return d.astype(np.float32)

@@ -33,6 +33,27 @@ def test_wide_reductions(hip_lib, genes, samples, k):
     pu.run_stepwise(hip_lib, pu.synthetic(genes, samples), 25, trace=(genes < 5000), nPatterns=k, seed=123, total_iter=50, check_every=5)
 
 
+@pytest.mark.parametrize("genes,samples,k,iters,zeros", [(300, 50, 30, 60, 0.85), (9000, 40, 6, 25, 0.9), (2000, 3000, 50, 8, 0.95), (64, 64, 3, 200, 0.5)])
+def test_sparse_model_stepwise(hip_lib, genes, samples, k, iters, zeros):
+    """useSparseOptimization: bit-flag data vectors, HybridMatrix row / column copies, Z1 / Z2 tables, sparse chi2"""
+    data = pu.synthetic_counts(genes, samples, zeros=zeros, seed=genes + samples)
+    pu.run_stepwise(hip_lib, data, iters, trace=genes * samples < 50000, nPatterns=k, seed=11, total_iter=max(iters, 40), check_every=5, sparseOptimization=True)
+
+
+def test_sparse_model_full_run(hip_lib, oracle):
+    from cogaps_amd import _capi
+    data = pu.synthetic_counts(400, 60, zeros=0.85, seed=33)
+    kw = dict(nPatterns=5, nIterations=100, seed=42, outputFrequency=20, sparseOptimization=True)
+    r = _capi.run(data, lib=hip_lib, **kw)
+    o = oracle.run(data, math_mode=oracle.MATH_PORTABLE, redW_A=hip_lib.cogaps_reduction_width(60), redW_P=hip_lib.cogaps_reduction_width(400), redG=4, **kw)
+    for f in ("Amean", "Asd", "Pmean", "Psd", "chisq", "atomsA", "atomsP"):
+        assert np.array_equal(r[f], o[f]), f
+    assert r["totalUpdates"] == o["totalUpdates"] and r["meanChiSq"] == o["meanChiSq"]
+    # the reference's scalar order gives a statistically equivalent chain
+    q = oracle.run(data, **kw)
+    assert abs(q["meanChiSq"] - r["meanChiSq"]) / q["meanChiSq"] < 0.05
+
+
 def test_tiny_domain(hip_lib):
     pu.run_stepwise(hip_lib, pu.synthetic(5, 6, rank=2, seed=3), 300, nPatterns=2, seed=9, total_iter=200, check_every=50)
 
