@@ -45,7 +45,9 @@ inline const char *rt_platform_name() { return "emulator (test only)"; }
 
 #define RT_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 typedef hipStream_t rt_stream_t;
-inline void *rt_malloc(size_t n) { void *p = nullptr; RT_CHECK(hipMalloc(&p, n ? n : 1)); RT_CHECK(hipMemset(p, 0, n ? n : 1)); return p; }
+// zero-filled device memory.  hipMemset runs on the null stream, which the library's non-blocking stream does not wait
+// for: without the synchronisation an upload enqueued right after the allocation could be overtaken by the fill.
+inline void *rt_malloc(size_t n) { void *p = nullptr; RT_CHECK(hipMalloc(&p, n ? n : 1)); RT_CHECK(hipMemset(p, 0, n ? n : 1)); RT_CHECK(hipStreamSynchronize(nullptr)); return p; }
 inline void rt_free(void *p) { if (p) (void)hipFree(p); }
 inline void *rt_malloc_host(size_t n) { void *p = nullptr; RT_CHECK(hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault)); return p; }
 inline void rt_free_host(void *p) { if (p) (void)hipHostFree(p); }
