@@ -29,6 +29,7 @@ class CogapsParamsC(C.Structure):
         ("whichMatrixFixed", C.c_char), ("fixedPatterns", C.POINTER(C.c_float)),
         ("fixedRows", C.c_uint32), ("workerID", C.c_uint32), ("runningDistributed", C.c_int32),
         ("device", C.c_int32), ("interrupt", INTERRUPT_FN), ("interruptArg", C.c_void_p),
+        ("snapshotPhase", C.c_int32),
     ]
 
 
@@ -42,6 +43,10 @@ class CogapsResultC(C.Structure):
         ("totalUpdates", C.c_uint64), ("seed", C.c_uint32), ("totalRunningTime", C.c_uint32),
         ("meanChiSq", C.c_float), ("averageQueueLengthA", C.c_float), ("averageQueueLengthP", C.c_float),
         ("samplerSeconds", C.c_double),
+        ("pumpMatrix", C.POINTER(C.c_float)), ("meanPatternAssignment", C.POINTER(C.c_float)),
+        ("nEquilibrationSnapshots", C.c_uint32), ("nSamplingSnapshots", C.c_uint32),
+        ("equilibrationSnapshotsA", C.POINTER(C.c_float)), ("equilibrationSnapshotsP", C.POINTER(C.c_float)),
+        ("samplingSnapshotsA", C.POINTER(C.c_float)), ("samplingSnapshotsP", C.POINTER(C.c_float)),
     ]
 
 
@@ -138,7 +143,7 @@ def make_params(L, nPatterns=3, nIterations=1000, seed=0, outputFrequency=500, n
                 transposeData=False, subsetIndices=None, subsetDim=0, whichMatrixFixed="N",
                 fixedPatterns=None, sparseOptimization=False, asynchronousUpdates=True,
                 messages=False, workerID=1, device=-1, takePumpSamples=False,
-                checkpointInterval=0, nSnapshots=0):
+                checkpointInterval=0, nSnapshots=0, snapshotPhase="sampling", snapshotFrequency=None):
     p = CogapsParamsC()
     L.cogaps_default_params(C.byref(p))
     p.nPatterns, p.nIterations, p.seed = int(nPatterns), int(nIterations), int(seed)
@@ -151,6 +156,9 @@ def make_params(L, nPatterns=3, nIterations=1000, seed=0, outputFrequency=500, n
     p.asynchronousUpdates = int(bool(asynchronousUpdates))
     p.takePumpSamples = int(bool(takePumpSamples))
     p.checkpointInterval = int(checkpointInterval)
+    # Cogaps.cpp:104-123: nSnapshots -> snapshotFrequency = nIterations / nSnapshots; phase names
+    p.snapshotFrequency = int(snapshotFrequency) if snapshotFrequency is not None else (int(nIterations) // int(nSnapshots) if nSnapshots else 0)
+    p.snapshotPhase = {"all": 0, "equilibration": 1, "sampling": 2}[snapshotPhase] if isinstance(snapshotPhase, str) else int(snapshotPhase)
     p.workerID = int(workerID)
     p.device = int(device)
     keep = []
@@ -187,6 +195,15 @@ def result_to_dict(L, r):
         "averageQueueLengthP": float(r.averageQueueLengthP),
         "totalRunningTime": int(r.totalRunningTime), "samplerSeconds": float(r.samplerSeconds),
     }
+
+    def _arr(ptr, shape):
+        n = int(np.prod(shape))
+        return np.ctypeslib.as_array(ptr, shape=(max(n, 1),))[:n].reshape(shape).copy() if ptr else np.zeros(shape, dtype=np.float32)
+    if r.pumpMatrix:
+        out["pumpMatrix"] = _arr(r.pumpMatrix, (g, k)); out["meanPatternAssignment"] = _arr(r.meanPatternAssignment, (g, k))
+    ne, ns = int(r.nEquilibrationSnapshots), int(r.nSamplingSnapshots)
+    out["equilibrationSnapshotsA"] = _arr(r.equilibrationSnapshotsA, (ne, g, k)); out["equilibrationSnapshotsP"] = _arr(r.equilibrationSnapshotsP, (ne, s, k))
+    out["samplingSnapshotsA"] = _arr(r.samplingSnapshotsA, (ns, g, k)); out["samplingSnapshotsP"] = _arr(r.samplingSnapshotsP, (ns, s, k))
     L.cogaps_result_free(C.byref(r))
     return out
 

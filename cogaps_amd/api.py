@@ -60,7 +60,8 @@ def CoGAPS(data, params=None, nPatterns=None, nThreads=1, messages=True, outputF
                         maxGibbsMassA=params.maxGibbsMassA, maxGibbsMassP=params.maxGibbsMassP, transposeData=transposeData,
                         subsetIndices=params.subsetIndices, subsetDim=params.subsetDim, whichMatrixFixed=params.whichMatrixFixed,
                         fixedPatterns=params.fixedPatterns, sparseOptimization=params.sparseOptimization, messages=messages,
-                        workerID=workerID, device=device, takePumpSamples=params.takePumpSamples)
+                        workerID=workerID, device=device, takePumpSamples=params.takePumpSamples,
+                        nSnapshots=nSnapshots, snapshotPhase=snapshotPhase)
     return CogapsResult(raw, params=params, geneNames=params.geneNames, sampleNames=params.sampleNames)
 
 

@@ -130,3 +130,18 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(1024) mean_chisq_rows_kernel(SamplerDev P, const
     if (BS > 64u) { cg_sync(); eval_vfinish<1, V>(lds, tot); }
     if (t == 0) partial[j] = tot[0];
 }
+
+// GapsStatistics::updatePump (GapsStatistics.h:65-126): pumpMatrixUniqueThreshold and pumpMatrixCutThreshold are the
+// same code -- per row of A the first column holding the row maximum (strictly greater than everything before it,
+// starting from 0) gets +1.  A through operator(): the matrix itself, or the HybridMatrix row copy.
+CG_KERNEL void pump_kernel(SamplerDev A, float *pump)
+{
+    const uint32_t i = cg_bid() * cg_bdim() + cg_tid();
+    if (i >= A.M) return;
+    float maxV = 0.f; uint32_t maxI = 0;
+    for (uint32_t j = 0; j < A.K; ++j) {
+        const float v = A.sparse ? A.rows[(size_t)i * A.Kpad + j] : A.mat[(size_t)j * A.Mpad + i];
+        if (maxV < v) { maxV = v; maxI = j; }
+    }
+    pump[(size_t)i * A.K + maxI] += 1.f;
+}

@@ -156,6 +156,9 @@ struct HostSampler {
 };
 
 struct cogaps_session {
+    float *pump = nullptr; uint32_t pumpUpdates = 0;                 // mPumpMatrix [nGenes][K] row-major (device), mPumpUpdates
+    std::vector<float> snapA[2], snapP[2]; uint32_t nSnap[2] = {0, 0};   // [0] equilibration, [1] sampling snapshots, row-major
+
     cogaps_params p;
     std::vector<uint32_t> subset; std::vector<float> fixed;
     uint32_t nGenes = 0, nSamples = 0, K = 0;
@@ -550,6 +553,7 @@ cogaps_session *cogaps_session_create(const float *data, uint32_t nrow, uint32_t
         }
         s->Asum = dalloc<float>((size_t)s->K * s->A.d.Mpad); s->Asq = dalloc<float>((size_t)s->K * s->A.d.Mpad);
         s->Psum = dalloc<float>((size_t)s->K * s->P.d.Mpad); s->Psq = dalloc<float>((size_t)s->K * s->P.d.Mpad);
+        s->pump = dalloc<float>((size_t)s->nGenes * s->K);
         s->runnerRng = pcg_from_seed(s->seeder.next());
         // ASampler.sync(PSampler); PSampler.sync(ASampler); extraInitialization x2 (GapsRunner.cpp:444-447)
         if (p.useSparseOptimization) { do_sync(s, s->A, s->P); do_sync(s, s->P, s->A); }     // the lookup tables; extraInitialization is a no-op (SparseNormalModel.cpp:34-37)
@@ -572,7 +576,7 @@ void cogaps_session_destroy(cogaps_session *s)
     rt_graph_destroy(s->A.graph); rt_graph_destroy(s->P.graph);
     free_sampler(s->A); free_sampler(s->P);
     rt_free(s->dErf); rt_free(s->dErfinv); rt_free(s->dQgamma); rt_free(s->dLcgMul); rt_free(s->dLcgInc);
-    rt_free(s->Asum); rt_free(s->Asq); rt_free(s->Psum); rt_free(s->Psq);
+    rt_free(s->Asum); rt_free(s->Asq); rt_free(s->Psum); rt_free(s->Psq); rt_free(s->pump);
     rt_free_host(s->hGs);
     for (auto &e : s->evPool) rt_event_destroy(e);
     rt_stream_destroy(s->stream);
@@ -639,6 +643,7 @@ int cogaps_session_iterate(cogaps_session *s, uint32_t nA, uint32_t nP, int samp
         const uint32_t mode = (f == 'N') ? 0u : (f == 'P' ? 1u : 2u);   // P fixed -> updateA ; A fixed -> updateP
         RT_LAUNCH(stats_kernel, s->K, 256, s->stream, s->A.d, s->P.d, s->Asum, s->Asq, s->Psum, s->Psq, mode);
         s->statUpdates++;
+        if (f == 'N' && s->p.takePumpSamples) { RT_LAUNCH(pump_kernel, (s->A.d.M + 255u) / 256u, 256, s->stream, s->A.d, s->pump); s->pumpUpdates++; }   // GapsRunner.cpp:308-313
     }
     SESSION_END
 }
@@ -657,6 +662,15 @@ int cogaps_session_run_iterations(cogaps_session *s, int phase, uint32_t firstIt
         uint32_t nA, nP; cogaps_session_draw_steps(s, &nA, &nP);
         if (cogaps_session_iterate(s, nA, nP, phase == 2)) return 1;
         if (updates) *updates += (uint64_t)nA + nP;
+        if ((s->p.snapshotPhase == 0 || s->p.snapshotPhase == phase) && s->p.snapshotFrequency > 0 && ((it + 1) % s->p.snapshotFrequency) == 0) {
+            // GapsStatistics::takeSnapshot (GapsStatistics.h:188-202): getMatrix() of both samplers
+            const int w = phase - 1;
+            const size_t na = (size_t)s->nGenes * s->K, np_ = (size_t)s->nSamples * s->K;
+            s->snapA[w].resize((size_t)(s->nSnap[w] + 1) * na); s->snapP[w].resize((size_t)(s->nSnap[w] + 1) * np_);
+            if (cogaps_session_get_rows(s, 'A', s->snapA[w].data() + (size_t)s->nSnap[w] * na)) return 1;
+            if (cogaps_session_get_rows(s, 'P', s->snapP[w].data() + (size_t)s->nSnap[w] * np_)) return 1;
+            s->nSnap[w]++;
+        }
         if (s->p.outputFrequency > 0 && ((it + 1) % s->p.outputFrequency) == 0) {        // displayStatus, :162-199
             const float cs = (s->p.whichMatrixFixed == 'P') ? chisq_of(s, s->A) : chisq_of(s, s->P);
             s->chisqHist.push_back(cs); s->atomHistA.push_back(s->A.nAtoms); s->atomHistP.push_back(s->P.nAtoms);
@@ -757,6 +771,22 @@ int cogaps_session_finish(cogaps_session *s, cogaps_result *out)
         float c = 0.f; for (uint32_t j = 0; j < s->P.d.M; ++j) c += part[j];
         out->meanChiSq = c;
     }
+    if (s->p.takePumpSamples) {                                                       // GapsRunner.cpp:487-492, GapsStatistics.cpp:113-131
+        const size_t na = (size_t)s->nGenes * K;
+        std::vector<float> pm = fetch(s->pump, na);
+        const float denom = s->pumpUpdates != 0 ? (float)s->pumpUpdates : 1.f;
+        out->pumpMatrix = (float *)malloc(na * 4 + 4); out->meanPatternAssignment = (float *)calloc(na + 1, 4);
+        for (size_t t = 0; t < na; ++t) out->pumpMatrix[t] = pm[t] / denom;
+        for (uint32_t i = 0; i < s->nGenes; ++i) {                                    // meanPattern(): the same rule on Amean
+            float maxV = 0.f; uint32_t maxI = 0;
+            for (uint32_t j = 0; j < K; ++j) { const float v = out->Amean[(size_t)i * K + j]; if (maxV < v) { maxV = v; maxI = j; } }
+            out->meanPatternAssignment[(size_t)i * K + maxI] += 1.f;
+        }
+    }
+    out->nEquilibrationSnapshots = s->nSnap[0]; out->nSamplingSnapshots = s->nSnap[1];
+    auto dup = [](const std::vector<float> &v) { float *p = (float *)malloc(v.size() * 4 + 4); if (!v.empty()) memcpy(p, v.data(), v.size() * 4); return p; };
+    out->equilibrationSnapshotsA = dup(s->snapA[0]); out->equilibrationSnapshotsP = dup(s->snapP[0]);
+    out->samplingSnapshotsA = dup(s->snapA[1]); out->samplingSnapshotsP = dup(s->snapP[1]);
     SESSION_END
 }
 
@@ -856,6 +886,8 @@ void cogaps_result_free(cogaps_result *r)
 {
     if (!r) return;
     free(r->Amean); free(r->Asd); free(r->Pmean); free(r->Psd); free(r->chisqHistory); free(r->atomHistoryA); free(r->atomHistoryP);
+    free(r->pumpMatrix); free(r->meanPatternAssignment);
+    free(r->equilibrationSnapshotsA); free(r->equilibrationSnapshotsP); free(r->samplingSnapshotsA); free(r->samplingSnapshotsP);
     memset(r, 0, sizeof(*r));
 }
 

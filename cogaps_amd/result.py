@@ -14,6 +14,12 @@ class CogapsResult:
         self.sampleNames = sampleNames
         diag = {k: raw[k] for k in ("chisq", "atomsA", "atomsP", "averageQueueLengthA", "averageQueueLengthP",
                                     "totalUpdates", "totalRunningTime") if k in raw}
+        # Cogaps.cpp:176-185: pumpStat, meanPatternAssignment, the four snapshot lists
+        if "pumpMatrix" in raw:
+            diag["pumpStat"] = raw["pumpMatrix"]; diag["meanPatternAssignment"] = raw["meanPatternAssignment"]
+        for k in ("equilibrationSnapshotsA", "equilibrationSnapshotsP", "samplingSnapshotsA", "samplingSnapshotsP"):
+            if k in raw:
+                diag[k] = list(raw[k])
         for k in ("firstPass", "unmatchedPatterns", "clusteredPatterns", "CorrToMeanPattern", "subsets", "consensus"):
             if k in raw:
                 diag[k] = raw[k]

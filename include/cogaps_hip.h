@@ -32,7 +32,8 @@ typedef struct cogaps_params {
     uint32_t maxThreads;         /* accepted for API parity; the GPU path ignores it */
     uint32_t outputFrequency;    /* default 500 */
     uint32_t checkpointInterval; /* accepted, must be 0 (checkpoints are disabled, Cogaps.cpp:224-231) */
-    uint32_t snapshotFrequency;  /* accepted, must be 0 in this round */
+    uint32_t snapshotFrequency;  /* GapsRunner.cpp:316-322: a copy of A and P every so many iterations of the snapshot phase(s); 0 = none.
+                                    cogaps_cpp derives it as nIterations / nSnapshots (Cogaps.cpp:104-109) */
     float alphaA, alphaP;        /* default 0.01 */
     float maxGibbsMassA, maxGibbsMassP; /* default 100 */
     int32_t transposeData;
@@ -41,8 +42,8 @@ typedef struct cogaps_params {
     int32_t subsetGenes;         /* subsetDim == 1 (rows of A) else samples */
     const uint32_t *dataIndicesSubset; /* 1-based indices, as R passes them (Matrix.cpp:55-62) */
     uint32_t nSubset;
-    int32_t useSparseOptimization; /* must be 0: SparseNormalModel is not built in this round */
-    int32_t takePumpSamples;       /* must be 0 in this round */
+    int32_t useSparseOptimization; /* SparseNormalModel (default uncertainty only) instead of DenseNormalModel */
+    int32_t takePumpSamples;       /* GapsStatistics::updatePump per sampling iteration (GapsRunner.cpp:310-313) */
     int32_t asynchronousUpdates;   /* must be 1: this library IS the asynchronous sampler */
     char whichMatrixFixed;         /* 'N', 'A' or 'P' */
     const float *fixedPatterns;    /* row-major [fixedRows][nPatterns] when whichMatrixFixed != 'N' */
@@ -52,6 +53,7 @@ typedef struct cogaps_params {
     int32_t device;                /* HIP device ordinal, -1 = current */
     int (*interrupt)(void *);      /* polled once per iteration (GapsRunner.cpp:280); non-zero aborts */
     void *interruptArg;
+    int32_t snapshotPhase;         /* 0 = all phases (GAPS_ALL_PHASES, the default of GapsParameters.h:98), 1 = equilibration, 2 = sampling */
 } cogaps_params;
 
 /* POD mirror of GapsResult (reference src/GapsResult.h:17-36) + the names cogapsRun returns */
@@ -69,6 +71,11 @@ typedef struct cogaps_result {
     float meanChiSq;
     float averageQueueLengthA, averageQueueLengthP;
     double samplerSeconds;       /* wall time of the two phases, for proposals/s */
+    float *pumpMatrix;           /* diagnostics$pumpStat, row-major [nGenes][nPatterns]; NULL unless takePumpSamples */
+    float *meanPatternAssignment;/* diagnostics$meanPatternAssignment, same shape */
+    uint32_t nEquilibrationSnapshots, nSamplingSnapshots;
+    float *equilibrationSnapshotsA, *equilibrationSnapshotsP;   /* [n][rows][nPatterns] row-major */
+    float *samplingSnapshotsA, *samplingSnapshotsP;
 } cogaps_result;
 
 void cogaps_default_params(cogaps_params *p);

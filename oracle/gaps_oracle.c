@@ -1435,6 +1435,8 @@ struct go_session {
     float *chisqHist; uint32_t *atomHistA, *atomHistP; uint32_t nHist, histCap;
     uint64_t totalUpdates;
     double samplerSeconds;
+    float *pump; unsigned pumpUpdates;           /* mPumpMatrix [nGenes][K] row-major, mPumpUpdates */
+    float *snapA[2], *snapP[2]; uint32_t nSnap[2], capSnap[2];   /* [0] equilibration, [1] sampling */
 };
 
 void go_default_params(go_params *p)
@@ -1471,6 +1473,7 @@ go_session *go_create(const float *data, uint32_t nrow, uint32_t ncol, const go_
     size_t na = (size_t)s->nGenes * s->K, np = (size_t)s->nSamples * s->K;
     s->Amean = (float *)calloc(na, 4); s->Astd = (float *)calloc(na, 4);
     s->Pmean = (float *)calloc(np, 4); s->Pstd = (float *)calloc(np, 4);
+    s->pump = (float *)calloc(na, 4);
     rng_init(&s->rng, s->rs);                                   /* GapsRunner.cpp:437 */
     sampler_sync(&s->A, &s->P);                                 /* :444-447 */
     sampler_sync(&s->P, &s->A);
@@ -1483,6 +1486,7 @@ void go_destroy(go_session *s)
     if (!s) return;
     sampler_free(&s->A); sampler_free(&s->P);
     free(s->Amean); free(s->Astd); free(s->Pmean); free(s->Pstd);
+    free(s->pump); for (int w = 0; w < 2; ++w) { free(s->snapA[w]); free(s->snapP[w]); }
     free(s->chisqHist); free(s->atomHistA); free(s->atomHistP); free(s->rs); free(s);
 }
 static go_sampler *pick(go_session *s, char which) { return which == 'A' ? &s->A : &s->P; }
@@ -1584,6 +1588,21 @@ static void hist_push(go_session *s, float cs, uint32_t nA, uint32_t nP)
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 /* runOnePhase, GapsRunner.cpp:272-327 (no checkpoints, snapshots or PUMP) */
+/* pumpMatrixUniqueThreshold == pumpMatrixCutThreshold (GapsStatistics.h:65-111): per row the first column holding the
+ * row maximum (strictly greater than everything before, starting from 0) gets +1.  src == NULL: the A sampler's
+ * mMatrix through operator(); else a row-major [nGenes][K] matrix (meanPattern on Amean). */
+static void pump_update(const go_session *s, const float *src, float *stat)
+{
+    const go_sampler *A = &s->A; const uint32_t K = s->K;
+    for (uint32_t i = 0; i < s->nGenes; ++i) {
+        float maxV = 0.f; uint32_t maxI = 0;
+        for (uint32_t j = 0; j < K; ++j) {
+            const float v = src ? src[(size_t)i * K + j] : (A->sparse ? A->rows[(size_t)i * K + j] : A->mat[(size_t)j * A->M + i]);
+            if (maxV < v) { maxV = v; maxI = j; }
+        }
+        stat[(size_t)i * K + maxI] += 1.f;
+    }
+}
 static void run_phase(go_session *s, int phase)
 {
     const go_params *p = &s->p;
@@ -1594,7 +1613,22 @@ static void run_phase(go_session *s, int phase)
         }
         uint32_t nA, nP; go_draw_steps(s, &nA, &nP);
         s->totalUpdates += go_iterate(s, nA, nP);
-        if (phase == 2) go_stats_update(s);
+        if (phase == 2) {
+            go_stats_update(s);
+            if (p->whichMatrixFixed == 'N' && p->takePumpSamples) pump_update(s, NULL, s->pump), ++s->pumpUpdates;   /* GapsRunner.cpp:308-313 */
+        }
+        if ((p->snapshotPhase == 0 || p->snapshotPhase == phase) && p->snapshotFrequency > 0 && ((iter + 1) % p->snapshotFrequency) == 0) {
+            /* takeSnapshot, GapsStatistics.h:188-202: AModel.mMatrix.getMatrix() = operator() values */
+            const int w = phase - 1;
+            if (s->nSnap[w] == s->capSnap[w]) {
+                s->capSnap[w] = s->capSnap[w] ? 2 * s->capSnap[w] : 4;
+                s->snapA[w] = (float *)realloc(s->snapA[w], (size_t)s->capSnap[w] * s->nGenes * s->K * 4);
+                s->snapP[w] = (float *)realloc(s->snapP[w], (size_t)s->capSnap[w] * s->nSamples * s->K * 4);
+            }
+            go_get_rows(s, 'A', s->snapA[w] + (size_t)s->nSnap[w] * s->nGenes * s->K);
+            go_get_rows(s, 'P', s->snapP[w] + (size_t)s->nSnap[w] * s->nSamples * s->K);
+            ++s->nSnap[w];
+        }
         if (p->outputFrequency > 0 && ((iter + 1) % p->outputFrequency) == 0) { /* displayStatus :162-199 */
             float cs = (p->whichMatrixFixed == 'P') ? sampler_chisq(&s->A) : sampler_chisq(&s->P);
             hist_push(s, cs, s->A.dom.n, s->P.dom.n);
@@ -1663,6 +1697,20 @@ void go_finish(go_session *s, go_result *out)
     out->averageQueueLengthA = s->A.avgQueue; out->averageQueueLengthP = s->P.avgQueue;
     out->meanChiSq = (s->p.whichMatrixFixed != 'N') ? 0.f : mean_chisq(s); /* GapsRunner.cpp:478-484 */
     out->samplerSeconds = s->samplerSeconds;
+    if (s->p.takePumpSamples) {   /* GapsRunner.cpp:487-492, GapsStatistics.cpp:113-131 */
+        const float denom = s->pumpUpdates != 0 ? (float)s->pumpUpdates : 1.f;
+        out->pumpMatrix = (float *)malloc(na * 4); out->meanPatternAssignment = (float *)calloc(na, 4);
+        for (size_t t = 0; t < na; ++t) out->pumpMatrix[t] = s->pump[t] / denom;
+        pump_update(s, out->Amean, out->meanPatternAssignment);
+    }
+    out->nEquilibrationSnapshots = s->nSnap[0]; out->nSamplingSnapshots = s->nSnap[1];
+    float **dst[4] = {&out->equilibrationSnapshotsA, &out->equilibrationSnapshotsP, &out->samplingSnapshotsA, &out->samplingSnapshotsP};
+    for (int w = 0; w < 2; ++w) {
+        size_t sa = (size_t)s->nSnap[w] * na, sp = (size_t)s->nSnap[w] * np;
+        *dst[2 * w] = (float *)malloc(sa * 4 + 4); *dst[2 * w + 1] = (float *)malloc(sp * 4 + 4);
+        if (sa) memcpy(*dst[2 * w], s->snapA[w], sa * 4);
+        if (sp) memcpy(*dst[2 * w + 1], s->snapP[w], sp * 4);
+    }
 }
 int go_run(const float *data, uint32_t nrow, uint32_t ncol, const go_params *p, const float *unc, go_result *out)
 {
@@ -1678,5 +1726,7 @@ int go_run(const float *data, uint32_t nrow, uint32_t ncol, const go_params *p, 
 void go_result_free(go_result *r)
 {
     free(r->Amean); free(r->Asd); free(r->Pmean); free(r->Psd); free(r->chisqHistory); free(r->atomHistoryA); free(r->atomHistoryP);
+    free(r->pumpMatrix); free(r->meanPatternAssignment);
+    free(r->equilibrationSnapshotsA); free(r->equilibrationSnapshotsP); free(r->samplingSnapshotsA); free(r->samplingSnapshotsP);
     memset(r, 0, sizeof(*r));
 }

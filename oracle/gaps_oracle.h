@@ -43,6 +43,9 @@ typedef struct go_params {
     uint32_t redW_A, redW_P;   /* reduction lanes for A / P sampler; 0 or 1 = sequential (reference scalar order) */
     uint32_t redG;             /* lane granularity in elements (1 = reference PackedFloat pattern, 4 = float4) */
     int32_t useSparseOptimization; /* SparseNormalModel instead of DenseNormalModel (GapsRunner.cpp:65-91) */
+    int32_t takePumpSamples;       /* GapsStatistics::updatePump per sampling iteration (GapsRunner.cpp:310-313) */
+    uint32_t snapshotFrequency;    /* GapsRunner.cpp:316-322; 0 = none */
+    int32_t snapshotPhase;         /* 0 = all phases (the default, GapsParameters.h:98), 1 = equilibration, 2 = sampling */
 } go_params;
 
 typedef struct go_result {
@@ -56,6 +59,9 @@ typedef struct go_result {
     float meanChiSq;
     float averageQueueLengthA, averageQueueLengthP;
     double samplerSeconds;     /* wall time of the two phases (first update to last) */
+    float *pumpMatrix, *meanPatternAssignment;   /* row-major [nGenes][nPatterns], NULL unless takePumpSamples */
+    uint32_t nEquilibrationSnapshots, nSamplingSnapshots;
+    float *equilibrationSnapshotsA, *equilibrationSnapshotsP, *samplingSnapshotsA, *samplingSnapshotsP; /* [n][rows][nPatterns] */
 } go_result;
 
 /* one queued proposal as it leaves populate (ProposalQueue.h:15-28) */

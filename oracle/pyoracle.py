@@ -26,7 +26,8 @@ class GoParams(C.Structure):
         ("whichMatrixFixed", C.c_char), ("fixedPatterns", C.POINTER(C.c_float)),
         ("fixedRows", C.c_uint32), ("math_mode", C.c_int32),
         ("redW_A", C.c_uint32), ("redW_P", C.c_uint32), ("redG", C.c_uint32),
-        ("useSparseOptimization", C.c_int32),
+        ("useSparseOptimization", C.c_int32), ("takePumpSamples", C.c_int32),
+        ("snapshotFrequency", C.c_uint32), ("snapshotPhase", C.c_int32),
     ]
 
 
@@ -40,6 +41,10 @@ class GoResult(C.Structure):
         ("totalUpdates", C.c_uint64), ("meanChiSq", C.c_float),
         ("averageQueueLengthA", C.c_float), ("averageQueueLengthP", C.c_float),
         ("samplerSeconds", C.c_double),
+        ("pumpMatrix", C.POINTER(C.c_float)), ("meanPatternAssignment", C.POINTER(C.c_float)),
+        ("nEquilibrationSnapshots", C.c_uint32), ("nSamplingSnapshots", C.c_uint32),
+        ("equilibrationSnapshotsA", C.POINTER(C.c_float)), ("equilibrationSnapshotsP", C.POINTER(C.c_float)),
+        ("samplingSnapshotsA", C.POINTER(C.c_float)), ("samplingSnapshotsP", C.POINTER(C.c_float)),
     ]
 
 
@@ -138,7 +143,8 @@ def make_params(nPatterns=3, nIterations=1000, seed=0, outputFrequency=500, maxT
                 alphaA=0.01, alphaP=0.01, maxGibbsMassA=100.0, maxGibbsMassP=100.0,
                 transposeData=False, subsetIndices=None, subsetDim=0,
                 whichMatrixFixed="N", fixedPatterns=None, math_mode=MATH_LIBM,
-                redW_A=1, redW_P=1, redG=1, sparseOptimization=False):
+                redW_A=1, redW_P=1, redG=1, sparseOptimization=False, takePumpSamples=False,
+                snapshotFrequency=0, snapshotPhase=0):
     p = GoParams()
     lib().go_default_params(C.byref(p))
     p.nPatterns, p.nIterations, p.seed = nPatterns, nIterations, seed
@@ -162,6 +168,8 @@ def make_params(nPatterns=3, nIterations=1000, seed=0, outputFrequency=500, maxT
     p.math_mode = math_mode
     p.redW_A, p.redW_P, p.redG = redW_A, redW_P, redG
     p.useSparseOptimization = int(bool(sparseOptimization))
+    p.takePumpSamples = int(bool(takePumpSamples))
+    p.snapshotFrequency, p.snapshotPhase = int(snapshotFrequency), int(snapshotPhase)
     p._keep = keep
     return p
 
@@ -181,6 +189,14 @@ def _result_to_dict(r):
         "averageQueueLengthP": float(r.averageQueueLengthP),
         "samplerSeconds": float(r.samplerSeconds),
     }
+    def _arr(ptr, shape):
+        n = int(np.prod(shape))
+        return np.ctypeslib.as_array(ptr, shape=(max(n, 1),))[:n].reshape(shape).copy() if ptr else np.zeros(shape, dtype=np.float32)
+    if r.pumpMatrix:
+        out["pumpMatrix"] = _arr(r.pumpMatrix, (g, k)); out["meanPatternAssignment"] = _arr(r.meanPatternAssignment, (g, k))
+    ne, ns = int(r.nEquilibrationSnapshots), int(r.nSamplingSnapshots)
+    out["equilibrationSnapshotsA"] = _arr(r.equilibrationSnapshotsA, (ne, g, k)); out["equilibrationSnapshotsP"] = _arr(r.equilibrationSnapshotsP, (ne, s, k))
+    out["samplingSnapshotsA"] = _arr(r.samplingSnapshotsA, (ns, g, k)); out["samplingSnapshotsP"] = _arr(r.samplingSnapshotsP, (ns, s, k))
     return out
 
 

@@ -77,3 +77,21 @@ def test_full_run_matches_oracle(emul_lib, modsim, oracle):
         assert np.array_equal(r[f], o[f]), f
     assert r["totalUpdates"] == o["totalUpdates"] and r["meanChiSq"] == o["meanChiSq"]
     assert r["averageQueueLengthA"] == o["averageQueueLengthA"]
+
+
+def test_pump_statistics_and_snapshots(emul_lib, modsim, oracle):
+    """takePumpSamples (GapsStatistics.h:65-126) and nSnapshots / snapshotPhase (GapsRunner.cpp:316-322,
+    Cogaps.cpp:104-123) against the oracle, dense and sparse model"""
+    from cogaps_amd import _capi
+    lib = emul_lib(256)
+    for sparse, data in ((False, modsim), (True, pu.synthetic_counts(80, 24, zeros=0.7, seed=4))):
+        kw = dict(nPatterns=3, nIterations=40, seed=42, outputFrequency=10, takePumpSamples=True, sparseOptimization=sparse)
+        for phase, code in (("all", 0), ("equilibration", 1), ("sampling", 2)):
+            r = _capi.run(data, lib=lib, nSnapshots=4, snapshotPhase=phase, **kw)
+            w_a, w_p = lib.cogaps_reduction_width(data.shape[1]), lib.cogaps_reduction_width(data.shape[0])
+            o = oracle.run(data, math_mode=oracle.MATH_PORTABLE, redW_A=w_a, redW_P=w_p, redG=4, snapshotFrequency=10, snapshotPhase=code, **kw)
+            for f in ("Amean", "Pmean", "pumpMatrix", "meanPatternAssignment", "equilibrationSnapshotsA", "equilibrationSnapshotsP",
+                      "samplingSnapshotsA", "samplingSnapshotsP"):
+                assert np.array_equal(r[f], o[f]), (sparse, phase, f)
+            assert r["equilibrationSnapshotsA"].shape[0] == (4 if code != 2 else 0) and r["samplingSnapshotsP"].shape[0] == (4 if code != 1 else 0)
+            assert np.allclose(r["pumpMatrix"].sum(axis=1), 1.0) and set(np.unique(r["meanPatternAssignment"])) <= {0.0, 1.0}
