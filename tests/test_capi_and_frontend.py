@@ -102,3 +102,20 @@ def test_readers(tmp_path, gist):
     p = tmp_path / "x.csv"
     p.write_text(",s1,s2\ng1,1.5,2\ng2,3,4e-1\n")
     assert np.array_equal(read_matrix(str(p)), np.array([[1.5, 2], [3, 0.4]], dtype=np.float32))
+
+
+def test_input_file_formats(gist):
+    """the reference's GIST data set in its four input formats gives one fp32 matrix (tests/testthat/test_reading_input_files.R
+    checks the same through CoGAPS()); scientific notation follows MatrixElement.cpp:24-46"""
+    import os
+    from conftest import GOLDEN
+    from cogaps_amd.io import read_matrix, parse_value
+    for ext in ("mtx", "csv", "tsv", "gct"):
+        m, rown, coln = read_matrix(os.path.join(GOLDEN, "GIST." + ext), return_names=True)
+        assert m.dtype == np.float32 and np.array_equal(m, gist), ext
+        if ext != "mtx":
+            assert len(rown) == 1363 and rown[0] == "Hs.101174" and len(coln) == 9 and coln[0] == "IM00"
+    assert parse_value("1.5e3") == np.float32(1500.0) and parse_value("-2e-2") == np.float32(np.float32(-2.0) * np.power(np.float32(10.0), np.float32(-2.0)))
+    assert parse_value("0.1") == np.float32(0.1)
+    with pytest.raises(ValueError):
+        parse_value("abc")

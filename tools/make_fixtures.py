@@ -1,7 +1,8 @@
 """Build the committed data fixtures under tests/golden/ from the reference's own data files.
 
 Run in the build container only (it reads /root/reference); the outputs are data, not source:
-  tests/golden/GIST.mtx          -- verbatim copy of inst/extdata/GIST.mtx (test data file, 1363x9)
+  tests/golden/GIST.{mtx,csv,tsv,gct} -- verbatim copies of inst/extdata/GIST.* (the reference's test data files, 1363x9,
+                                    one matrix in the four input formats of src/file_parser/)
   tests/golden/modsimdata.csv    -- data/modsimdata.rda (gzip + XDR data.frame, 25x20) printed with
                                     %.17g so that text -> fp32 equals the double -> fp32 cast the
                                     reference applies to R matrices (Cogaps.cpp:21-32)
@@ -98,8 +99,9 @@ def read_modsim():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    shutil.copyfile(os.path.join(REF, "inst", "extdata", "GIST.mtx"), os.path.join(OUT, "GIST.mtx"))
-    os.chmod(os.path.join(OUT, "GIST.mtx"), 0o644)
+    for ext in ("mtx", "csv", "tsv", "gct"):
+        shutil.copyfile(os.path.join(REF, "inst", "extdata", "GIST." + ext), os.path.join(OUT, "GIST." + ext))
+        os.chmod(os.path.join(OUT, "GIST." + ext), 0o644)
     m = read_modsim()
     with open(os.path.join(OUT, "modsimdata.csv"), "w") as f:
         for row in m:
