@@ -27,6 +27,42 @@ CG_DEVICE float sp_dot(const float *a, const float *b, uint32_t n)
     return d;
 }
 
+// the same dot with the second operand a row of a row copy in HBM (16-byte aligned, padded to a multiple of 4):
+// float4 loads, all issued before the first use, then the additions in gaps::dot's order
+CG_DEVICE float sp_dot_row(const float *a, const float *row, uint32_t n)
+{
+    float d = 0.f;
+    const uint32_t nq = (n + 3u) >> 2;
+    if (n <= 25u) {
+        cg_f4 r[7];
+#pragma unroll
+        for (uint32_t c = 0; c < 7u; ++c) r[c] = c < nq ? ld4(row, c) : f4_zero();
+#pragma unroll
+        for (uint32_t c = 7u; c-- > 0u;) {
+            const uint32_t i = 4u * c;
+            if (i + 3u < n) d = d + a[i + 3u] * r[c].w;
+            if (i + 2u < n) d = d + a[i + 2u] * r[c].z;
+            if (i + 1u < n) d = d + a[i + 1u] * r[c].y;
+            if (i < n) d = d + a[i] * r[c].x;
+        }
+        return d;
+    }
+    for (uint32_t c0 = 0; c0 < nq; c0 += 8u) {
+        cg_f4 r[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; ++u) r[u] = (c0 + u) < nq ? ld4(row, c0 + u) : f4_zero();
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; ++u) {
+            const uint32_t i = 4u * (c0 + u);
+            if (i < n) d = d + a[i] * r[u].x;
+            if (i + 1u < n) d = d + a[i + 1u] * r[u].y;
+            if (i + 2u < n) d = d + a[i + 2u] * r[u].z;
+            if (i + 3u < n) d = d + a[i + 3u] * r[u].w;
+        }
+    }
+    return d;
+}
+
 #define SP_MODE_ONE 0
 #define SP_MODE_CH 1
 #define SP_MODE_SAME 2
@@ -51,7 +87,7 @@ CG_DEVICE void sp_partial(const SamplerDev &S, uint32_t row, uint32_t col, uint3
             common &= common - 1ull;
             const uint32_t idx = 64u * w + bit;
             const float d_val = data[base + (uint32_t)cg_popc64(dfl & ((1ull << bit) - 1ull))];
-            const float ap = sp_dot(arow, S.orows + (size_t)idx * S.oKpad, K);
+            const float ap = sp_dot_row(arow, S.orows + (size_t)idx * S.oKpad, K);
             if (MODE == SP_MODE_SAME) {
                 const float d_recip = 1.f / d_val;
                 const float term1 = 1.f - d_recip * d_recip;
@@ -281,7 +317,7 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(1024) chisq_sparse_kernel(SamplerDev S, float *p
             for (uint32_t e = 0; e < 4u; ++e) {
                 const uint32_t i = 4u * c + e;
                 if (i < S.N) {
-                    const float dot = sp_dot(arow, S.orows + (size_t)i * S.oKpad, K);
+                    const float dot = sp_dot_row(arow, S.orows + (size_t)i * S.oKpad, K);
                     acc = acc + dot * dot;
                     const unsigned long long fl = fD[i >> 6];
                     if ((fl >> (i & 63u)) & 1ull) {
