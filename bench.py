@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--patterns", type=int, default=50)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--sparse", action="store_true",
+                    help="not the headline: the SparseNormalModel on the same product with 95 %% of the entries zeroed (BASELINE configs[4] "
+                         "uses --genes 50000 --samples 12500 per GPU)")
     args = ap.parse_args()
 
     import torch
@@ -104,7 +107,9 @@ def main():
     n_iter = (W + K + 1) // 2
     # shard `rank` of the gene-wise partition: its own 20000-gene block (contiguous explicit sets)
     data = synthetic_dense(args.genes, args.samples, seed=12345 + rank)
-    params = dict(nPatterns=args.patterns, nIterations=n_iter, seed=42, outputFrequency=max(1, n_iter // 10))
+    if args.sparse:     # the same product, 95 % of the entries zeroed i.i.d.
+        data *= (np.random.Generator(np.random.MT19937(777 + rank)).random(data.shape) >= 0.95)
+    params = dict(nPatterns=args.patterns, nIterations=n_iter, seed=42, outputFrequency=max(1, n_iter // 10), sparseOptimization=args.sparse)
     S = _capi.Session(data, device=local_rank, **params)
 
     def run_steps(first, n):
@@ -164,7 +169,7 @@ def main():
         # the roofline kernel: the fused evaluation kernel, which serves the sampler whose data vectors have at most
         # 4096 elements (A in the headline workload: one workgroup of 512 threads per proposal); the other sampler's
         # long vectors go through the split alpha/apply kernels, reported alongside
-        roof = "A" if S.dims("A")[1] <= 4096 else "P"
+        roof = "A" if (args.sparse or S.dims("A")[1] <= 4096) else "P"
         rk = kt[roof]
         achieved = (rk["bytes"] / 1e9) / (rk["eval_us"] * rk["batches"] / 1e6) if rk["batches"] else 0.0
         gen_ms = sum(kt[w]["gen_us"] * kt[w]["batches"] for w in "AP") / 1e3
@@ -176,19 +181,20 @@ def main():
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * max_dt / K,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "synthetic dense %dx%d fp32 per GPU, nPatterns=%d, asynchronous sampler, seed 42 (BASELINE configs[2]%s)"
+            "config": {"workload": ("synthetic sparse %dx%d fp32 per GPU (95 %% zeros), sparseOptimization, nPatterns=%d, asynchronous sampler, seed 42 (cf. BASELINE configs[4]%s)"
+                                    if args.sparse else "synthetic dense %dx%d fp32 per GPU, nPatterns=%d, asynchronous sampler, seed 42 (BASELINE configs[2]%s)")
                                    % (args.genes, args.samples, args.patterns, "; GWCoGAPS nSets=%d gene-wise shards, configs[3]" % world if world > 1 else ""),
                        "nIterations": n_iter, "proposals_timed": int(tot_updates), "batches_rank0": int(batches),
                        "avg_queue_A": S.avg_queue("A"), "avg_queue_P": S.avg_queue("P"),
                        "atoms_A": S.natoms("A"), "atoms_P": S.natoms("P"),
                        "gen_kernel_ms_rank0": gen_ms, "eval_kernel_ms_rank0": ev_ms,
                        "launches_per_batch": (kt["A"]["launches"] + kt["P"]["launches"]) / max(1, batches)},
-            "roofline": {"bound": "hbm", "kernel": "eval_kernel<EVAL_FUSED> (sampler %s)" % roof, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": ("eval_sparse_kernel (sampler %s)" if args.sparse else "eval_kernel<EVAL_FUSED> (sampler %s)") % roof, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "bytes_per_launch": rk["bytes"] / max(1, rk["batches"]), "avg_launch_us": rk["eval_us"],
                          "empty_queue_launch_us": rk["eval_empty_us"], "launches": int(rk["batches"]),
                          "note": "one launch = one batch of sampler %s" % roof,
-                         "other_sampler": {"kernels": "eval_kernel<EVAL_ALPHA> + eval_kernel<EVAL_APPLY> (sampler %s, two launches per batch)" % other,
+                         "other_sampler": {"kernels": ("eval_sparse_kernel (sampler %s)" if args.sparse else "eval_kernel<EVAL_ALPHA> + eval_kernel<EVAL_APPLY> (sampler %s, two launches per batch)") % other,
                                            "bytes_per_batch": ok["bytes"] / max(1, ok["batches"]), "avg_batch_us": ok["eval_us"], "batches": int(ok["batches"]),
                                            "achieved": (ok["bytes"] / 1e9) / (ok["eval_us"] * ok["batches"] / 1e6) if ok["batches"] else 0.0}},
         }

@@ -27,13 +27,46 @@ CG_DEVICE float sp_dot(const float *a, const float *b, uint32_t n)
     return d;
 }
 
-// the same dot with the second operand a row of a row copy in HBM (16-byte aligned, padded to a multiple of 4):
-// float4 loads, all issued before the first use, then the additions in gaps::dot's order
+// A row of the other matrix's row copy (16-byte aligned, padded to a multiple of 4) held in registers: up to 64
+// elements, all float4 loads issued together.
+struct SpRow { cg_f4 r[16]; };
+CG_DEVICE void sp_row_load(SpRow &R, const float *row, uint32_t n)
+{
+    const uint32_t nq = (n + 3u) >> 2;
+#pragma unroll
+    for (uint32_t c = 0; c < 16u; ++c) R.r[c] = c < nq ? ld4(row, c) : f4_zero();
+}
+// gaps::dot(a, row) in the scalar build's order (sp_dot) with the row in registers, n <= 64
+CG_DEVICE float sp_row_dot(const float *a, const SpRow &R, uint32_t n)
+{
+    float d = 0.f;
+    if (n <= 25u) {
+#pragma unroll
+        for (uint32_t c = 7u; c-- > 0u;) {
+            const uint32_t i = 4u * c;
+            if (i + 3u < n) d = d + a[i + 3u] * R.r[c].w;
+            if (i + 2u < n) d = d + a[i + 2u] * R.r[c].z;
+            if (i + 1u < n) d = d + a[i + 1u] * R.r[c].y;
+            if (i < n) d = d + a[i] * R.r[c].x;
+        }
+        return d;
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < 16u; ++c) {
+        const uint32_t i = 4u * c;
+        if (i < n) d = d + a[i] * R.r[c].x;
+        if (i + 1u < n) d = d + a[i + 1u] * R.r[c].y;
+        if (i + 2u < n) d = d + a[i + 2u] * R.r[c].z;
+        if (i + 3u < n) d = d + a[i + 3u] * R.r[c].w;
+    }
+    return d;
+}
+// any length: straight from memory, 8 float4 at a time
 CG_DEVICE float sp_dot_row(const float *a, const float *row, uint32_t n)
 {
     float d = 0.f;
     const uint32_t nq = (n + 3u) >> 2;
-    if (n <= 25u) {
+    if (n <= 25u) {      // last-to-first: at most 7 chunks, all loaded first
         cg_f4 r[7];
 #pragma unroll
         for (uint32_t c = 0; c < 7u; ++c) r[c] = c < nq ? ld4(row, c) : f4_zero();
@@ -67,9 +100,30 @@ CG_DEVICE float sp_dot_row(const float *a, const float *row, uint32_t n)
 #define SP_MODE_CH 1
 #define SP_MODE_SAME 2
 
-// per-lane partial sums of one alpha evaluation over this thread's flag words
+// one common non-zero's term added to the lane's partial sums (SparseNormalModel.cpp:176-186, 222-233, 274-285)
 template <int MODE>
-CG_DEVICE void sp_partial(const SamplerDev &S, uint32_t row, uint32_t col, uint32_t col2, float ch, const float *arow, float &ps, float &pm)
+CG_DEVICE void sp_term(float d_val, float v_val, float v2_val, float ex, float ap, float ch, float &ps, float &pm)
+{
+    if (MODE == SP_MODE_SAME) {
+        const float d_recip = 1.f / d_val;
+        const float term1 = 1.f - d_recip * d_recip;
+        const float v_diff = v_val - v2_val;
+        ps = ps - v_diff * v_diff * term1;
+        pm = pm + v_diff * (ap * term1 + d_recip);
+    } else {
+        const float term1 = v_val / d_val;
+        const float term2 = v_val - term1 / d_val;
+        ps = ps + (term1 * term1 - v_val * v_val);
+        pm = pm + (term1 + term2 * ap);
+        if (MODE == SP_MODE_CH) pm = pm + term2 * ex * ch;
+    }
+}
+
+// per-lane partial sums of one alpha evaluation over this thread's flag words.  Two common non-zeros are in flight at
+// a time (data value, column entries and the other matrix's row of both are loaded before either is used); their terms
+// are added in index order.
+template <int MODE>
+CG_DEVICE void sp_partial(const SamplerDev &S, uint32_t row, uint32_t col, uint32_t col2, float ch, const float *arow, float &ps, float &pm, uint32_t &visited)
 {
     const uint32_t BS = cg_bdim(), t = cg_tid(), K = S.K;
     const unsigned long long *fD = S.dflags + (size_t)row * S.Wn;
@@ -82,26 +136,32 @@ CG_DEVICE void sp_partial(const SamplerDev &S, uint32_t row, uint32_t col, uint3
         const unsigned long long dfl = fD[w];
         unsigned long long common = dfl & (MODE == SP_MODE_SAME ? (fV[w] | fV2[w]) : fV[w]);
         const uint32_t base = pre[w];
+        visited += (uint32_t)cg_popc64(common);
         while (common != 0ull) {
-            const uint32_t bit = (uint32_t)cg_ctz64(common);
+            const uint32_t bit0 = (uint32_t)cg_ctz64(common);
             common &= common - 1ull;
-            const uint32_t idx = 64u * w + bit;
-            const float d_val = data[base + (uint32_t)cg_popc64(dfl & ((1ull << bit) - 1ull))];
-            const float ap = sp_dot_row(arow, S.orows + (size_t)idx * S.oKpad, K);
-            if (MODE == SP_MODE_SAME) {
-                const float d_recip = 1.f / d_val;
-                const float term1 = 1.f - d_recip * d_recip;
-                const float v_diff = V[idx] - V2[idx];
-                ps = ps - v_diff * v_diff * term1;
-                pm = pm + v_diff * (ap * term1 + d_recip);
+            const bool second = common != 0ull;
+            const uint32_t bit1 = second ? (uint32_t)cg_ctz64(common) : bit0;
+            if (second) common &= common - 1ull;
+            const uint32_t idx0 = 64u * w + bit0, idx1 = 64u * w + bit1;
+            const float d0 = data[base + (uint32_t)cg_popc64(dfl & ((1ull << bit0) - 1ull))];
+            const float d1 = data[base + (uint32_t)cg_popc64(dfl & ((1ull << bit1) - 1ull))];
+            const float v0 = V[idx0], v1 = V[idx1];
+            const float w0 = (MODE == SP_MODE_SAME) ? V2[idx0] : 0.f, w1 = (MODE == SP_MODE_SAME) ? V2[idx1] : 0.f;
+            const float e0 = (MODE == SP_MODE_CH) ? S.orows[(size_t)idx0 * S.oKpad + col] : 0.f, e1 = (MODE == SP_MODE_CH) ? S.orows[(size_t)idx1 * S.oKpad + col] : 0.f;
+            float ap0, ap1 = 0.f;
+            if (K <= 64u) {
+                SpRow R0, R1;
+                sp_row_load(R0, S.orows + (size_t)idx0 * S.oKpad, K);
+                sp_row_load(R1, S.orows + (size_t)idx1 * S.oKpad, K);
+                ap0 = sp_row_dot(arow, R0, K);
+                if (second) ap1 = sp_row_dot(arow, R1, K);
             } else {
-                const float v_val = V[idx];
-                const float term1 = v_val / d_val;
-                const float term2 = v_val - term1 / d_val;
-                ps = ps + (term1 * term1 - v_val * v_val);
-                pm = pm + (term1 + term2 * ap);
-                if (MODE == SP_MODE_CH) pm = pm + term2 * S.orows[(size_t)idx * S.oKpad + col] * ch;
+                ap0 = sp_dot_row(arow, S.orows + (size_t)idx0 * S.oKpad, K);
+                if (second) ap1 = sp_dot_row(arow, S.orows + (size_t)idx1 * S.oKpad, K);
             }
+            sp_term<MODE>(d0, v0, w0, e0, ap0, ch, ps, pm);
+            if (second) sp_term<MODE>(d1, v1, w1, e1, ap1, ch, ps, pm);
         }
     }
 }
@@ -143,7 +203,9 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S)
 {
     CG_SHARED float lds[16 * 4];
     CG_SHARED float arowA[SP_KMAX], arowB[SP_KMAX];
+    CG_SHARED float z2A[SP_KMAX], z2B[SP_KMAX];        // the Z2 columns of c1 / c2 (table terms)
     CG_SHARED float decf; CG_SHARED uint32_t deci;
+    CG_SHARED uint32_t nzShared;           // common non-zeros visited by this workgroup (roofline bookkeeping)
     const uint32_t t = cg_tid(), BS = cg_bdim(), K = S.K;
     const float lambda = S.lambda, beta = S.beta;
     const bool multiWave = BS > 64u;
@@ -161,16 +223,22 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S)
         const bool need = (p.type == 'B') ? gibbs1 : ((p.type == 'D' || p.type == 'M') ? true : (gibbs1 || gibbs2));
         const bool diff = two && p.r1 != p.r2;
         float s = 0.f, smu = 0.f;
-        uint32_t nz = 0;          // common non-zeros visited (roofline bookkeeping)
+        uint32_t nz = 0;
+        if (t == 0) nzShared = 0u;
         if (need) {
             // this sampler's matrix row(s), read by every lane for the K-length dots
-            for (uint32_t k = t; k < K; k += BS) { arowA[k] = S.rows[(size_t)p.r1 * S.Kpad + k]; if (diff) arowB[k] = S.rows[(size_t)p.r2 * S.Kpad + k]; }
+            for (uint32_t k = t; k < K; k += BS) {
+                arowA[k] = S.rows[(size_t)p.r1 * S.Kpad + k]; z2A[k] = S.Z2[(size_t)p.c1 * K + k];
+                if (diff) arowB[k] = S.rows[(size_t)p.r2 * S.Kpad + k];
+                if (two) z2B[k] = S.Z2[(size_t)p.c2 * K + k];
+            }
             cg_sync();
             float x[4] = {0.f, 0.f, 0.f, 0.f};
-            if (diff) { sp_partial<SP_MODE_ONE>(S, p.r1, p.c1, 0u, 0.f, arowA, x[0], x[1]); sp_partial<SP_MODE_ONE>(S, p.r2, p.c2, 0u, 0.f, arowB, x[2], x[3]); }
-            else if (p.type == 'D') sp_partial<SP_MODE_CH>(S, p.r1, p.c1, 0u, -1.f * m1, arowA, x[0], x[1]);
-            else if (two) sp_partial<SP_MODE_SAME>(S, p.r1, p.c1, p.c2, 0.f, arowA, x[0], x[1]);
-            else sp_partial<SP_MODE_ONE>(S, p.r1, p.c1, 0u, 0.f, arowA, x[0], x[1]);
+            if (diff) { sp_partial<SP_MODE_ONE>(S, p.r1, p.c1, 0u, 0.f, arowA, x[0], x[1], nz); sp_partial<SP_MODE_ONE>(S, p.r2, p.c2, 0u, 0.f, arowB, x[2], x[3], nz); }
+            else if (p.type == 'D') sp_partial<SP_MODE_CH>(S, p.r1, p.c1, 0u, -1.f * m1, arowA, x[0], x[1], nz);
+            else if (two) sp_partial<SP_MODE_SAME>(S, p.r1, p.c1, p.c2, 0.f, arowA, x[0], x[1], nz);
+            else sp_partial<SP_MODE_ONE>(S, p.r1, p.c1, 0u, 0.f, arowA, x[0], x[1], nz);
+            if (nz) cg_atomic_add_u32(&nzShared, nz);
             for (int off = 1; off < 64; off <<= 1) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) x[c] = x[c] + cg_shfl_xor_f32(x[c], off);
@@ -184,18 +252,18 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S)
             if (scalarLane) {
                 // table terms (SparseNormalModel.cpp:160-161, 205-207, 256-258), then beta
                 if (diff) {
-                    const float sa = (S.Z1[p.c1] + tot[0]) * beta, ma = (-1.f * sp_dot(arowA, S.Z2 + (size_t)p.c1 * K, K) + tot[1]) * beta;
-                    const float sb = (S.Z1[p.c2] + tot[2]) * beta, mb = (-1.f * sp_dot(arowB, S.Z2 + (size_t)p.c2 * K, K) + tot[3]) * beta;
+                    const float sa = (S.Z1[p.c1] + tot[0]) * beta, ma = (-1.f * sp_dot(arowA, z2A, K) + tot[1]) * beta;
+                    const float sb = (S.Z1[p.c2] + tot[2]) * beta, mb = (-1.f * sp_dot(arowB, z2B, K) + tot[3]) * beta;
                     s = sa + sb; smu = ma - mb;                                    // AlphaParameters.cpp:11-14
                 } else if (two) {
-                    float s0 = S.Z1[p.c1] - 2.f * S.Z2[(size_t)p.c2 * K + p.c1] + S.Z1[p.c2];
+                    float s0 = S.Z1[p.c1] - 2.f * z2B[p.c1] + S.Z1[p.c2];
                     float d0 = 0.f;
-                    for (uint32_t k = 0; k < K; ++k) d0 += arowA[k] * (S.Z2[(size_t)p.c1 * K + k] - S.Z2[(size_t)p.c2 * K + k]);   // dot_diff, VectorMath.h:137-155
+                    for (uint32_t k = 0; k < K; ++k) d0 += arowA[k] * (z2A[k] - z2B[k]);   // dot_diff, VectorMath.h:137-155
                     float m0 = -1.f * d0;
                     s = (s0 + tot[0]) * beta; smu = (m0 + tot[1]) * beta;
                 } else {
-                    float m0 = -1.f * sp_dot(arowA, S.Z2 + (size_t)p.c1 * K, K);
-                    if (p.type == 'D') m0 -= (-1.f * m1) * S.Z2[(size_t)p.c1 * K + p.c1];
+                    float m0 = -1.f * sp_dot(arowA, z2A, K);
+                    if (p.type == 'D') m0 -= (-1.f * m1) * z2A[p.c1];
                     s = (S.Z1[p.c1] + tot[0]) * beta; smu = (m0 + tot[1]) * beta;
                 }
             }
@@ -245,12 +313,12 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S)
                 S.atoms[p.h1].mass = n1; S.atoms[p.h2].mass = n2;
             }
         }
-        (void)nz;
         if (writer) {
-            // roofline bookkeeping in bytes (sparse): flag words of the data vector and the column(s) per alpha
-            // call + the matrix row + a Z2 column; the per-non-zero gathers are data dependent and are not counted
+            // roofline bookkeeping in bytes (sparse): per alpha call the flag words of the data vector and of the
+            // column(s), this matrix row and a Z2 column; per common non-zero the data value, the column entry and a row of
+            // the other matrix.  (Every path above has passed a barrier since the lanes added their counts, or is one wave.)
             uint32_t bytes = 0;
-            if (need) bytes = (diff ? 2u : 1u) * (16u * S.Wn + 8u * K) + ((two && !diff) ? 8u * S.Wn : 0u);
+            if (need) bytes = (diff ? 2u : 1u) * (16u * S.Wn + 8u * K) + ((two && !diff) ? 8u * S.Wn : 0u) + nzShared * (8u + 4u * K);
             S.queueUnits[q] = bytes;
         }
         if (q + cg_gdim() >= qlen) break;
