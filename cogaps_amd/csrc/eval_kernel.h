@@ -257,7 +257,10 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices)
 #endif
         // ---------------------------------------------------------------- alpha parameters (DenseNormalModel.cpp:161-240)
         // which reduction the step needs: birth with Gibbs, death, move, exchange with canUseGibbs(c1,c2)
-        const bool need = (p.type == 'B') ? gibbs1 : ((p.type == 'D' || p.type == 'M') ? true : (gibbs1 || gibbs2));
+        bool need = (p.type == 'B') ? gibbs1 : ((p.type == 'D' || p.type == 'M') ? true : (gibbs1 || gibbs2));
+#if defined(GEN_PROFILE)
+        if (S.dbg & 16u) need = false;     // timing experiment: no reduction at all
+#endif
         const bool diff = two && p.r1 != p.r2;
         float s = 0.f, smu = 0.f;          // un-annealed sums, valid in wave 0
         if (need) {
@@ -290,6 +293,9 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices)
         EVAL_PIN(s); EVAL_TS(3);
         if (PHASE == EVAL_ALPHA) { if (q + qStep >= qlen) break; cg_sync(); continue; }
         s = s * T; smu = smu * T;
+#if defined(GEN_PROFILE)
+        if (S.dbg & 8u) { if (q + qStep >= qlen) break; cg_sync(); continue; }    // timing experiment: stop before the scalar step
+#endif
         if (p.type == 'B') {
             // ---------------------------------------------------------------- birth (:127-144)
             float bv = 0.f; uint32_t bhas = 0;

@@ -8,7 +8,7 @@ import ctypes
 PL = _capi.bind(ctypes.CDLL(os.path.join(os.path.dirname(_capi.LIB_PATH), 'libcogaps_hip_REPLAY_DEV.so')))
 warm = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 for which in 'AP':
-    for flags, name in [(0, 'full'), (2, 'no AP update'), (6, 'no row loads, no update'), (1, 'record+scalars only')]:
+    for flags, name in [(0, 'full'), (2, 'no AP update'), (6, 'no row loads, no update'), (14, '... and no scalar step'), (30, '... and no reduction'), (1, 'record only')]:
         S = _capi.Session(synthetic_dense(20000, 2000), lib=PL, nPatterns=50, nIterations=100, seed=42)
         S.run_iterations(1, 0, warm)
         us = S.debug_replay(which, 1, 200, flags)
