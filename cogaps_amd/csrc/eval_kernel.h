@@ -29,6 +29,18 @@ typedef float4 cg_f4;
 #endif
 
 CG_DEVICE cg_f4 ld4(const float *base, uint32_t j) { return reinterpret_cast<const cg_f4 *>(base)[j]; }
+// streaming read (data / uncertainty rows are used once per batch): keeps them from displacing the lookup tables,
+// the queue and the atom records in L2
+#if defined(COGAPS_EMUL)
+CG_DEVICE cg_f4 ld4_stream(const float *base, uint32_t j) { return ld4(base, j); }
+#else
+typedef float cg_v4f __attribute__((ext_vector_type(4)));
+CG_DEVICE cg_f4 ld4_stream(const float *base, uint32_t j)
+{
+    const cg_v4f v = __builtin_nontemporal_load(reinterpret_cast<const cg_v4f *>(base) + j);
+    cg_f4 o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w; return o;
+}
+#endif
 CG_DEVICE void st4(float *base, uint32_t j, cg_f4 v) { reinterpret_cast<cg_f4 *>(base)[j] = v; }
 CG_DEVICE cg_f4 f4_zero() { cg_f4 z; z.x = 0.f; z.y = 0.f; z.z = 0.f; z.w = 0.f; return z; }
 CG_DEVICE cg_f4 f4_one() { cg_f4 z; z.x = 1.f; z.y = 1.f; z.z = 1.f; z.w = 1.f; return z; }
@@ -114,7 +126,7 @@ CG_DEVICE void eval_alpha(const SamplerDev &S, const uint32_t (&row)[NR], const 
         for (int r = 0; r < NR; ++r) {
             const float *Dr = S.D + (size_t)row[r] * S.Npad, *Sr = S.S2 + (size_t)row[r] * S.Npad, *Ar = S.AP + (size_t)row[r] * S.Npad;
             const float *Vr = S.other + (size_t)col[r] * S.Npad, *V2 = S.other + (size_t)col2 * S.Npad;
-            v[r] = ld4(Vr, j); d[r] = ld4(Dr, j); s[r] = ld4(Sr, j); p[r] = ld4(Ar, j); if (MODE == EVAL_MODE_SAME) w2 = ld4(V2, j);
+            v[r] = ld4(Vr, j); d[r] = ld4_stream(Dr, j); s[r] = ld4_stream(Sr, j); p[r] = ld4(Ar, j); if (MODE == EVAL_MODE_SAME) w2 = ld4(V2, j);
         }
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
