@@ -403,4 +403,4 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices)
 
 // the split kernels are built for two resident 1024-thread workgroups per compute unit (<= 64 VGPRs)
 template <int PHASE>
-CG_KERNEL void CG_LAUNCH_BOUNDS2(1024, (PHASE == EVAL_FUSED ? 4 : 8)) eval_kernel(SamplerDev S, uint32_t slices) { eval_body<PHASE>(S, slices); }
+CG_KERNEL void CG_LAUNCH_BOUNDS2(1024, (PHASE == EVAL_FUSED ? 4 : 8)) eval_kernel(SamplerDev S, uint32_t slices) { cg_kernarg_warm<sizeof(SamplerDev) + 4>(); eval_body<PHASE>(S, slices); }

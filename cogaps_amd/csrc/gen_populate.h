@@ -687,4 +687,4 @@ CG_DEVICE void gen_body(const SamplerDev &S)
 }
 
 template <int WIN>
-CG_KERNEL void CG_LAUNCH_BOUNDS(WIN) gen_kernel(SamplerDev S) { gen_body<WIN>(S); }
+CG_KERNEL void CG_LAUNCH_BOUNDS(WIN) gen_kernel(SamplerDev S) { cg_kernarg_warm<sizeof(SamplerDev)>(); gen_body<WIN>(S); }

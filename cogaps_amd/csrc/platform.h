@@ -30,6 +30,28 @@ CG_DEVICE void cg_sync() { __syncthreads(); }
 // (__syncthreads waits for vmcnt(0) as well).  Only where the lanes exchange nothing through global memory.
 CG_DEVICE void cg_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Pull the whole kernel-argument segment into the scalar cache with one memory trip.  The scalar cache is
+// cold at kernel entry and the compiler loads the fields of a by-value argument struct where they are first
+// used: without this a kernel that walks through a 500-byte struct pays one full-latency miss per 64-byte line,
+// one after the other.
+template <int BYTES>
+CG_DEVICE void cg_kernarg_warm()
+{
+    static_assert(BYTES <= 640, "extend the line list");
+    const auto p = __builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t d0, d1, d2, d3, d4, d5, d6, d7, d8, d9;
+    constexpr int L = BYTES - 4;      // last dword of the explicit arguments
+#define CG_KA_OFF(i) ((i) * 64 < L ? (i) * 64 : L)
+    asm volatile("s_load_dword %0, %10, %11\n\ts_load_dword %1, %10, %12\n\ts_load_dword %2, %10, %13\n\ts_load_dword %3, %10, %14\n\t"
+                 "s_load_dword %4, %10, %15\n\ts_load_dword %5, %10, %16\n\ts_load_dword %6, %10, %17\n\ts_load_dword %7, %10, %18\n\t"
+                 "s_load_dword %8, %10, %19\n\ts_load_dword %9, %10, %20\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6), "=&s"(d7), "=&s"(d8), "=&s"(d9)
+                 : "s"(p), "n"(CG_KA_OFF(0)), "n"(CG_KA_OFF(1)), "n"(CG_KA_OFF(2)), "n"(CG_KA_OFF(3)), "n"(CG_KA_OFF(4)), "n"(CG_KA_OFF(5)),
+                   "n"(CG_KA_OFF(6)), "n"(CG_KA_OFF(7)), "n"(CG_KA_OFF(8)), "n"(CG_KA_OFF(9))
+                 : "memory");
+#undef CG_KA_OFF
+}
+
 // global-memory atomics (device scope)
 CG_DEVICE uint32_t cg_atomic_add_u32(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 CG_DEVICE uint32_t cg_atomic_sub_u32(uint32_t *p, uint32_t v) { return atomicSub(p, v); }

@@ -325,7 +325,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S)
         cg_sync();
     }
 }
-CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_kernel(SamplerDev S) { eval_sparse_body(S); }
+CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_kernel(SamplerDev S) { cg_kernarg_warm<sizeof(SamplerDev)>(); eval_sparse_body(S); }
 
 // SparseNormalModel::generateLookupTables (SparseNormalModel.cpp:294-311): Z1[i] = sum_k other(k,i)^2 through the
 // other matrix's ROW copy, Z2(i,j) = dot of its column copies.  One workgroup per (i, j >= i) pair plus one per i;

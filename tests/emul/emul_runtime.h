@@ -29,6 +29,7 @@ inline unsigned cg_bdim() { return cgemu::g_lane.bdim; }
 inline unsigned cg_gdim() { return cgemu::g_lane.gdim; }
 inline void cg_sync() { cgemu::block_barrier(); }
 inline void cg_sync_lds() { cg_sync(); }
+template <int BYTES> inline void cg_kernarg_warm() {}
 
 // fibers only switch at barriers / wave exchanges, so plain read-modify-write is atomic here
 inline uint32_t cg_atomic_add_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
