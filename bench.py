@@ -72,6 +72,48 @@ def cpu_baseline(data, params, budget_s):
     return best
 
 
+def chains_main(args):
+    """--chains C (informational): C shards of the headline shape in flight on this GPU (distributed._run_shards)."""
+    import threading
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    from cogaps_amd import _capi
+    K, W, C = args.steps, args.warmup, args.chains
+    n_iter = (W + K + 1) // 2
+    params = dict(nPatterns=args.patterns, nIterations=n_iter, seed=42, outputFrequency=max(1, n_iter // 10))
+    S = [_capi.Session(synthetic_dense(args.genes, args.samples, seed=12345 + c), device=0, **params) for c in range(C)]
+    upd = [0] * C
+
+    def steps(c, first, n):
+        done = 0
+        while done < n:
+            it = first + done
+            m = min(n - done, n_iter - it) if it < n_iter else n - done
+            upd[c] += S[c].run_iterations(1 if it < n_iter else 2, it if it < n_iter else it - n_iter, m)
+            done += m
+
+    def phase(first, n):
+        th = [threading.Thread(target=steps, args=(c, first, n)) for c in range(C)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return time.perf_counter() - t0
+    phase(0, W)
+    upd = [0] * C
+    torch.cuda.synchronize()
+    dt = phase(W, K)
+    print(json.dumps({"metric": METRIC + " [informational: %d chains in flight on one GPU]" % C, "value": sum(upd) / dt, "unit": "proposals/s",
+                      "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak",
+                      "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": "%d independent synthetic dense %dx%d shards in flight on one GPU, nPatterns=%d" % (C, args.genes, args.samples, args.patterns),
+                                 "per_chain": [u / dt for u in upd]}}))
+    for s in S:
+        s.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,7 +127,12 @@ def main():
     ap.add_argument("--sparse", action="store_true",
                     help="not the headline: the SparseNormalModel on the same product with 95 %% of the entries zeroed (BASELINE configs[4] "
                          "uses --genes 50000 --samples 12500 per GPU)")
+    ap.add_argument("--chains", type=int, default=1,
+                    help="not the headline: that many independent chains (shards of the same shape) in flight per GPU, one host thread "
+                         "and one stream each, as distributed.py runs a rank's shards; value = aggregate proposals/s")
     args = ap.parse_args()
+    if args.chains > 1:
+        return chains_main(args)
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))

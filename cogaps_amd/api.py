@@ -53,7 +53,11 @@ def CoGAPS(data, params=None, nPatterns=None, nThreads=1, messages=True, outputF
         raise ValueError("asynchronousUpdates=FALSE selects the reference's sequential sampler; this library is the asynchronous one")
     if params.distributed is not None:
         from .distributed import distributedCogaps
-        raw = distributedCogaps(data, params, unc, messages=messages, outputFrequency=outputFrequency, transposeData=transposeData, device=device)
+        # BPPARAM: the reference hands the subsets to that many BiocParallel workers (R/DistributedCogaps.R:60-63); here: shards in
+        # flight per GPU (an int, or an object with a `workers` attribute; default 2)
+        in_flight = 2 if BPPARAM is None else int(getattr(BPPARAM, "workers", BPPARAM))
+        raw = distributedCogaps(data, params, unc, messages=messages, outputFrequency=outputFrequency, transposeData=transposeData, device=device,
+                                shardsInFlight=in_flight)
     else:
         raw = _capi.run(data, unc=unc, nPatterns=params.nPatterns, nIterations=params.nIterations, seed=params.seed,
                         outputFrequency=outputFrequency, nThreads=nThreads, alphaA=params.alphaA, alphaP=params.alphaP,

@@ -45,9 +45,24 @@ inline const char *rt_platform_name() { return "emulator (test only)"; }
 
 #define RT_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 typedef hipStream_t rt_stream_t;
-// zero-filled device memory.  hipMemset runs on the null stream, which the library's non-blocking stream does not wait
-// for: without the synchronisation an upload enqueued right after the allocation could be overtaken by the fill.
-inline void *rt_malloc(size_t n) { void *p = nullptr; RT_CHECK(hipMalloc(&p, n ? n : 1)); RT_CHECK(hipMemset(p, 0, n ? n : 1)); RT_CHECK(hipStreamSynchronize(nullptr)); return p; }
+// zero-filled device memory.  The fill runs on a private non-blocking stream of the calling thread and is waited for:
+// the legacy null stream is never used (sessions on other host threads may be capturing a graph, which makes any
+// legacy-stream operation fail), and an upload enqueued right after the allocation cannot be overtaken by the fill.
+inline hipStream_t rt_fill_stream()
+{
+    static thread_local hipStream_t fill[64] = {};
+    int dev = 0; RT_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) throw std::runtime_error("device ordinal out of range");
+    if (!fill[dev]) RT_CHECK(hipStreamCreateWithFlags(&fill[dev], hipStreamNonBlocking));
+    return fill[dev];
+}
+inline void *rt_malloc(size_t n)
+{
+    void *p = nullptr; RT_CHECK(hipMalloc(&p, n ? n : 1));
+    hipStream_t f = rt_fill_stream();
+    RT_CHECK(hipMemsetAsync(p, 0, n ? n : 1, f)); RT_CHECK(hipStreamSynchronize(f));
+    return p;
+}
 inline void rt_free(void *p) { if (p) (void)hipFree(p); }
 inline void *rt_malloc_host(size_t n) { void *p = nullptr; RT_CHECK(hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault)); return p; }
 inline void rt_free_host(void *p) { if (p) (void)hipHostFree(p); }

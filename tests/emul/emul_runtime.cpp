@@ -6,6 +6,7 @@
 #include <string.h>
 #include <sys/mman.h>
 #include <vector>
+#include <mutex>
 
 extern "C" void cgemu_ctx_switch(void **from_sp, void **to_sp);
 asm(R"(
@@ -156,6 +157,9 @@ static void run_block(unsigned bid, unsigned bdim, unsigned gdim, const std::fun
 
 void launch(unsigned grid, unsigned block, const std::function<void()> &body)
 {
+    // one emulated device: sessions driven from several host threads (shards in flight) take turns
+    static std::mutex device;
+    std::lock_guard<std::mutex> hold(device);
     for (unsigned b = 0; b < grid; ++b) run_block(b, block, grid, body);
 }
 

@@ -140,3 +140,29 @@ def test_headline_size_invariants(hip_lib):
     for a, b in zip(runs[0][:2], runs[1][:2]):
         assert np.array_equal(a, b)
     assert runs[0][3:] == runs[1][3:] and np.array_equal(runs[0][2]["pos"], runs[1][2]["pos"])
+
+
+def test_sessions_in_flight_on_one_gpu(hip_lib, gist):
+    """shards in flight (distributed.py): four sessions driven from four host threads on their own streams give the
+    bits of the same runs made one after the other (graph capture, reallocation of the atom tables and the timing
+    events of one session must not disturb another)"""
+    import threading
+    from cogaps_amd import _capi
+    kw = [dict(nPatterns=3 + c, nIterations=60, seed=7 + c, outputFrequency=20) for c in range(4)]
+    alone = [_capi.run(gist, **k) for k in kw]
+    together, errors = [None] * 4, []
+
+    def work(c):
+        try:
+            together[c] = _capi.run(gist, **kw[c])
+        except Exception as e:       # noqa: BLE001 -- reported below
+            errors.append(repr(e))
+    th = [threading.Thread(target=work, args=(c,)) for c in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    for a, b in zip(alone, together):
+        for k in ("Amean", "Pmean", "Asd", "Psd", "atomsA", "atomsP", "chisq", "totalUpdates"):
+            assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
