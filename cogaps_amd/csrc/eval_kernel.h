@@ -90,7 +90,7 @@ CG_DEVICE void eval_vfinish(const float *lds, float (&tot)[NC])
         float z = y[0];
         for (int off = 1; off < V; off <<= 1) z = z + cg_shfl_xor_f32(z, off);     // lanes c*V .. c*V+V-1: the V slots of component c
 #pragma unroll
-        for (int c = 0; c < NC; ++c) tot[c] = cg_shfl_f32(z, c * V);
+        for (int c = 0; c < NC; ++c) tot[c] = cg_lane_read_f32(z, c * V);
     }
 }
 
@@ -98,7 +98,7 @@ CG_DEVICE void eval_vfinish(const float *lds, float (&tot)[NC])
 template <int V>
 CG_DEVICE void eval_vpark(float x, int j, float *lds, float (&tot)[1])
 {
-    for (int off = 1; off < 64; off <<= 1) x = x + cg_shfl_xor_f32(x, off);
+    x = cg_wave_allsum_f32(x);
     const uint32_t t = cg_tid();
     if (cg_bdim() > 64u) { if ((t & 63u) == 0) lds[(t >> 6) * V + j] = x; }
     else tot[0] = x;
@@ -143,10 +143,8 @@ CG_DEVICE void eval_alpha(const SamplerDev &S, const uint32_t (&row)[NR], const 
     }
     { float z_ = ps[0]; EVAL_PIN(z_); ps[0] = z_; } EVAL_TS(10);
     // bits 0-5 of the lane index: the wave butterfly
-    for (int off = 1; off < 64; off <<= 1) {
 #pragma unroll
-        for (int r = 0; r < NR; ++r) { ps[r] = ps[r] + cg_shfl_xor_f32(ps[r], off); pm[r] = pm[r] + cg_shfl_xor_f32(pm[r], off); }
-    }
+    for (int r = 0; r < NR; ++r) { ps[r] = cg_wave_allsum_f32(ps[r]); pm[r] = cg_wave_allsum_f32(pm[r]); }
     if (nw > 1) {
         if ((t & 63u) == 0) {
 #pragma unroll
@@ -242,6 +240,14 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices)
     unsigned long long eprof_last = cg_clock(); (void)eprof_last;
     const float lambda = S.lambda;
     EVAL_TS(0);
+    if (PHASE == EVAL_APPLY) {
+        // (every slice workgroup of the split form repeats the scalar step.)  The scalar step makes two dependent lookups in the normal-distribution tables (12 + 20 KB).  After a kernel
+        // boundary they come from the Infinity Cache; touching every 128-byte line now, under the record's trip,
+        // leaves them in this XCD's L2 by the time the step needs them.
+        float touch = 0.f;
+        for (uint32_t i = t; i < 94u + 157u; i += BS) touch += (i < 94u) ? S.luts.erf[i * 32u] : S.luts.erfinv[(i - 94u) * 32u];
+        cg_keep_f32(touch);
+    }
     const bool multiWave = BS > 64u;
     const bool scalarLane = !multiWave || t < 64u;       // the per-proposal scalar math (LUTs, fp64 log) runs in wave 0 only
     const uint32_t slice = (PHASE == EVAL_FUSED) ? 0u : cg_bid() % slices;
@@ -297,7 +303,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices)
                     const uint32_t slots = S.redW / BS;
                     float z = ((t & 15u) < slices) ? S.partials[(size_t)q * 64u + t] : 0.f;
                     for (uint32_t st = 1; st < slots; st <<= 1) z = z + cg_shfl_xor_f32(z, (int)st);
-                    tot[0] = cg_shfl_f32(z, 0); tot[1] = cg_shfl_f32(z, 16); tot[2] = cg_shfl_f32(z, 32); tot[3] = cg_shfl_f32(z, 48);
+                    tot[0] = cg_lane_read_f32(z, 0); tot[1] = cg_lane_read_f32(z, 16); tot[2] = cg_lane_read_f32(z, 32); tot[3] = cg_lane_read_f32(z, 48);
                 }
             }
             s = diff ? tot[0] + tot[2] : tot[0]; smu = diff ? tot[1] - tot[3] : tot[1];        // AlphaParameters.cpp:11-14

@@ -173,34 +173,24 @@ CG_HD float gm_max(float a, float b) { return a < b ? b : a; }   // Math.cpp:28-
 CG_HD float pcg_exponential(uint64_t &s, float lambda) { return -1.f * gm_logf(pcg_uniform(s)) / lambda; }
 
 // Random.cpp:307-326
+// (selects instead of branches: the two table reads of a truncated normal's bounds then travel together)
 CG_HD float gm_p_norm_fast(const GapsLuts &L, float p, float mean, float sd)
 {
-    float term = (p - mean) / (sd * GAPS_SQRT2F);
-    float erf_ = 0.f;
-    if (term < 0.f) {
-        term = gm_max(term, -3.f);
-        const unsigned ndx = (unsigned)(-term * 1000.f);
-        erf_ = -L.erf[ndx];
-    } else {
-        term = gm_min(term, 3.f);
-        const unsigned ndx = (unsigned)(term * 1000.f);
-        erf_ = L.erf[ndx];
-    }
-    return 0.5f * (1.f + erf_);
+    const float term = (p - mean) / (sd * GAPS_SQRT2F);
+    const bool neg = term < 0.f;
+    const float mag = neg ? -gm_max(term, -3.f) : gm_min(term, 3.f);
+    const unsigned ndx = (unsigned)(mag * 1000.f);
+    const float e = L.erf[ndx];
+    return 0.5f * (1.f + (neg ? -e : e));
 }
 // Random.cpp:328-345
 CG_HD float gm_q_norm_fast(const GapsLuts &L, float q, float mean, float sd)
 {
-    float term = 2.f * q - 1.f;
-    float erfinv_ = 0.f;
-    if (term < 0.f) {
-        const unsigned ndx = (unsigned)(-term * (float)(GAPS_ERFINV_N - 1));
-        erfinv_ = -L.erfinv[ndx];
-    } else {
-        const unsigned ndx = (unsigned)(term * (float)(GAPS_ERFINV_N - 1));
-        erfinv_ = L.erfinv[ndx];
-    }
-    return mean + sd * GAPS_SQRT2F * erfinv_;
+    const float term = 2.f * q - 1.f;
+    const bool neg = term < 0.f;
+    const unsigned ndx = (unsigned)((neg ? -term : term) * (float)(GAPS_ERFINV_N - 1));
+    const float e = L.erfinv[ndx];
+    return mean + sd * GAPS_SQRT2F * (neg ? -e : e);
 }
 
 struct OptF { float v; bool has; };

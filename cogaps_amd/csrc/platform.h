@@ -52,6 +52,9 @@ CG_DEVICE void cg_kernarg_warm()
 #undef CG_KA_OFF
 }
 
+// keeps a loaded value (and so the load) alive without using it
+CG_DEVICE void cg_keep_f32(float x) { asm volatile("" :: "v"(x)); }
+
 // global-memory atomics (device scope)
 CG_DEVICE uint32_t cg_atomic_add_u32(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 CG_DEVICE uint32_t cg_atomic_sub_u32(uint32_t *p, uint32_t v) { return atomicSub(p, v); }
@@ -70,6 +73,26 @@ CG_DEVICE int cg_popc64(unsigned long long x) { return __popcll(x); }
 CG_DEVICE unsigned long long cg_load_l2_u64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 CG_DEVICE float cg_shfl_xor_f32(float v, int mask) { return __shfl_xor(v, mask, 64); }
 CG_DEVICE float cg_shfl_f32(float v, int lane) { return __shfl(v, lane, 64); }
+// the value lane `lane` holds (lane: the same in every lane of the wave) -- a lane read instead of an LDS-crossbar permute
+CG_DEVICE float cg_lane_read_f32(float v, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane)); }
+// Sum over the 64 lanes in the order of the ascending xor butterfly (x += x[lane ^ 1], ^ 2, ... ^ 32), the same
+// bits in every lane.  After the level-1 and level-2 steps the four lanes of a quad hold one value, so the partner
+// of the ^4 (^8) step may be any lane of the other quad (other half row): DPP row_half_mirror / row_mirror instead
+// of two more LDS-crossbar permutes (~100 cycles each against a VALU op); the rows' sums are then combined from
+// four lane reads as (r0 + r1) + (r2 + r3), which is what the ^16 and ^32 steps compute.  a + b == b + a bitwise.
+CG_DEVICE float cg_wave_allsum_f32(float x)
+{
+#define CG_DPP_ADD(ctrl) x = x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), (ctrl), 0xF, 0xF, false))
+    CG_DPP_ADD(0xB1);      // quad_perm [1,0,3,2]
+    CG_DPP_ADD(0x4E);      // quad_perm [2,3,0,1]
+    CG_DPP_ADD(0x141);     // row_half_mirror
+    CG_DPP_ADD(0x140);     // row_mirror
+#undef CG_DPP_ADD
+    const int xi = __builtin_bit_cast(int, x);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 48));
+    return (r0 + r1) + (r2 + r3);
+}
 CG_DEVICE unsigned long long cg_clock() { return __builtin_readcyclecounter(); }
 CG_DEVICE int cg_clz64(unsigned long long x) { return __clzll((long long)x); }
 CG_DEVICE int cg_ctz64(unsigned long long x) { return __ffsll((long long)x) - 1; }

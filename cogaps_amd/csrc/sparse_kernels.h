@@ -239,10 +239,8 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S)
             else if (two) sp_partial<SP_MODE_SAME>(S, p.r1, p.c1, p.c2, 0.f, arowA, x[0], x[1], nz);
             else sp_partial<SP_MODE_ONE>(S, p.r1, p.c1, 0u, 0.f, arowA, x[0], x[1], nz);
             if (nz) cg_atomic_add_u32(&nzShared, nz);
-            for (int off = 1; off < 64; off <<= 1) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) x[c] = x[c] + cg_shfl_xor_f32(x[c], off);
-            }
+            for (int c = 0; c < 4; ++c) x[c] = cg_wave_allsum_f32(x[c]);
             float tot[4] = {x[0], x[1], x[2], x[3]};
             if (multiWave) {
                 if ((t & 63u) == 0) { for (int c = 0; c < 4; ++c) lds[(t >> 6) * 4 + c] = x[c]; }

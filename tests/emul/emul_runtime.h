@@ -30,6 +30,7 @@ inline unsigned cg_gdim() { return cgemu::g_lane.gdim; }
 inline void cg_sync() { cgemu::block_barrier(); }
 inline void cg_sync_lds() { cg_sync(); }
 template <int BYTES> inline void cg_kernarg_warm() {}
+inline void cg_keep_f32(float) {}
 
 // fibers only switch at barriers / wave exchanges, so plain read-modify-write is atomic here
 inline uint32_t cg_atomic_add_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
@@ -46,7 +47,9 @@ inline unsigned long long cg_ballot(bool p) { return cgemu::wave_ballot(p); }
 inline int cg_popc64(unsigned long long x) { return __builtin_popcountll(x); }
 inline unsigned long long cg_load_l2_u64(const unsigned long long *p) { return *p; }
 inline float cg_shfl_xor_f32(float v, int mask) { return cgemu::wave_exchange_f32(v, mask); }
+inline float cg_wave_allsum_f32(float x) { for (int off = 1; off < 64; off <<= 1) x = x + cgemu::wave_exchange_f32(x, off); return x; }
 inline float cg_shfl_f32(float v, int lane) { return cgemu::wave_read_f32(v, lane); }
+inline float cg_lane_read_f32(float v, int lane) { return cgemu::wave_read_f32(v, lane); }
 inline unsigned long long cg_clock() { return 0; }
 inline int cg_clz64(unsigned long long x) { return x ? __builtin_clzll(x) : 64; }
 inline int cg_ctz64(unsigned long long x) { return x ? __builtin_ctzll(x) : -1; }
