@@ -223,6 +223,17 @@ def main():
         ev_ms = sum(kt[w]["eval_us"] * kt[w]["batches"] for w in "AP") / 1e3
         other = "P" if roof == "A" else "A"
         ok = kt[other]
+        # HBM bytes per launch of the roofline kernel from the PMC counters: collected in two separate rocprofv3 --pmc passes
+        # (FETCH_SIZE, WRITE_SIZE; tools/pmc_pass.sh) over this same command and committed under profiles/ -- a bench run cannot
+        # collect them itself.  Only quoted for the workload they were measured on.
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if (not args.sparse and roof == "A" and (args.genes, args.samples, args.patterns, K, W) == (20000, 2000, 50, 190, 10) and os.path.exists(pmc)):
+            k0 = json.load(open(pmc))["kernels"].get("eval_kernel<0>")
+            if k0:
+                traffic = k0["hbm_bytes_per_launch"]
+                traffic_src = ("profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + --pmc WRITE_SIZE, separate passes over "
+                               "this command, mean over the %d launches of the timed region that moved data" % k0["launches"])
         out = {
             "metric": METRIC, "value": tot_updates / max_dt, "unit": "proposals/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * max_dt / K,
@@ -237,7 +248,7 @@ def main():
                        "gen_kernel_ms_rank0": gen_ms, "eval_kernel_ms_rank0": ev_ms,
                        "launches_per_batch": (kt["A"]["launches"] + kt["P"]["launches"]) / max(1, batches)},
             "roofline": {"bound": "hbm", "kernel": ("eval_sparse_kernel (sampler %s)" if args.sparse else "eval_kernel<EVAL_FUSED> (sampler %s)") % roof, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_launch": rk["bytes"] / max(1, rk["batches"]), "avg_launch_us": rk["eval_us"],
                          "empty_queue_launch_us": rk["eval_empty_us"], "launches": int(rk["batches"]),
                          "note": "one launch = one batch of sampler %s" % roof,

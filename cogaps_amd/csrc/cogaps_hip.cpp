@@ -171,6 +171,7 @@ struct cogaps_session {
     std::vector<float> chisqHist; std::vector<uint32_t> atomHistA, atomHistP;
     uint64_t totalUpdates = 0; double samplerSeconds = 0; double syncMs = 0;
     bool timing = false; bool evInit = false;
+    bool noGraph = getenv("COGAPS_NO_GRAPH") != nullptr;     // diagnostics: every launch as a plain call (counter collection tools)
     std::vector<rt_event_pair> evPool; std::vector<int> evKind; std::vector<HostSampler *> evOwner; std::vector<uint64_t> evOrd; size_t evUsed = 0;
     GenScalars *hGs = nullptr;    // pinned staging
 };
@@ -429,7 +430,7 @@ static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool t
         if (chunk > 4096u) chunk = 4096u;
         firstChunk = false;
         uint32_t plain = chunk;
-        if (rt_graphs_supported() && !trace && plain >= GRAPH_PAIRS) {
+        if (rt_graphs_supported() && !s->noGraph && !trace && plain >= GRAPH_PAIRS) {
             ensure_graph(s, h);
             for (; plain >= GRAPH_PAIRS; plain -= GRAPH_PAIRS) { rt_graph_launch(h.graph, s->stream); h.genLaunches += GRAPH_PAIRS; h.evalLaunches += GRAPH_PAIRS; h.updLaunches += GRAPH_PAIRS; }
         }

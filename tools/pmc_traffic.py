@@ -1,0 +1,41 @@
+"""Per-launch HBM traffic of the evaluation kernels from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate
+passes: the TCC block cannot hold both) over `python bench.py --no-cpu` with COGAPS_NO_GRAPH=1 (counter collection
+hangs on replayed graphs).  For each kernel: the launches of the timed region = the last `launches` dispatches that
+moved data (empty-queue launches, FETCH < 64 KB, are left out as bench.py leaves them out).  FETCH_SIZE is doubled
+(gfx950 tallies the 128-byte requests of 16 B/lane coalesced reads at 64 B: MI355X_MICROARCH.md, HBM section);
+WRITE_SIZE is reported as the tool gives it (uncalibrated).  usage: pmc_traffic.py <fetch_dir> <write_dir> <bench_json> <out_json>"""
+import csv, glob, json, sys, collections
+
+
+def per_kernel(d, counter):
+    rows = collections.defaultdict(list)
+    for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r['Counter_Name'] == counter:
+                rows[r['Kernel_Name'].split('(')[0]].append((int(r['Dispatch_Id']), float(r['Counter_Value'])))
+    for v in rows.values():
+        v.sort()
+    return rows
+
+
+fetch, write = per_kernel(sys.argv[1], 'FETCH_SIZE'), per_kernel(sys.argv[2], 'WRITE_SIZE')
+bench = json.load(open(sys.argv[3]))
+want = {'eval_kernel<0>': bench['roofline']['launches'], 'eval_kernel<1>': bench['roofline']['other_sampler']['batches'],
+        'eval_kernel<2>': bench['roofline']['other_sampler']['batches'], 'gen_kernel<256>': None}
+out = {}
+for name, n in want.items():
+    fk = [k for k in fetch if name in k]; wk = [k for k in write if name in k]
+    if not fk or not wk:
+        continue
+    f, w = fetch[fk[0]], write[wk[0]]
+    n = n or len(f)
+    # the same dispatches in both passes (deterministic run): select on the fetch pass, by position
+    idx = [i for i, (_, v) in enumerate(f) if v >= 64.0 or name.startswith('gen')][-n:]
+    fb = sum(f[i][1] for i in idx) / len(idx) * 1024.0 * 2.0
+    wb = sum(w[i][1] for i in idx if i < len(w)) / len(idx) * 1024.0
+    out[name] = {'launches': len(idx), 'fetch_bytes_per_launch_corrected_x2': fb, 'write_bytes_per_launch': wb, 'hbm_bytes_per_launch': fb + wb,
+                 'all_launches_in_run': len(f)}
+    print(name, out[name])
+json.dump({'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) -- COGAPS_NO_GRAPH=1 python bench.py --no-cpu', 'kernels': out,
+           'bench_algorithmic_bytes_per_launch': {'eval_kernel<0>': bench['roofline']['bytes_per_launch'], 'eval_kernel<1>+<2>': bench['roofline']['other_sampler']['bytes_per_batch']}},
+          open(sys.argv[4], 'w'), indent=1)
