@@ -12,7 +12,11 @@
  * Plain pointers and sizes only; the callee copies its inputs; results are callee-allocated and
  * released with cogaps_result_free.  All functions return 0 on success and a non-zero code plus a
  * message (cogaps_last_error) on failure; nothing calls exit() (reference: utils/GapsAssert.h:19-25).
- * One host thread drives one GPU; the library keeps no global mutable state besides the last error.
+ * Threading: a session (or a cogaps_run call) is driven by one host thread at a time; different sessions may run
+ * concurrently from different host threads, on the same GPU or on different ones (each owns a non-blocking
+ * stream; no legacy-stream operation is issued; graph capture is thread-local).  The library keeps no global
+ * mutable state besides the per-thread last error.  Environment: COGAPS_NO_GRAPH (any value) sends every
+ * kernel as a plain launch instead of replaying captured graphs -- for counter-collection tools only.
  */
 #ifndef COGAPS_HIP_H
 #define COGAPS_HIP_H
