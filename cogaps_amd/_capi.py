@@ -75,6 +75,7 @@ EXPORTS = [
     "cogaps_session_get_atoms", "cogaps_session_dims", "cogaps_session_avg_queue",
     "cogaps_session_finish", "cogaps_session_set_timing", "cogaps_session_perf",
     "cogaps_session_perf_sampler", "cogaps_session_get_rows", "cogaps_sparse_width", "cogaps_reduction_width", "cogaps_session_debug_prof", "cogaps_session_debug_replay",
+    "cogaps_run_from_file", "cogaps_read_matrix_file", "cogaps_matrix_free", "cogaps_file_info",
 ]
 
 
@@ -116,6 +117,11 @@ def bind(L):
     L.cogaps_sparse_width.argtypes = [C.c_uint32]
     L.cogaps_session_get_rows.argtypes = [vp, C.c_char, fp]
     L.cogaps_reduction_width.argtypes = [C.c_uint32]
+    L.cogaps_run_from_file.argtypes = [C.c_char_p, C.POINTER(CogapsParamsC), C.c_char_p, C.POINTER(CogapsResultC)]
+    L.cogaps_read_matrix_file.argtypes = [C.c_char_p, u32p, u32p, C.POINTER(fp)]
+    L.cogaps_matrix_free.argtypes = [fp]
+    L.cogaps_matrix_free.restype = None
+    L.cogaps_file_info.argtypes = [C.c_char_p, u32p, u32p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     return L
 
 
@@ -346,6 +352,41 @@ class Session:
         r = CogapsResultC()
         self._ck(self.L.cogaps_session_finish(self.h, C.byref(r)))
         return result_to_dict(self.L, r)
+
+
+def read_matrix_file(path, lib=None):
+    """The library's own reader (csrc/file_reader.h): the file as a dense fp32 matrix.  Host only."""
+    L = lib or load()
+    nr, nc, ptr = C.c_uint32(), C.c_uint32(), C.POINTER(C.c_float)()
+    if L.cogaps_read_matrix_file(os.fsencode(path), C.byref(nr), C.byref(nc), C.byref(ptr)):
+        raise RuntimeError(L.cogaps_last_error().decode())
+    try:
+        return np.ctypeslib.as_array(ptr, shape=(nr.value, nc.value)).copy() if nr.value * nc.value else np.zeros((nr.value, nc.value), np.float32)
+    finally:
+        L.cogaps_matrix_free(ptr)
+
+
+def file_info(path, lib=None):
+    """getFileInfo_cpp: (nrow, ncol, rowNames, colNames)"""
+    L = lib or load()
+    nr, nc, rn, cn = C.c_uint32(), C.c_uint32(), C.c_size_t(), C.c_size_t()
+    if L.cogaps_file_info(os.fsencode(path), C.byref(nr), C.byref(nc), None, 0, C.byref(rn), None, 0, C.byref(cn)):
+        raise RuntimeError(L.cogaps_last_error().decode())
+    rb, cb = C.create_string_buffer(rn.value), C.create_string_buffer(cn.value)
+    if L.cogaps_file_info(os.fsencode(path), C.byref(nr), C.byref(nc), rb, rn.value, None, cb, cn.value, None):
+        raise RuntimeError(L.cogaps_last_error().decode())
+    names = lambda b: b.value.decode().split("\n") if b.value else []
+    return nr.value, nc.value, names(rb), names(cb)
+
+
+def run_from_file(path, unc_path=None, lib=None, **kw):
+    """cogaps_run_from_file: the reference's file entry point, parsed natively."""
+    L = lib if lib is not None else load()
+    params = make_params(L, **kw)
+    res = CogapsResultC()
+    if L.cogaps_run_from_file(os.fsencode(path), C.byref(params), os.fsencode(unc_path) if unc_path else None, C.byref(res)):
+        raise RuntimeError("cogaps_run_from_file: " + L.cogaps_last_error().decode())
+    return result_to_dict(L, res)
 
 
 def run(data, unc=None, lib=None, **kw):

@@ -9,6 +9,7 @@
 #include "rt.h"
 #include "gaps_state.h"
 #include "gen_kernel.h"
+#include "file_reader.h"
 #include "eval_kernel.h"
 #include "aux_kernels.h"
 #include "sparse_kernels.h"
@@ -881,6 +882,55 @@ int cogaps_run(const float *data, uint32_t nrow, uint32_t ncol, const cogaps_par
     if (!rc) rc = cogaps_session_finish(s, out);
     cogaps_session_destroy(s);
     return rc;
+}
+
+// ---- the file entry point (gaps::run(const std::string&...), GapsRunner.h:24-29; cogaps_from_file_cpp, Cogaps.cpp:217-227) ----
+int cogaps_read_matrix_file(const char *path, uint32_t *nrow, uint32_t *ncol, float **data)
+{
+    try {
+        if (!path || !nrow || !ncol || !data) return fail("null argument");
+        cgio::Table t = cgio::read_matrix_file(path);
+        float *v = (float *)malloc(std::max<size_t>(1, t.v.size()) * sizeof(float));
+        if (!v) return fail("out of memory");
+        memcpy(v, t.v.data(), t.v.size() * sizeof(float));
+        *nrow = t.nrow; *ncol = t.ncol; *data = v;
+        return 0;
+    } catch (const std::exception &e) { return fail(e.what()); }
+}
+
+void cogaps_matrix_free(float *data) { free(data); }
+
+// getFileInfo_cpp (Cogaps.cpp:229-246): dimensions and the names the file carries, '\n'-joined into caller buffers
+// (a NULL buffer or zero capacity skips the names; *needed reports the bytes a complete copy takes, terminator included)
+int cogaps_file_info(const char *path, uint32_t *nrow, uint32_t *ncol, char *rowNames, size_t rowCap, size_t *rowNeeded,
+                     char *colNames, size_t colCap, size_t *colNeeded)
+{
+    try {
+        if (!path || !nrow || !ncol) return fail("null argument");
+        cgio::Table t = cgio::read_matrix_file(path);
+        *nrow = t.nrow; *ncol = t.ncol;
+        auto join = [](const std::vector<std::string> &v, char *out, size_t cap, size_t *needed) {
+            std::string s; for (size_t i = 0; i < v.size(); ++i) { if (i) s += '\n'; s += v[i]; }
+            if (needed) *needed = s.size() + 1;
+            if (out && cap) { const size_t n = std::min(cap - 1, s.size()); memcpy(out, s.data(), n); out[n] = 0; }
+        };
+        join(t.rowNames, rowNames, rowCap, rowNeeded); join(t.colNames, colNames, colCap, colNeeded);
+        return 0;
+    } catch (const std::exception &e) { return fail(e.what()); }
+}
+
+int cogaps_run_from_file(const char *dataPath, const cogaps_params *params, const char *uncertaintyPath, cogaps_result *out)
+{
+    try {
+        if (!dataPath || !params || !out) return fail("null argument");
+        cgio::Table d = cgio::read_matrix_file(dataPath), u;
+        const bool haveUnc = uncertaintyPath && uncertaintyPath[0];
+        if (haveUnc) {
+            u = cgio::read_matrix_file(uncertaintyPath);
+            if (u.nrow != d.nrow || u.ncol != d.ncol) return fail("uncertainty matrix has different dimensions than the data");
+        }
+        return cogaps_run(d.v.data(), d.nrow, d.ncol, params, haveUnc ? u.v.data() : nullptr, out);
+    } catch (const std::exception &e) { return fail(e.what()); }
 }
 
 void cogaps_result_free(cogaps_result *r)

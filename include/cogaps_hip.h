@@ -88,6 +88,17 @@ void cogaps_default_params(cogaps_params *p);
  * transposeData), uncertainty the same shape or NULL.  Host pointers. */
 int cogaps_run(const float *data, uint32_t nrow, uint32_t ncol, const cogaps_params *params,
                const float *uncertainty, cogaps_result *out);
+/* gaps::run for a matrix file (src/GapsRunner.h:24-29; Rcpp cogaps_from_file_cpp, src/Cogaps.cpp:217-227): .mtx, .csv, .tsv
+ * or .gct, read as the reference's parsers read them (src/file_parser/, incl. the text -> fp32 rule of
+ * MatrixElement.cpp:10-47); uncertaintyPath NULL or "" for the default uncertainty. */
+int cogaps_run_from_file(const char *dataPath, const cogaps_params *params, const char *uncertaintyPath, cogaps_result *out);
+/* the file as a dense row-major fp32 matrix (callee-allocated; release with cogaps_matrix_free).  Host only: no GPU needed. */
+int cogaps_read_matrix_file(const char *path, uint32_t *nrow, uint32_t *ncol, float **data);
+void cogaps_matrix_free(float *data);
+/* getFileInfo_cpp (src/Cogaps.cpp:229-246): dimensions and the row / column names the file carries, '\n'-joined into the
+ * caller's buffers (NULL / 0 to skip; *needed = bytes of a complete copy incl. the terminator).  Host only. */
+int cogaps_file_info(const char *path, uint32_t *nrow, uint32_t *ncol, char *rowNames, size_t rowCap, size_t *rowNeeded,
+                     char *colNames, size_t colCap, size_t *colNeeded);
 void cogaps_result_free(cogaps_result *r);
 const char *cogaps_last_error(void);
 

@@ -119,3 +119,44 @@ def test_input_file_formats(gist):
     assert parse_value("0.1") == np.float32(0.1)
     with pytest.raises(ValueError):
         parse_value("abc")
+
+
+def test_native_file_reader_matches_fixtures_and_python_reader(tmp_path, gist):
+    """csrc/file_reader.h (behind cogaps_read_matrix_file / cogaps_file_info, host only) against the four GIST fixtures, the
+    Python reader and hand-made edge cases of the reference's parsers (CharacterDelimitedParser.cpp, MtxParser.cpp,
+    MatrixElement.cpp:10-47)"""
+    import ctypes
+    from conftest import GOLDEN
+    from cogaps_amd import _capi
+    from cogaps_amd.io import read_matrix
+    L = _capi.bind(ctypes.CDLL(_capi.LIB_PATH))
+    for ext in ("mtx", "csv", "tsv", "gct"):
+        path = os.path.join(GOLDEN, "GIST." + ext)
+        m = _capi.read_matrix_file(path, lib=L)
+        assert m.dtype == np.float32 and np.array_equal(m, gist), ext
+        nr, nc, rown, coln = _capi.file_info(path, lib=L)
+        assert (nr, nc) == (1363, 9)
+        if ext != "mtx":
+            assert len(rown) == 1363 and rown[0] == "Hs.101174" and rown[-1] == read_matrix(path, return_names=True)[1][-1] and coln[0] == "IM00" and len(coln) == 9
+    cases = {
+        "a.csv": ',"s1",s2\r\n"g1", 1.5 ,2\r\ng2,3,4e-1\r\n\r\n',                   # quotes, blanks, CRLF, trailing blank line, row names
+        "b.csv": "s1,s2,s3\n1,2,3\n-4.25,5e2,6.\n",                                      # no row names
+        "c.tsv": "\ts1\ts2\ng1\t1e-3\t-2.5e1\ng2\t0\t.5\n",
+        "d.mtx": "%%MatrixMarket matrix coordinate real general\n% comment\n3 2 3\n1 1 1.5\n3 2 2e-2\n2 1 -7\n",
+        "e.gct": "#1.2\n2\t3\nName\tDescription\tx\ty\tz\nr1\td1\t1\t2\t3\nr2\td2\t4.5\t5e0\t-6\n",
+    }
+    for name, text in cases.items():
+        f = tmp_path / name
+        f.write_bytes(text.encode())
+        a, b = _capi.read_matrix_file(str(f), lib=L), read_matrix(str(f))
+        assert a.shape == b.shape and np.array_equal(a, b), name
+    assert _capi.read_matrix_file(str(tmp_path / "c.tsv"), lib=L)[0, 0] == np.float32(np.float32(1.0) * np.power(np.float32(10.0), np.float32(-3.0)))
+    assert _capi.file_info(str(tmp_path / "b.csv"), lib=L) == (2, 3, [], ["s1", "s2", "s3"])
+    assert _capi.file_info(str(tmp_path / "e.gct"), lib=L) == (2, 3, ["r1", "r2"], ["x", "y", "z"])
+    for name, text in {"bad1.csv": ",a\nr,abc\n", "bad2.csv": ",a,b\nr,1\n", "bad3.gct": "#1.2\n3\t1\nN\tD\tx\nr\td\t1\n", "bad.xyz": "1"}.items():
+        f = tmp_path / name
+        f.write_text(text)
+        with pytest.raises(RuntimeError):
+            _capi.read_matrix_file(str(f), lib=L)
+    with pytest.raises(RuntimeError):
+        _capi.read_matrix_file(str(tmp_path / "missing.csv"), lib=L)

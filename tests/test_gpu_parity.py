@@ -166,3 +166,26 @@ def test_sessions_in_flight_on_one_gpu(hip_lib, gist):
     for a, b in zip(alone, together):
         for k in ("Amean", "Pmean", "Asd", "Psd", "atomsA", "atomsP", "chisq", "totalUpdates"):
             assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+
+
+def test_run_from_file_equals_run_on_the_matrix(hip_lib, gist, tmp_path):
+    """cogaps_run_from_file (the reference's gaps::run(path) / cogaps_from_file_cpp): the four formats of the GIST fixture give
+    the bits of cogaps_run on the in-memory matrix; an uncertainty file is honoured"""
+    from cogaps_amd import _capi
+    kw = dict(nPatterns=4, nIterations=40, seed=9, outputFrequency=10)
+    ref = _capi.run(gist, **kw)
+    for ext in ("mtx", "csv", "tsv", "gct"):
+        r = _capi.run_from_file(os.path.join(GOLDEN, "GIST." + ext), **kw)
+        for k in ("Amean", "Pmean", "Asd", "Psd", "atomsA", "atomsP", "chisq", "totalUpdates"):
+            assert np.array_equal(np.asarray(r[k]), np.asarray(ref[k])), (ext, k)
+    unc = np.maximum(gist * np.float32(0.2), np.float32(0.3)).astype(np.float32)
+    upath = tmp_path / "unc.tsv"
+    with open(upath, "w") as f:                       # plain decimals with 12 fractional digits read back as the same fp32
+        f.write("\t".join("s%d" % j for j in range(unc.shape[1])) + "\n")
+        for row in unc:
+            f.write("\t".join("%.12f" % float(x) for x in row) + "\n")
+    assert np.array_equal(_capi.read_matrix_file(str(upath)), unc)
+    ru, rf = _capi.run(gist, unc=unc, **kw), _capi.run_from_file(os.path.join(GOLDEN, "GIST.mtx"), unc_path=str(upath), **kw)
+    assert np.array_equal(ru["Amean"], rf["Amean"]) and np.array_equal(ru["chisq"], rf["chisq"]) and not np.array_equal(ru["chisq"], ref["chisq"])
+    with pytest.raises(RuntimeError):
+        _capi.run_from_file(os.path.join(GOLDEN, "nope.csv"), **kw)
