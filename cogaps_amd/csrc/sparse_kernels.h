@@ -36,28 +36,30 @@ CG_DEVICE void sp_row_load(SpRow &R, const float *row, uint32_t n)
 #pragma unroll
     for (uint32_t c = 0; c < 16u; ++c) R.r[c] = c < nq ? ld4(row, c) : f4_zero();
 }
-// gaps::dot(a, row) in the scalar build's order (sp_dot) with the row in registers, n <= 64
+// gaps::dot(a, row) in the scalar build's order (sp_dot) with the row in registers, n <= 64.  `a` (LDS) and the row are
+// zero-padded to a multiple of 4, so whole chunks are accumulated without per-element tests: a padding element adds
+// a*0 = +-0 to the sum, which leaves its bits unchanged (the sum starts at +0), and one uniform test per chunk replaces
+// four compare-and-branch pairs -- the kernel was issue-bound on exactly those.
 CG_DEVICE float sp_row_dot(const float *a, const SpRow &R, uint32_t n)
 {
     float d = 0.f;
+    const uint32_t nq = (n + 3u) >> 2;
     if (n <= 25u) {
 #pragma unroll
         for (uint32_t c = 7u; c-- > 0u;) {
-            const uint32_t i = 4u * c;
-            if (i + 3u < n) d = d + a[i + 3u] * R.r[c].w;
-            if (i + 2u < n) d = d + a[i + 2u] * R.r[c].z;
-            if (i + 1u < n) d = d + a[i + 1u] * R.r[c].y;
-            if (i < n) d = d + a[i] * R.r[c].x;
+            if (c < nq) {
+                const uint32_t i = 4u * c;
+                d = d + a[i + 3u] * R.r[c].w; d = d + a[i + 2u] * R.r[c].z; d = d + a[i + 1u] * R.r[c].y; d = d + a[i] * R.r[c].x;
+            }
         }
         return d;
     }
 #pragma unroll
     for (uint32_t c = 0; c < 16u; ++c) {
-        const uint32_t i = 4u * c;
-        if (i < n) d = d + a[i] * R.r[c].x;
-        if (i + 1u < n) d = d + a[i + 1u] * R.r[c].y;
-        if (i + 2u < n) d = d + a[i + 2u] * R.r[c].z;
-        if (i + 3u < n) d = d + a[i + 3u] * R.r[c].w;
+        if (c < nq) {
+            const uint32_t i = 4u * c;
+            d = d + a[i] * R.r[c].x; d = d + a[i + 1u] * R.r[c].y; d = d + a[i + 2u] * R.r[c].z; d = d + a[i + 3u] * R.r[c].w;
+        }
     }
     return d;
 }
@@ -227,10 +229,11 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S)
         if (t == 0) nzShared = 0u;
         if (need) {
             // this sampler's matrix row(s), read by every lane for the K-length dots
-            for (uint32_t k = t; k < K; k += BS) {
-                arowA[k] = S.rows[(size_t)p.r1 * S.Kpad + k]; z2A[k] = S.Z2[(size_t)p.c1 * K + k];
+            // (the row copy is zero-padded to Kpad, a multiple of 4: sp_row_dot reads whole chunks)
+            for (uint32_t k = t; k < S.Kpad; k += BS) {
+                arowA[k] = S.rows[(size_t)p.r1 * S.Kpad + k];
                 if (diff) arowB[k] = S.rows[(size_t)p.r2 * S.Kpad + k];
-                if (two) z2B[k] = S.Z2[(size_t)p.c2 * K + k];
+                if (k < K) { z2A[k] = S.Z2[(size_t)p.c1 * K + k]; if (two) z2B[k] = S.Z2[(size_t)p.c2 * K + k]; }
             }
             cg_sync();
             float x[4] = {0.f, 0.f, 0.f, 0.f};
