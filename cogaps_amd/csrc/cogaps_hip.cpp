@@ -15,6 +15,7 @@
 #include "sparse_kernels.h"
 
 #include <math.h>
+#include <cmath>
 #include <stdio.h>
 #include <time.h>
 #include <algorithm>
@@ -143,6 +144,7 @@ struct HostSampler {
     float *partial = nullptr;     // [M] chi2 partials
     uint32_t nAtoms = 0;          // host copy after the last update
     float avgQueue = 0.f;
+    float dataSparsity = 0.f;     // DenseNormalModel::dataSparsity
     float stepsPerBatch = 0.f;
     float anneal = 1.f;           // annealing temperature of the next update
     rt_graph graph;               // GRAPH_PAIRS (generate, evaluate) pairs, replayed while the kernel parameters stay the same
@@ -157,6 +159,7 @@ struct HostSampler {
 };
 
 struct cogaps_session {
+    double startTime = 0.0;                                          // gaps::run's startTime (GapsRunner.cpp:383): status lines, totalRunningTime
     float *pump = nullptr; uint32_t pumpUpdates = 0;                 // mPumpMatrix [nGenes][K] row-major (device), mPumpUpdates
     std::vector<float> snapA[2], snapP[2]; uint32_t nSnap[2] = {0, 0};   // [0] equilibration, [1] sampling snapshots, row-major
 
@@ -224,6 +227,7 @@ static void build_sampler(cogaps_session *s, HostSampler &h, char name, const fl
             sum += v; if (v > 0.f) ++nnz;                                    // gaps::nonZeroMean, MatrixMath.cpp:39-55
         }
     const float meanD = sum / (float)nnz;
+    h.dataSparsity = 1.f - (float)(uint32_t)nnz / (float)(d.M * d.N);       // gaps::sparsity, MatrixMath.cpp:6-21 (unsigned count, float product of the dimensions)
     d.alpha = alpha;
     d.lambda = alpha * sqrtf((float)(uint64_t)d.K / meanD);
     d.maxGibbsMass = maxGibbsMass / d.lambda;
@@ -501,6 +505,8 @@ cogaps_session *cogaps_session_create(const float *data, uint32_t nrow, uint32_t
         rt_set_device(p.device);
         s = new cogaps_session();
         s->p = p;
+        s->startTime = now_s();
+        if (p.printMessages) { printf("Loading Data..."); fflush(stdout); }                  // GapsRunner.cpp:399
         if (p.subsetData && p.dataIndicesSubset) s->subset.assign(p.dataIndicesSubset, p.dataIndicesSubset + p.nSubset);
         s->stream = rt_stream_create();
         std::vector<float> hostData, hostUnc;
@@ -564,6 +570,13 @@ cogaps_session *cogaps_session_create(const float *data, uint32_t nrow, uint32_t
             RT_LAUNCH(init_ap_kernel, (s->P.d.N + 255) / 256, 256, s->stream, s->P.d);
         }
         rt_sync(s->stream);
+        if (p.printMessages) {                                                   // GapsRunner.cpp:412-426
+            const unsigned el = (unsigned)(now_s() - s->startTime);
+            printf("Done! (%02u:%02u:%02u)\n", el / 3600u, (el % 3600u) / 60u, el % 60u);
+            if (!p.useSparseOptimization && s->A.dataSparsity > 0.80f) printf("\nWarning: data is more than 80%% sparse and sparseOptimization is not enabled\n");
+        }
+        if (p.runningDistributed) printf("    worker %u is starting!\n", p.workerID);         // :428-433
+        fflush(stdout);
         return s;
     } catch (const std::exception &e) {
         fail(e.what());
@@ -655,6 +668,7 @@ int cogaps_session_run_iterations(cogaps_session *s, int phase, uint32_t firstIt
 {
     SESSION_TRY
     const double t0 = now_s();
+    if (s->p.printMessages && firstIter == 0 && n > 0) { printf(phase == 1 ? "-- Equilibration Phase --\n" : "-- Sampling Phase --\n"); fflush(stdout); }   // GapsRunner.cpp:446-457
     for (uint32_t it = firstIter; it < firstIter + n; ++it) {
         if (s->p.interrupt && s->p.interrupt(s->p.interruptArg)) return fail("interrupted");
         if (phase == 1) {
@@ -676,7 +690,20 @@ int cogaps_session_run_iterations(cogaps_session *s, int phase, uint32_t firstIt
         if (s->p.outputFrequency > 0 && ((it + 1) % s->p.outputFrequency) == 0) {        // displayStatus, :162-199
             const float cs = (s->p.whichMatrixFixed == 'P') ? chisq_of(s, s->A) : chisq_of(s, s->P);
             s->chisqHist.push_back(cs); s->atomHistA.push_back(s->A.nAtoms); s->atomHistP.push_back(s->P.nAtoms);
-            if (s->p.printMessages) { printf("%u of %u, Atoms: %u(A), %u(P), ChiSq: %.0f\n", it + 1, s->p.nIterations, s->A.nAtoms, s->P.nAtoms, cs); fflush(stdout); }
+            if (s->p.printMessages) {
+                // elapsed / estimated total time (estimatedPercentComplete, GapsRunner.cpp:127-159)
+                const double nIter = (double)it + (phase == 2 ? (double)s->p.nIterations : 0.0), totalIter = 2.0 * (double)s->p.nIterations;
+                auto est = [](double current, double total, double nAtoms) {
+                    const double coef = nAtoms / std::log(current);
+                    return coef * std::log(std::sqrt(2.0 * total * 3.14159265358979323846)) + total * coef * std::log(total) - total * coef; };
+                const double done = est(nIter, nIter, s->A.nAtoms) + est(nIter, nIter, s->P.nAtoms), all = est(nIter, totalIter, s->A.nAtoms) + est(nIter, totalIter, s->P.nAtoms);
+                const unsigned el = (unsigned)(now_s() - s->startTime);
+                const double frac = done / all;
+                const unsigned tt = (frac > 0.0 && std::isfinite((double)el / frac)) ? (unsigned)((double)el / frac) : 0u;
+                printf("%u of %u, Atoms: %u(A), %u(P), ChiSq: %.0f, Time: %02u:%02u:%02u / %02u:%02u:%02u\n", it + 1, s->p.nIterations, s->A.nAtoms, s->P.nAtoms, cs,
+                       el / 3600u, (el % 3600u) / 60u, el % 60u, tt / 3600u, (tt % 3600u) / 60u, tt % 60u);
+                fflush(stdout);
+            }
         }
     }
     rt_sync(s->stream);
@@ -763,7 +790,7 @@ int cogaps_session_finish(cogaps_session *s, cogaps_result *out)
     memcpy(out->chisqHistory, s->chisqHist.data(), out->nHistory * 4); memcpy(out->atomHistoryA, s->atomHistA.data(), out->nHistory * 4); memcpy(out->atomHistoryP, s->atomHistP.data(), out->nHistory * 4);
     out->totalUpdates = s->totalUpdates; out->seed = s->p.seed;
     out->averageQueueLengthA = s->A.avgQueue; out->averageQueueLengthP = s->P.avgQueue;
-    out->samplerSeconds = s->samplerSeconds; out->totalRunningTime = (uint32_t)s->samplerSeconds;
+    out->samplerSeconds = s->samplerSeconds; out->totalRunningTime = (uint32_t)(now_s() - s->startTime);   // GapsRunner.cpp:463
     out->meanChiSq = 0.f;                                                             // GapsRunner.cpp:478-484
     if (s->p.whichMatrixFixed == 'N' && s->statUpdates > 0) {
         const float n2 = (float)s->statUpdates * (float)s->statUpdates;
@@ -789,6 +816,10 @@ int cogaps_session_finish(cogaps_session *s, cogaps_result *out)
     auto dup = [](const std::vector<float> &v) { float *p = (float *)malloc(v.size() * 4 + 4); if (!v.empty()) memcpy(p, v.data(), v.size() * 4); return p; };
     out->equilibrationSnapshotsA = dup(s->snapA[0]); out->equilibrationSnapshotsP = dup(s->snapP[0]);
     out->samplingSnapshotsA = dup(s->snapA[1]); out->samplingSnapshotsP = dup(s->snapP[1]);
+        if (s->p.runningDistributed) {                                                     // GapsRunner.cpp:494-500
+        const unsigned el = (unsigned)(now_s() - s->startTime);
+        printf("    worker %u is finished! Time: %02u:%02u:%02u\n", s->p.workerID, el / 3600u, (el % 3600u) / 60u, el % 60u); fflush(stdout);
+    }
     SESSION_END
 }
 
