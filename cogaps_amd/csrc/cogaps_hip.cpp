@@ -266,6 +266,7 @@ static void build_sampler(cogaps_session *s, HostSampler &h, char name, const fl
     // atomic domain
     const uint64_t nBins = (uint64_t)d.M * d.K;
     d.atomCap = (uint32_t)std::min<uint64_t>(nBins + 65536ull, 0x7FFFFFF0ull);
+    if (const char *e = getenv("COGAPS_INITIAL_ATOM_CAP")) d.atomCap = (uint32_t)std::max(64l, atol(e));      // tests: exercises grow_atoms
     d.atoms = dalloc<AtomRec>(d.atomCap); d.vec = dalloc<uint32_t>(d.atomCap); d.freeHandles = dalloc<uint32_t>(d.atomCap);
     d.binHead = dalloc<uint32_t>(nBins); rt_memset(d.binHead, 0xFF, nBins * 4, s->stream);
     d.nWords0 = (uint32_t)((nBins + 63) / 64); d.nWords1 = (d.nWords0 + 63) / 64; d.nWords2 = (d.nWords1 + 63) / 64;

@@ -95,3 +95,11 @@ def test_pump_statistics_and_snapshots(emul_lib, modsim, oracle):
                 assert np.array_equal(r[f], o[f]), (sparse, phase, f)
             assert r["equilibrationSnapshotsA"].shape[0] == (4 if code != 2 else 0) and r["samplingSnapshotsP"].shape[0] == (4 if code != 1 else 0)
             assert np.allclose(r["pumpMatrix"].sum(axis=1), 1.0) and set(np.unique(r["meanPatternAssignment"])) <= {0.0, 1.0}
+
+
+def test_atom_tables_grow(emul_lib, gist, monkeypatch):
+    """grow_atoms: with a 64-atom initial capacity (COGAPS_INITIAL_ATOM_CAP, a test switch) the atom tables are
+    reallocated many times on the way to ~1300 atoms; the chain stays bit-identical to the oracle"""
+    monkeypatch.setenv("COGAPS_INITIAL_ATOM_CAP", "64")
+    a, p, props = pu.run_stepwise(emul_lib(256), gist, 40, trace=False, nPatterns=7, seed=42, total_iter=40)
+    assert a > 1000

@@ -189,3 +189,10 @@ def test_run_from_file_equals_run_on_the_matrix(hip_lib, gist, tmp_path):
     assert np.array_equal(ru["Amean"], rf["Amean"]) and np.array_equal(ru["chisq"], rf["chisq"]) and not np.array_equal(ru["chisq"], ref["chisq"])
     with pytest.raises(RuntimeError):
         _capi.run_from_file(os.path.join(GOLDEN, "nope.csv"), **kw)
+
+
+def test_atom_tables_grow(hip_lib, gist, monkeypatch):
+    """grow_atoms on the device path (reallocation invalidates the captured launch graphs): 64-atom initial capacity"""
+    monkeypatch.setenv("COGAPS_INITIAL_ATOM_CAP", "64")
+    a, p, props = pu.run_stepwise(hip_lib, gist, 150, trace=False, nPatterns=7, seed=42, total_iter=150, check_every=10)
+    assert a > 2500
