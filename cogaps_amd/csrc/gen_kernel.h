@@ -78,7 +78,9 @@ __device__ unsigned long long g_timeline[(GEN_WIN / 64) * 64];
 #define GEN_K_INL 3u
 #define GEN_GS_WORDS ((uint32_t)(offsetof(GenScalars, evalProps) / 4u + 2u))      // words [0, GEN_GS_WORDS) of GenScalars are written back by the generator
 #define GEN_GS_ERROR_WORD ((uint32_t)(offsetof(GenScalars, error) / 4u))
+#ifndef FLUSH_MAX
 #define FLUSH_MAX 64                 // erase caches up to this size are flushed in parallel
+#endif
 #define CG_KEEP 0xFFFFFFFEu          // "front unchanged" marker
 
 struct GenTabVal { uint32_t used, gap, inl, pad; };

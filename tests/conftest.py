@@ -41,11 +41,11 @@ def emul_lib():
     from cogaps_amd import _capi
     libs = {}
 
-    def get(win=256):
-        if win not in libs:
-            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emul"), "WIN=%d" % win])
-            libs[win] = _capi.bind(ctypes.CDLL(os.path.join(ROOT, "tests", "emul", "libcogaps_emul_TESTONLY_w%d.so" % win)))
-        return libs[win]
+    def get(win=256, extra="", tag=""):
+        if (win, tag) not in libs:
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emul"), "WIN=%d" % win, "EXTRA=" + extra, "TAG=" + tag])
+            libs[(win, tag)] = _capi.bind(ctypes.CDLL(os.path.join(ROOT, "tests", "emul", "libcogaps_emul_TESTONLY_w%d%s.so" % (win, tag))))
+        return libs[(win, tag)]
     return get
 
 

@@ -103,3 +103,10 @@ def test_atom_tables_grow(emul_lib, gist, monkeypatch):
     monkeypatch.setenv("COGAPS_INITIAL_ATOM_CAP", "64")
     a, p, props = pu.run_stepwise(emul_lib(256), gist, 40, trace=False, nPatterns=7, seed=42, total_iter=40)
     assert a > 1000
+
+
+def test_serial_flush_fallback(emul_lib, gist):
+    """an erase cache longer than FLUSH_MAX is flushed by one lane exactly as the reference does it
+    (ConcurrentAtomicDomain.cpp:71-79).  Erases are rare (this chain: 60 batches with one, 6 with two or three in 50
+    iterations), so the variant is built with FLUSH_MAX = 1 and run long enough to take the path several times"""
+    pu.run_stepwise(emul_lib(256, extra="-DFLUSH_MAX=1", tag="_flush1"), gist, 50, trace=False, nPatterns=7, seed=42, total_iter=40)
