@@ -160,3 +160,16 @@ def test_native_file_reader_matches_fixtures_and_python_reader(tmp_path, gist):
             _capi.read_matrix_file(str(f), lib=L)
     with pytest.raises(RuntimeError):
         _capi.read_matrix_file(str(tmp_path / "missing.csv"), lib=L)
+
+
+def test_compute_calls_fail_loudly_without_a_gpu():
+    """no device, no result: the library reports the HIP error through the C ABI (non-zero code + message), nothing falls
+    back to the host"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: this is the no-device behaviour")
+    from cogaps_amd import _capi, CoGAPS
+    with pytest.raises(RuntimeError, match="device"):
+        _capi.run(np.ones((10, 8), np.float32), nPatterns=2, nIterations=5)
+    with pytest.raises(RuntimeError, match="device"):
+        CoGAPS(np.ones((10, 8), np.float32) * 2, nPatterns=2, nIterations=5, messages=False)
