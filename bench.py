@@ -142,11 +142,20 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    # test hook: COGAPS_BENCH_BACKEND=gloo lets the ranks of a multi-process run share the GPUs that exist (collectives on
+    # host tensors), so the N > 1 code path can be exercised on a one-GPU box; the driver's runs use RCCL ("nccl")
+    backend = os.environ.get("COGAPS_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
+    comm_dev = "cuda" if backend == "nccl" else "cpu"
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, init_method="env://")
 
     from cogaps_amd import _capi
 
@@ -182,7 +191,7 @@ def main():
     updates = run_steps(W, K)
     if dist is not None:
         # the one exchange of the GWCoGAPS path: all-gather of the shared-dimension factor
-        fac = torch.from_numpy(S.matrix("P")).cuda()
+        fac = torch.from_numpy(S.matrix("P")).to(comm_dev)
         gathered = [torch.empty_like(fac) for _ in range(world)]
         dist.all_gather(gathered, fac)
     torch.cuda.synchronize()
@@ -194,7 +203,7 @@ def main():
 
     tot_updates, max_dt = float(updates), dt
     if dist is not None:
-        t = torch.tensor([float(updates), dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([float(updates), dt], dtype=torch.float64, device=comm_dev)
         u = t.clone()
         dist.all_reduce(u, op=dist.ReduceOp.SUM)
         m = t.clone()

@@ -196,3 +196,23 @@ def test_atom_tables_grow(hip_lib, gist, monkeypatch):
     monkeypatch.setenv("COGAPS_INITIAL_ATOM_CAP", "64")
     a, p, props = pu.run_stepwise(hip_lib, gist, 150, trace=False, nPatterns=7, seed=42, total_iter=150, check_every=10)
     assert a > 2500
+
+
+def test_bench_multi_rank_path_on_one_gpu():
+    """bench.py's N > 1 path (rendezvous, barrier, all-gather of the shared factor, sum / max over ranks, one JSON line
+    from rank 0) with two ranks sharing this box's GPU through the gloo test hook (the driver's runs use RCCL)"""
+    import json, socket, subprocess, sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, COGAPS_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "4",
+                          "--genes", "4000", "--samples", "400", "--patterns", "10"],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 12 and d["warmup"] == 4 and d["scaling"] == "weak" and d["unit"] == "proposals/s"
+    assert d["value"] > 0 and d["cpu_baseline"] is None and d["roofline"]["traffic"] is None
+    assert d["config"]["proposals_timed"] > 0
