@@ -216,3 +216,24 @@ def test_bench_multi_rank_path_on_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 12 and d["warmup"] == 4 and d["scaling"] == "weak" and d["unit"] == "proposals/s"
     assert d["value"] > 0 and d["cpu_baseline"] is None and d["roofline"]["traffic"] is None
     assert d["config"]["proposals_timed"] > 0
+
+
+def test_gwcogaps_driver_on_the_gpu(hip_lib, gist):
+    """GWCoGAPS through the front-end on this GPU: four gene-wise shards, two in flight (BPPARAM = 2) -- the same bits as one
+    shard at a time; the stitched result has the reference's structure (DistributedCogaps.R:226-278)"""
+    from cogaps_amd import GWCoGAPS, CogapsParams
+
+    def go(workers):
+        p = CogapsParams(nPatterns=3, seed=5, nIterations=60)
+        p.distributed = "genome-wide"
+        p.setDistributedParams(nSets=4, minNS=2)
+        p.explicitSets = [list(range(1 + 120 * i, 121 + 120 * i)) for i in range(4)]
+        return GWCoGAPS(gist[:480], p, messages=False, outputFrequency=20, BPPARAM=workers)
+    a, b = go(2), go(1)
+    assert np.array_equal(a.featureLoadings, b.featureLoadings) and np.array_equal(a.loadingStdDev, b.loadingStdDev)
+    assert np.array_equal(a.sampleFactors, b.sampleFactors)
+    cons = a.metadata["diagnostics"]["consensus"]
+    k = cons.shape[1]
+    assert a.featureLoadings.shape == (480, k) and a.sampleFactors.shape == (9, k) and k >= 1
+    assert np.allclose(cons.max(axis=0), 1.0) and not a.sampleFactors.any()        # the fixed side comes back zero, as in the reference
+    assert len(a.metadata["diagnostics"]["unmatchedPatterns"]) == 4
