@@ -304,6 +304,7 @@ static void grow_atoms(cogaps_session *s, HostSampler &h, uint32_t need)
 {
     SamplerDev &d = h.d;
     if (need <= d.atomCap) return;
+    rt_alloc_scope allocOn(s->stream);
     uint32_t cap = d.atomCap;
     while (cap < need) cap = (uint32_t)std::min<uint64_t>((uint64_t)cap * 2, 0x7FFFFFF0ull);
     auto regrow = [&](auto *&ptr, size_t elt) {
@@ -510,6 +511,7 @@ cogaps_session *cogaps_session_create(const float *data, uint32_t nrow, uint32_t
         if (p.printMessages) { printf("Loading Data..."); fflush(stdout); }                  // GapsRunner.cpp:399
         if (p.subsetData && p.dataIndicesSubset) s->subset.assign(p.dataIndicesSubset, p.dataIndicesSubset + p.nSubset);
         s->stream = rt_stream_create();
+        rt_alloc_scope allocOn(s->stream);
         std::vector<float> hostData, hostUnc;
         if (data_on_device) {          // device-resident input: stage through the host once, outside any timed region
             hostData.resize((size_t)nrow * ncol); rt_d2h(hostData.data(), data, hostData.size() * 4, s->stream);
@@ -599,7 +601,7 @@ void cogaps_session_destroy(cogaps_session *s)
     delete s;
 }
 
-#define SESSION_TRY try {
+#define SESSION_TRY try { rt_alloc_scope allocOn_(s->stream);      // allocations made on behalf of a session fill on its stream
 #define SESSION_END } catch (const std::exception &e) { return fail(e.what()); } return 0;
 
 static HostSampler &pick(cogaps_session *s, char w) { return w == 'A' ? s->A : s->P; }

@@ -14,6 +14,7 @@
 
 typedef int rt_stream_t;
 inline void *rt_malloc(size_t n) { void *p = calloc(n ? n : 1, 1); if (!p) throw std::runtime_error("out of memory"); return p; }
+struct rt_alloc_scope { explicit rt_alloc_scope(rt_stream_t) {} };
 inline void rt_free(void *p) { free(p); }
 inline void *rt_malloc_host(size_t n) { return rt_malloc(n); }
 inline void rt_free_host(void *p) { free(p); }
@@ -45,22 +46,25 @@ inline const char *rt_platform_name() { return "emulator (test only)"; }
 
 #define RT_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 typedef hipStream_t rt_stream_t;
-// zero-filled device memory.  The fill runs on a private non-blocking stream of the calling thread and is waited for:
-// the legacy null stream is never used (sessions on other host threads may be capturing a graph, which makes any
-// legacy-stream operation fail), and an upload enqueued right after the allocation cannot be overtaken by the fill.
-inline hipStream_t rt_fill_stream()
-{
-    static thread_local hipStream_t fill[64] = {};
-    int dev = 0; RT_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) throw std::runtime_error("device ordinal out of range");
-    if (!fill[dev]) RT_CHECK(hipStreamCreateWithFlags(&fill[dev], hipStreamNonBlocking));
-    return fill[dev];
-}
+// zero-filled device memory.  The fill runs on the stream the calling thread has announced (rt_alloc_scope: the session's
+// own stream) or, outside such a scope, on a temporary non-blocking stream, and is waited for: the legacy null stream is
+// never used (sessions on other host threads may be capturing a graph, which makes any legacy-stream operation fail),
+// an upload enqueued right after the allocation cannot be overtaken by the fill, and no extra long-lived stream takes
+// one of the process's four hardware queues away from the sessions.
+inline hipStream_t &rt_alloc_stream_slot() { static thread_local hipStream_t s = nullptr; return s; }
+struct rt_alloc_scope {
+    hipStream_t prev;
+    explicit rt_alloc_scope(hipStream_t s) : prev(rt_alloc_stream_slot()) { rt_alloc_stream_slot() = s; }
+    ~rt_alloc_scope() { rt_alloc_stream_slot() = prev; }
+};
 inline void *rt_malloc(size_t n)
 {
     void *p = nullptr; RT_CHECK(hipMalloc(&p, n ? n : 1));
-    hipStream_t f = rt_fill_stream();
+    hipStream_t f = rt_alloc_stream_slot();
+    const bool temp = f == nullptr;
+    if (temp) RT_CHECK(hipStreamCreateWithFlags(&f, hipStreamNonBlocking));
     RT_CHECK(hipMemsetAsync(p, 0, n ? n : 1, f)); RT_CHECK(hipStreamSynchronize(f));
+    if (temp) (void)hipStreamDestroy(f);
     return p;
 }
 inline void rt_free(void *p) { if (p) (void)hipFree(p); }

@@ -169,7 +169,7 @@ def _run_shards(call, ids, in_flight):
     """This rank's shards, `in_flight` at a time (the role of BPPARAM's workers, DistributedCogaps.R:60-63, 84-87): one
     host thread, one HIP stream and one session per shard in flight.  A single chain keeps one workgroup busy in
     its generator kernel and a few hundred in its evaluation kernel, alternately; further chains on the same GPU
-    fill the gaps (3 chains: 2.5x the proposals/s of one on an MI355X; a 4th shares a hardware queue and loses: DESIGN.md section 5)."""
+    fill the gaps (4 chains: 3.1x the proposals/s of one on an MI355X; a 5th shares a hardware queue and loses: DESIGN.md section 5)."""
     ids = list(ids)
     if in_flight <= 1 or len(ids) <= 1:
         return {i: call(i) for i in ids}
@@ -180,7 +180,7 @@ def _run_shards(call, ids, in_flight):
 
 
 def distributedCogaps(data, params, uncertainty=None, messages=False, outputFrequency=1000, transposeData=False,
-                      device=-1, run_fn=None, comm_device=None, shardsInFlight=3):
+                      device=-1, run_fn=None, comm_device=None, shardsInFlight=4):
     run_fn = run_fn or _capi.run
     shardsInFlight = max(1, int(shardsInFlight))
     genome_wide = params.distributed == "genome-wide"

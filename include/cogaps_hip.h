@@ -13,8 +13,9 @@
  * released with cogaps_result_free.  All functions return 0 on success and a non-zero code plus a
  * message (cogaps_last_error) on failure; nothing calls exit() (reference: utils/GapsAssert.h:19-25).
  * Threading: a session (or a cogaps_run call) is driven by one host thread at a time; different sessions may run
- * concurrently from different host threads, on the same GPU or on different ones (each owns a non-blocking
- * stream; no legacy-stream operation is issued; graph capture is thread-local).  The library keeps no global
+ * concurrently from different host threads, on the same GPU or on different ones (each owns one non-blocking
+ * stream and the library creates no other; no legacy-stream operation is issued; graph capture is thread-local).
+ * Up to four sessions per process and GPU run truly side by side (HIP's four hardware queues per process).  The library keeps no global
  * mutable state besides the per-thread last error.  Environment: COGAPS_NO_GRAPH (any value) sends every
  * kernel as a plain launch instead of replaying captured graphs -- for counter-collection tools only.
  */

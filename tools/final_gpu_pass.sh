@@ -13,4 +13,5 @@ cp $(find /tmp/prof -name '*kernel_stats.csv' | head -1) $O/rocprofv3_kernel_sta
 head -6 $O/rocprofv3_kernel_trace_summary.txt
 timeout 300 python bench.py --no-cpu --chains 2 > $O/bench_chains2.json 2>/dev/null; cut -c1-250 $O/bench_chains2.json
 timeout 300 python bench.py --no-cpu --chains 3 > $O/bench_chains3.json 2>/dev/null; cut -c1-250 $O/bench_chains3.json
+timeout 300 python bench.py --no-cpu --chains 4 > $O/bench_chains4.json 2>/dev/null; cut -c1-250 $O/bench_chains4.json
 timeout 600 python bench.py --no-cpu --sparse > $O/bench_sparse.json 2>/dev/null; cut -c1-250 $O/bench_sparse.json
