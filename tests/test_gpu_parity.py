@@ -237,3 +237,27 @@ def test_gwcogaps_driver_on_the_gpu(hip_lib, gist):
     assert a.featureLoadings.shape == (480, k) and a.sampleFactors.shape == (9, k) and k >= 1
     assert np.allclose(cons.max(axis=0), 1.0) and not a.sampleFactors.any()        # the fixed side comes back zero, as in the reference
     assert len(a.metadata["diagnostics"]["unmatchedPatterns"]) == 4
+
+
+def test_bench_lines_small_workload():
+    """bench.py end to end on a small workload: the default line carries roofline + cpu_baseline (the oracle port timed on
+    the host), `--chains` and `--sparse` print their informational lines"""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    small = ["--genes", "3000", "--samples", "300", "--patterns", "8", "--steps", "16", "--warmup", "4"]
+
+    def line(extra):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + small + extra, cwd=root, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        js = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(js) == 1
+        return json.loads(js[0])
+    d = line(["--cpu-seconds", "2"])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["higher_is_better"] and d["dtype"] == "f32" and d["vs_baseline"] is None
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["traffic"] is None
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+    assert line(["--no-cpu", "--chains", "2"])["value"] > 0
+    s = line(["--no-cpu", "--sparse"])
+    assert s["value"] > 0 and "sparse" in s["config"]["workload"]
