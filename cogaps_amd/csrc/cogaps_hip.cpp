@@ -231,10 +231,14 @@ static void build_sampler(cogaps_session *s, HostSampler &h, char name, const fl
     d.alpha = alpha;
     d.lambda = alpha * sqrtf((float)(uint64_t)d.K / meanD);
     d.maxGibbsMass = maxGibbsMass / d.lambda;
-    float *dD = dalloc<float>(tot), *dS2 = dalloc<float>(tot); h.Sraw = dalloc<float>(tot);
-    rt_h2d(dD, D.data(), tot * 4, s->stream); rt_h2d(dS2, S2.data(), tot * 4, s->stream); rt_h2d(h.Sraw, SR.data(), tot * 4, s->stream);
+    // With the default uncertainty the evaluation kernel recomputes S*S = max(0.1 D, 0.1)^2 from the D value it loads anyway
+    // (bit-identical: the same three fp32 operations as the fill above): no S2 array, one row less per proposal from HBM.
+    // (COGAPS_READ_S: diagnostics, keeps the array and the loads.)
+    const bool defaultS = !sparse && unc == nullptr && !getenv("COGAPS_READ_S");
+    float *dD = dalloc<float>(tot), *dS2 = defaultS ? nullptr : dalloc<float>(tot); h.Sraw = dalloc<float>(tot);
+    rt_h2d(dD, D.data(), tot * 4, s->stream); if (dS2) rt_h2d(dS2, S2.data(), tot * 4, s->stream); rt_h2d(h.Sraw, SR.data(), tot * 4, s->stream);
     rt_sync(s->stream);
-    d.D = dD; d.S2 = dS2;
+    d.D = dD; d.S2 = dS2; d.defaultS = defaultS ? 1u : 0u;
     d.unitBytes = 4u * d.N;
     if (!sparse) d.AP = dalloc<float>(tot);
     else {

@@ -126,7 +126,16 @@ CG_DEVICE void eval_alpha(const SamplerDev &S, const uint32_t (&row)[NR], const 
         for (int r = 0; r < NR; ++r) {
             const float *Dr = S.D + (size_t)row[r] * S.Npad, *Sr = S.S2 + (size_t)row[r] * S.Npad, *Ar = S.AP + (size_t)row[r] * S.Npad;
             const float *Vr = S.other + (size_t)col[r] * S.Npad, *V2 = S.other + (size_t)col2 * S.Npad;
-            v[r] = ld4(Vr, j); d[r] = ld4_stream(Dr, j); s[r] = ld4_stream(Sr, j); p[r] = ld4(Ar, j); if (MODE == EVAL_MODE_SAME) w2 = ld4(V2, j);
+            v[r] = ld4(Vr, j); d[r] = ld4_stream(Dr, j); if (!S.defaultS) s[r] = ld4_stream(Sr, j); p[r] = ld4(Ar, j); if (MODE == EVAL_MODE_SAME) w2 = ld4(V2, j);
+        }
+        if (S.defaultS) {
+            // default uncertainty S = max(0.1 D, 0.1) (MatrixMath.cpp:74-84), S*S: the same three fp32 operations the host
+            // made when it filled S2, on the value just loaded -- one row less to bring in from HBM per proposal
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const float sx = gm_max(d[r].x * 0.1f, 0.1f), sy = gm_max(d[r].y * 0.1f, 0.1f), sz = gm_max(d[r].z * 0.1f, 0.1f), sw = gm_max(d[r].w * 0.1f, 0.1f);
+                s[r].x = sx * sx; s[r].y = sy * sy; s[r].z = sz * sz; s[r].w = sw * sw;
+            }
         }
 #pragma unroll
         for (int r = 0; r < NR; ++r) {

@@ -130,6 +130,7 @@ struct SamplerDev {
     float *Z1, *Z2;        // [K], column-major [K][K]
     float beta;
     uint32_t unitBytes;    // bytes per unit of queueUnits (4N with the dense model, 1 with the sparse one)
+    uint32_t defaultS;     // no uncertainty matrix was given: S2 = max(0.1 D, 0.1)^2 is recomputed from D instead of read
     GenScalars *gs;
     // ---- optional trace (parity tests) -------------------------------------------------------
     PropRec *trace;        // [traceCap] copies of queued proposals
