@@ -261,3 +261,28 @@ def test_bench_lines_small_workload():
     assert line(["--no-cpu", "--chains", "2"])["value"] > 0
     s = line(["--no-cpu", "--sparse"])
     assert s["value"] > 0 and "sparse" in s["config"]["workload"]
+
+
+def test_sccogaps_sparse_driver_on_the_gpu(hip_lib):
+    """scCoGAPS (cell-wise shards, subsetDim = 2) with sparseOptimization through the front-end: shards in flight give the bits
+    of one at a time; shard 0's first pass equals the oracle's chain on the same cell subset (SparseNormalModel)"""
+    import pyoracle as po
+    from cogaps_amd import scCoGAPS, CogapsParams
+    data = pu.synthetic_counts(120, 90, zeros=0.8, seed=3)
+
+    def go(workers):
+        p = CogapsParams(nPatterns=3, seed=11, nIterations=50, sparseOptimization=True)
+        p.distributed = "single-cell"
+        p.setDistributedParams(nSets=3, minNS=2)
+        p.explicitSets = [list(range(1 + 30 * i, 31 + 30 * i)) for i in range(3)]
+        return scCoGAPS(data, p, messages=False, outputFrequency=10, BPPARAM=workers)
+    a, b = go(3), go(1)
+    assert np.array_equal(a.sampleFactors, b.sampleFactors) and np.array_equal(a.featureLoadings, b.featureLoadings)
+    diag = a.metadata["diagnostics"]
+    k = diag["consensus"].shape[1]
+    assert a.sampleFactors.shape == (90, k) and a.featureLoadings.shape == (120, k) and not a.featureLoadings.any()
+    # shard 0 = cells 1..30: the A sampler sees data vectors of 30 cells, the P sampler of 120 genes
+    o = po.run(data, nPatterns=3, nIterations=50, seed=11, outputFrequency=10, math_mode=po.MATH_PORTABLE, sparseOptimization=True,
+               redW_A=hip_lib.cogaps_reduction_width(30), redW_P=hip_lib.cogaps_reduction_width(120), redG=4,
+               subsetIndices=np.arange(1, 31, dtype=np.uint32), subsetDim=2)
+    assert np.array_equal(o["Amean"], diag["unmatchedPatterns"][0])
