@@ -286,3 +286,19 @@ def test_sccogaps_sparse_driver_on_the_gpu(hip_lib):
                redW_A=hip_lib.cogaps_reduction_width(30), redW_P=hip_lib.cogaps_reduction_width(120), redG=4,
                subsetIndices=np.arange(1, 31, dtype=np.uint32), subsetDim=2)
     assert np.array_equal(o["Amean"], diag["unmatchedPatterns"][0])
+
+
+def test_distributed_with_transposed_input(hip_lib, gist):
+    """transposeData: the gene-wise shards of a samples x genes file are its column blocks (SubsetData.R:85-116); the
+    result is the one of the untransposed run"""
+    from cogaps_amd import GWCoGAPS, CogapsParams
+
+    def go(data, transpose):
+        p = CogapsParams(nPatterns=3, seed=5, nIterations=40)
+        p.distributed = "genome-wide"
+        p.setDistributedParams(nSets=3, minNS=2)
+        p.explicitSets = [list(range(1 + 100 * i, 101 + 100 * i)) for i in range(3)]
+        return GWCoGAPS(data, p, messages=False, outputFrequency=10, transposeData=transpose)
+    a, b = go(gist[:300], False), go(np.ascontiguousarray(gist[:300].T), True)
+    assert np.array_equal(a.featureLoadings, b.featureLoadings) and np.array_equal(a.loadingStdDev, b.loadingStdDev)
+    assert np.array_equal(a.metadata["diagnostics"]["consensus"], b.metadata["diagnostics"]["consensus"])
