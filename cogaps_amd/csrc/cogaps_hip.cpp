@@ -839,18 +839,19 @@ int cogaps_session_debug_replay(cogaps_session *s, char which, int kind, uint32_
     {   // arm a fresh update of 4096 steps and generate one batch so that the queue is populated
         read_gs(s, h);
         GenScalars g = *s->hGs;
-        if (h.seedCap < 4096) { rt_free(h.seeds); h.seedCap = 8192; h.seeds = dalloc<uint64_t>(h.seedCap); }
-        std::vector<uint64_t> sd(4096); for (auto &x : sd) x = s->seeder.next();
+        const uint32_t steps = kind >= 2 ? 65536u : 4096u;       // kinds 2 (generator alone) / 3 (pairs) run many real batches
+        if (h.seedCap < steps) { rt_free(h.seeds); h.seedCap = 2u * steps; h.seeds = dalloc<uint64_t>(h.seedCap); }
+        std::vector<uint64_t> sd(steps); for (auto &x : sd) x = s->seeder.next();
         rt_h2d(h.seeds, sd.data(), sd.size() * 8, s->stream); h.d.seeds = h.seeds;
-        g.nSteps = 4096; g.nDone = 0; g.updateFlushed = 0; g.qlen = 0; g.traceOn = 0;
+        g.nSteps = steps; g.nDone = 0; g.updateFlushed = 0; g.qlen = 0; g.traceOn = 0;
         *s->hGs = g; rt_h2d(h.d.gs, s->hGs, sizeof(GenScalars), s->stream);
         launch_gen(s, h);
-        if (kind == 0) launch_eval(s, h);
+        if (kind == 0 || kind == 3) launch_eval(s, h);
     }
     rt_sync(s->stream);
     h.d.dbg = dbgFlags;
     const double t0 = now_s();
-    for (uint32_t i = 0; i < n; ++i) { if (kind == 0) { launch_gen(s, h); launch_eval(s, h); } else launch_eval(s, h); }
+    for (uint32_t i = 0; i < n; ++i) { if (kind == 0 || kind == 3) { launch_gen(s, h); launch_eval(s, h); } else if (kind == 2) launch_gen(s, h); else launch_eval(s, h); }
     rt_sync(s->stream);
     *usPerLaunch = 1e6 * (now_s() - t0) / (double)n;
     h.d.dbg = 0;
