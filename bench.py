@@ -80,7 +80,7 @@ def chains_main(args):
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
     from cogaps_amd import _capi
     K, W, C = args.steps, args.warmup, args.chains
-    n_iter = (W + K + 1) // 2
+    n_iter = max(100, (W + K + 1) // 2)
     params = dict(nPatterns=args.patterns, nIterations=n_iter, seed=42, outputFrequency=max(1, n_iter // 10))
     S = [_capi.Session(synthetic_dense(args.genes, args.samples, seed=12345 + c), device=0, **params) for c in range(C)]
     upd = [0] * C
@@ -101,10 +101,13 @@ def chains_main(args):
         for t in th:
             t.join()
         return time.perf_counter() - t0
-    phase(0, W)
+    burn = max(0, 2 * n_iter - (W + K))      # as in main(): the timed steps are the last K of the schedule
+    if burn:
+        phase(0, burn)
+    phase(burn, W)
     upd = [0] * C
     torch.cuda.synchronize()
-    dt = phase(W, K)
+    dt = phase(burn + W, K)
     print(json.dumps({"metric": METRIC + " [informational: %d chains in flight on one GPU]" % C, "value": sum(upd) / dt, "unit": "proposals/s",
                       "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak",
                       "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -160,7 +163,9 @@ def main():
     from cogaps_amd import _capi
 
     K, W = args.steps, args.warmup
-    n_iter = (W + K + 1) // 2
+    # the chain is BASELINE's: nIterations = 100 equilibration + 100 sampling iterations; a step is one iteration, and the W + K
+    # steps walk through that schedule from its start, whatever K is (the defaults cover it exactly; a longer request extends it)
+    n_iter = max(100, (W + K + 1) // 2)
     # shard `rank` of the gene-wise partition: its own 20000-gene block (contiguous explicit sets)
     data = synthetic_dense(args.genes, args.samples, seed=12345 + rank)
     if args.sparse:     # the same product, 95 % of the entries zeroed i.i.d.
@@ -181,14 +186,20 @@ def main():
             done += m
         return upd
 
-    run_steps(0, W)
+    # The timed steps are the LAST K iterations of the schedule, the W before them the warm-up: with the defaults that is the
+    # whole BASELINE run but its first ten iterations.  A shorter request (--steps 5) first walks, untimed, through the part of
+    # the schedule that precedes them, so that it measures the named configuration's populated chain and not the first
+    # iterations of an empty one (a few dozen atoms, batches of three proposals).
+    burn = max(0, 2 * n_iter - (W + K))
+    run_steps(0, burn)
+    run_steps(burn, W)
     perf0 = {w: S.perf(w) for w in "AP"}
     S.set_timing(True)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    updates = run_steps(W, K)
+    updates = run_steps(burn + W, K)
     if dist is not None:
         # the one exchange of the GWCoGAPS path: all-gather of the shared-dimension factor
         fac = torch.from_numpy(S.matrix("P")).to(comm_dev)
@@ -251,7 +262,7 @@ def main():
             "config": {"workload": ("synthetic sparse %dx%d fp32 per GPU (95 %% zeros), sparseOptimization, nPatterns=%d, asynchronous sampler, seed 42 (cf. BASELINE configs[4]%s)"
                                     if args.sparse else "synthetic dense %dx%d fp32 per GPU, nPatterns=%d, asynchronous sampler, seed 42 (BASELINE configs[2]%s)")
                                    % (args.genes, args.samples, args.patterns, "; GWCoGAPS nSets=%d gene-wise shards, configs[3]" % world if world > 1 else ""),
-                       "nIterations": n_iter, "proposals_timed": int(tot_updates), "batches_rank0": int(batches),
+                       "nIterations": n_iter, "untimed_schedule_steps_before_warmup": burn, "proposals_timed": int(tot_updates), "batches_rank0": int(batches),
                        "avg_queue_A": S.avg_queue("A"), "avg_queue_P": S.avg_queue("P"),
                        "atoms_A": S.natoms("A"), "atoms_P": S.natoms("P"),
                        "gen_kernel_ms_rank0": gen_ms, "eval_kernel_ms_rank0": ev_ms,
