@@ -45,30 +45,35 @@ def cpu_baseline(data, params, budget_s):
     """The oracle (oracle/gaps_oracle.c: OpenMP over the queue exactly like the reference's
     `#pragma omp parallel for`, sequential fp32 reductions + libm = the reference's scalar build) timed on
     this host on the first iterations of the SAME chain.  A batch holds only ~50-160 proposals, so more
-    threads than that only add fork/join cost: a few thread counts share the time budget and the best
+    threads than that only add fork/join cost: two thread counts share the time budget and the best
     rate is reported (cores = the thread count that produced it)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
     ncpu = os.cpu_count() or 1
-    cands = sorted({min(ncpu, c) for c in (8, 16, 32, 64)})
+    cands = sorted({min(ncpu, c) for c in (8, 16)})      # (32 and 64 threads never won on the 256-core hosts of the pool: fork/join cost)
     n_iter = params["nIterations"]
     best = None
     for threads in cands:
         O = po.Session(data, omp=True, maxThreads=threads, math_mode=po.MATH_LIBM, redW_A=1, redW_P=1, redG=1, **params)
-        props, it, t0 = 0, 0, time.time()
+        props, it, t0, marks = 0, 0, time.time(), [(0, 0.0)]
         while it < n_iter and time.time() - t0 < budget_s / len(cands):
             O.set_annealing(min(1.0, 2.0 * it / n_iter))
             nA, nP = O.draw_steps()
             O.iterate(nA, nP)
             props += nA + nP
             it += 1
+            marks.append((props, time.time() - t0))
         dt = time.time() - t0
         O.close()
-        rate = props / dt
+        # the chain fills up as it goes (longer batches, more work per OpenMP region): the rate over the last third of the
+        # sampled iterations is the fairest this bounded sample can be to the CPU; the whole-sample rate is quoted too
+        p0, s0 = marks[(2 * it) // 3]
+        rate = (props - p0) / max(dt - s0, 1e-9)
         if best is None or rate > best["value"]:
             best = {"value": rate, "unit": "proposals/s", "cores": threads, "kind": "port", "host_cpus": ncpu,
-                    "sample": "first %d equilibration iterations of the same chain (%d proposals, %.1f s); best of OMP threads %s"
-                              % (it, props, dt, cands)}
+                    "sample": "iterations %d-%d of the same chain (%d proposals, %.1f s; the whole sample, iterations 1-%d: %d proposals, "
+                              "%.1f s, %.3g proposals/s); best of OMP threads %s"
+                              % ((2 * it) // 3 + 1, it, props - p0, dt - s0, it, props, dt, props / dt, cands)}
     return best
 
 
