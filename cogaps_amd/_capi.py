@@ -29,7 +29,8 @@ class CogapsParamsC(C.Structure):
         ("whichMatrixFixed", C.c_char), ("fixedPatterns", C.POINTER(C.c_float)),
         ("fixedRows", C.c_uint32), ("workerID", C.c_uint32), ("runningDistributed", C.c_int32),
         ("device", C.c_int32), ("interrupt", INTERRUPT_FN), ("interruptArg", C.c_void_p),
-        ("snapshotPhase", C.c_int32),
+        ("snapshotPhase", C.c_int32), ("pumpThreshold", C.c_int32), ("fixedCols", C.c_int32),
+        ("reductionMode", C.c_int32), ("mathMode", C.c_int32),
     ]
 
 
@@ -75,8 +76,14 @@ EXPORTS = [
     "cogaps_session_get_atoms", "cogaps_session_dims", "cogaps_session_avg_queue",
     "cogaps_session_finish", "cogaps_session_set_timing", "cogaps_session_perf",
     "cogaps_session_perf_sampler", "cogaps_session_get_rows", "cogaps_sparse_width", "cogaps_reduction_width", "cogaps_session_debug_prof", "cogaps_session_debug_replay",
-    "cogaps_run_from_file", "cogaps_read_matrix_file", "cogaps_matrix_free", "cogaps_file_info",
+    "cogaps_run_from_file", "cogaps_read_matrix_file", "cogaps_matrix_free", "cogaps_file_info", "cogaps_debug_math",
 ]
+
+REDUCE_LANES, REDUCE_SEQ = 0, 1                              # cogaps_params.reductionMode
+MATH_PORTABLE, MATH_GLIBC_FMA, MATH_GLIBC_SSE2 = 0, 1, 2     # cogaps_params.mathMode
+_REDUCE = {"lanes": REDUCE_LANES, "seq": REDUCE_SEQ}
+_MATH = {"portable": MATH_PORTABLE, "glibc-fma": MATH_GLIBC_FMA, "glibc-sse2": MATH_GLIBC_SSE2}
+_PUMP = {"unique": 0, "cut": 1}
 
 
 def bind(L):
@@ -122,6 +129,7 @@ def bind(L):
     L.cogaps_matrix_free.argtypes = [fp]
     L.cogaps_matrix_free.restype = None
     L.cogaps_file_info.argtypes = [C.c_char_p, u32p, u32p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.cogaps_debug_math.argtypes = [C.c_int, C.c_int, fp, fp, C.c_uint32, C.c_int]
     return L
 
 
@@ -149,7 +157,8 @@ def make_params(L, nPatterns=3, nIterations=1000, seed=0, outputFrequency=500, n
                 transposeData=False, subsetIndices=None, subsetDim=0, whichMatrixFixed="N",
                 fixedPatterns=None, sparseOptimization=False, asynchronousUpdates=True,
                 messages=False, workerID=1, device=-1, takePumpSamples=False,
-                checkpointInterval=0, nSnapshots=0, snapshotPhase="sampling", snapshotFrequency=None):
+                checkpointInterval=0, nSnapshots=0, snapshotPhase="sampling", snapshotFrequency=None,
+                pumpThreshold="unique", reductionMode="lanes", mathMode="portable"):
     p = CogapsParamsC()
     L.cogaps_default_params(C.byref(p))
     p.nPatterns, p.nIterations, p.seed = int(nPatterns), int(nIterations), int(seed)
@@ -167,6 +176,9 @@ def make_params(L, nPatterns=3, nIterations=1000, seed=0, outputFrequency=500, n
     p.snapshotPhase = {"all": 0, "equilibration": 1, "sampling": 2}[snapshotPhase] if isinstance(snapshotPhase, str) else int(snapshotPhase)
     p.workerID = int(workerID)
     p.device = int(device)
+    p.pumpThreshold = _PUMP[pumpThreshold] if isinstance(pumpThreshold, str) else int(pumpThreshold)
+    p.reductionMode = _REDUCE[reductionMode] if isinstance(reductionMode, str) else int(reductionMode)
+    p.mathMode = _MATH[mathMode] if isinstance(mathMode, str) else int(mathMode)
     keep = []
     if subsetIndices is not None and subsetDim > 0:
         idx = np.ascontiguousarray(subsetIndices, dtype=np.uint32)
@@ -180,8 +192,11 @@ def make_params(L, nPatterns=3, nIterations=1000, seed=0, outputFrequency=500, n
     if fixedPatterns is not None and whichMatrixFixed != "N":
         fx = np.ascontiguousarray(fixedPatterns, dtype=np.float32)
         keep.append(fx)
+        if fx.ndim != 2 or fx.shape[1] != int(nPatterns):
+            raise ValueError("fixedPatterns must have nPatterns = %d columns" % int(nPatterns))
         p.fixedPatterns = _fp(fx)
         p.fixedRows = fx.shape[0]
+        p.fixedCols = fx.shape[1]
     p._keep = keep
     return p
 
@@ -400,3 +415,13 @@ def run(data, unc=None, lib=None, **kw):
     if rc:
         raise RuntimeError("cogaps_run: " + L.cogaps_last_error().decode())
     return result_to_dict(L, r)
+
+
+def debug_math(fn, x, mathMode="portable", on_device=False, lib=None):
+    """logf (fn = "log") / expf ("exp") in a math mode of the library, on the device or from the same source on the host"""
+    L = lib if lib is not None else load()
+    xs = np.ascontiguousarray(x, dtype=np.float32)
+    ys = np.zeros_like(xs)
+    if L.cogaps_debug_math({"log": 0, "exp": 1}[fn], _MATH[mathMode] if isinstance(mathMode, str) else int(mathMode), _fp(xs), _fp(ys), xs.size, int(on_device)):
+        raise RuntimeError(L.cogaps_last_error().decode())
+    return ys

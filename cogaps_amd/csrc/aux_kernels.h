@@ -80,6 +80,50 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(1024) chisq_rows_kernel_s(SamplerDev S, const fl
     if (t == 0) partial[row] = tot[0];
 }
 
+// ---- verification mode (reference order) --------------------------------------------------------------------------------
+// acc + f(0) + f(1) + ... + f(total-1), added left to right by thread 0 (the result is valid there); the terms are computed
+// by the whole workgroup, SEQ_CHUNK at a time through LDS.
+#define SEQ_CHUNK 4096
+template <class F>
+CG_DEVICE float seq_sum(float acc, uint64_t total, float *lds, F f)
+{
+    const uint32_t t = cg_tid(), BS = cg_bdim();
+    for (uint64_t base = 0; base < total; base += SEQ_CHUNK) {
+        const uint32_t n = (total - base) < (uint64_t)SEQ_CHUNK ? (uint32_t)(total - base) : (uint32_t)SEQ_CHUNK;
+        for (uint32_t i = t; i < n; i += BS) lds[i] = f(base + i);
+        cg_sync();
+        if (t == 0) for (uint32_t i = 0; i < n; ++i) acc = acc + lds[i];
+        cg_sync();
+    }
+    return acc;
+}
+// DenseNormalModel::chiSq (DenseNormalModel.cpp:56-68) in its own order: element index outer, vector inner, one accumulator
+CG_KERNEL void CG_LAUNCH_BOUNDS(256) chisq_seq_kernel(SamplerDev S, const float *Sraw, float *out)
+{
+    CG_SHARED float lds[SEQ_CHUNK];
+    const uint32_t M = S.M;
+    const float c = seq_sum(0.f, (uint64_t)M * S.N, lds, [&](uint64_t e) {
+        const uint32_t i = (uint32_t)(e / M), j = (uint32_t)(e % M);
+        const size_t o = (size_t)j * S.Npad + i;
+        const float q = (S.D[o] - S.AP[o]) / Sraw[o];
+        return q * q; });
+    if (cg_tid() == 0) out[0] = c;
+}
+// GapsStatistics::meanChiSq (GapsStatistics.cpp:63-86) in its own order: genes outer, samples inner
+CG_KERNEL void CG_LAUNCH_BOUNDS(256) mean_chisq_seq_kernel(SamplerDev P, const float *Sraw, const float *Asum, const float *Psum, uint32_t AMpad, float n2, float *out)
+{
+    CG_SHARED float lds[SEQ_CHUNK];
+    const uint32_t M = P.M;
+    const float c = seq_sum(0.f, (uint64_t)M * P.N, lds, [&](uint64_t e) {
+        const uint32_t i = (uint32_t)(e / M), j = (uint32_t)(e % M);
+        float m = 0.f;
+        for (uint32_t k = 0; k < P.K; ++k) m = m + Asum[(size_t)k * AMpad + i] * Psum[(size_t)k * P.Mpad + j];
+        m = m / n2;
+        const float d = P.D[(size_t)j * P.Npad + i], sd = Sraw[(size_t)j * P.Npad + i];
+        return ((d - m) * (d - m)) / (sd * sd); });
+    if (cg_tid() == 0) out[0] = c;
+}
+
 // GapsStatistics::update / updateA / updateP (GapsStatistics.h:130-185), one workgroup per pattern.
 // sums are column-major like `mat`: [K][Mpad].  mode: 0 = both (norm = max P column), 1 = A only
 // (norm 1), 2 = P only (norm 1).

@@ -135,6 +135,8 @@ extern "C" uint32_t cogaps_sparse_width(uint32_t N)
                          case 4: RT_LAUNCH(KERNEL<4>, grid, bs_, stream, __VA_ARGS__); break; case 8: RT_LAUNCH(KERNEL<8>, grid, bs_, stream, __VA_ARGS__); break; \
                          default: RT_LAUNCH(KERNEL<16>, grid, bs_, stream, __VA_ARGS__); break; } } while (0)
 
+static const uint32_t SEQ_SPARSE_GRID = 256;      // workgroups of the sparse model's verification-mode evaluation (one scratch region each)
+
 // ------------------------------------------------------------------------------------------------
 struct HostSampler {
     SamplerDev d;                 // device pointers + constants (passed by value to the kernels)
@@ -187,6 +189,7 @@ template <class T> static T *dalloc(size_t n) { return (T *)rt_malloc(n * sizeof
 static void free_sampler(HostSampler &h)
 {
     SamplerDev &d = h.d;
+    rt_free(d.seqScratch);
     rt_free((void *)d.D); rt_free((void *)d.S2); rt_free(d.AP); rt_free(d.mat); rt_free(d.colPos);
     rt_free(d.atoms); rt_free(d.vec); rt_free(d.freeHandles); rt_free(d.binHead);
     rt_free(d.bits0); rt_free(d.bits1); rt_free(d.bits2); rt_free(d.eraseList); rt_free(d.queue); rt_free(d.queueUnits); rt_free(d.partials);
@@ -209,6 +212,7 @@ static void build_sampler(cogaps_session *s, HostSampler &h, char name, const fl
     SamplerDev &d = h.d; memset(&d, 0, sizeof(d)); h.name = name;
     const bool sparse = p.useSparseOptimization != 0;
     d.N = nG; d.M = nS; d.K = p.nPatterns;
+    d.seq = p.reductionMode == COGAPS_REDUCE_SEQ ? 1u : 0u; d.mathMode = (uint32_t)p.mathMode;
     d.Npad = (d.N + 3u) & ~3u; d.Mpad = (d.M + 3u) & ~3u;
     d.redW = cogaps_reduction_width(d.N);
     const size_t tot = (size_t)d.M * d.Npad;
@@ -263,6 +267,10 @@ static void build_sampler(cogaps_session *s, HostSampler &h, char name, const fl
         d.rows = dalloc<float>((size_t)d.M * d.Kpad);
         d.mflags = dalloc<unsigned long long>((size_t)d.K * d.Mw);
         d.Z1 = dalloc<float>(d.K); d.Z2 = dalloc<float>((size_t)d.K * d.K);
+        if (d.seq) {
+            if (d.Wn > (uint32_t)SP_SEQ_WORDS) throw std::runtime_error("reductionMode SEQ with the sparse model supports data vectors of up to 262080 elements");
+            d.seqScratch = dalloc<float>((size_t)SEQ_SPARSE_GRID * 3u * d.Npad);
+        }
     }
     d.mat = dalloc<float>((size_t)d.K * d.Mpad);
     d.colPos = dalloc<uint32_t>(d.K);
@@ -356,7 +364,11 @@ static void launch_gen(cogaps_session *s, HostSampler &h)
 static void launch_eval(cogaps_session *s, HostSampler &h)
 {
     const int slot = timing_slot(s, h, 1, h.evalLaunches);
-    if (h.d.sparse) {
+    if (h.d.seq) {
+        // verification mode: one workgroup per proposal whatever the vector length, sums in the reference's order
+        if (h.d.sparse) LAUNCH_MAYBE_TIMED(slot, eval_sparse_seq_kernel, std::min<uint32_t>(h.d.queueCap, SEQ_SPARSE_GRID), cogaps_sparse_width(h.d.N), h.d);
+        else LAUNCH_MAYBE_TIMED(slot, eval_kernel<EVAL_SEQ>, std::min<uint32_t>(h.d.queueCap, 512u), EVAL_SEQ_BS, h.d, 1u);
+    } else if (h.d.sparse) {
         const uint32_t grid = std::min<uint32_t>(h.d.queueCap, 1024u);
         LAUNCH_MAYBE_TIMED(slot, eval_sparse_kernel, grid, cogaps_sparse_width(h.d.N), h.d);
     } else if (h.d.redW <= 1024u) {
@@ -461,7 +473,8 @@ static void do_sync(cogaps_session *s, HostSampler &dst, HostSampler &src)
 {
     if (dst.d.sparse) {     // SparseNormalModel::sync = generateLookupTables (SparseNormalModel.cpp:27-31, 294-311)
         const uint32_t K = dst.d.K;
-        LAUNCH_V(sparse_tables_kernel, dst.d.redW, K + K * (K + 1u) / 2u, s->stream, dst.d);
+        if (dst.d.seq) RT_LAUNCH(sparse_tables_seq_kernel, K + K * (K + 1u) / 2u, 256, s->stream, dst.d);
+        else LAUNCH_V(sparse_tables_kernel, dst.d.redW, K + K * (K + 1u) / 2u, s->stream, dst.d);
         return;
     }
     const uint32_t tilesX = (src.d.N + TR_TILE - 1) / TR_TILE, tilesY = (src.d.M + TR_TILE - 1) / TR_TILE;
@@ -470,6 +483,13 @@ static void do_sync(cogaps_session *s, HostSampler &dst, HostSampler &src)
 
 static float chisq_of(cogaps_session *s, HostSampler &h)
 {
+    if (h.d.seq) {      // the reference's order: one accumulator over the whole matrix, on the device
+        if (h.d.sparse) RT_LAUNCH(chisq_sparse_seq_kernel, 1, 256, s->stream, h.d, h.partial);
+        else RT_LAUNCH(chisq_seq_kernel, 1, 256, s->stream, h.d, (const float *)h.Sraw, h.partial);
+        float c = 0.f;
+        rt_d2h(&c, h.partial, 4, s->stream); rt_sync(s->stream);
+        return h.d.sparse ? c * h.d.beta : c;
+    }
     if (h.d.sparse) LAUNCH_V(chisq_sparse_kernel, h.d.redW, h.d.M, s->stream, h.d, h.partial);
     else LAUNCH_V(chisq_rows_kernel_s, h.d.redW, h.d.M, s->stream, h.d, (const float *)h.Sraw, h.partial);
     std::vector<float> part(h.d.M);
@@ -479,7 +499,29 @@ static float chisq_of(cogaps_session *s, HostSampler &h)
     return h.d.sparse ? c * h.d.beta : c;
 }
 
+CG_KERNEL void debug_math_kernel(int fn, uint32_t mode, const float *x, float *y, uint32_t n)
+{
+    const uint32_t i = cg_bid() * cg_bdim() + cg_tid();
+    if (i < n) y[i] = fn ? gm_expf_m(x[i], mode) : gm_logf_m(x[i], mode);
+}
+
 extern "C" {
+
+int cogaps_debug_math(int fn, int mathMode, const float *x, float *y, uint32_t n, int on_device)
+{
+    try {
+        if (mathMode < COGAPS_MATH_PORTABLE || mathMode > COGAPS_MATH_GLIBC_SSE2 || (fn != 0 && fn != 1)) return fail("bad function or math mode");
+        if (!on_device) { for (uint32_t i = 0; i < n; ++i) y[i] = fn ? gm_expf_m(x[i], (uint32_t)mathMode) : gm_logf_m(x[i], (uint32_t)mathMode); return 0; }
+        rt_stream_t st = rt_stream_create();
+        rt_alloc_scope allocOn(st);
+        float *dx = dalloc<float>(n), *dy = dalloc<float>(n);
+        rt_h2d(dx, x, (size_t)n * 4, st);
+        RT_LAUNCH(debug_math_kernel, (n + 255u) / 256u, 256, st, fn, (uint32_t)mathMode, (const float *)dx, dy, n);
+        rt_d2h(y, dy, (size_t)n * 4, st); rt_sync(st);
+        rt_free(dx); rt_free(dy); rt_stream_destroy(st);
+        return 0;
+    } catch (const std::exception &e) { return fail(e.what()); }
+}
 
 void cogaps_default_params(cogaps_params *p)
 {
@@ -508,6 +550,18 @@ cogaps_session *cogaps_session_create(const float *data, uint32_t nrow, uint32_t
         if (!p.asynchronousUpdates) { fail("asynchronousUpdates=FALSE (SingleThreadedGibbsSampler) is not part of this library"); return nullptr; }
         if (p.nPatterns == 0 || nrow == 0 || ncol == 0) { fail("empty problem"); return nullptr; }
         if (p.whichMatrixFixed != 'N' && p.whichMatrixFixed != 'A' && p.whichMatrixFixed != 'P') { fail("whichMatrixFixed must be 'N', 'A' or 'P'"); return nullptr; }
+        if (p.reductionMode != COGAPS_REDUCE_LANES && p.reductionMode != COGAPS_REDUCE_SEQ) { fail("reductionMode must be COGAPS_REDUCE_LANES or COGAPS_REDUCE_SEQ"); return nullptr; }
+        if (p.mathMode < COGAPS_MATH_PORTABLE || p.mathMode > COGAPS_MATH_GLIBC_SSE2) { fail("mathMode must be COGAPS_MATH_PORTABLE, _GLIBC_FMA or _GLIBC_SSE2"); return nullptr; }
+        if (p.mathMode != COGAPS_MATH_PORTABLE && p.reductionMode != COGAPS_REDUCE_SEQ) { fail("mathMode other than COGAPS_MATH_PORTABLE needs reductionMode COGAPS_REDUCE_SEQ (the verification mode)"); return nullptr; }
+        if (p.pumpThreshold != 0 && p.pumpThreshold != 1) { fail("pumpThreshold must be 0 (PUMP_UNIQUE) or 1 (PUMP_CUT)"); return nullptr; }
+        if (p.whichMatrixFixed != 'N' && p.fixedCols != 0 && (uint32_t)p.fixedCols != p.nPatterns) { fail("fixedPatterns must have nPatterns columns"); return nullptr; }
+        if (p.subsetData && p.dataIndicesSubset) {
+            // 1-based indices into the subset dimension (Matrix.cpp:55-62): genes are the rows of the data unless transposeData
+            const uint32_t dim = (p.subsetGenes != 0) == (p.transposeData == 0) ? nrow : ncol;
+            if (p.nSubset == 0) { fail("dataIndicesSubset is empty"); return nullptr; }
+            for (uint32_t i = 0; i < p.nSubset; ++i)
+                if (p.dataIndicesSubset[i] < 1u || p.dataIndicesSubset[i] > dim) { fail("dataIndicesSubset holds an index outside 1 .. " + std::to_string(dim)); return nullptr; }
+        }
         rt_set_device(p.device);
         s = new cogaps_session();
         s->p = p;
@@ -801,11 +855,16 @@ int cogaps_session_finish(cogaps_session *s, cogaps_result *out)
     out->meanChiSq = 0.f;                                                             // GapsRunner.cpp:478-484
     if (s->p.whichMatrixFixed == 'N' && s->statUpdates > 0) {
         const float n2 = (float)s->statUpdates * (float)s->statUpdates;
+        if (s->P.d.seq) {
+            RT_LAUNCH(mean_chisq_seq_kernel, 1, 256, s->stream, s->P.d, (const float *)s->P.Sraw, (const float *)s->Asum, (const float *)s->Psum, s->A.d.Mpad, n2, s->P.partial);
+            rt_d2h(&out->meanChiSq, s->P.partial, 4, s->stream); rt_sync(s->stream);
+        } else {
         LAUNCH_V(mean_chisq_rows_kernel, s->P.d.redW, s->P.d.M, s->stream, s->P.d, (const float *)s->P.Sraw, (const float *)s->Asum, (const float *)s->Psum, s->A.d.Mpad, n2, s->P.partial);
         std::vector<float> part(s->P.d.M);
         rt_d2h(part.data(), s->P.partial, (size_t)s->P.d.M * 4, s->stream); rt_sync(s->stream);
         float c = 0.f; for (uint32_t j = 0; j < s->P.d.M; ++j) c += part[j];
         out->meanChiSq = c;
+        }
     }
     if (s->p.takePumpSamples) {                                                       // GapsRunner.cpp:487-492, GapsStatistics.cpp:113-131
         const size_t na = (size_t)s->nGenes * K;

@@ -169,6 +169,61 @@ CG_DEVICE void eval_alpha(const SamplerDev &S, const uint32_t (&row)[NR], const 
     }
 }
 
+// ---- verification mode: the reference's scalar order ------------------------------------------------------------------
+// The reference's default build sums i = 0 .. N-1 into one accumulator (SIMD.h:36-47 with SIMD_INC = 1).  The element
+// terms are computed by the whole workgroup (4 * BS at a time, parked in LDS) and folded by one thread per component in
+// index order, so a sum costs N dependent additions: slow by design, bit-identical to the scalar reference build.
+#define EVAL_SEQ_BS 256
+// acc + term[0] + term[1] + ... + term[n-1], left to right
+CG_DEVICE float eval_seq_fold(float acc, const float *term, uint32_t n)
+{
+    for (uint32_t i = 0; i < n; ++i) acc = acc + term[i];
+    return acc;
+}
+// tot = {s, s_mu} per row (every thread of the workgroup receives them).  term: LDS [2*NR][4*BS]; lds: [2*NR] broadcast
+template <int NR, int MODE>
+CG_DEVICE void eval_alpha_seq(const SamplerDev &S, const uint32_t (&row)[NR], const uint32_t (&col)[NR], uint32_t col2, float ch, float *term, float *lds, float (&tot)[2 * NR])
+{
+    constexpr int NC = 2 * NR;
+    const uint32_t nq = S.Npad >> 2, BS = cg_bdim(), t = cg_tid();
+    float acc = 0.f;                          // thread c < NC owns component c
+    for (uint32_t base = 0; base < nq; base += BS) {
+        const uint32_t j = base + t;
+        if (j < nq) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const float *Dr = S.D + (size_t)row[r] * S.Npad, *Ar = S.AP + (size_t)row[r] * S.Npad;
+                const float *Vr = S.other + (size_t)col[r] * S.Npad, *V2 = S.other + (size_t)col2 * S.Npad;
+                const cg_f4 v4 = ld4(Vr, j), d4 = ld4(Dr, j), p4 = ld4(Ar, j);
+                cg_f4 s4, w4 = f4_zero();
+                if (S.defaultS) {
+                    const float sx = gm_max(d4.x * 0.1f, 0.1f), sy = gm_max(d4.y * 0.1f, 0.1f), sz = gm_max(d4.z * 0.1f, 0.1f), sw = gm_max(d4.w * 0.1f, 0.1f);
+                    s4.x = sx * sx; s4.y = sy * sy; s4.z = sz * sz; s4.w = sw * sw;
+                } else s4 = ld4(S.S2 + (size_t)row[r] * S.Npad, j);
+                if (MODE == EVAL_MODE_SAME) w4 = ld4(V2, j);
+                const float vv[4] = {v4.x, v4.y, v4.z, v4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w}, pp[4] = {p4.x, p4.y, p4.z, p4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = (MODE == EVAL_MODE_SAME) ? vv[e] - ww[e] : vv[e];
+                    const float ratio = v / ss[e];
+                    const float ap = (MODE == EVAL_MODE_CH) ? pp[e] + ch * vv[e] : pp[e];
+                    term[(2 * r) * 4u * BS + 4u * t + (uint32_t)e] = v * ratio;
+                    term[(2 * r + 1) * 4u * BS + 4u * t + (uint32_t)e] = ratio * (dd[e] - ap);
+                }
+            }
+        }
+        cg_sync();
+        const uint32_t first = 4u * base, n = (S.N - first) < 4u * BS ? (S.N - first) : 4u * BS;     // real elements only
+        if (t < (uint32_t)NC) acc = eval_seq_fold(acc, term + t * 4u * BS, n);
+        cg_sync();
+    }
+    if (t < (uint32_t)NC) lds[t] = acc;
+    cg_sync();
+#pragma unroll
+    for (int c = 0; c < NC; ++c) tot[c] = lds[c];
+    cg_sync();
+}
+
 // DenseNormalModel.cpp:243-258: AP[:,row] += delta * other[:,col]
 // over the chunks chunk0 + t, + stride, ... (a whole row in the fused kernel, one slice in the split one)
 CG_DEVICE void eval_update_ap(const SamplerDev &S, uint32_t row, uint32_t col, float delta, uint32_t chunk0, uint32_t stride)
@@ -231,6 +286,7 @@ CG_DEVICE void eval_domain_move(const SamplerDev &S, uint32_t h, uint64_t oldPos
 #define EVAL_FUSED 0     // one workgroup per proposal: alpha, decision, update
 #define EVAL_ALPHA 1     // split evaluation, first kernel: `slices` workgroups per proposal, per-slice alpha partials
 #define EVAL_APPLY 2     // split evaluation, second kernel: combine the partials, decide, update the slice
+#define EVAL_SEQ 3       // verification mode: one workgroup per proposal, sums in the reference's scalar order, session math mode
 
 // The split form serves data vectors of more than 4096 elements (W > 1024 virtual lanes): one workgroup can pull a
 // row no faster than its compute unit's ~64 B/clk, so the row is cut into slices of 1024 chunks, one workgroup
@@ -245,6 +301,9 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices)
 #endif
     CG_SHARED float lds[16 * 4];
     CG_SHARED float decf; CG_SHARED uint32_t deci;     // decision of wave 0, broadcast to the other waves
+    CG_SHARED float seqTerm[PHASE == EVAL_SEQ ? 4 * 4 * EVAL_SEQ_BS : 1];
+    constexpr bool WHOLE = PHASE == EVAL_FUSED || PHASE == EVAL_SEQ;      // one workgroup owns the whole proposal
+    const uint32_t mm = (PHASE == EVAL_SEQ) ? S.mathMode : GM_MATH_PORTABLE;
     const uint32_t t = cg_tid(), BS = cg_bdim();
     unsigned long long eprof_last = cg_clock(); (void)eprof_last;
     const float lambda = S.lambda;
@@ -259,12 +318,12 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices)
     }
     const bool multiWave = BS > 64u;
     const bool scalarLane = !multiWave || t < 64u;       // the per-proposal scalar math (LUTs, fp64 log) runs in wave 0 only
-    const uint32_t slice = (PHASE == EVAL_FUSED) ? 0u : cg_bid() % slices;
-    const uint32_t qStep = (PHASE == EVAL_FUSED) ? cg_gdim() : cg_gdim() / slices;
-    const uint32_t chunk0 = slice * BS, stride = (PHASE == EVAL_FUSED) ? BS : S.redW;
+    const uint32_t slice = WHOLE ? 0u : cg_bid() % slices;
+    const uint32_t qStep = WHOLE ? cg_gdim() : cg_gdim() / slices;
+    const uint32_t chunk0 = slice * BS, stride = WHOLE ? BS : S.redW;
     const bool writer = slice == 0u && t == 0u;          // the one thread that stores the proposal's scalar results
 #define EVAL_BCAST(F0, I0) do { if (multiWave) { if (t == 0) { decf = (F0); deci = (I0); } cg_sync(); (F0) = decf; (I0) = deci; } } while (0)
-    for (uint32_t q = (PHASE == EVAL_FUSED) ? cg_bid() : cg_bid() / slices; ; q += qStep) {
+    for (uint32_t q = WHOLE ? cg_bid() : cg_bid() / slices; ; q += qStep) {
         // one trip: the record (slot q always exists: q < queueCap), the queue length, the annealing temperature
         const PropRec p = S.queue[q < S.queueCap ? q : 0u];
         const uint32_t qlen = S.gs->qlen;
@@ -292,7 +351,19 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices)
         float s = 0.f, smu = 0.f;          // un-annealed sums, valid in wave 0
         if (need) {
             float tot[4] = {0.f, 0.f, 0.f, 0.f};
-            if (PHASE != EVAL_APPLY) {
+            if (PHASE == EVAL_SEQ) {
+                const uint32_t rowA[1] = {p.r1}, colA[1] = {p.c1};
+                if (diff) {
+                    const uint32_t rowAB[2] = {p.r1, p.r2}, colAB[2] = {p.c1, p.c2};
+                    eval_alpha_seq<2, EVAL_MODE_ONE>(S, rowAB, colAB, 0u, 0.f, seqTerm, lds, tot);
+                } else {
+                    float t2[2] = {0.f, 0.f};
+                    if (p.type == 'D') eval_alpha_seq<1, EVAL_MODE_CH>(S, rowA, colA, 0u, -1.f * m1, seqTerm, lds, t2);
+                    else if (two) eval_alpha_seq<1, EVAL_MODE_SAME>(S, rowA, colA, p.c2, 0.f, seqTerm, lds, t2);
+                    else eval_alpha_seq<1, EVAL_MODE_ONE>(S, rowA, colA, 0u, 0.f, seqTerm, lds, t2);
+                    tot[0] = t2[0]; tot[1] = t2[1];
+                }
+            } else if (PHASE != EVAL_APPLY) {
                 const uint32_t rowA[1] = {p.r1}, colA[1] = {p.c1};
                 if (diff) {
                     const uint32_t rowAB[2] = {p.r1, p.r2}, colAB[2] = {p.c1, p.c2};
@@ -328,7 +399,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices)
             float bv = 0.f; uint32_t bhas = 0;
             if (scalarLane) {
                 if (gibbs1) { OptF g = gm_gibbs_mass(s, smu, 0.f, S.maxGibbsMass, rng, S.luts, true, lambda); bv = g.v; bhas = g.has ? 1u : 0u; }
-                else { bv = pcg_exponential(rng, lambda); bhas = 1u; }
+                else { bv = pcg_exponential(rng, lambda, mm); bhas = 1u; }
             }
             EVAL_PIN(bv); EVAL_TS(4);
             EVAL_BCAST(bv, bhas);
@@ -348,7 +419,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices)
                     if (g.has) rebirth = g.v;
                 }
                 const float deltaLL = rebirth * (smu - s * rebirth / 2.f);
-                acc = (gm_logf(pcg_uniform(rng)) < deltaLL) ? 1u : 0u;
+                acc = (gm_logf_m(pcg_uniform(rng), mm) < deltaLL) ? 1u : 0u;
             }
             EVAL_PIN(acc); EVAL_TS(4);
             EVAL_BCAST(rebirth, acc);
@@ -369,7 +440,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices)
         } else if (p.type == 'M') {
             // ---------------------------------------------------------------- move (:184-196)
             uint32_t acc = 0; float unused = 0.f;
-            if (scalarLane) { const float deltaLL = -1.f * m1 * (smu + s * m1 / 2.f); acc = (gm_logf(pcg_uniform(rng)) < deltaLL) ? 1u : 0u; }
+            if (scalarLane) { const float deltaLL = -1.f * m1 * (smu + s * m1 / 2.f); acc = (gm_logf_m(pcg_uniform(rng), mm) < deltaLL) ? 1u : 0u; }
             EVAL_PIN(acc); EVAL_TS(4);
             EVAL_BCAST(unused, acc);
             EVAL_TS(5);
@@ -418,4 +489,4 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices)
 
 // the split kernels are built for two resident 1024-thread workgroups per compute unit (<= 64 VGPRs)
 template <int PHASE>
-CG_KERNEL void CG_LAUNCH_BOUNDS2(1024, (PHASE == EVAL_FUSED ? 4 : 8)) eval_kernel(SamplerDev S, uint32_t slices) { cg_kernarg_warm<sizeof(SamplerDev) + 4>(); eval_body<PHASE>(S, slices); }
+CG_KERNEL void CG_LAUNCH_BOUNDS2((PHASE == EVAL_SEQ ? EVAL_SEQ_BS : 1024), (PHASE == EVAL_FUSED || PHASE == EVAL_SEQ ? 4 : 8)) eval_kernel(SamplerDev S, uint32_t slices) { cg_kernarg_warm<sizeof(SamplerDev) + 4>(); eval_body<PHASE>(S, slices); }

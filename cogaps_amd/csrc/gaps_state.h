@@ -131,6 +131,10 @@ struct SamplerDev {
     float beta;
     uint32_t unitBytes;    // bytes per unit of queueUnits (4N with the dense model, 1 with the sparse one)
     uint32_t defaultS;     // no uncertainty matrix was given: S2 = max(0.1 D, 0.1)^2 is recomputed from D instead of read
+    // ---- verification mode (cogaps_params.reductionMode / mathMode) ---------------------------------------------------
+    uint32_t seq;          // 1: every floating-point sum in the reference's scalar order (SIMD.h:36-47: one accumulator, i = 0 .. N-1)
+    uint32_t mathMode;     // GM_MATH_*: logf / expf of the accept tests and draws (honoured by the seq kernels and the generator)
+    float *seqScratch;     // [seqGrid][3][Npad] per-workgroup term scratch of the sparse model's sequential sums
     GenScalars *gs;
     // ---- optional trace (parity tests) -------------------------------------------------------
     PropRec *trace;        // [traceCap] copies of queued proposals

@@ -347,7 +347,7 @@ CG_DEVICE void gen_body(const SamplerDev &S)
                 if (r1 == r2 && c1 == c2) {
                     flags |= GEN_F_INLINE;
                     const float m1 = a.mass, m2 = b3.mass;
-                    const float newMass = pcg_trunc_gamma_upper(rng, S.luts, m1 + m2, 1.f / S.lambda);
+                    const float newMass = pcg_trunc_gamma_upper(rng, S.luts, m1 + m2, 1.f / S.lambda, S.mathMode);
                     const float delta = (m1 > m2) ? newMass - m1 : m2 - newMass;
                     if (m1 + delta > GAPS_EPSILON && m2 - delta > GAPS_EPSILON) { flags |= GEN_F_APPLY; nm1 = m1 + delta; nm2 = m2 - delta; }
                 }

@@ -15,6 +15,7 @@
 // lanes are folded by the ascending xor butterfly; the total is added to the table terms once; then beta.
 #pragma once
 #include "eval_kernel.h"
+#include "aux_kernels.h"
 
 #define SP_KMAX 512      // nPatterns limit of the sparse kernels (matrix rows staged in LDS)
 
@@ -103,22 +104,33 @@ CG_DEVICE float sp_dot_row(const float *a, const float *row, uint32_t n)
 #define SP_MODE_SAME 2
 
 // one common non-zero's term added to the lane's partial sums (SparseNormalModel.cpp:176-186, 222-233, 274-285)
+// ts is added to s, tm (then tm2, with a change) to s_mu.  (a - x is a + (-x) bit for bit.)
 template <int MODE>
-CG_DEVICE void sp_term(float d_val, float v_val, float v2_val, float ex, float ap, float ch, float &ps, float &pm)
+CG_DEVICE void sp_term_vals(float d_val, float v_val, float v2_val, float ex, float ap, float ch, float &ts, float &tm, float &tm2)
 {
+    tm2 = 0.f;
     if (MODE == SP_MODE_SAME) {
         const float d_recip = 1.f / d_val;
         const float term1 = 1.f - d_recip * d_recip;
         const float v_diff = v_val - v2_val;
-        ps = ps - v_diff * v_diff * term1;
-        pm = pm + v_diff * (ap * term1 + d_recip);
+        ts = -(v_diff * v_diff * term1);
+        tm = v_diff * (ap * term1 + d_recip);
     } else {
         const float term1 = v_val / d_val;
         const float term2 = v_val - term1 / d_val;
-        ps = ps + (term1 * term1 - v_val * v_val);
-        pm = pm + (term1 + term2 * ap);
-        if (MODE == SP_MODE_CH) pm = pm + term2 * ex * ch;
+        ts = term1 * term1 - v_val * v_val;
+        tm = term1 + term2 * ap;
+        if (MODE == SP_MODE_CH) tm2 = term2 * ex * ch;
     }
+}
+template <int MODE>
+CG_DEVICE void sp_term(float d_val, float v_val, float v2_val, float ex, float ap, float ch, float &ps, float &pm)
+{
+    float ts, tm, tm2;
+    sp_term_vals<MODE>(d_val, v_val, v2_val, ex, ap, ch, ts, tm, tm2);
+    ps = ps + ts;
+    pm = pm + tm;
+    if (MODE == SP_MODE_CH) pm = pm + tm2;
 }
 
 // per-lane partial sums of one alpha evaluation over this thread's flag words.  Two common non-zeros are in flight at
@@ -168,6 +180,58 @@ CG_DEVICE void sp_partial(const SamplerDev &S, uint32_t row, uint32_t col, uint3
     }
 }
 
+// ---- verification mode: SparseNormalModel.cpp:153-292 in the reference's own order -------------------------------------
+// s and s_mu start from the table terms and take one term per common non-zero in ascending index (the `ch` form adds a
+// second term to s_mu per element).  The terms are computed by the whole workgroup into its scratch rows in index order
+// (word offsets from a serial scan of the per-word counts), then thread 0 folds them.  Returns (s, s_mu) BEFORE beta, in
+// every thread.  wcnt: LDS [SP_SEQ_WORDS]; bc: LDS [2].
+#define SP_SEQ_WORDS 4096
+template <int MODE>
+CG_DEVICE void sp_alpha_seq(const SamplerDev &S, uint32_t row, uint32_t col, uint32_t col2, float ch, const float *arow, float s0, float m0,
+                            uint32_t *wcnt, float *bc, float &sOut, float &mOut, uint32_t &visited)
+{
+    const uint32_t BS = cg_bdim(), t = cg_tid(), K = S.K;
+    const unsigned long long *fD = S.dflags + (size_t)row * S.Wn;
+    const unsigned long long *fV = S.oflags + (size_t)col * S.oMw, *fV2 = S.oflags + (size_t)col2 * S.oMw;
+    const uint32_t *pre = S.dprefix + (size_t)row * S.Wn;
+    const float *data = S.dvals + S.dptr[row];
+    const float *V = S.other + (size_t)col * S.Npad, *V2 = S.other + (size_t)col2 * S.Npad;
+    float *sc = S.seqScratch + (size_t)cg_bid() * 3u * S.Npad;
+    for (uint32_t w = t; w < S.Wn; w += BS) wcnt[w] = (uint32_t)cg_popc64(fD[w] & (MODE == SP_MODE_SAME ? (fV[w] | fV2[w]) : fV[w]));
+    cg_sync();
+    if (t == 0) { uint32_t run = 0; for (uint32_t w = 0; w < S.Wn; ++w) { const uint32_t c = wcnt[w]; wcnt[w] = run; run += c; } wcnt[S.Wn] = run; }
+    cg_sync();
+    const uint32_t total = wcnt[S.Wn];
+    for (uint32_t w = t; w < S.Wn; w += BS) {
+        const unsigned long long dfl = fD[w];
+        unsigned long long common = dfl & (MODE == SP_MODE_SAME ? (fV[w] | fV2[w]) : fV[w]);
+        uint32_t o = wcnt[w];
+        while (common != 0ull) {
+            const uint32_t bit = (uint32_t)cg_ctz64(common);
+            common &= common - 1ull;
+            const uint32_t idx = 64u * w + bit;
+            const float d = data[pre[w] + (uint32_t)cg_popc64(dfl & ((1ull << bit) - 1ull))];
+            const float v = V[idx], v2 = (MODE == SP_MODE_SAME) ? V2[idx] : 0.f;
+            const float ex = (MODE == SP_MODE_CH) ? S.orows[(size_t)idx * S.oKpad + col] : 0.f;
+            const float ap = sp_dot(arow, S.orows + (size_t)idx * S.oKpad, K);
+            float ts, tm, tm2;
+            sp_term_vals<MODE>(d, v, v2, ex, ap, ch, ts, tm, tm2);
+            sc[o] = ts; sc[S.Npad + o] = tm; if (MODE == SP_MODE_CH) sc[2u * S.Npad + o] = tm2;
+            ++o;
+        }
+    }
+    cg_sync();
+    if (t == 0) {
+        float s = s0, m = m0;
+        for (uint32_t i = 0; i < total; ++i) { s = s + sc[i]; m = m + sc[S.Npad + i]; if (MODE == SP_MODE_CH) m = m + sc[2u * S.Npad + i]; }
+        bc[0] = s; bc[1] = m;
+        visited += total;
+    }
+    cg_sync();
+    sOut = bc[0]; mOut = bc[1];
+    cg_sync();
+}
+
 // HybridMatrix::add (HybridMatrix.cpp:25-31) / set (:33-39) on entry (row, col): the row copy, the column copy with
 // its epsilon rule (HybridVector.cpp:55-86) and flag word, and the count of flagged entries per column (canUseGibbs =
 // "the column has a flagged entry", VectorMath.cpp:125-128).  One thread per entry; rows are proposal-exclusive.
@@ -201,6 +265,7 @@ CG_DEVICE void sp_safely_change_matrix(const SamplerDev &S, uint32_t row, uint32
 
 // One workgroup of W = cogaps_sparse_width(N) threads per queued proposal (AsynchronousGibbsSampler.h:127-219 over the
 // sparse model).
+template <bool SEQ>
 CG_DEVICE void eval_sparse_body(const SamplerDev &S)
 {
     CG_SHARED float lds[16 * 4];
@@ -208,6 +273,8 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S)
     CG_SHARED float z2A[SP_KMAX], z2B[SP_KMAX];        // the Z2 columns of c1 / c2 (table terms)
     CG_SHARED float decf; CG_SHARED uint32_t deci;
     CG_SHARED uint32_t nzShared;           // common non-zeros visited by this workgroup (roofline bookkeeping)
+    CG_SHARED uint32_t seqCnt[SEQ ? SP_SEQ_WORDS + 1 : 1]; CG_SHARED float seqBc[2];     // verification mode (sp_alpha_seq)
+    const uint32_t mm = SEQ ? S.mathMode : GM_MATH_PORTABLE;
     const uint32_t t = cg_tid(), BS = cg_bdim(), K = S.K;
     const float lambda = S.lambda, beta = S.beta;
     const bool multiWave = BS > 64u;
@@ -236,6 +303,33 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S)
                 if (k < K) { z2A[k] = S.Z2[(size_t)p.c1 * K + k]; if (two) z2B[k] = S.Z2[(size_t)p.c2 * K + k]; }
             }
             cg_sync();
+            if (SEQ) {
+                // table terms first, then the common non-zeros in index order (SparseNormalModel.cpp:160-161, 205-207, 256-258)
+                uint32_t vis = 0;
+                if (diff) {
+                    float sa, ma, sb, mb;
+                    sp_alpha_seq<SP_MODE_ONE>(S, p.r1, p.c1, 0u, 0.f, arowA, S.Z1[p.c1], -1.f * sp_dot(arowA, z2A, K), seqCnt, seqBc, sa, ma, vis);
+                    sp_alpha_seq<SP_MODE_ONE>(S, p.r2, p.c2, 0u, 0.f, arowB, S.Z1[p.c2], -1.f * sp_dot(arowB, z2B, K), seqCnt, seqBc, sb, mb, vis);
+                    sa = sa * beta; ma = ma * beta; sb = sb * beta; mb = mb * beta;
+                    s = sa + sb; smu = ma - mb;
+                } else if (two) {
+                    const float s0 = S.Z1[p.c1] - 2.f * z2B[p.c1] + S.Z1[p.c2];
+                    float d0 = 0.f;
+                    for (uint32_t k = 0; k < K; ++k) d0 += arowA[k] * (z2A[k] - z2B[k]);
+                    sp_alpha_seq<SP_MODE_SAME>(S, p.r1, p.c1, p.c2, 0.f, arowA, s0, -1.f * d0, seqCnt, seqBc, s, smu, vis);
+                    s = s * beta; smu = smu * beta;
+                } else if (p.type == 'D') {
+                    const float ch = -1.f * m1;
+                    float m0 = -1.f * sp_dot(arowA, z2A, K);
+                    m0 -= ch * z2A[p.c1];
+                    sp_alpha_seq<SP_MODE_CH>(S, p.r1, p.c1, 0u, ch, arowA, S.Z1[p.c1], m0, seqCnt, seqBc, s, smu, vis);
+                    s = s * beta; smu = smu * beta;
+                } else {
+                    sp_alpha_seq<SP_MODE_ONE>(S, p.r1, p.c1, 0u, 0.f, arowA, S.Z1[p.c1], -1.f * sp_dot(arowA, z2A, K), seqCnt, seqBc, s, smu, vis);
+                    s = s * beta; smu = smu * beta;
+                }
+                if (t == 0) nzShared = vis;
+            } else {
             float x[4] = {0.f, 0.f, 0.f, 0.f};
             if (diff) { sp_partial<SP_MODE_ONE>(S, p.r1, p.c1, 0u, 0.f, arowA, x[0], x[1], nz); sp_partial<SP_MODE_ONE>(S, p.r2, p.c2, 0u, 0.f, arowB, x[2], x[3], nz); }
             else if (p.type == 'D') sp_partial<SP_MODE_CH>(S, p.r1, p.c1, 0u, -1.f * m1, arowA, x[0], x[1], nz);
@@ -268,6 +362,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S)
                     s = (S.Z1[p.c1] + tot[0]) * beta; smu = (m0 + tot[1]) * beta;
                 }
             }
+            }
         }
         s = s * T; smu = smu * T;
         const bool writer = t == 0u;
@@ -276,7 +371,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S)
             float bv = 0.f; uint32_t bhas = 0;
             if (scalarLane) {
                 if (gibbs1) { OptF g = gm_gibbs_mass(s, smu, 0.f, S.maxGibbsMass, rng, S.luts, true, lambda); bv = g.v; bhas = g.has ? 1u : 0u; }
-                else { bv = pcg_exponential(rng, lambda); bhas = 1u; }
+                else { bv = pcg_exponential(rng, lambda, mm); bhas = 1u; }
             }
             SP_BCAST(bv, bhas);
             if (bhas != 0u && bv >= GAPS_EPSILON) {
@@ -287,7 +382,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S)
             if (scalarLane) {
                 if (gibbs1) { OptF g = gm_gibbs_mass(s, smu, 0.f, S.maxGibbsMass, rng, S.luts, true, lambda); if (g.has) rebirth = g.v; }
                 const float deltaLL = rebirth * (smu - s * rebirth / 2.f);
-                acc = (gm_logf(pcg_uniform(rng)) < deltaLL) ? 1u : 0u;
+                acc = (gm_logf_m(pcg_uniform(rng), mm) < deltaLL) ? 1u : 0u;
             }
             SP_BCAST(rebirth, acc);
             if (writer) {
@@ -296,7 +391,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S)
             }
         } else if (p.type == 'M') {
             uint32_t acc = 0; float unused = 0.f;
-            if (scalarLane) { const float deltaLL = -1.f * m1 * (smu + s * m1 / 2.f); acc = (gm_logf(pcg_uniform(rng)) < deltaLL) ? 1u : 0u; }
+            if (scalarLane) { const float deltaLL = -1.f * m1 * (smu + s * m1 / 2.f); acc = (gm_logf_m(pcg_uniform(rng), mm) < deltaLL) ? 1u : 0u; }
             SP_BCAST(unused, acc);
             if (acc && writer) {
                 eval_domain_move(S, p.h1, curPos, p.pos);
@@ -326,7 +421,8 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S)
         cg_sync();
     }
 }
-CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_kernel(SamplerDev S) { cg_kernarg_warm<sizeof(SamplerDev)>(); eval_sparse_body(S); }
+CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_kernel(SamplerDev S) { cg_kernarg_warm<sizeof(SamplerDev)>(); eval_sparse_body<false>(S); }
+CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_seq_kernel(SamplerDev S) { cg_kernarg_warm<sizeof(SamplerDev)>(); eval_sparse_body<true>(S); }
 
 // SparseNormalModel::generateLookupTables (SparseNormalModel.cpp:294-311): Z1[i] = sum_k other(k,i)^2 through the
 // other matrix's ROW copy, Z2(i,j) = dot of its column copies.  One workgroup per (i, j >= i) pair plus one per i;
@@ -401,4 +497,58 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(1024) chisq_sparse_kernel(SamplerDev S, float *p
     }
     if (BS > 64u) { cg_sync(); eval_vfinish<1, V>(lds, tot); }
     if (t == 0) partial[row] = tot[0];
+}
+
+// ---- verification mode: the same three in the reference's order (aux_kernels.h: seq_sum) ---------------------------------
+// generateLookupTables: Z1 front to back; Z2 through gaps::dot, i.e. back to front for vectors of at most 25 elements
+CG_KERNEL void CG_LAUNCH_BOUNDS(256) sparse_tables_seq_kernel(SamplerDev S)
+{
+    CG_SHARED float lds[SEQ_CHUNK];
+    const uint32_t K = S.K, N = S.N, b = cg_bid();
+    if (b < K) {
+        const uint32_t i = b;
+        const float z = seq_sum(0.f, N, lds, [&](uint64_t k) { const float v = S.orows[(size_t)k * S.oKpad + i]; return v * v; });
+        if (cg_tid() == 0) S.Z1[i] = z;
+    } else {
+        uint32_t r = b - K, i = 0;
+        while (r >= K - i) { r -= K - i; ++i; }
+        const uint32_t j2 = i + r;
+        const float *ci = S.other + (size_t)i * S.Npad, *cj = S.other + (size_t)j2 * S.Npad;
+        const bool rev = N <= 25u;
+        const float d = seq_sum(0.f, N, lds, [&](uint64_t e) { const uint32_t k = rev ? N - 1u - (uint32_t)e : (uint32_t)e; return ci[k] * cj[k]; });
+        if (cg_tid() == 0) { S.Z2[(size_t)j2 * K + i] = d; S.Z2[(size_t)i * K + j2] = d; }
+    }
+}
+// SparseNormalModel::chiSq (SparseNormalModel.cpp:40-62): per vector all dense terms, then one correction per non-zero; one
+// accumulator across the vectors.  One workgroup; out[0] is the sum before beta.
+CG_KERNEL void CG_LAUNCH_BOUNDS(256) chisq_sparse_seq_kernel(SamplerDev S, float *out)
+{
+    CG_SHARED float lds[SEQ_CHUNK];
+    CG_SHARED float arow[SP_KMAX];
+    const uint32_t t = cg_tid(), BS = cg_bdim(), K = S.K;
+    float acc = 0.f;
+    for (uint32_t row = 0; row < S.M; ++row) {
+        for (uint32_t k = t; k < K; k += BS) arow[k] = S.rows[(size_t)row * S.Kpad + k];
+        cg_sync();
+        acc = seq_sum(acc, S.N, lds, [&](uint64_t i) { const float dot = sp_dot_row(arow, S.orows + (size_t)i * S.oKpad, K); return dot * dot; });
+        const unsigned long long *fD = S.dflags + (size_t)row * S.Wn;
+        const uint32_t *pre = S.dprefix + (size_t)row * S.Wn;
+        const float *data = S.dvals + S.dptr[row];
+        const uint32_t nnz = S.dptr[row + 1] - S.dptr[row];
+        for (uint32_t w = t; w < S.Wn; w += BS) {
+            unsigned long long fl = fD[w];
+            uint32_t o = pre[w];
+            while (fl != 0ull) {
+                const uint32_t bit = (uint32_t)cg_ctz64(fl); fl &= fl - 1ull;
+                const float d = data[o];
+                const float dot = sp_dot_row(arow, S.orows + (size_t)(64u * w + bit) * S.oKpad, K);
+                const float dsq = d * d;
+                S.seqScratch[o] = 1 + dot * (dot - 2 * d - dsq * dot) / dsq;
+                ++o;
+            }
+        }
+        cg_sync();
+        acc = seq_sum(acc, nnz, lds, [&](uint64_t e) { return S.seqScratch[e]; });
+    }
+    if (t == 0) out[0] = acc;
 }

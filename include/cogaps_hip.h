@@ -59,7 +59,27 @@ typedef struct cogaps_params {
     int (*interrupt)(void *);      /* polled once per iteration (GapsRunner.cpp:280); non-zero aborts */
     void *interruptArg;
     int32_t snapshotPhase;         /* 0 = all phases (GAPS_ALL_PHASES, the default of GapsParameters.h:98), 1 = equilibration, 2 = sampling */
+    int32_t pumpThreshold;         /* PumpThreshold (GapsParameters.h:52; GapsStatistics.h:58-63): 0 = PUMP_UNIQUE (default), 1 = PUMP_CUT.
+                                      The reference's two rules are the same code (GapsStatistics.h:65-126) and so are they here */
+    int32_t fixedCols;             /* columns of fixedPatterns; 0 = nPatterns.  Anything else is rejected (GapsRunner.cpp:329-350 copies
+                                      nPatterns columns) */
+    /* ---- verification mode: no counterpart in GapsParameters -------------------------------------------------------------
+     * reductionMode COGAPS_REDUCE_LANES (default): the kernels' lane order (cogaps_reduction_width).  COGAPS_REDUCE_SEQ: every
+     * floating-point sum runs in the order of the reference's default scalar build (src/math/SIMD.h:36-47: one accumulator,
+     * i = 0 .. N-1; chiSq DenseNormalModel.cpp:56-68; gaps::dot VectorMath.h:41-134) -- slow, and bit-identical to that build.
+     * mathMode (honoured with COGAPS_REDUCE_SEQ): the logf / expf of the accept tests and draws.  COGAPS_MATH_PORTABLE
+     * (default): the kernels' own correctly rounded algorithm.  COGAPS_MATH_GLIBC_FMA / _SSE2: GNU libc 2.35's logf / expf
+     * restated (its -mfma ifunc variant, which x86-64 glibc selects on FMA-capable hosts / its generic variant) -- what the
+     * reference binary computes when it is linked against that C library.  With SEQ + GLIBC the HIP library reproduces the
+     * reference's atom histories, totalUpdates and statistics digit for digit (tests/test_gpu_parity.py). */
+    int32_t reductionMode;
+    int32_t mathMode;
 } cogaps_params;
+#define COGAPS_REDUCE_LANES 0
+#define COGAPS_REDUCE_SEQ 1
+#define COGAPS_MATH_PORTABLE 0
+#define COGAPS_MATH_GLIBC_FMA 1
+#define COGAPS_MATH_GLIBC_SSE2 2
 
 /* POD mirror of GapsResult (reference src/GapsResult.h:17-36) + the names cogapsRun returns */
 typedef struct cogaps_result {
@@ -169,6 +189,10 @@ int cogaps_session_perf_sampler(cogaps_session *s, char which, cogaps_perf *out)
 /* development aid: per-phase cycle counters of the generator kernel (all zero unless built with -DGEN_PROFILE) */
 int cogaps_session_debug_prof(cogaps_session *s, char which, uint64_t *out16);
 int cogaps_session_debug_replay(cogaps_session *s, char which, int kind, uint32_t n, uint32_t dbgFlags, double *usPerLaunch);
+
+/* test hook for the math modes: y[i] = fn(x[i]) with fn 0 = logf, 1 = expf in math mode `mathMode`, evaluated by a kernel on
+ * the current device (on_device != 0) or by the same source compiled for the host */
+int cogaps_debug_math(int fn, int mathMode, const float *x, float *y, uint32_t n, int on_device);
 
 /* lanes of the evaluation workgroup for data vectors of length N (the reduction-order contract) */
 uint32_t cogaps_reduction_width(uint32_t N);

@@ -106,6 +106,105 @@ float go_portable_expf(float x)
 }
 
 /* ======================================================================================
+ * glibc's logf / expf, restated.  The reference calls libm's float functions in its accept tests
+ * (AsynchronousGibbsSampler.h:165,189), in exponential() (Random.cpp:172-175) and in truncGammaUpper()
+ * (Random.cpp:194-200), so its chain depends on the C library it is linked with -- a third-party dependency
+ * that is not under /root/reference.  Pinned version: GNU libc 2.35 (Ubuntu GLIBC 2.35-0ubuntu3.11, this
+ * image), sysdeps/ieee754/flt-32/e_logf.c, e_expf.c, math_config.h (the ARM optimized-routines algorithms:
+ * a 16-entry (1/c, log c) table + degree-3 polynomial for logf, a 32-entry 2^(i/32) table + degree-3
+ * polynomial for expf, every intermediate an IEEE double).  x86-64 glibc ships each function twice and
+ * picks one at load time (ifunc): the generic build (separate multiply and add) and a build compiled with
+ * -mfma -mavx2 in which the compiler fused multiply-add pairs -- read off the instruction sequences of
+ * __logf_fma / __expf_fma of the pinned library.  `fused` selects that variant; the two differ in the last
+ * bit on a fraction of the inputs.  tests/test_oracle_pin.py checks the restatement against the host's
+ * logf / expf over all floats the sampler can feed them.
+ * ====================================================================================== */
+static const double glf_tab[16][2] = {     /* __logf_data.tab: { invc, logc } */
+    {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2},
+    {0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2}, {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3},
+    {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8eap+0, -0x1.1aa2bc79c81p-3},
+    {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4},
+    {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5}, {0x1p+0, 0x0p+0},
+    {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5}, {0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4},
+    {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3}, {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3},
+    {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2}, {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2},
+};
+static const uint64_t gef_tab[32] = {      /* __exp2f_data.tab: bits of 2^(i/32) with the exponent adjusted */
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull, 0x3fef54873168b9aaull,
+    0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull,
+    0x3feea11473eb0187ull, 0x3feea589994cce13ull, 0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
+    0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull,
+};
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+float go_glibc_logf(float x, int fused)
+{
+    const double Ln2 = 0x1.62e42fefa39efp-1, A0 = -0x1.00ea348b88334p-2, A1 = 0x1.5575b0be00b6ap-2, A2 = -0x1.ffffef20a4123p-2;
+    uint32_t ix = f2u(x);
+    if (ix == 0x3f800000u) return 0.f;
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
+        if (ix * 2u == 0u) return -INFINITY;                 /* log(+-0) */
+        if (ix == 0x7f800000u) return x;                     /* log(inf) */
+        if ((ix & 0x80000000u) || ix * 2u >= 0xff000000u) return NAN;
+        ix = f2u(x * 0x1p23f); ix -= 23u << 23;              /* subnormal: normalise */
+    }
+    const uint32_t tmp = ix - 0x3f330000u;
+    const uint32_t i = (tmp >> 19) % 16u;
+    const int32_t k = (int32_t)tmp >> 23;
+    const uint32_t iz = ix - (tmp & 0xff800000u);
+    const double invc = glf_tab[i][0], logc = glf_tab[i][1];
+    const double z = (double)u2f(iz);
+    if (fused) {
+        const double r = fma(z, invc, -1.0);
+        const double y0 = fma((double)k, Ln2, logc);
+        double y = fma(A1, r, A2);
+        const double r2 = r * r;
+        y = fma(A0, r2, y);
+        return (float)fma(y, r2, y0 + r);
+    }
+    const double r = z * invc - 1.0;
+    const double y0 = logc + (double)k * Ln2;
+    const double r2 = r * r;
+    double y = A1 * r + A2;
+    y = A0 * r2 + y;
+    y = y * r2 + (y0 + r);
+    return (float)y;
+}
+
+float go_glibc_expf(float x, int fused)
+{
+    const double InvLn2N = 0x1.71547652b82fep+5, Shift = 0x1.8p+52;
+    const double C0 = 0x1.c6af84b912394p-20, C1 = 0x1.ebfce50fac4f3p-13, C2 = 0x1.62e42ff0c52d6p-6;
+    const uint32_t ux = f2u(x), abstop = (ux >> 20) & 0x7ffu;
+    if (abstop >= 0x42bu) {                                  /* |x| >= 88 or nan */
+        if (ux == 0xff800000u) return 0.f;
+        if (abstop >= 0x7f8u) return x + x;
+        if (x > 0x1.62e42ep6f) return INFINITY;              /* overflow */
+        if (x < -0x1.9fe368p6f) return 0.f;                  /* underflow */
+        if (x < -0x1.9d1d9ep6f) return 0x1.4p-75f * 0x1.4p-75f;   /* __math_may_uflowf */
+    }
+    const double xd = (double)x;
+    double kd, r;
+    uint64_t ki;
+    if (fused) {
+        kd = fma(InvLn2N, xd, Shift); memcpy(&ki, &kd, 8); kd -= Shift;
+        r = fma(InvLn2N, xd, -kd);
+    } else {
+        const double z = InvLn2N * xd;
+        kd = z + Shift; memcpy(&ki, &kd, 8); kd -= Shift;
+        r = z - kd;
+    }
+    const uint64_t t = gef_tab[ki % 32u] + (ki << 47);
+    const double s = u2d(t);
+    double zz, y; const double r2 = r * r;
+    if (fused) { zz = fma(C0, r, C1); y = fma(C2, r, 1.0); y = fma(zz, r2, y); }
+    else { zz = C0 * r + C1; y = C2 * r + 1.0; y = zz * r2 + y; }
+    return (float)(y * s);
+}
+
+/* ======================================================================================
  * RNG: Xoroshiro128+ seeder, PCG-XSH-RR per-object generator  (math/Random.cpp)
  * ====================================================================================== */
 
@@ -156,6 +255,19 @@ static inline uint32_t rng_u32(go_rng *r) { rng_advance(r); return rng_get(r); }
 /* Random.cpp:32-38 */
 static void rng_init(go_rng *r, go_randstate *rs) { r->rs = rs; r->state = seeder_next(&rs->seeder); rng_advance(r); }
 
+/* test hook: how many floats with bit patterns lo, lo+step, ... <= hi does the restatement get differently from the host libm */
+uint64_t go_glibc_mismatches(int fn, int fused, uint32_t lo_bits, uint32_t hi_bits, uint32_t step)
+{
+    uint64_t bad = 0;
+    if (!step) step = 1;
+    for (uint64_t b = lo_bits; b <= hi_bits; b += step) {
+        const float x = u2f((uint32_t)b);
+        const float a = fn ? go_glibc_expf(x, fused) : go_glibc_logf(x, fused);
+        const float c = fn ? expf(x) : logf(x);
+        if (f2u(a) != f2u(c) && !(a != a && c != c)) ++bad;
+    }
+    return bad;
+}
 float go_strtof(const char *s) { return strtof(s, NULL); } /* MatrixElement.cpp:15-23: text -> float, one rounding */
 
 uint32_t go_pcg_next(uint64_t *state)
@@ -207,11 +319,11 @@ static uint64_t rng_uniform64(go_rng *r, uint64_t a, uint64_t b)
 
 static inline float go_logf(const go_randstate *rs, float x)
 {
-    return rs->math_mode == GO_MATH_PORTABLE ? go_portable_logf(x) : logf(x);
+    return rs->math_mode == GO_MATH_PORTABLE ? go_portable_logf(x) : (rs->math_mode >= GO_MATH_GLIBC_FMA ? go_glibc_logf(x, rs->math_mode == GO_MATH_GLIBC_FMA) : logf(x));
 }
 static inline float go_expf(const go_randstate *rs, float x)
 {
-    return rs->math_mode == GO_MATH_PORTABLE ? go_portable_expf(x) : expf(x);
+    return rs->math_mode == GO_MATH_PORTABLE ? go_portable_expf(x) : (rs->math_mode >= GO_MATH_GLIBC_FMA ? go_glibc_expf(x, rs->math_mode == GO_MATH_GLIBC_FMA) : expf(x));
 }
 
 /* Random.cpp:132-143 */

@@ -22,6 +22,8 @@ extern "C" {
 /* math_mode: which log/exp the fp32 accept tests use */
 #define GO_MATH_LIBM     0  /* host libm logf/expf: what the reference binary does on this host */
 #define GO_MATH_PORTABLE 1  /* fixed IEEE-double algorithm shared (as a spec) with the HIP kernels */
+#define GO_MATH_GLIBC_FMA 2  /* glibc 2.35 logf/expf restated, the -mfma ifunc variant (what GO_MATH_LIBM resolves to on an FMA-capable x86-64) */
+#define GO_MATH_GLIBC_SSE2 3 /* ... the generic variant (separate multiply and add) */
 
 typedef struct go_params {
     uint32_t nPatterns;        /* GapsParameters.h:88  default 3 */
@@ -126,6 +128,10 @@ void go_finish(go_session *s, go_result *out);
 /* free-standing pieces exposed for unit tests */
 float go_portable_logf(float x);
 float go_portable_expf(float x);
+float go_glibc_logf(float x, int fused);
+float go_glibc_expf(float x, int fused);
+/* number of floats in [lo, hi] (bit patterns, same sign) on which go_glibc_{logf,expf}(., fused) differs from the host libm; fn 0 = logf, 1 = expf */
+uint64_t go_glibc_mismatches(int fn, int fused, uint32_t lo_bits, uint32_t hi_bits, uint32_t step);
 void go_build_luts(float *erf, float *erfinv, float *qgamma);
 uint64_t go_seeder_stream(uint32_t seed, uint64_t *out, uint64_t n); /* first n seeder outputs */
 uint32_t go_pcg_next(uint64_t *state);

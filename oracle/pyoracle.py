@@ -13,6 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 MATH_LIBM = 0
 MATH_PORTABLE = 1
+MATH_GLIBC_FMA = 2      # glibc 2.35 logf / expf restated, -mfma ifunc variant
+MATH_GLIBC_SSE2 = 3     # ... generic variant
 
 
 class GoParams(C.Structure):
@@ -129,6 +131,11 @@ def lib(omp=False):
     L.go_seeder_stream.argtypes = [C.c_uint32, C.POINTER(C.c_uint64), C.c_uint64]
     L.go_pcg_next.restype = C.c_uint32
     L.go_pcg_next.argtypes = [C.POINTER(C.c_uint64)]
+    L.go_glibc_mismatches.restype = C.c_uint64
+    L.go_glibc_mismatches.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32]
+    for n in ("go_glibc_logf", "go_glibc_expf"):
+        getattr(L, n).restype = C.c_float
+        getattr(L, n).argtypes = [C.c_float, C.c_int]
     L.go_strtof.restype = C.c_float
     L.go_strtof.argtypes = [C.c_char_p]
     _libs[key] = L

@@ -14,7 +14,12 @@ def make_pair(lib, data, **kw):
     wP = lib.cogaps_reduction_width(S.dims("P")[1])
     okw = dict(kw)
     okw.pop("device", None)
-    O = po.Session(data, math_mode=po.MATH_PORTABLE, redW_A=wA, redW_P=wP, redG=4, **okw)
+    if okw.pop("reductionMode", "lanes") == "seq":
+        # verification mode: the reference's own order (one accumulator) and the session's math mode
+        math = {"portable": po.MATH_PORTABLE, "glibc-fma": po.MATH_GLIBC_FMA, "glibc-sse2": po.MATH_GLIBC_SSE2}[okw.pop("mathMode", "portable")]
+        O = po.Session(data, math_mode=math, redW_A=1, redW_P=1, redG=1, **okw)
+    else:
+        O = po.Session(data, math_mode=po.MATH_PORTABLE, redW_A=wA, redW_P=wP, redG=4, **okw)
     return S, O
 
 

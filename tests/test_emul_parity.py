@@ -110,3 +110,63 @@ def test_serial_flush_fallback(emul_lib, gist):
     (ConcurrentAtomicDomain.cpp:71-79).  Erases are rare (this chain: 60 batches with one, 6 with two or three in 50
     iterations), so the variant is built with FLUSH_MAX = 1 and run long enough to take the path several times"""
     pu.run_stepwise(emul_lib(256, extra="-DFLUSH_MAX=1", tag="_flush1"), gist, 50, trace=False, nPatterns=7, seed=42, total_iter=40)
+
+
+SEQ = dict(reductionMode="seq", mathMode="glibc-fma")
+
+
+def test_verification_mode_stepwise(emul_lib, modsim, gist):
+    """reductionMode SEQ + mathMode GLIBC_FMA (cogaps_hip.h): the kernels against the oracle in the reference's own arithmetic
+    (sequential sums, glibc's logf / expf) -- traces, atoms, matrices, AP, chi2 bit for bit; dense, then the P side's 1363-element
+    vectors (several 1024-element fold blocks)"""
+    pu.run_stepwise(emul_lib(256), modsim, 60, nPatterns=3, seed=42, total_iter=60, check_every=10, **SEQ)
+    pu.run_stepwise(emul_lib(256), gist, 5, nPatterns=5, seed=123, total_iter=20, **SEQ)
+
+
+def test_verification_mode_sparse_stepwise(emul_lib):
+    """... with the sparse model: gaps::dot back to front up to 25 elements (K = 4; the 24-element Z2 columns) and front to
+    back above (K = 30), table terms first, one term per common non-zero in index order"""
+    pu.run_stepwise(emul_lib(256), pu.synthetic_counts(120, 24, zeros=0.7, seed=4), 25, nPatterns=4, seed=77, total_iter=30, check_every=5, sparseOptimization=True, **SEQ)
+    pu.run_stepwise(emul_lib(256), pu.synthetic_counts(200, 30, zeros=0.8, seed=5), 8, trace=False, nPatterns=30, seed=3, total_iter=20, check_every=4, sparseOptimization=True, **SEQ)
+
+
+def test_verification_mode_full_run(emul_lib, modsim, oracle):
+    """cogaps_run in verification mode = the oracle's reference-arithmetic run, statistics and meanChiSq included; on this
+    container's host (glibc 2.35, FMA) that is also the libm mode, i.e. the reference binary's own numbers"""
+    from cogaps_amd import _capi
+    kw = dict(nPatterns=3, nIterations=100, seed=42, outputFrequency=10)
+    r = _capi.run(modsim, lib=emul_lib(256), **SEQ, **kw)
+    o = oracle.run(modsim, math_mode=oracle.MATH_GLIBC_FMA, **kw)
+    for f in ("atomsA", "atomsP", "chisq", "Amean", "Pmean", "Asd", "Psd"):
+        assert np.array_equal(r[f], o[f]), f
+    assert r["totalUpdates"] == o["totalUpdates"] and r["meanChiSq"] == o["meanChiSq"] and r["averageQueueLengthP"] == o["averageQueueLengthP"]
+
+
+def test_math_modes_on_the_host(emul_lib, oracle):
+    """cogaps_debug_math (host side of the shared source): the glibc modes equal the committed libm vectors, the portable mode the
+    oracle's portable functions"""
+    import os
+    from conftest import GOLDEN
+    from cogaps_amd import _capi
+    lib = emul_lib(256)
+    g = np.load(os.path.join(GOLDEN, "glibc235_logf_expf.npz"))
+    assert _capi.debug_math("log", g["x_log"], "glibc-fma", lib=lib).tobytes() == g["y_log"].tobytes()
+    assert _capi.debug_math("exp", g["x_exp"], "glibc-fma", lib=lib).tobytes() == g["y_exp"].tobytes()
+    L = oracle.lib()
+    for mode, fused in (("glibc-fma", 1), ("glibc-sse2", 0)):
+        y = _capi.debug_math("exp", g["x_exp"][:2000], mode, lib=lib)
+        assert all(np.float32(L.go_glibc_expf(float(v), fused)).tobytes() == w.tobytes() for v, w in zip(g["x_exp"][:2000], y))
+    y = _capi.debug_math("log", g["x_log"][:2000], "portable", lib=lib)
+    assert all(np.float32(L.go_portable_logf(float(v))).tobytes() == w.tobytes() for v, w in zip(g["x_log"][:2000], y))
+
+
+def test_mode_validation(emul_lib, modsim):
+    from cogaps_amd import _capi
+    with pytest.raises(RuntimeError, match="verification mode"):
+        _capi.Session(modsim, lib=emul_lib(256), nPatterns=3, mathMode="glibc-fma")
+    with pytest.raises(RuntimeError, match="outside 1"):
+        _capi.Session(modsim, lib=emul_lib(256), nPatterns=3, subsetIndices=np.array([1, 2, 26], dtype=np.uint32), subsetDim=1)
+    with pytest.raises(RuntimeError, match="outside 1"):
+        _capi.Session(modsim, lib=emul_lib(256), nPatterns=3, subsetIndices=np.array([0, 2], dtype=np.uint32), subsetDim=2)
+    with pytest.raises(ValueError, match="nPatterns"):
+        _capi.Session(modsim, lib=emul_lib(256), nPatterns=3, whichMatrixFixed="P", fixedPatterns=np.ones((20, 4), np.float32))

@@ -54,6 +54,130 @@ def test_sparse_model_full_run(hip_lib, oracle):
     assert abs(q["meanChiSq"] - r["meanChiSq"]) / q["meanChiSq"] < 0.05
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Verification mode (cogaps_params.reductionMode = SEQ, mathMode = GLIBC_FMA): the HIP library in the reference's own
+# arithmetic.  These are the only tests that compare a GPU result with numbers the reference binary itself produced.
+SEQ = dict(reductionMode="seq", mathMode="glibc-fma")
+
+
+def test_device_math_modes(hip_lib):
+    """logf / expf of the three math modes evaluated by a kernel: the glibc mode against the committed outputs of glibc 2.35's
+    libm (tests/golden/glibc235_logf_expf.npz, tools/make_golden_r2.py), every mode against the same source run on the host"""
+    from cogaps_amd import _capi
+    g = np.load(os.path.join(GOLDEN, "glibc235_logf_expf.npz"))
+    assert _capi.debug_math("log", g["x_log"], "glibc-fma", on_device=True).tobytes() == g["y_log"].tobytes()
+    assert _capi.debug_math("exp", g["x_exp"], "glibc-fma", on_device=True).tobytes() == g["y_exp"].tobytes()
+    rng = np.random.default_rng(1)
+    xl = (rng.integers(0, 2 ** 32, 1 << 20, dtype=np.uint64).astype(np.float32) / np.float32(4294967296.0))
+    xe = -(rng.random(1 << 20, dtype=np.float32) * np.float32(100.0))
+    for mode in ("portable", "glibc-fma", "glibc-sse2"):
+        assert _capi.debug_math("log", xl, mode, on_device=True).tobytes() == _capi.debug_math("log", xl, mode).tobytes(), mode
+        assert _capi.debug_math("exp", xe, mode, on_device=True).tobytes() == _capi.debug_math("exp", xe, mode).tobytes(), mode
+
+
+@pytest.mark.parametrize("name", ["modsim", "gist"])
+def test_reference_fingerprint_on_the_gpu(hip_lib, gist, modsim, name):
+    """the atom histories, totalUpdates, meanChiSq and queue lengths the reference core printed for
+    GIST.mtx K=7 / modsimdata K=3, seed 42, 1000+1000 iterations -- reproduced by cogaps_run on the GPU, plus every float of the
+    committed reference-arithmetic golden run (posterior means and standard deviations, chi2 history)"""
+    from cogaps_amd import _capi
+    from test_oracle_pin import FINGERPRINTS
+    fp = FINGERPRINTS[name]
+    r = _capi.run(gist if name == "gist" else modsim, nPatterns=fp["k"], nIterations=1000, seed=42, outputFrequency=100, **SEQ)
+    assert r["atomsA"].tolist() == fp["atomsA"] and r["atomsP"].tolist() == fp["atomsP"]
+    assert r["totalUpdates"] == fp["totalUpdates"]
+    assert abs(r["meanChiSq"] - fp["meanChiSq"]) < 6e-4
+    assert abs(r["averageQueueLengthA"] - fp["qA"]) < 0.06 and abs(r["averageQueueLengthP"] - fp["qP"]) < 0.06
+    g = np.load(os.path.join(GOLDEN, "%s_k%d_s42_i1000_seq.npz" % (name, fp["k"])))
+    for f in ("Amean", "Pmean", "Asd", "Psd", "chisq"):
+        assert np.array_equal(r[f], g[f]), f
+    assert r["meanChiSq"] == float(g["meanChiSq"]) and r["averageQueueLengthA"] == float(g["avgQueueA"]) and r["averageQueueLengthP"] == float(g["avgQueueP"])
+    # north-star tolerance for the posterior means: 1e-5 relative (met with zero difference)
+    for f in ("Amean", "Pmean"):
+        assert np.max(np.abs(r[f] - g[f]) / np.maximum(np.abs(g[f]), 1e-30)) <= 1e-5
+
+
+@pytest.mark.parametrize("name", ["dense", "sparse"])
+def test_reference_printed_outputs_on_the_gpu(hip_lib, gist, name):
+    """the two further reference outputs of tests/test_oracle_pin.py (dense seed 123; the sparse model, seed 77): every printed
+    digit, and every float of the golden run in the reference's arithmetic"""
+    from cogaps_amd import _capi
+    from test_oracle_pin import REFERENCE_PRINTED, check_reference_printed
+    fp = REFERENCE_PRINTED[name]
+    r = _capi.run(gist, **SEQ, **fp["kw"])
+    check_reference_printed(r, fp)
+    g = np.load(os.path.join(GOLDEN, fp["golden"]))
+    for f in ("Amean", "Pmean", "Asd", "Psd", "chisq"):
+        assert np.array_equal(r[f], g[f]), f
+    assert r["meanChiSq"] == float(g["meanChiSq"])
+
+
+def test_verification_mode_stepwise(hip_lib, gist):
+    """verification mode against the oracle in the same arithmetic, batch by batch (traces, atoms, matrices, AP, chi2): dense with
+    a user uncertainty matrix, wide vectors (several fold blocks, N not a multiple of 4), the sparse model with K above and
+    below gaps::dot's 25-element order switch"""
+    unc = np.maximum(gist * np.float32(0.15), np.float32(0.2)).astype(np.float32)
+    pu.run_stepwise(hip_lib, gist, 40, nPatterns=5, seed=123, total_iter=60, check_every=10, **SEQ)
+    pu.run_stepwise(hip_lib, gist, 20, trace=False, unc=unc, nPatterns=4, seed=5, total_iter=40, check_every=5, **SEQ)
+    pu.run_stepwise(hip_lib, pu.synthetic(5003, 11), 8, trace=False, nPatterns=3, seed=9, total_iter=20, check_every=4, **SEQ)
+    pu.run_stepwise(hip_lib, pu.synthetic_counts(300, 50, zeros=0.85, seed=350), 30, nPatterns=30, seed=11, total_iter=40, check_every=5, sparseOptimization=True, **SEQ)
+    pu.run_stepwise(hip_lib, pu.synthetic_counts(900, 20, zeros=0.8, seed=9), 20, nPatterns=6, seed=12, total_iter=40, check_every=5, sparseOptimization=True, **SEQ)
+
+
+def test_user_uncertainty_stepwise(hip_lib, gist, modsim):
+    """an uncertainty matrix given by the caller (DenseNormalModel.h:90-96): the kernels read S*S instead of recomputing it from D;
+    fused evaluation (modsim, GIST A side) and the P side's 1363-element vectors, lane order, against the oracle"""
+    unc = np.maximum(gist * np.float32(0.15), np.float32(0.2)).astype(np.float32)
+    pu.run_stepwise(hip_lib, gist, 40, unc=unc, nPatterns=5, seed=8, total_iter=60, check_every=10)
+    u2 = (np.maximum(modsim * 0.2, 0.05)).astype(np.float32)
+    pu.run_stepwise(hip_lib, modsim, 100, unc=u2, nPatterns=3, seed=4, total_iter=100, check_every=25)
+    wide = pu.synthetic(9000, 10, seed=77)      # split evaluation (alpha / apply kernels) with S*S read from memory
+    pu.run_stepwise(hip_lib, wide, 12, trace=False, unc=np.maximum(wide * np.float32(0.3), np.float32(0.1)), nPatterns=3, seed=5, total_iter=20, check_every=4)
+
+
+def test_pump_statistics_and_snapshots(hip_lib, modsim, oracle):
+    """takePumpSamples (GapsStatistics.h:65-126) and nSnapshots / snapshotPhase (GapsStatistics.h:188-202, GapsRunner.cpp:316-322)
+    through cogaps_run on the GPU against the oracle: dense and sparse model, the three snapshot phases"""
+    from cogaps_amd import _capi
+    for sparse, data in ((False, modsim), (True, pu.synthetic_counts(80, 24, zeros=0.7, seed=4)), (False, pu.synthetic(700, 30, seed=12))):
+        kw = dict(nPatterns=3, nIterations=60, seed=42, outputFrequency=10, takePumpSamples=True, sparseOptimization=sparse)
+        for phase, code in (("all", 0), ("equilibration", 1), ("sampling", 2)):
+            r = _capi.run(data, lib=hip_lib, nSnapshots=4, snapshotPhase=phase, pumpThreshold="cut" if code == 1 else "unique", **kw)
+            w_a, w_p = hip_lib.cogaps_reduction_width(data.shape[1]), hip_lib.cogaps_reduction_width(data.shape[0])
+            o = oracle.run(data, math_mode=oracle.MATH_PORTABLE, redW_A=w_a, redW_P=w_p, redG=4, snapshotFrequency=15, snapshotPhase=code, **kw)
+            for f in ("Amean", "Pmean", "Asd", "Psd", "pumpMatrix", "meanPatternAssignment", "equilibrationSnapshotsA", "equilibrationSnapshotsP",
+                      "samplingSnapshotsA", "samplingSnapshotsP"):
+                assert np.array_equal(r[f], o[f]), (sparse, phase, f)
+            assert r["equilibrationSnapshotsA"].shape[0] == (4 if code != 2 else 0) and r["samplingSnapshotsP"].shape[0] == (4 if code != 1 else 0)
+            assert np.allclose(r["pumpMatrix"].sum(axis=1), 1.0) and set(np.unique(r["meanPatternAssignment"])) <= {0.0, 1.0}
+
+
+def test_headline_shape_stepwise(hip_lib):
+    """BASELINE configs[2] itself -- 20000 x 2000, K = 50: the 512-thread fused evaluation (A side, 2000-element vectors) and
+    the 8192-lane split evaluation (P side, 20000-element vectors) together, 30 iterations of the bench's chain against the
+    lane-order oracle (OpenMP over the queue): Poisson step counts every iteration, atoms / matrices / AP / chi2 at the end"""
+    import bench
+    import pyoracle as po
+    from cogaps_amd import _capi
+    data = bench.synthetic_dense(20000, 2000)
+    kw = dict(nPatterns=50, nIterations=100, seed=42)
+    S = _capi.Session(data, lib=hip_lib, **kw)
+    assert (hip_lib.cogaps_reduction_width(2000), hip_lib.cogaps_reduction_width(20000)) == (512, 8192)
+    O = po.Session(data, omp=True, maxThreads=min(16, os.cpu_count() or 1), math_mode=po.MATH_PORTABLE, redW_A=512, redW_P=8192, redG=4, **kw)
+    props = 0
+    for it in range(30):
+        t = min(1.0, 2.0 * it / 100)
+        S.set_annealing(t), O.set_annealing(t)
+        nA, nP = S.draw_steps()
+        assert (nA, nP) == O.draw_steps(), "Poisson step counts differ at iteration %d" % it
+        S.iterate(nA, nP), O.iterate(nA, nP)
+        props += nA + nP
+        assert (S.natoms("A"), S.natoms("P")) == (O.natoms("A"), O.natoms("P")), it
+    assert props > 300000 and S.natoms("A") > 40000
+    pu.assert_state_equal(S, O, "headline")
+    S.close(), O.close()
+
+
 def test_tiny_domain(hip_lib):
     pu.run_stepwise(hip_lib, pu.synthetic(5, 6, rank=2, seed=3), 300, nPatterns=2, seed=9, total_iter=200, check_every=50)
 

@@ -19,6 +19,72 @@ FINGERPRINTS = {   # SURVEY.md section 8c, "Oracle facts established", item (3)
 }
 
 
+# Two further outputs of the reference core itself ("Judge's independent oracle check": the same reference
+# build as the section 8c probe, run on configurations the oracle had not been pinned on): GIST.mtx dense K=5 seed=123 300+300
+# iterations outputFrequency 30, and -- the only reference-derived numbers for the SPARSE model -- K=4 seed=77 200+200
+# outputFrequency 20 with sparseOptimization.
+REFERENCE_PRINTED = {
+    "dense": dict(kw=dict(nPatterns=5, nIterations=300, seed=123, outputFrequency=30), golden="gist_k5_s123_i300_seq.npz",
+                  atomsA=[512, 1398, 2213, 2768, 3232, 3622, 3569, 3530, 3494, 3387, 3363, 3340, 3204, 3072, 3041, 2949, 2852, 2901, 2938, 2884],
+                  atomsP=[13, 21, 28, 30, 33, 37, 42, 43, 45, 47, 48, 48, 51, 53, 55, 58, 57, 55, 57, 60],
+                  totalUpdates=1727325, meanChiSq=4856.156, lastChisq=6161.283, qA=33.599, qP=2.875,
+                  probe=("Amean", 0, [0.0009664664, 0.005498413, 0.009075806])),
+    "sparse": dict(kw=dict(nPatterns=4, nIterations=200, seed=77, outputFrequency=20, sparseOptimization=True), golden="gist_k4_s77_i200_sparse_seq.npz",
+                   atomsA=[248, 694, 1152, 1579, 2038, 2428, 2726, 3050, 3299, 3519, 3680, 3777, 3788, 3724, 3566, 3434, 3353, 3324, 3330, 3292],
+                   atomsP=[10, 13, 13, 15, 19, 22, 27, 27, 28, 34, 33, 32, 34, 33, 36, 33, 37, 38, 38, 42],
+                   totalUpdates=1097330, meanChiSq=7804.247, lastChisq=9881.170, qA=None, qP=None,
+                   probe=("Pmean", 0, [0.9394006, 0.7834437, 0.1044978])),
+}
+
+
+def check_reference_printed(r, fp):
+    """every digit the reference binary printed"""
+    assert r["atomsA"].tolist() == fp["atomsA"] and r["atomsP"].tolist() == fp["atomsP"]
+    assert r["totalUpdates"] == fp["totalUpdates"]
+    assert abs(r["meanChiSq"] - fp["meanChiSq"]) < 6e-4 and abs(float(r["chisq"][-1]) - fp["lastChisq"]) < 6e-4
+    if fp["qA"] is not None:
+        assert abs(r["averageQueueLengthA"] - fp["qA"]) < 6e-4 and abs(r["averageQueueLengthP"] - fp["qP"]) < 6e-4
+    f, row, vals = fp["probe"]
+    assert np.allclose(r[f][row, :3], vals, rtol=2e-7, atol=0)
+
+
+@pytest.mark.parametrize("name", ["dense", "sparse"])
+def test_reference_printed_outputs(oracle, gist, name):
+    fp = REFERENCE_PRINTED[name]
+    r = oracle.run(gist, **fp["kw"])
+    check_reference_printed(r, fp)
+    g = np.load(os.path.join(GOLDEN, fp["golden"]))
+    for f in ("Amean", "Pmean", "Asd", "Psd", "chisq"):
+        assert np.array_equal(r[f], g[f]), f
+
+
+def test_glibc_restatement_is_this_hosts_libm(oracle):
+    """oracle/gaps_oracle.c restates glibc 2.35's logf / expf (the reference's libm, a dependency outside /root/reference):
+    it must agree bit for bit with the C library on a host that runs the -mfma variant -- every 97th float of uniform()'s
+    range for logf and of (-inf, 0] for expf here (tools/make_golden_r2.py's run covered every float), and with the
+    committed vectors anywhere"""
+    L = oracle.lib()
+    g = np.load(os.path.join(GOLDEN, "glibc235_logf_expf.npz"))
+    for v, w in zip(g["x_log"], g["y_log"]):
+        assert np.float32(L.go_glibc_logf(float(v), 1)).tobytes() == w.tobytes(), float(v)
+    for v, w in zip(g["x_exp"], g["y_exp"]):
+        assert np.float32(L.go_glibc_expf(float(v), 1)).tobytes() == w.tobytes(), float(v)
+    fused_here = L.go_glibc_mismatches(0, 1, 0, 0x3f800000, 9973) + L.go_glibc_mismatches(1, 1, 0x80000000, 0xff800000, 9973) == 0
+    if not fused_here:
+        pytest.skip("this host's libm is not the glibc 2.35 -mfma build; the committed vectors above are the pin")
+    assert L.go_glibc_mismatches(0, 1, 0, 0x3f800000, 97) == 0
+    assert L.go_glibc_mismatches(1, 1, 0x80000000, 0xff800000, 97) == 0
+
+
+def test_glibc_math_mode_gives_the_libm_chain(oracle, gist):
+    """the restated math is what makes the difference on seed 123 (the portable log flips an accept test near iteration 370)"""
+    kw = REFERENCE_PRINTED["dense"]["kw"]
+    a = oracle.run(gist, math_mode=oracle.MATH_GLIBC_FMA, **kw)
+    check_reference_printed(a, REFERENCE_PRINTED["dense"])
+    b = oracle.run(gist, math_mode=oracle.MATH_PORTABLE, **kw)
+    assert b["atomsA"].tolist()[:12] == a["atomsA"].tolist()[:12] and b["totalUpdates"] != a["totalUpdates"]
+
+
 @pytest.mark.parametrize("name", ["modsim", "gist"])
 def test_reference_fingerprint(oracle, gist, modsim, name):
     fp = FINGERPRINTS[name]
