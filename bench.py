@@ -227,38 +227,58 @@ def main():
         tot_updates, max_dt = float(u[0].item()), float(m[1].item())
 
     if rank == 0:
-        def kernel_times(w):
-            """HIP start/stop events ride on the dispatch packets of a sample of the launches (hipExtLaunchKernelGGL on
-            the kernels' stream): begin-to-end time of the dispatch, the quantity rocprofv3 --kernel-trace reports.
-            Launches enqueued past the end of an update (empty queue) are kept out of the average."""
-            d = {k: perf1[w][k] - perf0[w][k] for k in perf1[w]}
-            nb = max(1, d["batches"])
-            ev_noop = 1e3 * d["evalNoopMs"] / d["evalNoopTimed"] if d["evalNoopTimed"] else 0.0
-            return dict(batches=d["batches"], bytes=d["evalBytes"], eval_us=1e3 * d["evalMs"] / nb, gen_us=1e3 * d["genMs"] / nb,
-                        eval_empty_us=ev_noop, launches=d["evalLaunches"] + d["genLaunches"])
-        kt = {w: kernel_times(w) for w in "AP"}
+        # HIP start/stop events ride on the dispatch packets of a sample of the launches (hipExtLaunchKernelGGL on the kernels'
+        # own stream): begin-to-end time of the dispatch, the quantity rocprofv3 --kernel-trace reports.  The library scales the
+        # sampled time to the batches processed since set_timing(1) (cogaps_perf.timedBatches); launches enqueued past the end
+        # of an update (empty queue) are kept out of the averages; every sync (AP transpose) launch is timed.
+        def window(w):
+            d = {k: perf1[w][k] - perf0[w][k] for k in ("evalBytes", "batches", "evalLaunches", "genLaunches")}
+            for k in ("evalMs", "genMs", "timedBatches", "evalTimed", "genTimed", "evalNoopMs", "evalNoopTimed"):
+                d[k] = perf1[w][k]           # counted from set_timing(1)
+            return d
+        kt = {w: window(w) for w in "AP"}
+        tot = S.perf()
         batches = kt["A"]["batches"] + kt["P"]["batches"]
-        # the roofline kernel: the fused evaluation kernel, which serves the sampler whose data vectors have at most
-        # 4096 elements (A in the headline workload: one workgroup of 512 threads per proposal); the other sampler's
-        # long vectors go through the split alpha/apply kernels, reported alongside
-        roof = "A" if (args.sparse or S.dims("A")[1] <= 4096) else "P"
-        rk = kt[roof]
-        achieved = (rk["bytes"] / 1e9) / (rk["eval_us"] * rk["batches"] / 1e6) if rk["batches"] else 0.0
-        gen_ms = sum(kt[w]["gen_us"] * kt[w]["batches"] for w in "AP") / 1e3
-        ev_ms = sum(kt[w]["eval_us"] * kt[w]["batches"] for w in "AP") / 1e3
-        other = "P" if roof == "A" else "A"
-        ok = kt[other]
-        # HBM bytes per launch of the roofline kernel from the PMC counters: collected in two separate rocprofv3 --pmc passes
-        # (FETCH_SIZE, WRITE_SIZE; tools/pmc_pass.sh) over this same command and committed under profiles/ -- a bench run cannot
-        # collect them itself.  Only quoted for the workload they were measured on.
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if (not args.sparse and roof == "A" and (args.genes, args.samples, args.patterns, K, W) == (20000, 2000, 50, 190, 10) and os.path.exists(pmc)):
-            k0 = json.load(open(pmc))["kernels"].get("eval_kernel<0>")
-            if k0:
-                traffic = k0["hbm_bytes_per_launch"]
-                traffic_src = ("profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + --pmc WRITE_SIZE, separate passes over "
-                               "this command, mean over the %d launches of the timed region that moved data" % k0["launches"])
+        fusedA = args.sparse or S.dims("A")[1] <= 4096
+        fusedP = args.sparse or S.dims("P")[1] <= 4096
+        ev_name = lambda fused: "eval_sparse_kernel" if args.sparse else ("eval_kernel<EVAL_FUSED>" if fused else "eval_kernel<EVAL_ALPHA> + eval_kernel<EVAL_APPLY> (two launches per batch)")
+
+        def kernel_line(name, sampler, ms, launches, nbytes, sampled):
+            us = 1e3 * ms / launches if launches else 0.0
+            ach = (nbytes / 1e9) / (ms / 1e3) if ms > 0 else 0.0
+            return {"kernel": name, "sampler": sampler, "launches": int(launches), "sampled_launches": int(sampled), "avg_launch_us": us, "total_ms": ms,
+                    "bytes_per_launch": nbytes / launches if launches else 0.0, "achieved": ach, "frac": ach / HBM_PEAK_GBS}
+        kernels = [
+            kernel_line(ev_name(fusedA), "A", kt["A"]["evalMs"], kt["A"]["timedBatches"], kt["A"]["evalBytes"], kt["A"]["evalTimed"]),
+            kernel_line(ev_name(fusedP), "P", kt["P"]["evalMs"], kt["P"]["timedBatches"], kt["P"]["evalBytes"], kt["P"]["evalTimed"]),
+            kernel_line("gen_kernel<256>", "A", kt["A"]["genMs"], kt["A"]["timedBatches"], 0, kt["A"]["genTimed"]),
+            kernel_line("gen_kernel<256>", "P", kt["P"]["genMs"], kt["P"]["timedBatches"], 0, kt["P"]["genTimed"]),
+            kernel_line("sparse_tables_kernel (not timed)" if args.sparse else "transpose_kernel (sync)", "A+P", tot["syncMs"], tot["syncTimed"], tot["syncBytes"], tot["syncTimed"]),
+        ]
+        gen_ms = kt["A"]["genMs"] + kt["P"]["genMs"]
+        ev_ms = kt["A"]["evalMs"] + kt["P"]["evalMs"]
+        kernel_ms = gen_ms + ev_ms + tot["syncMs"]
+        b_alg = kt["A"]["evalBytes"] + kt["P"]["evalBytes"] + tot["syncBytes"]
+        # the kernels run back to back on one stream: their summed durations cannot exceed the wall time of the timed region
+        consistent = kernel_ms <= 1.05 * (1e3 * dt) and all(k["sampled_launches"] > 0 for k in kernels[:4] if k["launches"])
+        achieved = (b_alg / 1e9) / (kernel_ms / 1e3) if (consistent and kernel_ms > 0) else None
+        dominant = max(kernels, key=lambda k: k["total_ms"])
+        # HBM bytes from the PMC counters: two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; tools/pmc_pass.sh) over this
+        # same workload, committed under profiles/ -- a bench run cannot collect them itself.  Quoted whenever the workload shape
+        # is the one they were measured on (any --steps / --warmup: per-launch means of the populated chain).
+        traffic, traffic_src, traffic_kernels = None, None, None
+        if not args.sparse and (args.genes, args.samples, args.patterns) == (20000, 2000, 50):
+            import glob
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+            if files:
+                pk = json.load(open(files[-1]))["kernels"]
+                traffic_kernels = {k: v["hbm_bytes_per_launch"] for k, v in pk.items()}
+                tb = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in pk.values())
+                nb = sum(v["launches"] for k, v in pk.items() if k.startswith("gen_kernel"))
+                if nb:
+                    traffic = tb / nb
+                    traffic_src = ("%s: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + --pmc WRITE_SIZE, separate passes over this workload; sum over "
+                                   "the generator and evaluation kernels of (bytes per launch x launches) / batches" % os.path.relpath(files[-1], ROOT))
         out = {
             "metric": METRIC, "value": tot_updates / max_dt, "unit": "proposals/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * max_dt / K,
@@ -270,16 +290,16 @@ def main():
                        "nIterations": n_iter, "untimed_schedule_steps_before_warmup": burn, "proposals_timed": int(tot_updates), "batches_rank0": int(batches),
                        "avg_queue_A": S.avg_queue("A"), "avg_queue_P": S.avg_queue("P"),
                        "atoms_A": S.natoms("A"), "atoms_P": S.natoms("P"),
-                       "gen_kernel_ms_rank0": gen_ms, "eval_kernel_ms_rank0": ev_ms,
-                       "launches_per_batch": (kt["A"]["launches"] + kt["P"]["launches"]) / max(1, batches)},
-            "roofline": {"bound": "hbm", "kernel": ("eval_sparse_kernel (sampler %s)" if args.sparse else "eval_kernel<EVAL_FUSED> (sampler %s)") % roof, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "bytes_per_launch": rk["bytes"] / max(1, rk["batches"]), "avg_launch_us": rk["eval_us"],
-                         "empty_queue_launch_us": rk["eval_empty_us"], "launches": int(rk["batches"]),
-                         "note": "one launch = one batch of sampler %s" % roof,
-                         "other_sampler": {"kernels": ("eval_sparse_kernel (sampler %s)" if args.sparse else "eval_kernel<EVAL_ALPHA> + eval_kernel<EVAL_APPLY> (sampler %s, two launches per batch)") % other,
-                                           "bytes_per_batch": ok["bytes"] / max(1, ok["batches"]), "avg_batch_us": ok["eval_us"], "batches": int(ok["batches"]),
-                                           "achieved": (ok["bytes"] / 1e9) / (ok["eval_us"] * ok["batches"] / 1e6) if ok["batches"] else 0.0}},
+                       "timed_region_ms_rank0": 1e3 * dt, "gen_kernel_ms_rank0": gen_ms, "eval_kernel_ms_rank0": ev_ms, "sync_kernel_ms_rank0": tot["syncMs"],
+                       "launches_per_batch": sum(kt[w]["evalLaunches"] + kt[w]["genLaunches"] for w in "AP") / max(1, batches)},
+            # roofline.achieved = B_alg / (sum of kernel time) over the whole path -- generator, evaluation and sync
+            # kernels of the timed region -- with each kernel's own figure alongside.  One "launch" of the path = one batch.
+            "roofline": {"bound": "hbm", "kernel": "path: gen_kernel + evaluation kernels + sync, per batch (dominant by time: %s, sampler %s)" % (dominant["kernel"], dominant["sampler"]),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved is not None else None,
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_bytes_per_launch_by_kernel": traffic_kernels,
+                         "bytes_per_launch": b_alg / max(1, batches), "avg_launch_us": 1e3 * kernel_ms / max(1, batches), "launches": int(batches),
+                         "kernel_time_over_wall": kernel_ms / (1e3 * dt), "timing_consistent": bool(consistent),
+                         "kernels": kernels},
         }
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(data, params, args.cpu_seconds)

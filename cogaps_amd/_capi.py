@@ -57,6 +57,7 @@ class CogapsPerfC(C.Structure):
         ("batches", C.c_uint64), ("proposalsQueued", C.c_uint64),
         ("evalMs", C.c_double), ("genMs", C.c_double), ("syncMs", C.c_double),
         ("evalNoopMs", C.c_double), ("genNoopMs", C.c_double), ("evalNoopTimed", C.c_uint64), ("genNoopTimed", C.c_uint64),
+        ("timedBatches", C.c_uint64), ("evalTimed", C.c_uint64), ("genTimed", C.c_uint64), ("syncTimed", C.c_uint64), ("syncBytes", C.c_uint64),
     ]
 
 
@@ -76,7 +77,7 @@ EXPORTS = [
     "cogaps_session_get_atoms", "cogaps_session_dims", "cogaps_session_avg_queue",
     "cogaps_session_finish", "cogaps_session_set_timing", "cogaps_session_perf",
     "cogaps_session_perf_sampler", "cogaps_session_get_rows", "cogaps_sparse_width", "cogaps_reduction_width", "cogaps_session_debug_prof", "cogaps_session_debug_replay",
-    "cogaps_run_from_file", "cogaps_read_matrix_file", "cogaps_matrix_free", "cogaps_file_info", "cogaps_debug_math",
+    "cogaps_run_from_file", "cogaps_read_matrix_file", "cogaps_matrix_free", "cogaps_file_info", "cogaps_debug_math", "cogaps_current_device",
 ]
 
 REDUCE_LANES, REDUCE_SEQ = 0, 1                              # cogaps_params.reductionMode
@@ -130,6 +131,7 @@ def bind(L):
     L.cogaps_matrix_free.restype = None
     L.cogaps_file_info.argtypes = [C.c_char_p, u32p, u32p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.cogaps_debug_math.argtypes = [C.c_int, C.c_int, fp, fp, C.c_uint32, C.c_int]
+    L.cogaps_current_device.argtypes = [C.POINTER(C.c_int)]
     return L
 
 
@@ -158,7 +160,7 @@ def make_params(L, nPatterns=3, nIterations=1000, seed=0, outputFrequency=500, n
                 fixedPatterns=None, sparseOptimization=False, asynchronousUpdates=True,
                 messages=False, workerID=1, device=-1, takePumpSamples=False,
                 checkpointInterval=0, nSnapshots=0, snapshotPhase="sampling", snapshotFrequency=None,
-                pumpThreshold="unique", reductionMode="lanes", mathMode="portable"):
+                pumpThreshold="unique", reductionMode="lanes", mathMode="portable", runningDistributed=False):
     p = CogapsParamsC()
     L.cogaps_default_params(C.byref(p))
     p.nPatterns, p.nIterations, p.seed = int(nPatterns), int(nIterations), int(seed)
@@ -176,6 +178,7 @@ def make_params(L, nPatterns=3, nIterations=1000, seed=0, outputFrequency=500, n
     p.snapshotPhase = {"all": 0, "equilibration": 1, "sampling": 2}[snapshotPhase] if isinstance(snapshotPhase, str) else int(snapshotPhase)
     p.workerID = int(workerID)
     p.device = int(device)
+    p.runningDistributed = int(bool(runningDistributed))
     p.pumpThreshold = _PUMP[pumpThreshold] if isinstance(pumpThreshold, str) else int(pumpThreshold)
     p.reductionMode = _REDUCE[reductionMode] if isinstance(reductionMode, str) else int(reductionMode)
     p.mathMode = _MATH[mathMode] if isinstance(mathMode, str) else int(mathMode)
@@ -425,3 +428,12 @@ def debug_math(fn, x, mathMode="portable", on_device=False, lib=None):
     if L.cogaps_debug_math({"log": 0, "exp": 1}[fn], _MATH[mathMode] if isinstance(mathMode, str) else int(mathMode), _fp(xs), _fp(ys), xs.size, int(on_device)):
         raise RuntimeError(L.cogaps_last_error().decode())
     return ys
+
+
+def current_device(lib=None):
+    """hipGetDevice for the calling host thread"""
+    L = lib if lib is not None else load()
+    d = C.c_int(0)
+    if L.cogaps_current_device(C.byref(d)):
+        raise RuntimeError(L.cogaps_last_error().decode())
+    return d.value

@@ -39,8 +39,10 @@ def CoGAPS(data, params=None, nPatterns=None, nThreads=1, messages=True, outputF
            BPPARAM=None, workerID=1, asynchronousUpdates=True, nSnapshots=0, snapshotPhase="sampling", device=-1, **extra):
     if params is None:
         params = CogapsParams(**({} if nPatterns is None else {"nPatterns": nPatterns}))
-    elif nPatterns is not None:
-        params.setParam("nPatterns", nPatterns)
+    else:
+        params = params.copy()                                   # value semantics of the S4 object: the caller's params stay as they are
+        if nPatterns is not None:
+            params.setParam("nPatterns", nPatterns)
     for k, v in extra.items():                                   # parseExtraParams: named CogapsParams slots in ...
         params.setParam(k, v)
     params.validate()
@@ -57,7 +59,7 @@ def CoGAPS(data, params=None, nPatterns=None, nThreads=1, messages=True, outputF
         # flight per GPU (an int, or an object with a `workers` attribute; default 4)
         in_flight = 4 if BPPARAM is None else int(getattr(BPPARAM, "workers", BPPARAM))
         raw = distributedCogaps(data, params, unc, messages=messages, outputFrequency=outputFrequency, transposeData=transposeData, device=device,
-                                shardsInFlight=in_flight)
+                                shardsInFlight=in_flight, nSnapshots=nSnapshots, snapshotPhase=snapshotPhase)
     else:
         raw = _capi.run(data, unc=unc, nPatterns=params.nPatterns, nIterations=params.nIterations, seed=params.seed,
                         outputFrequency=outputFrequency, nThreads=nThreads, alphaA=params.alphaA, alphaP=params.alphaP,
@@ -71,14 +73,14 @@ def CoGAPS(data, params=None, nPatterns=None, nThreads=1, messages=True, outputF
 
 def GWCoGAPS(data, params=None, nPatterns=None, **kw):
     """R/CoGAPS.R:213-224"""
-    params = params or CogapsParams(**({} if nPatterns is None else {"nPatterns": nPatterns}))
+    params = params.copy() if params is not None else CogapsParams(**({} if nPatterns is None else {"nPatterns": nPatterns}))
     params.distributed = "genome-wide"
     return CoGAPS(data, params, nPatterns, **kw)
 
 
 def scCoGAPS(data, params=None, nPatterns=None, **kw):
     """R/CoGAPS.R:173-184"""
-    params = params or CogapsParams(**({} if nPatterns is None else {"nPatterns": nPatterns}))
+    params = params.copy() if params is not None else CogapsParams(**({} if nPatterns is None else {"nPatterns": nPatterns}))
     params.distributed = "single-cell"
     params.sparseOptimization = kw.pop("sparseOptimization", params.sparseOptimization)
     return CoGAPS(data, params, nPatterns, **kw)

@@ -158,6 +158,8 @@ struct HostSampler {
     // HIP-event samples, split into launches that processed a batch and launches past the end of an update
     double evalMs = 0, genMs = 0, evalNoopMs = 0, genNoopMs = 0; uint64_t evalTimed = 0, genTimed = 0, evalNoopTimed = 0, genNoopTimed = 0;
     uint64_t updLaunches = 0;    // (generator, evaluation) pairs enqueued in the current update
+    uint64_t batchesAtTimingOn = 0;   // `batches` when event timing was switched on: the sampled times are scaled to the batches since then
+    uint64_t plainRotor = 0;     // which graph replay of a chunk runs as plain, event-carrying launches while timing is on
 };
 
 struct cogaps_session {
@@ -175,7 +177,7 @@ struct cogaps_session {
     float *Asum = nullptr, *Asq = nullptr, *Psum = nullptr, *Psq = nullptr;
     unsigned statUpdates = 0;
     std::vector<float> chisqHist; std::vector<uint32_t> atomHistA, atomHistP;
-    uint64_t totalUpdates = 0; double samplerSeconds = 0; double syncMs = 0;
+    uint64_t totalUpdates = 0; double samplerSeconds = 0; double syncMs = 0; uint64_t syncTimed = 0, syncBytes = 0;
     bool timing = false; bool evInit = false;
     bool noGraph = getenv("COGAPS_NO_GRAPH") != nullptr;     // diagnostics: every launch as a plain call (counter collection tools)
     std::vector<rt_event_pair> evPool; std::vector<int> evKind; std::vector<HostSampler *> evOwner; std::vector<uint64_t> evOrd; size_t evUsed = 0;
@@ -336,7 +338,7 @@ static void grow_atoms(cogaps_session *s, HostSampler &h, uint32_t need)
 // chunk's synchronisation so that timing never stalls the queue.
 static int timing_slot(cogaps_session *s, HostSampler &h, int kind, uint64_t ordinal)
 {
-    if (!s->timing || (ordinal % 8) != 0 || s->evUsed >= s->evPool.size()) return -1;
+    if (!s->timing || (kind != 4 && (ordinal % 8) != 0) || s->evUsed >= s->evPool.size()) return -1;
     const int i = (int)s->evUsed++;
     s->evKind[i] = kind; s->evOwner[i] = &h; s->evOrd[i] = h.updLaunches;
     return i;
@@ -350,6 +352,7 @@ static void timing_resolve(cogaps_session *s, uint64_t realBatches)
         const bool real = s->evOrd[i] < realBatches;
         if (s->evKind[i] == 0) { if (real) { h->genMs += ms; h->genTimed++; } else { h->genNoopMs += ms; h->genNoopTimed++; } }
         else if (s->evKind[i] == 1) { if (real) { h->evalMs += ms; h->evalTimed++; } else { h->evalNoopMs += ms; h->evalNoopTimed++; } }
+        else if (s->evKind[i] == 4) { s->syncMs += ms; s->syncTimed++; }     // sync (AP transpose / lookup tables): every launch is timed
         else { if (real) h->evalMs += ms; else h->evalNoopMs += ms; }      // second kernel of a split evaluation: same sample as the first
     }
     s->evUsed = 0;
@@ -455,7 +458,15 @@ static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool t
         uint32_t plain = chunk;
         if (rt_graphs_supported() && !s->noGraph && !trace && plain >= GRAPH_PAIRS) {
             ensure_graph(s, h);
-            for (; plain >= GRAPH_PAIRS; plain -= GRAPH_PAIRS) { rt_graph_launch(h.graph, s->stream); h.genLaunches += GRAPH_PAIRS; h.evalLaunches += GRAPH_PAIRS; h.updLaunches += GRAPH_PAIRS; }
+            // HIP events cannot ride on replayed launches.  While timing is on, one replay of every chunk -- its position moves
+            // through the chunk from update to update -- is issued as plain launches that carry events, so that the sample covers
+            // the whole population of batches and not only the tail of each chunk (the remainder below).
+            const uint32_t nRep = plain / GRAPH_PAIRS;
+            const uint32_t timedRep = s->timing ? (uint32_t)((h.plainRotor++ * 7u) % nRep) : 0xFFFFFFFFu;
+            for (uint32_t r = 0; plain >= GRAPH_PAIRS; plain -= GRAPH_PAIRS, ++r) {
+                if (r == timedRep) { for (uint32_t b = 0; b < GRAPH_PAIRS; ++b) { launch_gen(s, h); launch_eval(s, h); h.updLaunches++; } continue; }
+                rt_graph_launch(h.graph, s->stream); h.genLaunches += GRAPH_PAIRS; h.evalLaunches += GRAPH_PAIRS; h.updLaunches += GRAPH_PAIRS;
+            }
         }
         for (uint32_t b = 0; b < plain; ++b) { launch_gen(s, h); launch_eval(s, h); h.updLaunches++; }
         read_gs(s, h);
@@ -478,7 +489,9 @@ static void do_sync(cogaps_session *s, HostSampler &dst, HostSampler &src)
         return;
     }
     const uint32_t tilesX = (src.d.N + TR_TILE - 1) / TR_TILE, tilesY = (src.d.M + TR_TILE - 1) / TR_TILE;
-    RT_LAUNCH(transpose_kernel, tilesX * tilesY, 256, s->stream, (const float *)src.d.AP, dst.d.AP, src.d.M, src.d.N, src.d.Npad, dst.d.Npad, tilesX);
+    const int slot = timing_slot(s, dst, 4, 0);
+    if (slot >= 0) s->syncBytes += 8ull * src.d.M * src.d.N;         // algorithmic traffic of a sync: M x N floats read and written
+    LAUNCH_MAYBE_TIMED(slot, transpose_kernel, tilesX * tilesY, 256, (const float *)src.d.AP, dst.d.AP, src.d.M, src.d.N, src.d.Npad, dst.d.Npad, tilesX);
 }
 
 static float chisq_of(cogaps_session *s, HostSampler &h)
@@ -521,6 +534,11 @@ int cogaps_debug_math(int fn, int mathMode, const float *x, float *y, uint32_t n
         rt_free(dx); rt_free(dy); rt_stream_destroy(st);
         return 0;
     } catch (const std::exception &e) { return fail(e.what()); }
+}
+
+int cogaps_current_device(int *device)
+{
+    try { if (!device) return fail("null argument"); *device = rt_get_device(); return 0; } catch (const std::exception &e) { return fail(e.what()); }
 }
 
 void cogaps_default_params(cogaps_params *p)
@@ -941,6 +959,13 @@ int cogaps_session_set_timing(cogaps_session *s, int on)
         for (auto &e : s->evPool) rt_event_create(e);
         s->evInit = true;
     }
+    if (on && !s->timing) {      // a new window: the sampled times are scaled to the batches processed from here on
+        for (HostSampler *h : {&s->A, &s->P}) {
+            h->batchesAtTimingOn = h->batches;
+            h->evalMs = h->genMs = h->evalNoopMs = h->genNoopMs = 0; h->evalTimed = h->genTimed = h->evalNoopTimed = h->genNoopTimed = 0;
+        }
+        s->syncMs = 0; s->syncTimed = 0; s->syncBytes = 0;
+    }
     s->timing = on != 0;
     SESSION_END
 }
@@ -949,9 +974,11 @@ static void add_perf(cogaps_session *s, HostSampler *h, cogaps_perf *out)
     read_gs(s, *h);
     out->evalBytes += s->hGs->evalBytes; out->proposalsQueued += s->hGs->evalProps;
     out->evalLaunches += h->evalLaunches; out->genLaunches += h->genLaunches; out->batches += h->batches;
-    // sampled event timing scaled to the launches that processed a batch
-    if (h->evalTimed) out->evalMs += h->evalMs * (double)h->batches / (double)h->evalTimed;
-    if (h->genTimed) out->genMs += h->genMs * (double)h->batches / (double)h->genTimed;
+    // sampled event timing scaled to the batches processed since timing was switched on
+    const double win = (double)(h->batches - h->batchesAtTimingOn);
+    out->timedBatches += h->batches - h->batchesAtTimingOn; out->evalTimed += h->evalTimed; out->genTimed += h->genTimed;
+    if (h->evalTimed) out->evalMs += h->evalMs * win / (double)h->evalTimed;
+    if (h->genTimed) out->genMs += h->genMs * win / (double)h->genTimed;
     out->evalNoopMs += h->evalNoopMs; out->evalNoopTimed += h->evalNoopTimed;
     out->genNoopMs += h->genNoopMs; out->genNoopTimed += h->genNoopTimed;
 }
@@ -959,8 +986,9 @@ int cogaps_session_perf(cogaps_session *s, cogaps_perf *out)
 {
     SESSION_TRY
     memset(out, 0, sizeof(*out));
+    rt_sync(s->stream); timing_resolve(s, 0);        // sync launches timed since the last update (generator / evaluation events are resolved per chunk)
     for (HostSampler *h : {&s->A, &s->P}) add_perf(s, h, out);
-    out->syncMs = s->syncMs;
+    out->syncMs = s->syncMs; out->syncTimed = s->syncTimed; out->syncBytes = s->syncBytes;
     SESSION_END
 }
 int cogaps_session_perf_sampler(cogaps_session *s, char which, cogaps_perf *out)

@@ -100,8 +100,8 @@ CG_HD float gm_expf(float x)
 // e_expf.c: table + degree-3 polynomial, every intermediate an IEEE double) with the multiply-add pairs fused exactly where
 // the library's -mfma build (__logf_fma / __expf_fma, what x86-64 glibc selects on FMA-capable hosts) fuses them; fused =
 // false gives the generic build.  Used by the verification mode (cogaps_params.mathMode) so that the GPU chain can be
-// compared with numbers the reference binary itself produced; oracle/gaps_oracle.c holds the same restatement and checks
-// it against the host's libm over every float.
+// compared with numbers the reference binary itself produced.  (The test suite keeps its own restatement of the algorithm
+// and checks it against a glibc 2.35 host's libm over every float.)
 #define GM_MATH_PORTABLE 0u
 #define GM_MATH_GLIBC_FMA 1u
 #define GM_MATH_GLIBC_SSE2 2u

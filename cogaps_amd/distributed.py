@@ -24,14 +24,62 @@ from . import _capi
 
 
 # ------------------------------------------------------------------------------------------------
-def create_sets(total, params):
+def _explicit_sets(params, names):
+    """sampleWithExplictSets, R/SubsetData.R:7-29: index sets as given (not sorted, as in the reference), or sets of gene /
+    sample names mapped through the names of the partitioned dimension (`which(allNames %in% set)`: ascending indices)"""
+    sets = list(params.explicitSets)
+    is_name = [all(isinstance(x, str) for x in s) and len(s) > 0 for s in sets]
+    if all(is_name):
+        if names is None:
+            raise ValueError("explicitSets holds names but no %s were given" % ("geneNames" if params.distributed == "genome-wide" else "sampleNames"))
+        lookup = {}
+        for i, n in enumerate(names):
+            lookup.setdefault(n, []).append(i + 1)
+        out = []
+        for st in sets:
+            if any(x not in lookup for x in st):
+                raise ValueError("some named genes in explicitSets not found")
+            out.append(np.sort(np.array([i for x in set(st) for i in lookup[x]], dtype=np.int64)))
+        return out
+    if any(is_name):
+        raise ValueError("explicitSets must be all index sets or all name sets")
+    return [np.asarray(s, dtype=np.int64) for s in sets]
+
+
+def _annotation_weight_sets(params, set_size, rng):
+    """sampleWithAnnotationWeights, R/SubsetData.R:37-55: every set draws `set_size` group labels with the given weights, then that
+    many members of each group with replacement; sorted.  (numpy's generator, not R's sample(): same distribution, other draws.)"""
+    ann = np.asarray(params.samplingAnnotation)
+    weight = dict(params.samplingWeight)
+    groups = sorted(set(ann.tolist()))
+    if sorted(weight) != groups:
+        raise ValueError("samplingWeight must name every group of samplingAnnotation")
+    prob = np.array([float(weight[g]) for g in groups], dtype=np.float64)
+    prob = prob / prob.sum()
+    sets = []
+    for _ in range(params.nSets):
+        counts = rng.multinomial(set_size, prob)
+        picks = [rng.choice(np.nonzero(ann == g)[0] + 1, size=c, replace=True) for g, c in zip(groups, counts) if c]
+        sets.append(np.sort(np.concatenate(picks)).astype(np.int64))
+    return sets
+
+
+def create_sets(total, params, names=None):
     """1-based index sets (R convention), R/SubsetData.R:85-116"""
     if params.explicitSets is not None:
         if len(params.explicitSets) != params.nSets:
             raise ValueError("nSets does not match number of explicit sets given")
-        return [np.sort(np.asarray(s, dtype=np.int64)) for s in params.explicitSets]
+        sets = _explicit_sets(params, names)
+        for st in sets:
+            if st.size == 0 or st.min() < 1 or st.max() > total:
+                raise ValueError("explicitSets holds an index outside 1 .. %d" % total)
+        return sets
     rng = np.random.Generator(np.random.MT19937(int(params.seed)))
     set_size = total // params.nSets
+    if params.samplingAnnotation is not None:
+        if len(params.samplingAnnotation) != total:
+            raise ValueError("samplingAnnotation must label every one of the %d partitioned rows / columns" % total)
+        return _annotation_weight_sets(params, set_size, rng)
     remaining = np.arange(1, total + 1)
     sets = []
     for _ in range(params.nSets - 1):                      # sampleUniformly, SubsetData.R:63-76
@@ -117,11 +165,11 @@ def pattern_match(all_patterns, params):
         if not parts:                                      # neither half reaches minNS: R would index NULL; drop the cluster
             clusters.pop(i)
             continue
+        # splitCluster (:151-158): the first half replaces the cluster, the second is appended; the loop goes on until no
+        # cluster exceeds maxNS (cutree(k = 2) always takes at least one column away, so it ends)
         clusters[i] = parts[0]
         if len(parts) > 1:
             clusters.append(parts[1])
-        elif parts[0].shape[1] == clusters[i].shape[1] and parts[0].shape[1] > params.maxNS:
-            break
     if not clusters:
         raise ValueError("no cluster of patterns reaches minNS members")
     mean_patterns = np.stack([
@@ -165,6 +213,19 @@ def _all_gather_arrays(local, shapes, dist, device):
     return res
 
 
+def _current_device(run_fn):
+    """ordinal of the calling thread's current GPU: torch's when it has initialised HIP, else hipGetDevice through the library"""
+    try:
+        import torch
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            return int(torch.cuda.current_device())
+    except Exception:
+        pass
+    if run_fn is _capi.run:
+        return _capi.current_device()
+    return 0
+
+
 def _run_shards(call, ids, in_flight):
     """This rank's shards, `in_flight` at a time (the role of BPPARAM's workers, DistributedCogaps.R:60-63, 84-87): one
     host thread, one HIP stream and one session per shard in flight.  A single chain keeps one workgroup busy in
@@ -180,17 +241,23 @@ def _run_shards(call, ids, in_flight):
 
 
 def distributedCogaps(data, params, uncertainty=None, messages=False, outputFrequency=1000, transposeData=False,
-                      device=-1, run_fn=None, comm_device=None, shardsInFlight=4):
+                      device=-1, run_fn=None, comm_device=None, shardsInFlight=4, nSnapshots=0, snapshotPhase="sampling"):
     run_fn = run_fn or _capi.run
     shardsInFlight = max(1, int(shardsInFlight))
     genome_wide = params.distributed == "genome-wide"
     subset_rows = bool(transposeData) != genome_wide          # xor, SubsetData.R:87-88
     total = data.shape[0] if subset_rows else data.shape[1]
-    sets = create_sets(total, params)
+    sets = create_sets(total, params, params.geneNames if genome_wide else params.sampleNames)
     if min(len(s) for s in sets) < params.nPatterns:
         raise ValueError("data subset dimension less than nPatterns")
     dist = _dist()
     world, rank = (dist.get_world_size(), dist.get_rank()) if dist else (1, 0)
+    if world > len(sets):                                      # every rank sees this before the first collective: none is left waiting
+        raise ValueError("more ranks (%d) than subsets (%d)" % (world, len(sets)))
+    if device is None or device < 0:
+        # The HIP current device belongs to the calling host thread; the shards in flight run on pool threads that start on
+        # device 0.  Resolve the ordinal once, here, and hand it to every shard explicitly.
+        device = _current_device(run_fn)
     if comm_device is None:
         comm_device = "cpu"
         if dist is not None and dist.get_backend() == "nccl":
@@ -199,11 +266,23 @@ def distributedCogaps(data, params, uncertainty=None, messages=False, outputFreq
     mine = list(range(rank, len(sets), world))
     common = dict(nIterations=params.nIterations, seed=params.seed, outputFrequency=outputFrequency, alphaA=params.alphaA,
                   alphaP=params.alphaP, maxGibbsMassA=params.maxGibbsMassA, maxGibbsMassP=params.maxGibbsMassP,
-                  transposeData=transposeData, sparseOptimization=params.sparseOptimization, device=device)
+                  transposeData=transposeData, sparseOptimization=params.sparseOptimization, device=device,
+                  takePumpSamples=params.takePumpSamples, nSnapshots=nSnapshots, snapshotPhase=snapshotPhase)      # allParams reaches every worker unchanged (:12-35)
+
+    shard_cache = {}
+
+    def shard(i):
+        """rows (columns) sets[i] of the data / uncertainty as their own contiguous matrices: the library then holds and uploads
+        one shard, never the whole matrix (Matrix(mat, genesInCols, subsetGenes, indices), Matrix.cpp:30-69, picks exactly these)"""
+        if i not in shard_cache:
+            idx = sets[i] - 1
+            cut = (lambda m: np.ascontiguousarray(m[idx, :] if subset_rows else m[:, idx], dtype=np.float32))
+            shard_cache[i] = (cut(data), None if uncertainty is None else cut(uncertainty))
+        return shard_cache[i]
 
     def call(i, n_patterns, fixed=None, which="N"):            # callInternalCoGAPS, DistributedCogaps.R:12-35
-        return run_fn(data, unc=uncertainty, nPatterns=n_patterns, subsetIndices=sets[i].astype(np.uint32),
-                      subsetDim=1 if genome_wide else 2, workerID=i + 1, messages=messages, whichMatrixFixed=which,
+        d, u = shard(i)
+        return run_fn(d, unc=u, nPatterns=n_patterns, runningDistributed=True, workerID=i + 1, messages=messages, whichMatrixFixed=which,
                       fixedPatterns=fixed, **common)
 
     initial, unmatched, matched = None, None, None
@@ -212,11 +291,8 @@ def distributedCogaps(data, params, uncertainty=None, messages=False, outputFreq
         key = "Pmean" if genome_wide else "Amean"
         local = {i: initial[i][key] for i in mine}
         if dist is not None:
-            shape = next(iter(local.values())).shape if local else None
-            shapes = [shape] * len(sets)
-            if shape is None:
-                raise ValueError("more ranks than subsets")
-            unmatched = _all_gather_arrays(local, shapes, dist, comm_device)
+            shape = next(iter(local.values())).shape
+            unmatched = _all_gather_arrays(local, [shape] * len(sets), dist, comm_device)
         else:
             unmatched = [local[i] for i in range(len(sets))]
         matched = find_consensus_matrix(unmatched, params)
@@ -229,12 +305,21 @@ def distributedCogaps(data, params, uncertainty=None, messages=False, outputFreq
 
     # stitchTogether (DistributedCogaps.R:226-278): collect the per-subset free factor on every rank
     free_key, free_sd = ("Amean", "Asd") if genome_wide else ("Pmean", "Psd")
+    shard_cache.clear()
     if dist is not None:
-        gathered = [None] * world
-        dist.all_gather_object(gathered, {i: {k: final[i][k] for k in (free_key, free_sd, "Pmean", "Amean", "meanChiSq")} for i in mine})
-        allf = {}
-        for g in gathered:
-            allf.update(g)
+        # tensor all-gathers (RCCL on GPUs): the free factor's mean and standard deviation, padded to the longest subset, and
+        # one small record per subset (meanChiSq); the shared factor comes back from every shard as the same all-zero matrix
+        rows = max(len(st) for st in sets)
+        k2 = consensus.shape[1]
+
+        def padded(key):
+            return {i: np.concatenate([final[i][key], np.zeros((rows - final[i][key].shape[0], k2), np.float32)], axis=0) for i in mine}
+        g_mean = _all_gather_arrays(padded(free_key), [(rows, k2)] * len(sets), dist, comm_device)
+        g_sd = _all_gather_arrays(padded(free_sd), [(rows, k2)] * len(sets), dist, comm_device)
+        g_chi = _all_gather_arrays({i: np.full((1, 1), final[i]["meanChiSq"], np.float32) for i in mine}, [(1, 1)] * len(sets), dist, comm_device)
+        shared_zero = np.zeros_like(final[mine[0]]["Pmean" if genome_wide else "Amean"])
+        allf = {i: {free_key: g_mean[i][:len(sets[i])], free_sd: g_sd[i][:len(sets[i])], "meanChiSq": float(g_chi[i][0, 0]),
+                    ("Pmean" if genome_wide else "Amean"): shared_zero} for i in range(len(sets))}
     else:
         allf = final
     order = list(range(len(sets)))

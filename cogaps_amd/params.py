@@ -88,6 +88,19 @@ class CogapsParams:
         self.validate()
         return self
 
+    def setAnnotationWeights(self, annotation, weights):
+        """methods-CogapsParams.R:179-187: group label per row / column of the partitioned dimension, and a weight per group (a
+        mapping group -> weight, R's named vector); used by createSets (R/SubsetData.R:37-55)"""
+        def fn():
+            self.samplingAnnotation = None if annotation is None else list(annotation)
+            self.samplingWeight = None if weights is None else dict(weights)
+        return self._guarded(fn)
+
+    def copy(self):
+        """R's S4 objects have value semantics: CoGAPS() works on its own copy"""
+        import copy
+        return copy.deepcopy(self)
+
     def setFixedPatterns(self, fixedPatterns, whichMatrixFixed):
         """methods-CogapsParams.R:139-150"""
         def fn():
@@ -120,6 +133,14 @@ class CogapsParams:
             raise ValueError("whichMatrixFixed is set without passing a fixedPatterns matrix")
         if self.distributed is not None and self.distributed not in ("genome-wide", "single-cell"):
             raise ValueError("distributed method must be either 'genome-wide' or 'single-cell'")
+        if (self.samplingAnnotation is None) != (self.samplingWeight is None):
+            raise ValueError("samplingAnnotation and samplingWeight must be set together (setAnnotationWeights)")
+        if self.samplingWeight is not None:
+            # class-CogapsParams.R validity: named, non-negative weights, one per annotation group
+            if any(float(w) < 0 for w in self.samplingWeight.values()):
+                raise ValueError("samplingWeight must be non-negative")
+            if set(self.samplingWeight) != set(self.samplingAnnotation):
+                raise ValueError("names of samplingWeight must match the groups of samplingAnnotation")
         if self.fixedPatterns is not None and np.any(np.asarray(self.fixedPatterns) < 0):
             raise ValueError("fixedPatterns must be non-negative")
         return True

@@ -123,6 +123,9 @@ int cogaps_file_info(const char *path, uint32_t *nrow, uint32_t *ncol, char *row
 void cogaps_result_free(cogaps_result *r);
 const char *cogaps_last_error(void);
 
+/* the HIP device ordinal that is current for the calling host thread (what cogaps_params.device = -1 resolves to) */
+int cogaps_current_device(int *device);
+
 /* the three trivial exports next to cogaps_cpp (src/Cogaps.cpp:217-246) */
 const char *cogaps_build_report(void);
 int cogaps_checkpoints_enabled(void);
@@ -178,9 +181,13 @@ int cogaps_session_finish(cogaps_session *s, cogaps_result *out);
 typedef struct cogaps_perf {
     uint64_t evalBytes;       /* sum over evaluated proposals of 16N/20N/32N + 12N per AP update */
     uint64_t evalLaunches, genLaunches, batches, proposalsQueued;
-    double evalMs, genMs, syncMs;   /* HIP-event time (dispatch begin to end) of the launches that processed a batch (sampled, scaled to `batches`) */
+    double evalMs, genMs, syncMs;   /* HIP-event time (dispatch begin to end) of the launches that processed a batch since timing was switched on
+                                       (a sample of them carries events; scaled to `timedBatches`) */
     double evalNoopMs, genNoopMs;   /* summed HIP-event time of sampled launches past the end of an update (empty queue) */
     uint64_t evalNoopTimed, genNoopTimed; /* ... and how many were sampled */
+    uint64_t timedBatches;    /* batches processed since cogaps_session_set_timing(1): what evalMs / genMs are scaled to */
+    uint64_t evalTimed, genTimed;   /* launches that carried events and processed a batch */
+    uint64_t syncTimed, syncBytes;  /* sync launches timed since then (all of them; their summed time is syncMs) and their algorithmic bytes (8 M N each) */
 } cogaps_perf;
 int cogaps_session_set_timing(cogaps_session *s, int on);
 int cogaps_session_perf(cogaps_session *s, cogaps_perf *out);                      /* both samplers */

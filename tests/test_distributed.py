@@ -51,6 +51,60 @@ def test_create_sets_cover_and_explicit():
     assert [s.tolist() for s in create_sets(40, p)] == p.explicitSets      # tests/testthat/test_subset_data.R:27-40
 
 
+def test_oversized_clusters_are_split_until_none_is_left():
+    """R/DistributedCogaps.R:160-166: splitCluster is called until no cluster exceeds maxNS, also when a split keeps one half
+    only (the other falls below minNS) and that half is still too large"""
+    from cogaps_amd.distributed import pattern_match
+    rng = np.random.default_rng(5)
+    t = np.linspace(0, 1, 80)
+    a, b = np.sin(6 * t) + 1.2, np.cos(5 * t) + 1.2
+    # 11 near-copies of pattern a with one of them an outlier (a 2-way cut of the cluster peels it off as a singleton), 4 of b
+    cols = [a * (1 + 0.002 * rng.random(80)) for _ in range(10)] + [a * (1 + 0.35 * rng.random(80))] + [b * (1 + 0.002 * rng.random(80)) for _ in range(4)]
+    p = _params(2, 4)
+    p.setDistributedParams(nSets=4, cut=2, minNS=2, maxNS=6)
+    r = pattern_match(np.stack(cols, axis=1), p)
+    sizes = [c.shape[1] for c in r["clusteredPatterns"]]
+    assert max(sizes) <= 6 and min(sizes) >= 2, sizes
+    assert np.allclose(r["consensus"].max(axis=0), 1.0)
+
+
+def test_named_and_weighted_sets():
+    """sampleWithExplictSets with names (SubsetData.R:14-27) and sampleWithAnnotationWeights (:37-55)"""
+    from cogaps_amd.distributed import create_sets
+    p = _params(2, 4)
+    p.setDistributedParams(nSets=2, minNS=2)
+    names = ["g%d" % i for i in range(1, 9)]
+    p.explicitSets = [["g3", "g1", "g2", "g8"], ["g4", "g5", "g6", "g7"]]
+    assert [s.tolist() for s in create_sets(8, p, names)] == [[1, 2, 3, 8], [4, 5, 6, 7]]
+    p.explicitSets = [["g3", "nope"], ["g4"]]
+    with pytest.raises(ValueError, match="not found"):
+        create_sets(8, p, names)
+    p.explicitSets = [[3, 1, 2], [4, 9]]
+    with pytest.raises(ValueError, match="outside"):
+        create_sets(8, p, names)
+    p.explicitSets = [[3, 1, 2], [4, 8]]
+    assert create_sets(8, p)[0].tolist() == [3, 1, 2]                       # index sets are used as given
+    q = _params(2, 3)
+    ann = ["a"] * 10 + ["b"] * 30 + ["c"] * 20
+    q.setAnnotationWeights(ann, {"a": 2.0, "b": 1.0, "c": 0.0})
+    sets = create_sets(60, q)
+    assert len(sets) == 3 and all(len(s) == 20 and s.min() >= 1 and s.max() <= 40 and np.all(np.diff(s) >= 0) for s in sets)    # group c has weight 0
+    with pytest.raises(ValueError):
+        q.setAnnotationWeights(ann, {"a": 1.0})                             # a weight per group
+    with pytest.raises(ValueError, match="setAnnotationWeights"):
+        q.setParam("samplingWeight", {"a": 1})
+
+
+def test_cogaps_does_not_modify_the_callers_params(emul_lib, modsim, monkeypatch):
+    from cogaps_amd import _capi, CoGAPS, CogapsParams
+    lib = emul_lib(256)
+    monkeypatch.setattr(_capi, "load", lambda: lib)
+    p = CogapsParams(nPatterns=3, seed=2, nIterations=20)
+    r = CoGAPS(modsim, p, nPatterns=2, messages=False, outputFrequency=10, alpha=0.02)
+    assert (p.nPatterns, p.alphaA, p.distributed) == (3, 0.01, None) and r.featureLoadings.shape == (25, 2)
+    assert r.metadata["params"].nPatterns == 2 and r.metadata["params"].alphaA == 0.02
+
+
 WORKER = r'''
 import os, sys, ctypes, numpy as np
 sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "oracle"))

@@ -20,8 +20,9 @@ def per_kernel(d, counter):
 
 fetch, write = per_kernel(sys.argv[1], 'FETCH_SIZE'), per_kernel(sys.argv[2], 'WRITE_SIZE')
 bench = json.load(open(sys.argv[3]))
-want = {'eval_kernel<0>': bench['roofline']['launches'], 'eval_kernel<1>': bench['roofline']['other_sampler']['batches'],
-        'eval_kernel<2>': bench['roofline']['other_sampler']['batches'], 'gen_kernel<256>': None}
+ks = bench['roofline']['kernels']        # [evaluation A, evaluation P, generator A, generator P, sync]
+want = {'eval_kernel<0>': ks[0]['launches'], 'eval_kernel<1>': ks[1]['launches'], 'eval_kernel<2>': ks[1]['launches'],
+        'gen_kernel<256>': ks[2]['launches'] + ks[3]['launches']}
 out = {}
 for name, n in want.items():
     fk = [k for k in fetch if name in k]; wk = [k for k in write if name in k]
@@ -30,12 +31,12 @@ for name, n in want.items():
     f, w = fetch[fk[0]], write[wk[0]]
     n = n or len(f)
     # the same dispatches in both passes (deterministic run): select on the fetch pass, by position
-    idx = [i for i, (_, v) in enumerate(f) if v >= 64.0 or name.startswith('gen')][-n:]
+    idx = [i for i, (_, v) in enumerate(f) if v >= 64.0 or name.startswith('gen')][-n:]      # (generator: the last n launches, empty-queue ones included)
     fb = sum(f[i][1] for i in idx) / len(idx) * 1024.0 * 2.0
     wb = sum(w[i][1] for i in idx if i < len(w)) / len(idx) * 1024.0
     out[name] = {'launches': len(idx), 'fetch_bytes_per_launch_corrected_x2': fb, 'write_bytes_per_launch': wb, 'hbm_bytes_per_launch': fb + wb,
                  'all_launches_in_run': len(f)}
     print(name, out[name])
 json.dump({'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) -- COGAPS_NO_GRAPH=1 python bench.py --no-cpu', 'kernels': out,
-           'bench_algorithmic_bytes_per_launch': {'eval_kernel<0>': bench['roofline']['bytes_per_launch'], 'eval_kernel<1>+<2>': bench['roofline']['other_sampler']['bytes_per_batch']}},
+           'bench_algorithmic_bytes_per_launch': {'eval_kernel<0>': ks[0]['bytes_per_launch'], 'eval_kernel<1>+<2>': ks[1]['bytes_per_launch'], 'path (per batch)': bench['roofline']['bytes_per_launch']}},
           open(sys.argv[4], 'w'), indent=1)
