@@ -462,7 +462,8 @@ static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool t
             // through the chunk from update to update -- is issued as plain launches that carry events, so that the sample covers
             // the whole population of batches and not only the tail of each chunk (the remainder below).
             const uint32_t nRep = plain / GRAPH_PAIRS;
-            const uint32_t timedRep = s->timing ? (uint32_t)((h.plainRotor++ * 7u) % nRep) : 0xFFFFFFFFu;
+            const uint64_t rot = s->timing ? h.plainRotor++ : 0;                       // (every fourth chunk: the plain launches leave longer gaps than a replay)
+            const uint32_t timedRep = (s->timing && (rot & 3u) == 0u) ? (uint32_t)(((rot >> 2) * 7u) % nRep) : 0xFFFFFFFFu;
             for (uint32_t r = 0; plain >= GRAPH_PAIRS; plain -= GRAPH_PAIRS, ++r) {
                 if (r == timedRep) { for (uint32_t b = 0; b < GRAPH_PAIRS; ++b) { launch_gen(s, h); launch_eval(s, h); h.updLaunches++; } continue; }
                 rt_graph_launch(h.graph, s->stream); h.genLaunches += GRAPH_PAIRS; h.evalLaunches += GRAPH_PAIRS; h.updLaunches += GRAPH_PAIRS;
@@ -565,7 +566,11 @@ cogaps_session *cogaps_session_create(const float *data, uint32_t nrow, uint32_t
     cogaps_session *s = nullptr;
     try {
         const cogaps_params &p = *params;
-        if (!p.asynchronousUpdates) { fail("asynchronousUpdates=FALSE (SingleThreadedGibbsSampler) is not part of this library"); return nullptr; }
+        // The reference's distributed caller forces asynchronousUpdates = FALSE on its workers (R/DistributedCogaps.R:28-29) -- there to keep
+        // BiocParallel workers single-threaded, not for the sampler's sake.  Documented deviation: a
+        // distributed worker call (runningDistributed, i.e. subsetDim > 0 in cogaps_cpp, Cogaps.cpp:82) runs the asynchronous sampler anyway,
+        // so that GWCoGAPS / scCoGAPS through the real R package reach this library.  Everywhere else FALSE is refused.
+        if (!p.asynchronousUpdates && !p.runningDistributed) { fail("asynchronousUpdates=FALSE (SingleThreadedGibbsSampler) is not part of this library"); return nullptr; }
         if (p.nPatterns == 0 || nrow == 0 || ncol == 0) { fail("empty problem"); return nullptr; }
         if (p.whichMatrixFixed != 'N' && p.whichMatrixFixed != 'A' && p.whichMatrixFixed != 'P') { fail("whichMatrixFixed must be 'N', 'A' or 'P'"); return nullptr; }
         if (p.reductionMode != COGAPS_REDUCE_LANES && p.reductionMode != COGAPS_REDUCE_SEQ) { fail("reductionMode must be COGAPS_REDUCE_LANES or COGAPS_REDUCE_SEQ"); return nullptr; }

@@ -49,7 +49,8 @@ typedef struct cogaps_params {
     uint32_t nSubset;
     int32_t useSparseOptimization; /* SparseNormalModel (default uncertainty only) instead of DenseNormalModel */
     int32_t takePumpSamples;       /* GapsStatistics::updatePump per sampling iteration (GapsRunner.cpp:310-313) */
-    int32_t asynchronousUpdates;   /* must be 1: this library IS the asynchronous sampler */
+    int32_t asynchronousUpdates;   /* must be 1: this library IS the asynchronous sampler.  One exception: 0 is accepted, and ignored, when
+                                      runningDistributed is set -- R's distributed caller forces FALSE on its workers (R/DistributedCogaps.R:28-29) */
     char whichMatrixFixed;         /* 'N', 'A' or 'P' */
     const float *fixedPatterns;    /* row-major [fixedRows][nPatterns] when whichMatrixFixed != 'N' */
     uint32_t fixedRows;

@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT
+from conftest import GOLDEN, ROOT
 
 
 def test_library_builds_loads_and_exports_header_symbols():
@@ -173,3 +173,25 @@ def test_compute_calls_fail_loudly_without_a_gpu():
         _capi.run(np.ones((10, 8), np.float32), nPatterns=2, nIterations=5)
     with pytest.raises(RuntimeError, match="device"):
         CoGAPS(np.ones((10, 8), np.float32) * 2, nPatterns=2, nIterations=5, messages=False)
+
+
+def test_plain_c_client_builds_and_fails_loudly_without_a_gpu():
+    """tests/c/rcpp_shim_test.c: getGapsParameters (src/Cogaps.cpp:64-139) restated in C99 against include/cogaps_hip.h.  It must
+    compile as C, link against the product library and -- on a box without a GPU -- end with the library's error text and a
+    non-zero status, never a crash or a silent CPU path (GAPS_ERROR -> Rcpp::stop in the reference, utils/GapsAssert.h:19-25)"""
+    import subprocess
+    cdir = os.path.join(ROOT, "tests", "c")
+    subprocess.check_call(["make", "-s", "-C", cdir])
+    exe = os.path.join(cdir, "rcpp_shim_test.bin")
+    out = subprocess.run([exe, os.path.join(GOLDEN, "GIST.mtx"), "checkpointInFile=x"], capture_output=True, text=True)
+    assert out.returncode == 1 and "checkpoints are disabled" in out.stderr
+    out = subprocess.run([exe, os.path.join(GOLDEN, "GIST.mtx"), "bogusKey=1"], capture_output=True, text=True)
+    assert out.returncode == 2
+    try:
+        import torch
+        gpu = torch.cuda.is_available()
+    except Exception:
+        gpu = False
+    if not gpu:
+        out = subprocess.run([exe, os.path.join(GOLDEN, "GIST.mtx"), "nPatterns=3", "nIterations=5", "messages=0"], capture_output=True, text=True)
+        assert out.returncode == 1 and out.stderr.startswith("CoGAPS terminated: ") and out.stdout == ""

@@ -178,6 +178,47 @@ def test_headline_shape_stepwise(hip_lib):
     S.close(), O.close()
 
 
+def test_plain_c_client_equals_the_ctypes_path(hip_lib, gist):
+    """the Rcpp-shaped C program (tests/c/rcpp_shim_test.c: allParams keys -> cogaps_params by the rules of src/Cogaps.cpp:64-139,
+    then cogaps_run / cogaps_run_from_file, no Python in the process) prints the result cogaps_run gives through ctypes; a
+    distributed worker call (subsetDim > 0) is accepted with R's forced asynchronousUpdates = FALSE (R/DistributedCogaps.R:28-29)"""
+    import subprocess
+    from cogaps_amd import _capi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "c", "rcpp_shim_test.bin")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tests", "c")])
+
+    def parse(txt):
+        d = {}
+        for ln in txt.splitlines():
+            k, _, v = ln.partition(" ")
+            d[k] = v
+        return d
+    mtx = os.path.join(GOLDEN, "GIST.mtx")
+    for entry in ("matrix", "file"):
+        out = subprocess.run([exe, mtx, "entry=" + entry, "nPatterns=4", "nIterations=60", "seed=9", "outputFrequency=20", "messages=0", "nSnapshots=3",
+                              "snapshotPhase=all", "takePumpSamples=1"], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr
+        d = parse(out.stdout)
+        r = _capi.run(gist, nPatterns=4, nIterations=60, seed=9, outputFrequency=20, nSnapshots=3, snapshotPhase="all", takePumpSamples=True)
+        assert [int(x) for x in d["atomsA"].split()] == r["atomsA"].tolist() and [int(x) for x in d["atomsP"].split()] == r["atomsP"].tolist()
+        assert int(d["totalUpdates"]) == r["totalUpdates"] and np.float32(d["meanChiSq"]) == np.float32(r["meanChiSq"])
+        assert [np.float32(x) for x in d["chisq"].split()] == r["chisq"].tolist()
+        assert float(d["sumAmean"]) == float(r["Amean"].astype(np.float64).sum()) and float(d["sumPsd"]) == float(r["Psd"].astype(np.float64).sum())
+        assert d["snapshots"] == "3 3 pump 1" and "HIP gfx950" in d["buildReport"]
+    # callInternalCoGAPS: subset + asynchronousUpdates = FALSE + workerID
+    out = subprocess.run([exe, mtx, "nPatterns=3", "nIterations=40", "seed=5", "outputFrequency=20", "subsetDim=1", "subsetIndices=1:300", "asynchronousUpdates=0",
+                          "workerID=2"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    d = parse(out.stdout)
+    r = _capi.run(gist, nPatterns=3, nIterations=40, seed=5, outputFrequency=20, subsetIndices=np.arange(1, 301, dtype=np.uint32), subsetDim=1, workerID=2)
+    assert d["nGenes"].split()[0] == "300" and int(d["totalUpdates"]) == r["totalUpdates"] and [int(x) for x in d["atomsA"].split()] == r["atomsA"].tolist()
+    assert "worker 2 is starting!" in out.stdout and "worker 2 is finished!" in out.stdout      # GapsRunner.cpp:428-433, 494-500
+    bad = subprocess.run([exe, mtx, "nPatterns=3", "nIterations=10", "asynchronousUpdates=0"], capture_output=True, text=True, timeout=600)
+    assert bad.returncode == 1 and "asynchronousUpdates=FALSE" in bad.stderr
+
+
 def test_tiny_domain(hip_lib):
     pu.run_stepwise(hip_lib, pu.synthetic(5, 6, rank=2, seed=3), 300, nPatterns=2, seed=9, total_iter=200, check_every=50)
 
