@@ -218,48 +218,62 @@ static void build_sampler(cogaps_session *s, HostSampler &h, char name, const fl
     d.Npad = (d.N + 3u) & ~3u; d.Mpad = (d.M + 3u) & ~3u;
     d.redW = cogaps_reduction_width(d.N);
     const size_t tot = (size_t)d.M * d.Npad;
-    std::vector<float> D(tot, 0.f), S2(tot, 1.f), SR(tot, 1.f);
+    // With the default uncertainty the evaluation kernel recomputes S*S = max(0.1 D, 0.1)^2 from the D value it loads anyway
+    // (bit-identical: the same three fp32 operations as the fill below): no S2 array, one row less per proposal from HBM.
+    // (COGAPS_READ_S: diagnostics, keeps the array and the loads.)
+    const bool defaultS = !sparse && unc == nullptr && !getenv("COGAPS_READ_S");
+    float *dD = dalloc<float>(tot), *dS2 = defaultS ? nullptr : dalloc<float>(tot); h.Sraw = dalloc<float>(tot);
+    if (sparse) {
+        if (d.K > SP_KMAX) throw std::runtime_error("useSparseOptimization supports at most 512 patterns");
+        d.Wn = d.N / 64u + 1u;
+    }
+    // The vectors are staged through the host in blocks of at most 16 M elements (pad: D = 0, S = S2 = 1) -- never three dense
+    // host copies of the matrix (BASELINE configs[4]'s shard is 2.5 GB per copy).  The sums run over the vectors in order, as
+    // gaps::nonZeroMean does (MatrixMath.cpp:39-55).
+    const uint32_t rowsPerBlock = (uint32_t)std::max<size_t>(1, std::min<size_t>(d.M, ((size_t)1 << 24) / std::max<uint32_t>(1u, d.Npad)));
+    std::vector<float> D((size_t)rowsPerBlock * d.Npad), S2(dS2 ? D.size() : 0), SR(D.size());
+    std::vector<unsigned long long> fl; std::vector<uint32_t> pre, ptr; std::vector<float> vals;
+    if (sparse) { fl.assign((size_t)d.M * d.Wn, 0ull); pre.assign((size_t)d.M * d.Wn, 0u); ptr.assign((size_t)d.M + 1, 0u); }
     float sum = 0.f; unsigned nnz = 0;
-    for (uint32_t j = 0; j < nS; ++j)
-        for (uint32_t i = 0; i < nG; ++i) {
-            const uint32_t dataRow = (subsetData && (subsetGenes != genesInCols)) ? indices[genesInCols ? j : i] - 1 : (genesInCols ? j : i);
-            const uint32_t dataCol = (subsetData && (subsetGenes == genesInCols)) ? indices[genesInCols ? i : j] - 1 : (genesInCols ? i : j);
-            float v = data[(size_t)dataRow * ncol + dataCol];
-            if (sparse && !(v > 0.f)) v = 0.f;                                // SparseVector keeps v > 0 only (SparseVector.cpp:20-33)
-            const size_t o = (size_t)j * d.Npad + i;
-            D[o] = v;
-            const float sd = (unc && !sparse) ? unc[(size_t)dataRow * ncol + dataCol] : gm_max(v * 0.1f, 0.1f);   // gaps::pmax, MatrixMath.cpp:74-84; the sparse model always assumes the default (SparseNormalModel.h:90-96)
-            SR[o] = sd; S2[o] = sd * sd;
-            sum += v; if (v > 0.f) ++nnz;                                    // gaps::nonZeroMean, MatrixMath.cpp:39-55
+    for (uint32_t j0 = 0; j0 < nS; j0 += rowsPerBlock) {
+        const uint32_t j1 = std::min(nS, j0 + rowsPerBlock);
+        std::fill(D.begin(), D.end(), 0.f); std::fill(SR.begin(), SR.end(), 1.f); if (dS2) std::fill(S2.begin(), S2.end(), 1.f);
+        for (uint32_t j = j0; j < j1; ++j) {
+            if (sparse) ptr[j] = (uint32_t)vals.size();
+            for (uint32_t i = 0; i < nG; ++i) {
+                const uint32_t dataRow = (subsetData && (subsetGenes != genesInCols)) ? indices[genesInCols ? j : i] - 1 : (genesInCols ? j : i);
+                const uint32_t dataCol = (subsetData && (subsetGenes == genesInCols)) ? indices[genesInCols ? i : j] - 1 : (genesInCols ? i : j);
+                float v = data[(size_t)dataRow * ncol + dataCol];
+                if (sparse && !(v > 0.f)) v = 0.f;                                // SparseVector keeps v > 0 only (SparseVector.cpp:20-33)
+                const size_t o = (size_t)(j - j0) * d.Npad + i;
+                D[o] = v;
+                const float sd = (unc && !sparse) ? unc[(size_t)dataRow * ncol + dataCol] : gm_max(v * 0.1f, 0.1f);   // gaps::pmax, MatrixMath.cpp:74-84; the sparse model always assumes the default (SparseNormalModel.h:90-96)
+                SR[o] = sd; if (dS2) S2[o] = sd * sd;
+                sum += v; if (v > 0.f) ++nnz;                                    // gaps::nonZeroMean, MatrixMath.cpp:39-55
+                if (sparse) {      // SparseMatrix: flag words, number of packed values before each word, the values
+                    const uint32_t w = i >> 6;
+                    if ((i & 63u) == 0u) pre[(size_t)j * d.Wn + w] = (uint32_t)vals.size() - ptr[j];
+                    if (v > 0.f) { fl[(size_t)j * d.Wn + w] |= 1ull << (i & 63u); vals.push_back(v); }
+                }
+            }
+            if (sparse) for (uint32_t w = (nG + 63u) >> 6; w < d.Wn; ++w) pre[(size_t)j * d.Wn + w] = (uint32_t)vals.size() - ptr[j];   // the word past the last element (Wn = N/64 + 1)
         }
+        const size_t off = (size_t)j0 * d.Npad, cnt = (size_t)(j1 - j0) * d.Npad;
+        rt_h2d(dD + off, D.data(), cnt * 4, s->stream); if (dS2) rt_h2d(dS2 + off, S2.data(), cnt * 4, s->stream); rt_h2d(h.Sraw + off, SR.data(), cnt * 4, s->stream);
+        rt_sync(s->stream);                                                     // the staging buffers are reused by the next block
+    }
     const float meanD = sum / (float)nnz;
     h.dataSparsity = 1.f - (float)(uint32_t)nnz / (float)(d.M * d.N);       // gaps::sparsity, MatrixMath.cpp:6-21 (unsigned count, float product of the dimensions)
     d.alpha = alpha;
     d.lambda = alpha * sqrtf((float)(uint64_t)d.K / meanD);
     d.maxGibbsMass = maxGibbsMass / d.lambda;
-    // With the default uncertainty the evaluation kernel recomputes S*S = max(0.1 D, 0.1)^2 from the D value it loads anyway
-    // (bit-identical: the same three fp32 operations as the fill above): no S2 array, one row less per proposal from HBM.
-    // (COGAPS_READ_S: diagnostics, keeps the array and the loads.)
-    const bool defaultS = !sparse && unc == nullptr && !getenv("COGAPS_READ_S");
-    float *dD = dalloc<float>(tot), *dS2 = defaultS ? nullptr : dalloc<float>(tot); h.Sraw = dalloc<float>(tot);
-    rt_h2d(dD, D.data(), tot * 4, s->stream); if (dS2) rt_h2d(dS2, S2.data(), tot * 4, s->stream); rt_h2d(h.Sraw, SR.data(), tot * 4, s->stream);
-    rt_sync(s->stream);
     d.D = dD; d.S2 = dS2; d.defaultS = defaultS ? 1u : 0u;
     d.unitBytes = 4u * d.N;
     if (!sparse) d.AP = dalloc<float>(tot);
     else {
         // SparseMatrix (flag words + packed values per vector) and the HybridMatrix copies; D / Sraw stay for meanChiSq
-        if (d.K > SP_KMAX) throw std::runtime_error("useSparseOptimization supports at most 512 patterns");
         d.sparse = 1; d.beta = 100.f; d.unitBytes = 1u;
-        d.Wn = d.N / 64u + 1u; d.Mw = d.M / 64u + 1u; d.Kpad = (d.K + 3u) & ~3u;
-        std::vector<unsigned long long> fl((size_t)d.M * d.Wn, 0ull); std::vector<uint32_t> pre((size_t)d.M * d.Wn, 0u), ptr((size_t)d.M + 1, 0u); std::vector<float> vals;
-        for (uint32_t j = 0; j < d.M; ++j) {
-            ptr[j] = (uint32_t)vals.size();
-            for (uint32_t w = 0; w < d.Wn; ++w) {
-                pre[(size_t)j * d.Wn + w] = (uint32_t)vals.size() - ptr[j];
-                for (uint32_t b = 0; b < 64u; ++b) { const uint32_t i = 64u * w + b; if (i < d.N && D[(size_t)j * d.Npad + i] > 0.f) { fl[(size_t)j * d.Wn + w] |= 1ull << b; vals.push_back(D[(size_t)j * d.Npad + i]); } }
-            }
-        }
+        d.Mw = d.M / 64u + 1u; d.Kpad = (d.K + 3u) & ~3u;
         ptr[d.M] = (uint32_t)vals.size();
         unsigned long long *dfl = dalloc<unsigned long long>(fl.size()); uint32_t *dpre = dalloc<uint32_t>(pre.size()), *dptr = dalloc<uint32_t>(ptr.size()); float *dv = dalloc<float>(vals.size() + 1);
         rt_h2d(dfl, fl.data(), fl.size() * 8, s->stream); rt_h2d(dpre, pre.data(), pre.size() * 4, s->stream); rt_h2d(dptr, ptr.data(), ptr.size() * 4, s->stream);

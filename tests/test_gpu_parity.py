@@ -383,6 +383,57 @@ def test_bench_multi_rank_path_on_one_gpu():
     assert d["config"]["proposals_timed"] > 0
 
 
+NCCL_WORKER = r'''
+import os, sys, numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "oracle"))
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%(port)d", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from cogaps_amd import CogapsParams
+from cogaps_amd.distributed import distributedCogaps
+import pyoracle as po
+data = po.read_mtx(os.path.join(%(root)r, "tests", "golden", "GIST.mtx"))[:360]
+p = CogapsParams(nPatterns=3, seed=5, nIterations=40)
+p.distributed = "genome-wide"; p.setDistributedParams(nSets=3, minNS=2)
+p.explicitSets = [list(range(1, 121)), list(range(121, 241)), list(range(241, 361))]
+out = distributedCogaps(data, p, outputFrequency=20)          # device = -1: resolved from torch's current device
+assert dist.get_backend() == "nccl"
+np.savez(sys.argv[1], Amean=out["Amean"], Asd=out["Asd"], Pmean=out["Pmean"], consensus=out["consensus"], meanChiSq=out["meanChiSq"],
+         u0=out["unmatchedPatterns"][0], u2=out["unmatchedPatterns"][2])
+dist.destroy_process_group()
+'''
+
+
+def test_rccl_path_with_one_rank(hip_lib, gist, tmp_path):
+    """the `nccl` (= RCCL) branch of distributed.py and bench.py on the one GPU of this box, world size 1: rendezvous with
+    device_id, device-tensor all-gathers of the shared factor and of the stitched factor, tensor placement.  The result equals
+    the run without a process group; bench.py under torch.distributed.run prints its line through the same branch."""
+    import json, socket, subprocess, sys
+    from cogaps_amd import CogapsParams
+    from cogaps_amd.distributed import distributedCogaps
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "nccl_worker.py"
+    script.write_text(NCCL_WORKER % {"root": root, "port": port})
+    out = subprocess.run([sys.executable, str(script), str(tmp_path / "r.npz")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    a = np.load(tmp_path / "r.npz")
+    p = CogapsParams(nPatterns=3, seed=5, nIterations=40)
+    p.distributed = "genome-wide"; p.setDistributedParams(nSets=3, minNS=2)
+    p.explicitSets = [list(range(1, 121)), list(range(121, 241)), list(range(241, 361))]
+    ref = distributedCogaps(gist[:360], p, outputFrequency=20)
+    for k in ("Amean", "Asd", "Pmean", "consensus"):
+        assert np.array_equal(ref[k], a[k]), k
+    assert np.array_equal(ref["unmatchedPatterns"][2], a["u2"]) and abs(float(a["meanChiSq"]) - ref["meanChiSq"]) < 1e-3 * abs(ref["meanChiSq"]) + 1e-6
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "2",
+                          "--genes", "4000", "--samples", "400", "--patterns", "10", "--no-cpu"], cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["timing_consistent"]
+
+
 def test_gwcogaps_driver_on_the_gpu(hip_lib, gist):
     """GWCoGAPS through the front-end on this GPU: four gene-wise shards, two in flight (BPPARAM = 2) -- the same bits as one
     shard at a time; the stitched result has the reference's structure (DistributedCogaps.R:226-278)"""
