@@ -293,8 +293,10 @@ CG_DEVICE void eval_domain_move(const SamplerDev &S, uint32_t h, uint64_t oldPos
 // each.  Slice j owns virtual lanes j*1024 .. j*1024+1023; the per-slice totals go through S.partials
 // ([queueCap][4][16]) and every workgroup of the second kernel folds them in the same ascending order (the top
 // bits of the butterfly), repeats the (deterministic) decision and updates its own slice of AP.
+// vbid / vgdim: this workgroup's index and the number of workgroups that serve THIS sampler's queue (the grid itself, or
+// one chain's share of a batched multi-chain launch)
 template <int PHASE>
-CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices)
+CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vbid, const uint32_t vgdim)
 {
 #if defined(GEN_TIMELINE) && !defined(COGAPS_EMUL)
     unsigned long long ets[11]; uint32_t ets_n = 0;
@@ -318,12 +320,12 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices)
     }
     const bool multiWave = BS > 64u;
     const bool scalarLane = !multiWave || t < 64u;       // the per-proposal scalar math (LUTs, fp64 log) runs in wave 0 only
-    const uint32_t slice = WHOLE ? 0u : cg_bid() % slices;
-    const uint32_t qStep = WHOLE ? cg_gdim() : cg_gdim() / slices;
+    const uint32_t slice = WHOLE ? 0u : vbid % slices;
+    const uint32_t qStep = WHOLE ? vgdim : vgdim / slices;
     const uint32_t chunk0 = slice * BS, stride = WHOLE ? BS : S.redW;
     const bool writer = slice == 0u && t == 0u;          // the one thread that stores the proposal's scalar results
 #define EVAL_BCAST(F0, I0) do { if (multiWave) { if (t == 0) { decf = (F0); deci = (I0); } cg_sync(); (F0) = decf; (I0) = deci; } } while (0)
-    for (uint32_t q = WHOLE ? cg_bid() : cg_bid() / slices; ; q += qStep) {
+    for (uint32_t q = WHOLE ? vbid : vbid / slices; ; q += qStep) {
         // one trip: the record (slot q always exists: q < queueCap), the queue length, the annealing temperature
         const PropRec p = S.queue[q < S.queueCap ? q : 0u];
         const uint32_t qlen = S.gs->qlen;
@@ -489,4 +491,16 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices)
 
 // the split kernels are built for two resident 1024-thread workgroups per compute unit (<= 64 VGPRs)
 template <int PHASE>
-CG_KERNEL void CG_LAUNCH_BOUNDS2((PHASE == EVAL_SEQ ? EVAL_SEQ_BS : 1024), (PHASE == EVAL_FUSED || PHASE == EVAL_SEQ ? 4 : 8)) eval_kernel(SamplerDev S, uint32_t slices) { cg_kernarg_warm<sizeof(SamplerDev) + 4>(); eval_body<PHASE>(S, slices); }
+CG_KERNEL void CG_LAUNCH_BOUNDS2((PHASE == EVAL_SEQ ? EVAL_SEQ_BS : 1024), (PHASE == EVAL_FUSED || PHASE == EVAL_SEQ ? 4 : 8)) eval_kernel(SamplerDev S, uint32_t slices) { cg_kernarg_warm<sizeof(SamplerDev) + 4>(); eval_body<PHASE>(S, slices, cg_bid(), cg_gdim()); }
+
+// Batched multi-chain launch: the samplers of C independent chains (GWCoGAPS / scCoGAPS shards on one GPU) stepped in lock-step by
+// one stream.  `arr` is a device array of their SamplerDev records read through the constant address space (scalar loads, as the
+// by-value kernel argument of the one-chain kernels is); workgroups [c * wgPerChain, (c + 1) * wgPerChain) serve chain c's queue.
+template <int PHASE>
+CG_KERNEL void CG_LAUNCH_BOUNDS2(1024, (PHASE == EVAL_FUSED ? 4 : 8)) eval_kernel_multi(const SamplerDev CG_CONSTANT *arr, uint32_t slices, uint32_t wgPerChain)
+{
+    const uint32_t chain = cg_bid() / wgPerChain;
+    const SamplerDev CG_CONSTANT *sp = arr + chain;
+    cg_const_warm<sizeof(SamplerDev)>(sp);
+    eval_body<PHASE>(*(const SamplerDev *)sp, slices, cg_bid() - chain * wgPerChain, wgPerChain);
+}

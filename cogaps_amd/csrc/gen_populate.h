@@ -702,3 +702,11 @@ CG_DEVICE void gen_body(const SamplerDev &S)
 
 template <int WIN>
 CG_KERNEL void CG_LAUNCH_BOUNDS(WIN) gen_kernel(SamplerDev S) { cg_kernarg_warm<sizeof(SamplerDev)>(); gen_body<WIN>(S); }
+// batched multi-chain launch (eval_kernel.h): one workgroup per chain
+template <int WIN>
+CG_KERNEL void CG_LAUNCH_BOUNDS(WIN) gen_kernel_multi(const SamplerDev CG_CONSTANT *arr)
+{
+    const SamplerDev CG_CONSTANT *sp = arr + cg_bid();
+    cg_const_warm<sizeof(SamplerDev)>(sp);
+    gen_body<WIN>(*(const SamplerDev *)sp);
+}

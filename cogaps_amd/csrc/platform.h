@@ -52,6 +52,21 @@ CG_DEVICE void cg_kernarg_warm()
 #undef CG_KA_OFF
 }
 
+// Constant address space: loads through such a pointer are invariant for the kernel's lifetime and, at a wave-uniform address,
+// scalar (s_load through the scalar cache) -- what a by-value kernel argument gets.  For records the host writes before the launch.
+#define CG_CONSTANT __attribute__((address_space(4)))
+// one memory trip for all the 64-byte lines of such a record (cg_kernarg_warm for a record in memory)
+template <int BYTES, class T>
+CG_DEVICE void cg_const_warm(const T CG_CONSTANT *p)
+{
+    static_assert(BYTES <= 640, "extend the line list");
+    const uint32_t CG_CONSTANT *w = (const uint32_t CG_CONSTANT *)p;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < (BYTES + 63) / 64; ++i) acc |= w[(i * 64 < BYTES - 4 ? i * 64 : BYTES - 4) / 4];
+    asm volatile("" :: "s"(acc));
+}
+
 // keeps a loaded value (and so the load) alive without using it
 CG_DEVICE void cg_keep_f32(float x) { asm volatile("" :: "v"(x)); }
 

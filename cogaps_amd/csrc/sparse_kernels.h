@@ -266,7 +266,7 @@ CG_DEVICE void sp_safely_change_matrix(const SamplerDev &S, uint32_t row, uint32
 // One workgroup of W = cogaps_sparse_width(N) threads per queued proposal (AsynchronousGibbsSampler.h:127-219 over the
 // sparse model).
 template <bool SEQ>
-CG_DEVICE void eval_sparse_body(const SamplerDev &S)
+CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const uint32_t vgdim)
 {
     CG_SHARED float lds[16 * 4];
     CG_SHARED float arowA[SP_KMAX], arowB[SP_KMAX];
@@ -279,7 +279,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S)
     const float lambda = S.lambda, beta = S.beta;
     const bool multiWave = BS > 64u;
     const bool scalarLane = !multiWave || t < 64u;
-    for (uint32_t q = cg_bid(); ; q += cg_gdim()) {
+    for (uint32_t q = vbid; ; q += vgdim) {
         const PropRec p = S.queue[q < S.queueCap ? q : 0u];
         const uint32_t qlen = S.gs->qlen;
         const float T = S.gs->annealTemp;
@@ -417,12 +417,19 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S)
             if (need) bytes = (diff ? 2u : 1u) * (16u * S.Wn + 8u * K) + ((two && !diff) ? 8u * S.Wn : 0u) + nzShared * (8u + 4u * K);
             S.queueUnits[q] = bytes;
         }
-        if (q + cg_gdim() >= qlen) break;
+        if (q + vgdim >= qlen) break;
         cg_sync();
     }
 }
-CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_kernel(SamplerDev S) { cg_kernarg_warm<sizeof(SamplerDev)>(); eval_sparse_body<false>(S); }
-CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_seq_kernel(SamplerDev S) { cg_kernarg_warm<sizeof(SamplerDev)>(); eval_sparse_body<true>(S); }
+CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_kernel(SamplerDev S) { cg_kernarg_warm<sizeof(SamplerDev)>(); eval_sparse_body<false>(S, cg_bid(), cg_gdim()); }
+CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_kernel_multi(const SamplerDev CG_CONSTANT *arr, uint32_t wgPerChain)
+{
+    const uint32_t chain = cg_bid() / wgPerChain;
+    const SamplerDev CG_CONSTANT *sp = arr + chain;
+    cg_const_warm<sizeof(SamplerDev)>(sp);
+    eval_sparse_body<false>(*(const SamplerDev *)sp, cg_bid() - chain * wgPerChain, wgPerChain);
+}
+CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_seq_kernel(SamplerDev S) { cg_kernarg_warm<sizeof(SamplerDev)>(); eval_sparse_body<true>(S, cg_bid(), cg_gdim()); }
 
 // SparseNormalModel::generateLookupTables (SparseNormalModel.cpp:294-311): Z1[i] = sum_k other(k,i)^2 through the
 // other matrix's ROW copy, Z2(i,j) = dot of its column copies.  One workgroup per (i, j >= i) pair plus one per i;

@@ -30,6 +30,8 @@ inline unsigned cg_gdim() { return cgemu::g_lane.gdim; }
 inline void cg_sync() { cgemu::block_barrier(); }
 inline void cg_sync_lds() { cg_sync(); }
 template <int BYTES> inline void cg_kernarg_warm() {}
+#define CG_CONSTANT
+template <int BYTES, class T> inline void cg_const_warm(const T *) {}
 inline void cg_keep_f32(float) {}
 
 // fibers only switch at barriers / wave exchanges, so plain read-modify-write is atomic here

@@ -205,7 +205,8 @@ def test_plain_c_client_equals_the_ctypes_path(hip_lib, gist):
         assert [int(x) for x in d["atomsA"].split()] == r["atomsA"].tolist() and [int(x) for x in d["atomsP"].split()] == r["atomsP"].tolist()
         assert int(d["totalUpdates"]) == r["totalUpdates"] and np.float32(d["meanChiSq"]) == np.float32(r["meanChiSq"])
         assert [np.float32(x) for x in d["chisq"].split()] == r["chisq"].tolist()
-        assert float(d["sumAmean"]) == float(r["Amean"].astype(np.float64).sum()) and float(d["sumPsd"]) == float(r["Psd"].astype(np.float64).sum())
+        seqsum = lambda m: float(np.cumsum(m.astype(np.float64).ravel())[-1])          # left to right, as the C program adds
+        assert float(d["sumAmean"]) == seqsum(r["Amean"]) and float(d["sumPsd"]) == seqsum(r["Psd"]) and float(d["sumPmean"]) == seqsum(r["Pmean"])
         assert d["snapshots"] == "3 3 pump 1" and "HIP gfx950" in d["buildReport"]
     # callInternalCoGAPS: subset + asynchronousUpdates = FALSE + workerID
     out = subprocess.run([exe, mtx, "nPatterns=3", "nIterations=40", "seed=5", "outputFrequency=20", "subsetDim=1", "subsetIndices=1:300", "asynchronousUpdates=0",
