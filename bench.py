@@ -86,7 +86,10 @@ def cpu_baseline(data, params, budget_s):
 
 
 def chains_main(args):
-    """--chains C (informational): C shards of the headline shape in flight on this GPU (distributed._run_shards)."""
+    """--chains C (informational, not the headline configuration): C shards of the headline shape on this one GPU -- the per-GPU
+    workload of a GWCoGAPS / scCoGAPS job with more subsets than GPUs.  Default: the batched multi-chain launches (cogaps_batch_*:
+    the C chains stepped in lock-step by one stream, one generator and one evaluation launch per step for all of them);
+    `--chains-mode threads`: one host thread, stream and session per chain (at most four run side by side)."""
     import threading
     import torch
     if not torch.cuda.is_available():
@@ -94,38 +97,84 @@ def chains_main(args):
     from cogaps_amd import _capi
     K, W, C = args.steps, args.warmup, args.chains
     n_iter = max(100, (W + K + 1) // 2)
-    params = dict(nPatterns=args.patterns, nIterations=n_iter, seed=42, outputFrequency=max(1, n_iter // 10))
-    S = [_capi.Session(synthetic_dense(args.genes, args.samples, seed=12345 + c), device=0, **params) for c in range(C)]
-    upd = [0] * C
+    params = dict(nPatterns=args.patterns, nIterations=n_iter, seed=42, outputFrequency=max(1, n_iter // 10), sparseOptimization=args.sparse)
 
-    def steps(c, first, n):
-        done = 0
+    def shard(c):
+        d = synthetic_dense(args.genes, args.samples, seed=12345 + c)
+        if args.sparse:
+            d *= (np.random.Generator(np.random.MT19937(777 + c)).random(d.shape) >= 0.95)
+        return d
+    S = [_capi.Session(shard(c), device=0, **params) for c in range(C)]
+    upd = [0] * C
+    batched = args.chains_mode == "batched"
+    B = _capi.Batch(S) if batched else None
+
+    def span(first, n):      # (phase, first iteration, count) pieces of schedule steps [first, first + n)
+        out, done = [], 0
         while done < n:
             it = first + done
             m = min(n - done, n_iter - it) if it < n_iter else n - done
-            upd[c] += S[c].run_iterations(1 if it < n_iter else 2, it if it < n_iter else it - n_iter, m)
+            out.append((1 if it < n_iter else 2, it if it < n_iter else it - n_iter, m))
             done += m
+        return out
+
+    def steps(c, first, n):
+        for ph, it, m in span(first, n):
+            upd[c] += S[c].run_iterations(ph, it, m)
 
     def phase(first, n):
-        th = [threading.Thread(target=steps, args=(c, first, n)) for c in range(C)]
         t0 = time.perf_counter()
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
+        if batched:
+            for ph, it, m in span(first, n):
+                for c, u in enumerate(B.run_iterations(ph, it, m)):
+                    upd[c] += u
+        else:
+            th = [threading.Thread(target=steps, args=(c, first, n)) for c in range(C)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
         return time.perf_counter() - t0
     burn = max(0, 2 * n_iter - (W + K))      # as in main(): the timed steps are the last K of the schedule
     if burn:
         phase(0, burn)
     phase(burn, W)
     upd = [0] * C
+    perf0 = [{w: s.perf(w) for w in "AP"} for s in S]
+    if batched:
+        B.set_timing(True)
     torch.cuda.synchronize()
     dt = phase(burn + W, K)
-    print(json.dumps({"metric": METRIC + " [informational: %d chains in flight on one GPU]" % C, "value": sum(upd) / dt, "unit": "proposals/s",
+    torch.cuda.synchronize()
+    roof = None
+    if batched:
+        # path-level figure as in the headline line: algorithmic bytes of all chains / summed duration of the batched launches
+        perf1 = [{w: s.perf(w) for w in "AP"} for s in S]
+        kern, tot_ms, tot_bytes = [], 0.0, 0.0
+        for w in "AP":
+            bp = B.perf(w)
+            nbytes = sum(p1[w]["evalBytes"] - p0[w]["evalBytes"] for p0, p1 in zip(perf0, perf1))
+            # steps of the batch in the timed window = the batches of its slowest chain
+            steps_w = max(p1[w]["batches"] - p0[w]["batches"] for p0, p1 in zip(perf0, perf1))
+            ev_ms, gen_ms = bp["eval_us"] * steps_w / 1e3, bp["gen_us"] * steps_w / 1e3
+            ach = (nbytes / 1e9) / (ev_ms / 1e3) if ev_ms > 0 else 0.0
+            kern.append({"kernel": "batched evaluation launch, sampler %s" % w, "steps": int(steps_w), "sampled_launches": bp["sampled"], "avg_launch_us": bp["eval_us"],
+                         "bytes_per_launch": nbytes / max(1, steps_w), "achieved": ach, "frac": ach / HBM_PEAK_GBS})
+            kern.append({"kernel": "batched generator launch, sampler %s" % w, "steps": int(steps_w), "avg_launch_us": bp["gen_us"]})
+            tot_ms += ev_ms + gen_ms
+            tot_bytes += nbytes
+        ach = (tot_bytes / 1e9) / (tot_ms / 1e3) if tot_ms > 0 else 0.0
+        roof = {"bound": "hbm", "kernel": "path: batched generator + evaluation launches", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": None, "kernel_time_over_wall": tot_ms / (1e3 * dt), "kernels": kern}
+    print(json.dumps({"metric": METRIC + " [informational: %d chains on one GPU, %s]" % (C, "batched multi-chain launches" if batched else "one thread and stream per chain"),
+                      "value": sum(upd) / dt, "unit": "proposals/s",
                       "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak",
                       "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                      "config": {"workload": "%d independent synthetic dense %dx%d shards in flight on one GPU, nPatterns=%d" % (C, args.genes, args.samples, args.patterns),
-                                 "per_chain": [u / dt for u in upd]}}))
+                      "config": {"workload": "%d independent synthetic %s %dx%d shards on one GPU, nPatterns=%d" % (C, "sparse (95 %% zeros)" if args.sparse else "dense", args.genes, args.samples, args.patterns),
+                                 "chains_mode": args.chains_mode, "per_chain": [u / dt for u in upd]},
+                      "roofline": roof, "cpu_baseline": None}))
+    if B is not None:
+        B.close()
     for s in S:
         s.close()
 
@@ -146,6 +195,7 @@ def main():
     ap.add_argument("--chains", type=int, default=1,
                     help="not the headline: that many independent chains (shards of the same shape) in flight per GPU, one host thread "
                          "and one stream each, as distributed.py runs a rank's shards; value = aggregate proposals/s")
+    ap.add_argument("--chains-mode", choices=("batched", "threads"), default="batched")
     args = ap.parse_args()
     if args.chains > 1:
         return chains_main(args)

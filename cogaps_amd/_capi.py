@@ -78,6 +78,7 @@ EXPORTS = [
     "cogaps_session_finish", "cogaps_session_set_timing", "cogaps_session_perf",
     "cogaps_session_perf_sampler", "cogaps_session_get_rows", "cogaps_sparse_width", "cogaps_reduction_width", "cogaps_session_debug_prof", "cogaps_session_debug_replay",
     "cogaps_run_from_file", "cogaps_read_matrix_file", "cogaps_matrix_free", "cogaps_file_info", "cogaps_debug_math", "cogaps_current_device",
+    "cogaps_batch_create", "cogaps_batch_destroy", "cogaps_batch_run_iterations", "cogaps_batch_set_timing", "cogaps_batch_perf",
 ]
 
 REDUCE_LANES, REDUCE_SEQ = 0, 1                              # cogaps_params.reductionMode
@@ -132,6 +133,13 @@ def bind(L):
     L.cogaps_file_info.argtypes = [C.c_char_p, u32p, u32p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.cogaps_debug_math.argtypes = [C.c_int, C.c_int, fp, fp, C.c_uint32, C.c_int]
     L.cogaps_current_device.argtypes = [C.POINTER(C.c_int)]
+    L.cogaps_batch_create.restype = vp
+    L.cogaps_batch_create.argtypes = [C.POINTER(vp), C.c_uint32]
+    L.cogaps_batch_destroy.argtypes = [vp]
+    L.cogaps_batch_destroy.restype = None
+    L.cogaps_batch_run_iterations.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+    L.cogaps_batch_set_timing.argtypes = [vp, C.c_int]
+    L.cogaps_batch_perf.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     return L
 
 
@@ -437,3 +445,67 @@ def current_device(lib=None):
     if L.cogaps_current_device(C.byref(d)):
         raise RuntimeError(L.cogaps_last_error().decode())
     return d.value
+
+
+class Batch:
+    """Batched multi-chain launches (cogaps_batch_* of include/cogaps_hip.h): the given sessions stepped in lock-step by one stream,
+    one generator / evaluation launch for all of them.  Every chain gives the bits it gives on its own."""
+
+    def __init__(self, sessions):
+        self.sessions = list(sessions)
+        self.L = self.sessions[0].L
+        arr = (C.c_void_p * len(self.sessions))(*[s.h for s in self.sessions])
+        self.h = self.L.cogaps_batch_create(arr, len(self.sessions))
+        if not self.h:
+            raise RuntimeError("cogaps_batch_create: " + self.L.cogaps_last_error().decode())
+
+    def _ck(self, rc):
+        if rc:
+            raise RuntimeError(self.L.cogaps_last_error().decode())
+
+    def run_iterations(self, phase, first, n):
+        upd = (C.c_uint64 * len(self.sessions))()
+        self._ck(self.L.cogaps_batch_run_iterations(self.h, phase, first, n, upd))
+        return [int(u) for u in upd]
+
+    def set_timing(self, on):
+        self._ck(self.L.cogaps_batch_set_timing(self.h, int(on)))
+
+    def perf(self, side):
+        g, e, n, l = C.c_double(), C.c_double(), C.c_uint64(), C.c_uint64()
+        self._ck(self.L.cogaps_batch_perf(self.h, {"A": 0, "P": 1}[side], C.byref(g), C.byref(e), C.byref(n), C.byref(l)))
+        return {"gen_us": g.value, "eval_us": e.value, "sampled": n.value, "launches": l.value}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.cogaps_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def run_batch(datas, uncs=None, lib=None, kws=None, **common):
+    """cogaps_run for several chains at once through the batched launches: datas[i] with the keyword arguments kws[i] (merged over
+    `common`).  All chains need the same nIterations.  Returns the result dicts in order."""
+    L = lib if lib is not None else load()
+    kws = kws or [{} for _ in datas]
+    uncs = uncs or [None] * len(datas)
+    ss = [Session(d, unc=u, lib=L, **dict(common, **k)) for d, u, k in zip(datas, uncs, kws)]
+    n_iter = {int(s.p.nIterations) for s in ss}
+    if len(n_iter) != 1:
+        raise ValueError("the chains of a batch need the same nIterations")
+    n_iter = n_iter.pop()
+    b = Batch(ss)
+    try:
+        b.run_iterations(1, 0, n_iter)
+        b.run_iterations(2, 0, n_iter)
+        out = [s.finish() for s in ss]
+    finally:
+        b.close()
+        for s in ss:
+            s.close()
+    return out

@@ -172,7 +172,7 @@ struct cogaps_session {
     uint32_t nGenes = 0, nSamples = 0, K = 0;
     HostSampler A, P;
     HostSeeder seeder; uint64_t runnerRng = 0;
-    rt_stream_t stream;
+    rt_stream_t stream; bool ownsStream = true;      // a session that joined a cogaps_batch runs on the batch's stream
     float *dErf = nullptr, *dErfinv = nullptr, *dQgamma = nullptr; uint64_t *dLcgMul = nullptr, *dLcgInc = nullptr;
     float *Asum = nullptr, *Asq = nullptr, *Psum = nullptr, *Psq = nullptr;
     unsigned statUpdates = 0;
@@ -692,7 +692,7 @@ void cogaps_session_destroy(cogaps_session *s)
     rt_free(s->Asum); rt_free(s->Asq); rt_free(s->Psum); rt_free(s->Psq); rt_free(s->pump);
     rt_free_host(s->hGs);
     for (auto &e : s->evPool) rt_event_destroy(e);
-    rt_stream_destroy(s->stream);
+    if (s->ownsStream) rt_stream_destroy(s->stream);
     delete s;
 }
 
@@ -744,13 +744,10 @@ int cogaps_session_sync(cogaps_session *s, char which)
     SESSION_END
 }
 
-// updateSampler (GapsRunner.cpp:201-222) + GapsStatistics::update* (GapsRunner.cpp:299-312)
-int cogaps_session_iterate(cogaps_session *s, uint32_t nA, uint32_t nP, int sampling)
+// the part of an iteration after the two updates: the proposal counter and GapsStatistics::update* (GapsRunner.cpp:297-313)
+static void iterate_tail(cogaps_session *s, uint32_t nA, uint32_t nP, int sampling)
 {
-    SESSION_TRY
     const char f = s->p.whichMatrixFixed;
-    if (f != 'A') { if (run_update(s, s->A, nA, false, 0)) return 1; if (f != 'P') do_sync(s, s->P, s->A); }
-    if (f != 'P') { if (run_update(s, s->P, nP, false, 0)) return 1; if (f != 'A') do_sync(s, s->A, s->P); }
     s->totalUpdates += (uint64_t)nA + nP;
     if (sampling) {
         const uint32_t mode = (f == 'N') ? 0u : (f == 'P' ? 1u : 2u);   // P fixed -> updateA ; A fixed -> updateP
@@ -758,7 +755,60 @@ int cogaps_session_iterate(cogaps_session *s, uint32_t nA, uint32_t nP, int samp
         s->statUpdates++;
         if (f == 'N' && s->p.takePumpSamples) { RT_LAUNCH(pump_kernel, (s->A.d.M + 255u) / 256u, 256, s->stream, s->A.d, s->pump); s->pumpUpdates++; }   // GapsRunner.cpp:308-313
     }
+}
+
+// updateSampler (GapsRunner.cpp:201-222) + GapsStatistics::update* (GapsRunner.cpp:299-312)
+int cogaps_session_iterate(cogaps_session *s, uint32_t nA, uint32_t nP, int sampling)
+{
+    SESSION_TRY
+    const char f = s->p.whichMatrixFixed;
+    if (f != 'A') { if (run_update(s, s->A, nA, false, 0)) return 1; if (f != 'P') do_sync(s, s->P, s->A); }
+    if (f != 'P') { if (run_update(s, s->P, nP, false, 0)) return 1; if (f != 'A') do_sync(s, s->A, s->P); }
+    iterate_tail(s, nA, nP, sampling);
     SESSION_END
+}
+
+// the head of one iteration of runOnePhase (GapsRunner.cpp:280-295): interrupt poll, annealing temperature, Poisson step counts
+static int iteration_head(cogaps_session *s, int phase, uint32_t it, uint32_t *nA, uint32_t *nP)
+{
+    if (s->p.interrupt && s->p.interrupt(s->p.interruptArg)) return fail("interrupted");
+    if (phase == 1) {
+        const float temp = (float)(2 * it) / (float)s->p.nIterations;
+        cogaps_session_set_annealing(s, gm_min(1.f, temp));
+    }
+    return cogaps_session_draw_steps(s, nA, nP);
+}
+// ... and its tail (:314-325): snapshots, status line / histories
+static int iteration_tail(cogaps_session *s, int phase, uint32_t it)
+{
+    if ((s->p.snapshotPhase == 0 || s->p.snapshotPhase == phase) && s->p.snapshotFrequency > 0 && ((it + 1) % s->p.snapshotFrequency) == 0) {
+        // GapsStatistics::takeSnapshot (GapsStatistics.h:188-202): getMatrix() of both samplers
+        const int w = phase - 1;
+        const size_t na = (size_t)s->nGenes * s->K, np_ = (size_t)s->nSamples * s->K;
+        s->snapA[w].resize((size_t)(s->nSnap[w] + 1) * na); s->snapP[w].resize((size_t)(s->nSnap[w] + 1) * np_);
+        if (cogaps_session_get_rows(s, 'A', s->snapA[w].data() + (size_t)s->nSnap[w] * na)) return 1;
+        if (cogaps_session_get_rows(s, 'P', s->snapP[w].data() + (size_t)s->nSnap[w] * np_)) return 1;
+        s->nSnap[w]++;
+    }
+    if (s->p.outputFrequency > 0 && ((it + 1) % s->p.outputFrequency) == 0) {        // displayStatus, :162-199
+        const float cs = (s->p.whichMatrixFixed == 'P') ? chisq_of(s, s->A) : chisq_of(s, s->P);
+        s->chisqHist.push_back(cs); s->atomHistA.push_back(s->A.nAtoms); s->atomHistP.push_back(s->P.nAtoms);
+        if (s->p.printMessages) {
+            // elapsed / estimated total time (estimatedPercentComplete, GapsRunner.cpp:127-159)
+            const double nIter = (double)it + (phase == 2 ? (double)s->p.nIterations : 0.0), totalIter = 2.0 * (double)s->p.nIterations;
+            auto est = [](double current, double total, double nAtoms) {
+                const double coef = nAtoms / std::log(current);
+                return coef * std::log(std::sqrt(2.0 * total * 3.14159265358979323846)) + total * coef * std::log(total) - total * coef; };
+            const double done = est(nIter, nIter, s->A.nAtoms) + est(nIter, nIter, s->P.nAtoms), all = est(nIter, totalIter, s->A.nAtoms) + est(nIter, totalIter, s->P.nAtoms);
+            const unsigned el = (unsigned)(now_s() - s->startTime);
+            const double frac = done / all;
+            const unsigned tt = (frac > 0.0 && std::isfinite((double)el / frac)) ? (unsigned)((double)el / frac) : 0u;
+            printf("%u of %u, Atoms: %u(A), %u(P), ChiSq: %.0f, Time: %02u:%02u:%02u / %02u:%02u:%02u\n", it + 1, s->p.nIterations, s->A.nAtoms, s->P.nAtoms, cs,
+                   el / 3600u, (el % 3600u) / 60u, el % 60u, tt / 3600u, (tt % 3600u) / 60u, tt % 60u);
+            fflush(stdout);
+        }
+    }
+    return 0;
 }
 
 // runOnePhase (GapsRunner.cpp:272-327) for iterations [firstIter, firstIter+n)
@@ -768,45 +818,267 @@ int cogaps_session_run_iterations(cogaps_session *s, int phase, uint32_t firstIt
     const double t0 = now_s();
     if (s->p.printMessages && firstIter == 0 && n > 0) { printf(phase == 1 ? "-- Equilibration Phase --\n" : "-- Sampling Phase --\n"); fflush(stdout); }   // GapsRunner.cpp:446-457
     for (uint32_t it = firstIter; it < firstIter + n; ++it) {
-        if (s->p.interrupt && s->p.interrupt(s->p.interruptArg)) return fail("interrupted");
-        if (phase == 1) {
-            const float temp = (float)(2 * it) / (float)s->p.nIterations;
-            cogaps_session_set_annealing(s, gm_min(1.f, temp));
-        }
-        uint32_t nA, nP; cogaps_session_draw_steps(s, &nA, &nP);
+        uint32_t nA, nP;
+        if (iteration_head(s, phase, it, &nA, &nP)) return 1;
         if (cogaps_session_iterate(s, nA, nP, phase == 2)) return 1;
         if (updates) *updates += (uint64_t)nA + nP;
-        if ((s->p.snapshotPhase == 0 || s->p.snapshotPhase == phase) && s->p.snapshotFrequency > 0 && ((it + 1) % s->p.snapshotFrequency) == 0) {
-            // GapsStatistics::takeSnapshot (GapsStatistics.h:188-202): getMatrix() of both samplers
-            const int w = phase - 1;
-            const size_t na = (size_t)s->nGenes * s->K, np_ = (size_t)s->nSamples * s->K;
-            s->snapA[w].resize((size_t)(s->nSnap[w] + 1) * na); s->snapP[w].resize((size_t)(s->nSnap[w] + 1) * np_);
-            if (cogaps_session_get_rows(s, 'A', s->snapA[w].data() + (size_t)s->nSnap[w] * na)) return 1;
-            if (cogaps_session_get_rows(s, 'P', s->snapP[w].data() + (size_t)s->nSnap[w] * np_)) return 1;
-            s->nSnap[w]++;
-        }
-        if (s->p.outputFrequency > 0 && ((it + 1) % s->p.outputFrequency) == 0) {        // displayStatus, :162-199
-            const float cs = (s->p.whichMatrixFixed == 'P') ? chisq_of(s, s->A) : chisq_of(s, s->P);
-            s->chisqHist.push_back(cs); s->atomHistA.push_back(s->A.nAtoms); s->atomHistP.push_back(s->P.nAtoms);
-            if (s->p.printMessages) {
-                // elapsed / estimated total time (estimatedPercentComplete, GapsRunner.cpp:127-159)
-                const double nIter = (double)it + (phase == 2 ? (double)s->p.nIterations : 0.0), totalIter = 2.0 * (double)s->p.nIterations;
-                auto est = [](double current, double total, double nAtoms) {
-                    const double coef = nAtoms / std::log(current);
-                    return coef * std::log(std::sqrt(2.0 * total * 3.14159265358979323846)) + total * coef * std::log(total) - total * coef; };
-                const double done = est(nIter, nIter, s->A.nAtoms) + est(nIter, nIter, s->P.nAtoms), all = est(nIter, totalIter, s->A.nAtoms) + est(nIter, totalIter, s->P.nAtoms);
-                const unsigned el = (unsigned)(now_s() - s->startTime);
-                const double frac = done / all;
-                const unsigned tt = (frac > 0.0 && std::isfinite((double)el / frac)) ? (unsigned)((double)el / frac) : 0u;
-                printf("%u of %u, Atoms: %u(A), %u(P), ChiSq: %.0f, Time: %02u:%02u:%02u / %02u:%02u:%02u\n", it + 1, s->p.nIterations, s->A.nAtoms, s->P.nAtoms, cs,
-                       el / 3600u, (el % 3600u) / 60u, el % 60u, tt / 3600u, (tt % 3600u) / 60u, tt % 60u);
-                fflush(stdout);
-            }
-        }
+        if (iteration_tail(s, phase, it)) return 1;
     }
     rt_sync(s->stream);
     s->samplerSeconds += now_s() - t0;
     SESSION_END
+}
+
+// ================================================================================================================================
+// Batched multi-chain launches: C independent chains -- the subsets of a GWCoGAPS / scCoGAPS job that share one GPU (nSets > #GPUs),
+// or replicas -- stepped in lock-step by ONE stream.  One chain alone alternates between a one-workgroup generator launch and an
+// evaluation launch of a few hundred workgroups, both latency-bound; with C chains the generator grid is C workgroups and the
+// evaluation grid C times as many, so a step of the batch costs about what a step of one chain costs and the evaluation kernels
+// finally move enough rows per launch to approach the HBM roofline.  Every chain is the same chain it would be on its own, bit for
+// bit (tests/test_gpu_parity.py::test_batched_chains_equal_single_sessions): the kernels are the one-chain kernels' bodies, fed from
+// a device array of SamplerDev records instead of a by-value argument.
+// ================================================================================================================================
+struct cogaps_batch {
+    std::vector<cogaps_session *> ss;
+    rt_stream_t stream;
+    SamplerDev *dev[2] = {nullptr, nullptr};            // [0] the A samplers' records, [1] the P samplers'
+    std::vector<SamplerDev> host[2];                    // what the device arrays hold
+    rt_graph graph[2]; bool graphValid[2] = {false, false};
+    GenScalars *hGs = nullptr;                          // pinned, [C]
+    bool sparse = false; char fixed = 'N';
+    uint64_t launches[2] = {0, 0}, stepsWithWork[2] = {0, 0};
+    // HIP-event samples of the plain-launch remainder of each chunk
+    bool timing = false; std::vector<rt_event_pair> ev; std::vector<int> evKind; std::vector<uint64_t> evOrd; size_t evUsed = 0;
+    double genMs[2] = {0, 0}, evalMs[2] = {0, 0}; uint64_t genTimed[2] = {0, 0}, evalTimed[2] = {0, 0};
+    uint64_t ord = 0;
+};
+
+static HostSampler &bpick(cogaps_batch *b, uint32_t c, int w) { return w == 0 ? b->ss[c]->A : b->ss[c]->P; }
+
+// launch geometry shared by the chains of a batch (checked at creation: equal reduction widths and slice counts)
+struct MultiGeom { uint32_t block, slices, wgPerChain; bool fused; };
+static MultiGeom multi_geom(cogaps_batch *b, int w)
+{
+    const SamplerDev &d = bpick(b, 0, w).d;
+    const uint32_t C = (uint32_t)b->ss.size();
+    uint32_t minCap = 0xFFFFFFFFu; for (uint32_t c = 0; c < C; ++c) minCap = std::min(minCap, bpick(b, c, w).d.queueCap);
+    MultiGeom g;
+    if (b->sparse) { g.block = cogaps_sparse_width(d.N); g.slices = 1; g.fused = true; g.wgPerChain = std::min<uint32_t>(minCap, std::max<uint32_t>(64u, 1024u / C)); return g; }
+    if (d.redW <= 1024u) { g.block = d.redW; g.slices = 1; g.fused = true; g.wgPerChain = std::min<uint32_t>(minCap, std::max<uint32_t>(64u, 2048u / C)); return g; }
+    g.fused = false;
+    g.block = std::max<uint32_t>(512u, d.redW / 16u);
+    g.slices = std::min<uint32_t>(d.redW / g.block, ((d.Npad >> 2) + g.block - 1u) / g.block);
+    const uint32_t perWave = std::max<uint32_t>(1u, (512u * (1024u / g.block)) / g.slices);      // (launch_eval: two resident 1024-thread workgroups per compute unit)
+    g.wgPerChain = std::min<uint32_t>(minCap, std::max<uint32_t>(4u, (2u * perWave) / C + 1u)) * g.slices;
+    return g;
+}
+static void multi_launch_pair(cogaps_batch *b, int w, const MultiGeom &g, int slotGen, int slotEval, int slotEval2)
+{
+    const uint32_t C = (uint32_t)b->ss.size();
+    const SamplerDev CG_CONSTANT *arr = (const SamplerDev CG_CONSTANT *)b->dev[w];
+#define MLAUNCH(slot, KERNEL, grid, block, ...) do { if ((slot) >= 0) RT_LAUNCH_TIMED(KERNEL, grid, block, b->stream, b->ev[slot], __VA_ARGS__); else RT_LAUNCH(KERNEL, grid, block, b->stream, __VA_ARGS__); } while (0)
+    MLAUNCH(slotGen, gen_kernel_multi<GEN_WIN>, C, GEN_WIN, arr);
+    if (b->sparse) MLAUNCH(slotEval, eval_sparse_kernel_multi, C * g.wgPerChain, g.block, arr, g.wgPerChain);
+    else if (g.fused) MLAUNCH(slotEval, eval_kernel_multi<EVAL_FUSED>, C * g.wgPerChain, g.block, arr, 1u, g.wgPerChain);
+    else {
+        MLAUNCH(slotEval, eval_kernel_multi<EVAL_ALPHA>, C * g.wgPerChain, g.block, arr, g.slices, g.wgPerChain);
+        MLAUNCH(slotEval2, eval_kernel_multi<EVAL_APPLY>, C * g.wgPerChain, g.block, arr, g.slices, g.wgPerChain);
+    }
+#undef MLAUNCH
+    b->launches[w]++;
+}
+
+// AsynchronousGibbsSampler::update of sampler `w` (0 = A, 1 = P) of every chain, nSteps[c] proposals each
+static int run_update_multi(cogaps_batch *b, int w, const std::vector<uint32_t> &nSteps)
+{
+    const uint32_t C = (uint32_t)b->ss.size();
+    rt_alloc_scope allocOn(b->stream);
+    for (uint32_t c = 0; c < C; ++c) rt_d2h(&b->hGs[c], bpick(b, c, w).d.gs, sizeof(GenScalars), b->stream);
+    rt_sync(b->stream);
+    std::vector<float> avgq(C); std::vector<char> done(C, 0);
+    for (uint32_t c = 0; c < C; ++c) {
+        cogaps_session *s = b->ss[c]; HostSampler &h = bpick(b, c, w);
+        GenScalars &g = b->hGs[c];
+        grow_atoms(s, h, g.nAtoms + nSteps[c] + 1024u);
+        const uint32_t n = nSteps[c];
+        if (h.seedCap < (size_t)n + 1) { rt_free(h.seeds); h.seedCap = (size_t)n * 5 / 4 + 1024; h.seeds = dalloc<uint64_t>(h.seedCap); }
+        if (h.hSeedCap < (size_t)n + 1) { rt_free_host(h.hSeeds); h.hSeedCap = (size_t)n * 5 / 4 + 1024; h.hSeeds = (uint64_t *)rt_malloc_host(h.hSeedCap * 8); }
+        for (uint32_t i = 0; i < n; ++i) h.hSeeds[i] = s->seeder.next();
+        rt_h2d(h.seeds, h.hSeeds, (size_t)n * 8, b->stream);
+        h.d.seeds = h.seeds;
+        g.annealTemp = h.anneal;
+        g.nSteps = n; g.nDone = 0; g.nBatches = 0; g.updateFlushed = 0; g.qlen = 0;
+        g.traceOn = 0; g.traceCount = 0; g.traceCap = 0; g.traceBatchCount = 0;
+        rt_h2d(h.d.gs, &g, sizeof(GenScalars), b->stream);
+        avgq[c] = h.stepsPerBatch > 1.f ? h.stepsPerBatch : (g.avgQueue > 1.f ? g.avgQueue : 1.f);
+        h.updLaunches = 0;
+    }
+    // the records the kernels read: re-uploaded when a pointer in one of them changed (atom tables regrown, seed buffer moved);
+    // the captured graph stays valid -- its kernels' arguments are the array's address and the launch geometry
+    bool changed = false;
+    for (uint32_t c = 0; c < C; ++c) if (memcmp(&b->host[w][c], &bpick(b, c, w).d, sizeof(SamplerDev)) != 0) { b->host[w][c] = bpick(b, c, w).d; changed = true; }
+    if (changed) rt_h2d(b->dev[w], b->host[w].data(), (size_t)C * sizeof(SamplerDev), b->stream);
+    rt_sync(b->stream);
+    const MultiGeom geo = multi_geom(b, w);
+    bool first = true;
+    for (;;) {
+        // pairs to enqueue: what the slowest unfinished chain still needs (launches past the end of a chain's update are no-ops for it)
+        uint32_t chunk = 0;
+        for (uint32_t c = 0; c < C; ++c) if (!done[c]) {
+            const uint32_t remaining = nSteps[c] - b->hGs[c].nDone;
+            chunk = std::max(chunk, (uint32_t)((double)remaining / avgq[c] * (first ? 0.97 : 1.0)) + (first ? 0u : 2u));
+        }
+        chunk = std::min(std::max(chunk, 6u), 4096u);
+        first = false;
+        uint32_t plain = chunk;
+        const bool noGraph = b->ss[0]->noGraph;
+        if (rt_graphs_supported() && !noGraph && plain >= GRAPH_PAIRS) {
+            if (!b->graphValid[w]) {
+                const uint64_t l0 = b->launches[w];
+                rt_capture_begin(b->stream);
+                for (uint32_t k = 0; k < GRAPH_PAIRS; ++k) multi_launch_pair(b, w, geo, -1, -1, -1);
+                rt_capture_end(b->stream, b->graph[w]);
+                b->launches[w] = l0; b->graphValid[w] = true;
+            }
+            for (; plain >= GRAPH_PAIRS; plain -= GRAPH_PAIRS) { rt_graph_launch(b->graph[w], b->stream); b->launches[w] += GRAPH_PAIRS; b->ord += GRAPH_PAIRS; }
+        }
+        for (uint32_t k = 0; k < plain; ++k) {
+            int sg = -1, se = -1, se2 = -1;
+            if (b->timing && (b->ord % 4u) == 0u && b->evUsed + 3 <= b->ev.size()) {
+                sg = (int)b->evUsed++; b->evKind[sg] = 0; se = (int)b->evUsed++; b->evKind[se] = 1;
+                if (!geo.fused) { se2 = (int)b->evUsed++; b->evKind[se2] = 2; }
+            }
+            multi_launch_pair(b, w, geo, sg, se, se2);
+            b->ord++;
+        }
+        for (uint32_t c = 0; c < C; ++c) rt_d2h(&b->hGs[c], bpick(b, c, w).d.gs, sizeof(GenScalars), b->stream);
+        rt_sync(b->stream);
+        for (size_t i = 0; i < b->evUsed; ++i) {          // (sampled launches near the end of a chunk: most chains still have work there)
+            const float ms = rt_event_ms(b->ev[i]);
+            if (b->evKind[i] == 0) { b->genMs[w] += ms; b->genTimed[w]++; } else { b->evalMs[w] += ms; if (b->evKind[i] == 1) b->evalTimed[w]++; }
+        }
+        b->evUsed = 0;
+        bool all = true;
+        for (uint32_t c = 0; c < C; ++c) {
+            const GenScalars &g = b->hGs[c];
+            if (g.error) return fail(std::string("device error code ") + std::to_string(g.error) + " in sampler " + (w ? 'P' : 'A') + " of chain " + std::to_string(c));
+            if (g.updateFlushed) done[c] = 1; else all = false;
+            if (g.nBatches > 0) avgq[c] = std::max(1.f, (float)g.nDone / (float)g.nBatches);
+        }
+        if (all) break;
+    }
+    for (uint32_t c = 0; c < C; ++c) {
+        HostSampler &h = bpick(b, c, w); const GenScalars &g = b->hGs[c];
+        h.nAtoms = g.nAtoms; h.avgQueue = g.avgQueue; h.batches += g.nBatches;
+        if (g.nBatches >= 8u) h.stepsPerBatch = (float)nSteps[c] / (float)g.nBatches;
+    }
+    return 0;
+}
+
+cogaps_batch *cogaps_batch_create(cogaps_session **sessions, uint32_t n)
+{
+    cogaps_batch *b = nullptr;
+    try {
+        if (!sessions || n == 0) { fail("no sessions"); return nullptr; }
+        const cogaps_session *s0 = sessions[0];
+        for (uint32_t c = 0; c < n; ++c) {
+            const cogaps_session *s = sessions[c];
+            if (!s) { fail("null session"); return nullptr; }
+            if (!s->ownsStream) { fail("a session can be in one batch only"); return nullptr; }
+            if (s->A.d.seq || s0->A.d.seq) { fail("the verification mode runs one chain at a time"); return nullptr; }
+            // one launch geometry for all chains: the same model, reduction widths and slice counts (subsets of one job have them)
+            if (s->p.useSparseOptimization != s0->p.useSparseOptimization || s->p.whichMatrixFixed != s0->p.whichMatrixFixed || s->p.device != s0->p.device
+                || s->A.d.redW != s0->A.d.redW || s->P.d.redW != s0->P.d.redW || ((s->A.d.Npad >> 2) + 511u) / 512u != ((s0->A.d.Npad >> 2) + 511u) / 512u
+                || ((s->P.d.Npad >> 2) + 511u) / 512u != ((s0->P.d.Npad >> 2) + 511u) / 512u
+                || cogaps_sparse_width(s->A.d.N) != cogaps_sparse_width(s0->A.d.N) || cogaps_sparse_width(s->P.d.N) != cogaps_sparse_width(s0->P.d.N))
+            { fail("the sessions of a batch must share the model, the fixed matrix, the device and the evaluation launch shape (equal reduction widths)"); return nullptr; }
+        }
+        rt_set_device(s0->p.device);
+        b = new cogaps_batch();
+        b->ss.assign(sessions, sessions + n);
+        b->sparse = s0->p.useSparseOptimization != 0; b->fixed = s0->p.whichMatrixFixed;
+        b->stream = rt_stream_create();
+        rt_alloc_scope allocOn(b->stream);
+        for (cogaps_session *s : b->ss) {      // from here on the sessions run on the batch's stream, one after the other
+            rt_sync(s->stream);
+            if (s->A.graphValid) { rt_graph_destroy(s->A.graph); s->A.graphValid = false; }
+            if (s->P.graphValid) { rt_graph_destroy(s->P.graph); s->P.graphValid = false; }
+            rt_stream_destroy(s->stream); s->stream = b->stream; s->ownsStream = false;
+        }
+        b->hGs = (GenScalars *)rt_malloc_host(sizeof(GenScalars) * n);
+        for (int w = 0; w < 2; ++w) { b->dev[w] = dalloc<SamplerDev>(n); b->host[w].resize(n); memset(b->host[w].data(), 0, sizeof(SamplerDev) * n); }
+        return b;
+    } catch (const std::exception &e) {
+        fail(e.what());
+        delete b;
+        return nullptr;
+    }
+}
+
+void cogaps_batch_destroy(cogaps_batch *b)
+{
+    if (!b) return;
+    try { rt_sync(b->stream); } catch (...) { }
+    for (cogaps_session *s : b->ss) { try { s->stream = rt_stream_create(); s->ownsStream = true; } catch (...) { } }      // the sessions outlive the batch
+    for (int w = 0; w < 2; ++w) { rt_graph_destroy(b->graph[w]); rt_free(b->dev[w]); }
+    for (auto &e : b->ev) rt_event_destroy(e);
+    rt_free_host(b->hGs);
+    rt_stream_destroy(b->stream);
+    delete b;
+}
+
+// runOnePhase for every chain of the batch: iterations [firstIter, firstIter + n) of `phase`; updates[c] += proposals of chain c
+int cogaps_batch_run_iterations(cogaps_batch *b, int phase, uint32_t firstIter, uint32_t n, uint64_t *updates)
+{
+    try {
+        rt_alloc_scope allocOn(b->stream);
+        const uint32_t C = (uint32_t)b->ss.size();
+        const double t0 = now_s();
+        for (cogaps_session *s : b->ss)
+            if (s->p.printMessages && firstIter == 0 && n > 0) { printf(phase == 1 ? "-- Equilibration Phase --\n" : "-- Sampling Phase --\n"); fflush(stdout); }
+        std::vector<uint32_t> nA(C), nP(C);
+        const char f = b->fixed;
+        for (uint32_t it = firstIter; it < firstIter + n; ++it) {
+            for (uint32_t c = 0; c < C; ++c) {
+                if (it >= b->ss[c]->p.nIterations && phase == 1) { /* a chain with fewer equilibration iterations keeps its last temperature */ }
+                if (iteration_head(b->ss[c], phase, it, &nA[c], &nP[c])) return 1;
+            }
+            // updateSampler (GapsRunner.cpp:201-222), every chain at once
+            if (f != 'A') { if (run_update_multi(b, 0, nA)) return 1; if (f != 'P') for (cogaps_session *s : b->ss) do_sync(s, s->P, s->A); }
+            if (f != 'P') { if (run_update_multi(b, 1, nP)) return 1; if (f != 'A') for (cogaps_session *s : b->ss) do_sync(s, s->A, s->P); }
+            for (uint32_t c = 0; c < C; ++c) {
+                iterate_tail(b->ss[c], nA[c], nP[c], phase == 2);
+                if (updates) updates[c] += (uint64_t)nA[c] + nP[c];
+                if (iteration_tail(b->ss[c], phase, it)) return 1;
+            }
+        }
+        rt_sync(b->stream);
+        const double dt = now_s() - t0;
+        for (cogaps_session *s : b->ss) s->samplerSeconds += dt;
+        return 0;
+    } catch (const std::exception &e) { return fail(e.what()); }
+}
+
+int cogaps_batch_set_timing(cogaps_batch *b, int on)
+{
+    try {
+        if (on && b->ev.empty()) { b->ev.resize(1536); b->evKind.resize(1536); for (auto &e : b->ev) rt_event_create(e); }
+        if (on && !b->timing) for (int w = 0; w < 2; ++w) { b->genMs[w] = b->evalMs[w] = 0; b->genTimed[w] = b->evalTimed[w] = 0; }
+        b->timing = on != 0;
+        return 0;
+    } catch (const std::exception &e) { return fail(e.what()); }
+}
+
+// mean HIP-event time of the sampled batched launches since cogaps_batch_set_timing(1), per sampler side (0 = A, 1 = P); the
+// algorithmic bytes and proposal counts are the sessions' own (cogaps_session_perf_sampler)
+int cogaps_batch_perf(cogaps_batch *b, int side, double *genUs, double *evalUs, uint64_t *sampled, uint64_t *launches)
+{
+    if (side < 0 || side > 1) return fail("side must be 0 (A) or 1 (P)");
+    if (genUs) *genUs = b->genTimed[side] ? 1e3 * b->genMs[side] / (double)b->genTimed[side] : 0.0;
+    if (evalUs) *evalUs = b->evalTimed[side] ? 1e3 * b->evalMs[side] / (double)b->evalTimed[side] : 0.0;
+    if (sampled) *sampled = b->evalTimed[side];
+    if (launches) *launches = b->launches[side];
+    return 0;
 }
 
 int cogaps_session_natoms(cogaps_session *s, char which, uint32_t *n) { *n = pick(s, which).nAtoms; return 0; }

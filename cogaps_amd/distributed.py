@@ -226,22 +226,42 @@ def _current_device(run_fn):
     return 0
 
 
-def _run_shards(call, ids, in_flight):
-    """This rank's shards, `in_flight` at a time (the role of BPPARAM's workers, DistributedCogaps.R:60-63, 84-87): one
-    host thread, one HIP stream and one session per shard in flight.  A single chain keeps one workgroup busy in
-    its generator kernel and a few hundred in its evaluation kernel, alternately; further chains on the same GPU
-    fill the gaps (4 chains: 3.1x the proposals/s of one on an MI355X; a 5th shares a hardware queue and loses: DESIGN.md section 5)."""
+def _run_shards(spec, ids, in_flight, run_fn):
+    """This rank's shards, `in_flight` at a time (the role of BPPARAM's workers, DistributedCogaps.R:60-63, 84-87).  spec(i) gives
+    (data, uncertainty, keyword arguments) of shard i's cogaps_run call.
+
+    With the product library the shards in flight run as ONE batch (cogaps_batch_*, batched multi-chain launches: one generator
+    launch with a workgroup per chain and one evaluation launch over all chains' queues per step) -- a single chain keeps one
+    workgroup busy in its generator kernel and a few hundred in its evaluation kernel, alternately, so the chains of a batch cost
+    about the time of one.  Shards whose evaluation launch shapes differ (very uneven subsets), or another run_fn (tests), fall back
+    to one host thread, one stream and one session per shard in flight.  Either way every shard's chain is bit-identical to the
+    chain it runs alone."""
     ids = list(ids)
     if in_flight <= 1 or len(ids) <= 1:
-        return {i: call(i) for i in ids}
+        return {i: run_fn(spec(i)[0], unc=spec(i)[1], **spec(i)[2]) for i in ids}
+    if run_fn is _capi.run:
+        out = {}
+        try:
+            for g0 in range(0, len(ids), in_flight):
+                grp = ids[g0:g0 + in_flight]
+                sp = [spec(i) for i in grp]
+                if len(grp) == 1:
+                    out[grp[0]] = run_fn(sp[0][0], unc=sp[0][1], **sp[0][2])
+                else:
+                    for i, r in zip(grp, _capi.run_batch([x[0] for x in sp], uncs=[x[1] for x in sp], kws=[x[2] for x in sp])):
+                        out[i] = r
+            return out
+        except RuntimeError as e:
+            if "launch shape" not in str(e):
+                raise
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=in_flight) as pool:
-        futs = {i: pool.submit(call, i) for i in ids}
+    with ThreadPoolExecutor(max_workers=min(in_flight, 4)) as pool:       # (HIP gives a process four hardware queues: DESIGN.md section 5)
+        futs = {i: pool.submit(lambda j=i: run_fn(spec(j)[0], unc=spec(j)[1], **spec(j)[2])) for i in ids}
         return {i: f.result() for i, f in futs.items()}
 
 
 def distributedCogaps(data, params, uncertainty=None, messages=False, outputFrequency=1000, transposeData=False,
-                      device=-1, run_fn=None, comm_device=None, shardsInFlight=4, nSnapshots=0, snapshotPhase="sampling"):
+                      device=-1, run_fn=None, comm_device=None, shardsInFlight=8, nSnapshots=0, snapshotPhase="sampling"):
     run_fn = run_fn or _capi.run
     shardsInFlight = max(1, int(shardsInFlight))
     genome_wide = params.distributed == "genome-wide"
@@ -280,14 +300,14 @@ def distributedCogaps(data, params, uncertainty=None, messages=False, outputFreq
             shard_cache[i] = (cut(data), None if uncertainty is None else cut(uncertainty))
         return shard_cache[i]
 
-    def call(i, n_patterns, fixed=None, which="N"):            # callInternalCoGAPS, DistributedCogaps.R:12-35
+    def spec(i, n_patterns, fixed=None, which="N"):            # callInternalCoGAPS, DistributedCogaps.R:12-35
         d, u = shard(i)
-        return run_fn(d, unc=u, nPatterns=n_patterns, runningDistributed=True, workerID=i + 1, messages=messages, whichMatrixFixed=which,
-                      fixedPatterns=fixed, **common)
+        return d, u, dict(nPatterns=n_patterns, runningDistributed=True, workerID=i + 1, messages=messages, whichMatrixFixed=which,
+                          fixedPatterns=fixed, **common)
 
     initial, unmatched, matched = None, None, None
     if params.fixedPatterns is None:
-        initial = _run_shards(lambda i: call(i, params.nPatterns), mine, shardsInFlight)
+        initial = _run_shards(lambda i: spec(i, params.nPatterns), mine, shardsInFlight, run_fn)
         key = "Pmean" if genome_wide else "Amean"
         local = {i: initial[i][key] for i in mine}
         if dist is not None:
@@ -301,7 +321,7 @@ def distributedCogaps(data, params, uncertainty=None, messages=False, outputFreq
 
     consensus = matched["consensus"]
     which = "P" if genome_wide else "A"
-    final = _run_shards(lambda i: call(i, consensus.shape[1], fixed=consensus, which=which), mine, shardsInFlight)
+    final = _run_shards(lambda i: spec(i, consensus.shape[1], fixed=consensus, which=which), mine, shardsInFlight, run_fn)
 
     # stitchTogether (DistributedCogaps.R:226-278): collect the per-subset free factor on every rank
     free_key, free_sd = ("Amean", "Asd") if genome_wide else ("Pmean", "Psd")

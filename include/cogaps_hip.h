@@ -194,6 +194,24 @@ int cogaps_session_set_timing(cogaps_session *s, int on);
 int cogaps_session_perf(cogaps_session *s, cogaps_perf *out);                      /* both samplers */
 int cogaps_session_perf_sampler(cogaps_session *s, char which, cogaps_perf *out);   /* the 'A' or the 'P' sampler alone */
 
+/* ------------------------------------------------------------------------------------------------
+ * Batched multi-chain launches: the sessions of a batch -- the subsets of a GWCoGAPS / scCoGAPS job that share one GPU
+ * (R/DistributedCogaps.R:60-68 hands them to BiocParallel workers), or replicas -- are stepped in lock-step by one stream: one
+ * generator launch with a workgroup per chain, one evaluation launch over all chains' queues.  Every chain produces exactly the
+ * bits it produces on its own.  The sessions must share the model (dense / sparse), whichMatrixFixed, the device and the
+ * evaluation launch shape (equal cogaps_reduction_width of their vector lengths); create them first, then the batch; drive the
+ * batch with cogaps_batch_run_iterations (phase 1, then phase 2), then cogaps_session_finish each session; destroy the batch
+ * before the sessions.  While a session belongs to a batch only the batch may step it.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct cogaps_batch cogaps_batch;
+cogaps_batch *cogaps_batch_create(cogaps_session **sessions, uint32_t n);
+void cogaps_batch_destroy(cogaps_batch *b);
+/* iterations [firstIter, firstIter + n) of `phase` for every chain; updates (may be NULL): [n chains], += proposals per chain */
+int cogaps_batch_run_iterations(cogaps_batch *b, int phase, uint32_t firstIter, uint32_t n, uint64_t *updates);
+int cogaps_batch_set_timing(cogaps_batch *b, int on);
+/* mean HIP-event time (us) of the sampled generator / evaluation launches of sampler side 0 (A) or 1 (P) since set_timing(1) */
+int cogaps_batch_perf(cogaps_batch *b, int side, double *genUs, double *evalUs, uint64_t *sampled, uint64_t *launches);
+
 /* development aid: per-phase cycle counters of the generator kernel (all zero unless built with -DGEN_PROFILE) */
 int cogaps_session_debug_prof(cogaps_session *s, char which, uint64_t *out16);
 int cogaps_session_debug_replay(cogaps_session *s, char which, int kind, uint32_t n, uint32_t dbgFlags, double *usPerLaunch);

@@ -170,3 +170,25 @@ def test_mode_validation(emul_lib, modsim):
         _capi.Session(modsim, lib=emul_lib(256), nPatterns=3, subsetIndices=np.array([0, 2], dtype=np.uint32), subsetDim=2)
     with pytest.raises(ValueError, match="nPatterns"):
         _capi.Session(modsim, lib=emul_lib(256), nPatterns=3, whichMatrixFixed="P", fixedPatterns=np.ones((20, 4), np.float32))
+
+
+def test_batched_chains_equal_single_sessions(emul_lib, gist):
+    """cogaps_batch_* (batched multi-chain launches): chains stepped in lock-step through gen_kernel_multi / eval_kernel_multi give the
+    bits of the same chains run one at a time -- dense with fused and split evaluation (shards of unequal size), the sparse
+    model, a fixed matrix; sessions whose launch shapes differ are refused"""
+    from cogaps_amd import _capi
+    lib = emul_lib(256)
+
+    def check(datas, kws, **common):
+        for d, k, r in zip(datas, kws, _capi.run_batch(datas, lib=lib, kws=kws, **common)):
+            o = _capi.run(d, lib=lib, **dict(common, **k))
+            for f in ("Amean", "Pmean", "Asd", "Psd", "atomsA", "atomsP", "chisq", "totalUpdates", "meanChiSq", "averageQueueLengthA", "averageQueueLengthP"):
+                assert np.array_equal(np.asarray(r[f]), np.asarray(o[f])), f
+    check([gist[:200], gist[200:400], gist[400:610]], [dict(seed=5), dict(seed=6), dict(seed=7)], nPatterns=3, nIterations=15, outputFrequency=5)
+    check([pu.synthetic(6000, 8, seed=1), pu.synthetic(6010, 8, seed=2)], [dict(seed=1), dict(seed=2)], nPatterns=3, nIterations=5, outputFrequency=5)
+    check([pu.synthetic_counts(120, 40, zeros=0.8, seed=s) for s in (1, 2, 3)], [dict(seed=s) for s in (4, 5, 6)], nPatterns=4, nIterations=16, outputFrequency=4,
+          sparseOptimization=True, takePumpSamples=True)
+    fp = np.abs(np.random.default_rng(1).normal(size=(9, 3))).astype(np.float32)
+    check([gist[:150], gist[150:300]], [dict(seed=1), dict(seed=2)], nPatterns=3, nIterations=10, outputFrequency=5, whichMatrixFixed="P", fixedPatterns=fp)
+    with pytest.raises(RuntimeError, match="launch shape"):
+        _capi.run_batch([pu.synthetic(6000, 8), pu.synthetic(300, 8)], lib=lib, nPatterns=3, nIterations=4)

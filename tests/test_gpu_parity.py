@@ -334,6 +334,35 @@ def test_sessions_in_flight_on_one_gpu(hip_lib, gist):
             assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
 
 
+def test_batched_chains_equal_single_sessions(hip_lib, gist):
+    """batched multi-chain launches (cogaps_batch_*: one generator workgroup per chain, one evaluation grid over all chains' queues,
+    replayed from one captured graph): eight chains in lock-step give the bits of the eight chains run one at a time -- dense (fused
+    and split evaluation), the sparse model, the fixed-matrix pass of GWCoGAPS; atom tables regrown in mid-run"""
+    from cogaps_amd import _capi
+
+    def check(datas, kws, **common):
+        for d, k, r in zip(datas, kws, _capi.run_batch(datas, lib=hip_lib, kws=kws, **common)):
+            o = _capi.run(d, lib=hip_lib, **dict(common, **k))
+            for f in ("Amean", "Pmean", "Asd", "Psd", "atomsA", "atomsP", "chisq", "totalUpdates", "meanChiSq", "averageQueueLengthA", "averageQueueLengthP"):
+                assert np.array_equal(np.asarray(r[f]), np.asarray(o[f])), f
+    check([gist[170 * c:170 * (c + 1)] for c in range(8)], [dict(seed=3 + c) for c in range(8)], nPatterns=4, nIterations=120, outputFrequency=20, takePumpSamples=True)
+    check([pu.synthetic(9000 + 4 * c, 24, seed=c) for c in range(4)], [dict(seed=c + 1) for c in range(4)], nPatterns=3, nIterations=40, outputFrequency=10)
+    check([pu.synthetic_counts(600, 200, zeros=0.9, seed=s) for s in range(5)], [dict(seed=s + 9) for s in range(5)], nPatterns=12, nIterations=60, outputFrequency=15,
+          sparseOptimization=True)
+    fp = np.abs(np.random.default_rng(1).normal(size=(9, 3))).astype(np.float32)
+    check([gist[:300], gist[300:600], gist[600:900]], [dict(seed=1), dict(seed=2), dict(seed=3)], nPatterns=3, nIterations=60, outputFrequency=20,
+          whichMatrixFixed="P", fixedPatterns=fp)
+
+
+def test_batched_chains_grow_their_atom_tables(hip_lib, gist, monkeypatch):
+    from cogaps_amd import _capi
+    monkeypatch.setenv("COGAPS_INITIAL_ATOM_CAP", "64")
+    datas, kws = [gist[:400], gist[400:800]], [dict(seed=1), dict(seed=2)]
+    for d, k, r in zip(datas, kws, _capi.run_batch(datas, lib=hip_lib, kws=kws, nPatterns=5, nIterations=80, outputFrequency=20)):
+        o = _capi.run(d, lib=hip_lib, nPatterns=5, nIterations=80, outputFrequency=20, **k)
+        assert np.array_equal(r["Amean"], o["Amean"]) and r["atomsA"].tolist() == o["atomsA"].tolist() and r["atomsA"][-1] > 500
+
+
 def test_run_from_file_equals_run_on_the_matrix(hip_lib, gist, tmp_path):
     """cogaps_run_from_file (the reference's gaps::run(path) / cogaps_from_file_cpp): the four formats of the GIST fixture give
     the bits of cogaps_run on the in-memory matrix; an uncertainty file is honoured"""
@@ -475,7 +504,9 @@ def test_bench_lines_small_workload():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["traffic"] is None
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
-    assert line(["--no-cpu", "--chains", "2"])["value"] > 0
+    c2 = line(["--no-cpu", "--chains", "2"])
+    assert c2["value"] > 0 and c2["config"]["chains_mode"] == "batched" and c2["roofline"]["frac"] > 0
+    assert line(["--no-cpu", "--chains", "2", "--chains-mode", "threads"])["value"] > 0
     s = line(["--no-cpu", "--sparse"])
     assert s["value"] > 0 and "sparse" in s["config"]["workload"]
 
