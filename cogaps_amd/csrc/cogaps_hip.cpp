@@ -172,6 +172,9 @@ struct cogaps_session {
     uint32_t nGenes = 0, nSamples = 0, K = 0;
     HostSampler A, P;
     HostSeeder seeder; uint64_t runnerRng = 0;
+    // The seeder's output sequence does not depend on how it is consumed (update k takes the next nSteps values, Random.cpp:221-248), so it
+    // is produced AHEAD of its use while the host waits for the GPU: seed_take() pops, seed_top_up() refills between launch and sync.
+    std::vector<uint64_t> seedFifo; size_t seedHead = 0;
     rt_stream_t stream; bool ownsStream = true;      // a session that joined a cogaps_batch runs on the batch's stream
     float *dErf = nullptr, *dErfinv = nullptr, *dQgamma = nullptr; uint64_t *dLcgMul = nullptr, *dLcgInc = nullptr;
     float *Asum = nullptr, *Asq = nullptr, *Psum = nullptr, *Psq = nullptr;
@@ -328,6 +331,24 @@ static void read_gs(cogaps_session *s, HostSampler &h)
     rt_sync(s->stream);
 }
 
+// the next n outputs of the session's seeder into dst, from the look-ahead buffer as far as it reaches
+static void seed_take(cogaps_session *s, uint64_t *dst, size_t n)
+{
+    const size_t avail = s->seedFifo.size() - s->seedHead, k = std::min(avail, n);
+    if (k) { memcpy(dst, s->seedFifo.data() + s->seedHead, k * 8); s->seedHead += k; }
+    for (size_t i = k; i < n; ++i) dst[i] = s->seeder.next();
+    if (s->seedHead == s->seedFifo.size()) { s->seedFifo.clear(); s->seedHead = 0; }
+}
+// look ahead until `target` outputs are waiting (called while the GPU works through a chunk of launches)
+static void seed_top_up(cogaps_session *s, size_t target)
+{
+    size_t avail = s->seedFifo.size() - s->seedHead;
+    if (avail >= target) return;
+    if (s->seedHead) { s->seedFifo.erase(s->seedFifo.begin(), s->seedFifo.begin() + (ptrdiff_t)s->seedHead); s->seedHead = 0; }
+    s->seedFifo.reserve(target);
+    for (; avail < target; ++avail) s->seedFifo.push_back(s->seeder.next());
+}
+
 static void grow_atoms(cogaps_session *s, HostSampler &h, uint32_t need)
 {
     SamplerDev &d = h.d;
@@ -440,7 +461,7 @@ static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool t
     // a failed attempt rolls the seeder back, Random.cpp:244-248)
     if (h.seedCap < (size_t)nSteps + 1) { rt_free(h.seeds); h.seedCap = (size_t)nSteps * 5 / 4 + 1024; h.seeds = dalloc<uint64_t>(h.seedCap); }
     if (h.hSeedCap < (size_t)nSteps + 1) { rt_free_host(h.hSeeds); h.hSeedCap = (size_t)nSteps * 5 / 4 + 1024; h.hSeeds = (uint64_t *)rt_malloc_host(h.hSeedCap * 8); }
-    for (uint32_t i = 0; i < nSteps; ++i) h.hSeeds[i] = s->seeder.next();
+    seed_take(s, h.hSeeds, nSteps);
     rt_h2d(h.seeds, h.hSeeds, (size_t)nSteps * 8, s->stream);
     d.seeds = h.seeds;
     if (trace) {
@@ -460,7 +481,7 @@ static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool t
     h.updLaunches = 0;
     // proposals per batch: the previous update of this sampler is the best predictor
     float avgq = h.stepsPerBatch > 1.f ? h.stepsPerBatch : (g.avgQueue > 1.f ? g.avgQueue : 1.f);
-    bool firstChunk = true;
+    bool firstChunk = true, topped = false;
     for (;;) {
         const uint32_t remaining = nSteps - s->hGs->nDone;
         // a pair enqueued past the end of the update is two wasted launches, a progress read-back is one short
@@ -484,6 +505,8 @@ static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool t
             }
         }
         for (uint32_t b = 0; b < plain; ++b) { launch_gen(s, h); launch_eval(s, h); h.updLaunches++; }
+        // while the GPU works: the seeds of the next update (the other sampler's, about one per atom it holds; Poisson spread + margin)
+        if (!topped) { HostSampler &o = (&h == &s->A) ? s->P : s->A; seed_top_up(s, (size_t)std::max(o.nAtoms, 10u) + (size_t)(6.0 * sqrt((double)std::max(o.nAtoms, 10u))) + 64u); topped = true; }
         read_gs(s, h);
         timing_resolve(s, s->hGs->nBatches);
         if (s->hGs->error) return fail(std::string("device error code ") + std::to_string(s->hGs->error) + " in sampler " + h.name);
@@ -903,7 +926,7 @@ static int run_update_multi(cogaps_batch *b, int w, const std::vector<uint32_t> 
         const uint32_t n = nSteps[c];
         if (h.seedCap < (size_t)n + 1) { rt_free(h.seeds); h.seedCap = (size_t)n * 5 / 4 + 1024; h.seeds = dalloc<uint64_t>(h.seedCap); }
         if (h.hSeedCap < (size_t)n + 1) { rt_free_host(h.hSeeds); h.hSeedCap = (size_t)n * 5 / 4 + 1024; h.hSeeds = (uint64_t *)rt_malloc_host(h.hSeedCap * 8); }
-        for (uint32_t i = 0; i < n; ++i) h.hSeeds[i] = s->seeder.next();
+        seed_take(s, h.hSeeds, n);
         rt_h2d(h.seeds, h.hSeeds, (size_t)n * 8, b->stream);
         h.d.seeds = h.seeds;
         g.annealTemp = h.anneal;
@@ -920,7 +943,7 @@ static int run_update_multi(cogaps_batch *b, int w, const std::vector<uint32_t> 
     if (changed) rt_h2d(b->dev[w], b->host[w].data(), (size_t)C * sizeof(SamplerDev), b->stream);
     rt_sync(b->stream);
     const MultiGeom geo = multi_geom(b, w);
-    bool first = true;
+    bool first = true, topped = false;
     for (;;) {
         // pairs to enqueue: what the slowest unfinished chain still needs (launches past the end of a chain's update are no-ops for it)
         uint32_t chunk = 0;
@@ -950,6 +973,10 @@ static int run_update_multi(cogaps_batch *b, int w, const std::vector<uint32_t> 
             }
             multi_launch_pair(b, w, geo, sg, se, se2);
             b->ord++;
+        }
+        if (!topped) {      // while the GPU works: every chain's seeds for its next update (the other sampler's)
+            for (uint32_t c = 0; c < C; ++c) { const uint32_t na = std::max(bpick(b, c, 1 - w).nAtoms, 10u); seed_top_up(b->ss[c], (size_t)na + (size_t)(6.0 * sqrt((double)na)) + 64u); }
+            topped = true;
         }
         for (uint32_t c = 0; c < C; ++c) rt_d2h(&b->hGs[c], bpick(b, c, w).d.gs, sizeof(GenScalars), b->stream);
         rt_sync(b->stream);
@@ -1209,7 +1236,7 @@ int cogaps_session_debug_replay(cogaps_session *s, char which, int kind, uint32_
         GenScalars g = *s->hGs;
         const uint32_t steps = kind >= 2 ? 65536u : 4096u;       // kinds 2 (generator alone) / 3 (pairs) run many real batches
         if (h.seedCap < steps) { rt_free(h.seeds); h.seedCap = 2u * steps; h.seeds = dalloc<uint64_t>(h.seedCap); }
-        std::vector<uint64_t> sd(steps); for (auto &x : sd) x = s->seeder.next();
+        std::vector<uint64_t> sd(steps); seed_take(s, sd.data(), sd.size());
         rt_h2d(h.seeds, sd.data(), sd.size() * 8, s->stream); h.d.seeds = h.seeds;
         g.nSteps = steps; g.nDone = 0; g.updateFlushed = 0; g.qlen = 0; g.traceOn = 0;
         *s->hGs = g; rt_h2d(h.d.gs, s->hGs, sizeof(GenScalars), s->stream);

@@ -133,50 +133,94 @@ CG_DEVICE void sp_term(float d_val, float v_val, float v2_val, float ex, float a
     if (MODE == SP_MODE_CH) pm = pm + tm2;
 }
 
-// per-lane partial sums of one alpha evaluation over this thread's flag words.  Two common non-zeros are in flight at
-// a time (data value, column entries and the other matrix's row of both are loaded before either is used); their terms
-// are added in index order.
+// ---- per-lane partial sums of one alpha evaluation, lane-balanced ------------------------------------------------------------
+// Lane order (the contract with the oracle): thread L owns the flag words L, L+W, ... and adds their common non-zeros' terms in
+// increasing word and bit order from +0.  The common non-zeros are unevenly spread over the words: a lane that owns a word with
+// five of them would do five K-length dots while its neighbours idle (data vectors of 2000 elements fill only 32 of the 64 lanes with a word at all).  Here the words' owners
+// only LIST their common non-zeros (element index, position of the data value) in LDS -- slots handed out by one LDS atomic per
+// word, the word's entries contiguous and in bit order --, every lane of the workgroup then takes listed entries round-robin and
+// computes the entry's complete term (the loads, the dot, sp_term_vals), and the owner folds its own word's terms back in bit
+// order: the same additions in the same order as if every owner had worked through its words alone.  A round (one word per thread)
+// that lists more than SP_BAL_CAP entries is done that way.
+#define SP_BAL_CAP 2048
+struct SpBal { uint32_t n; uint32_t idx[SP_BAL_CAP], dpos[SP_BAL_CAP]; float ts[SP_BAL_CAP], tm[SP_BAL_CAP], tm2[SP_BAL_CAP]; };
+
 template <int MODE>
-CG_DEVICE void sp_partial(const SamplerDev &S, uint32_t row, uint32_t col, uint32_t col2, float ch, const float *arow, float &ps, float &pm, uint32_t &visited)
+CG_DEVICE void sp_bal_term(const SamplerDev &S, uint32_t col, float ch, const float *arow, const float *data, const float *V, const float *V2,
+                           uint32_t idx, uint32_t dpos, float &ts, float &tm, float &tm2)
 {
-    const uint32_t BS = cg_bdim(), t = cg_tid(), K = S.K;
+    const float d = data[dpos];
+    const float v = V[idx], v2 = (MODE == SP_MODE_SAME) ? V2[idx] : 0.f;
+    const float ex = (MODE == SP_MODE_CH) ? S.orows[(size_t)idx * S.oKpad + col] : 0.f;
+    float ap;
+    if (S.K <= 64u) { SpRow R; sp_row_load(R, S.orows + (size_t)idx * S.oKpad, S.K); ap = sp_row_dot(arow, R, S.K); }
+    else ap = sp_dot_row(arow, S.orows + (size_t)idx * S.oKpad, S.K);
+    sp_term_vals<MODE>(d, v, v2, ex, ap, ch, ts, tm, tm2);
+}
+
+template <int MODE>
+CG_DEVICE void sp_partial_balanced(const SamplerDev &S, uint32_t row, uint32_t col, uint32_t col2, float ch, const float *arow, SpBal &bal, float &ps, float &pm, uint32_t &visited)
+{
+    const uint32_t BS = cg_bdim(), t = cg_tid();
     const unsigned long long *fD = S.dflags + (size_t)row * S.Wn;
     const unsigned long long *fV = S.oflags + (size_t)col * S.oMw, *fV2 = S.oflags + (size_t)col2 * S.oMw;
     const uint32_t *pre = S.dprefix + (size_t)row * S.Wn;
     const float *data = S.dvals + S.dptr[row];
     const float *V = S.other + (size_t)col * S.Npad, *V2 = S.other + (size_t)col2 * S.Npad;
     ps = 0.f; pm = 0.f;
-    for (uint32_t w = t; w < S.Wn; w += BS) {
-        const unsigned long long dfl = fD[w];
-        unsigned long long common = dfl & (MODE == SP_MODE_SAME ? (fV[w] | fV2[w]) : fV[w]);
-        const uint32_t base = pre[w];
-        visited += (uint32_t)cg_popc64(common);
-        while (common != 0ull) {
-            const uint32_t bit0 = (uint32_t)cg_ctz64(common);
-            common &= common - 1ull;
-            const bool second = common != 0ull;
-            const uint32_t bit1 = second ? (uint32_t)cg_ctz64(common) : bit0;
-            if (second) common &= common - 1ull;
-            const uint32_t idx0 = 64u * w + bit0, idx1 = 64u * w + bit1;
-            const float d0 = data[base + (uint32_t)cg_popc64(dfl & ((1ull << bit0) - 1ull))];
-            const float d1 = data[base + (uint32_t)cg_popc64(dfl & ((1ull << bit1) - 1ull))];
-            const float v0 = V[idx0], v1 = V[idx1];
-            const float w0 = (MODE == SP_MODE_SAME) ? V2[idx0] : 0.f, w1 = (MODE == SP_MODE_SAME) ? V2[idx1] : 0.f;
-            const float e0 = (MODE == SP_MODE_CH) ? S.orows[(size_t)idx0 * S.oKpad + col] : 0.f, e1 = (MODE == SP_MODE_CH) ? S.orows[(size_t)idx1 * S.oKpad + col] : 0.f;
-            float ap0, ap1 = 0.f;
-            if (K <= 64u) {
-                SpRow R0, R1;
-                sp_row_load(R0, S.orows + (size_t)idx0 * S.oKpad, K);
-                sp_row_load(R1, S.orows + (size_t)idx1 * S.oKpad, K);
-                ap0 = sp_row_dot(arow, R0, K);
-                if (second) ap1 = sp_row_dot(arow, R1, K);
-            } else {
-                ap0 = sp_dot_row(arow, S.orows + (size_t)idx0 * S.oKpad, K);
-                if (second) ap1 = sp_dot_row(arow, S.orows + (size_t)idx1 * S.oKpad, K);
+    for (uint32_t w0 = 0; w0 < S.Wn; w0 += BS) {
+        const uint32_t w = w0 + t;
+        if (t == 0) bal.n = 0u;
+        cg_sync();
+        unsigned long long dfl = 0ull, common = 0ull; uint32_t base = 0, cnt = 0, dbase = 0;
+        if (w < S.Wn) {
+            dfl = fD[w];
+            common = dfl & (MODE == SP_MODE_SAME ? (fV[w] | fV2[w]) : fV[w]);
+            dbase = pre[w];
+            cnt = (uint32_t)cg_popc64(common);
+            visited += cnt;
+            if (cnt) {
+                base = cg_atomic_add_u32(&bal.n, cnt);
+                if (base + cnt <= (uint32_t)SP_BAL_CAP) {
+                    unsigned long long c = common; uint32_t j = 0;
+                    while (c != 0ull) {
+                        const uint32_t bit = (uint32_t)cg_ctz64(c); c &= c - 1ull;
+                        bal.idx[base + j] = 64u * w + bit;
+                        bal.dpos[base + j] = dbase + (uint32_t)cg_popc64(dfl & ((1ull << bit) - 1ull));
+                        ++j;
+                    }
+                }
             }
-            sp_term<MODE>(d0, v0, w0, e0, ap0, ch, ps, pm);
-            if (second) sp_term<MODE>(d1, v1, w1, e1, ap1, ch, ps, pm);
         }
+        cg_sync();
+        const uint32_t total = bal.n;
+        if (total <= (uint32_t)SP_BAL_CAP) {
+            // every lane: listed entries round-robin, two in flight
+            for (uint32_t e = t; e < total; e += 2u * BS) {
+                const uint32_t e1 = e + BS; const bool second = e1 < total;
+                float a0, b0, c0, a1 = 0.f, b1 = 0.f, c1 = 0.f;
+                const uint32_t i0 = bal.idx[e], p0 = bal.dpos[e], i1 = second ? bal.idx[e1] : i0, p1 = second ? bal.dpos[e1] : p0;
+                sp_bal_term<MODE>(S, col, ch, arow, data, V, V2, i0, p0, a0, b0, c0);
+                if (second) sp_bal_term<MODE>(S, col, ch, arow, data, V, V2, i1, p1, a1, b1, c1);
+                bal.ts[e] = a0; bal.tm[e] = b0; if (MODE == SP_MODE_CH) bal.tm2[e] = c0;
+                if (second) { bal.ts[e1] = a1; bal.tm[e1] = b1; if (MODE == SP_MODE_CH) bal.tm2[e1] = c1; }
+            }
+            cg_sync();
+            for (uint32_t j = 0; j < cnt; ++j) {       // the word's owner: its terms in bit order
+                ps = ps + bal.ts[base + j];
+                pm = pm + bal.tm[base + j];
+                if (MODE == SP_MODE_CH) pm = pm + bal.tm2[base + j];
+            }
+        } else {
+            // a round with more common non-zeros than the list holds: every owner works through its own word
+            while (common != 0ull) {
+                const uint32_t bit = (uint32_t)cg_ctz64(common); common &= common - 1ull;
+                float a0, b0, c0;
+                sp_bal_term<MODE>(S, col, ch, arow, data, V, V2, 64u * w + bit, dbase + (uint32_t)cg_popc64(dfl & ((1ull << bit) - 1ull)), a0, b0, c0);
+                ps = ps + a0; pm = pm + b0; if (MODE == SP_MODE_CH) pm = pm + c0;
+            }
+        }
+        cg_sync();      // the list is reused by the next round / the next call
     }
 }
 
@@ -274,6 +318,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
     CG_SHARED float decf; CG_SHARED uint32_t deci;
     CG_SHARED uint32_t nzShared;           // common non-zeros visited by this workgroup (roofline bookkeeping)
     CG_SHARED uint32_t seqCnt[SEQ ? SP_SEQ_WORDS + 1 : 1]; CG_SHARED float seqBc[2];     // verification mode (sp_alpha_seq)
+    CG_SHARED SpBal bal;                   // lane-balanced term list (sp_partial_balanced); unused in verification mode
     const uint32_t mm = SEQ ? S.mathMode : GM_MATH_PORTABLE;
     const uint32_t t = cg_tid(), BS = cg_bdim(), K = S.K;
     const float lambda = S.lambda, beta = S.beta;
@@ -331,10 +376,10 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
                 if (t == 0) nzShared = vis;
             } else {
             float x[4] = {0.f, 0.f, 0.f, 0.f};
-            if (diff) { sp_partial<SP_MODE_ONE>(S, p.r1, p.c1, 0u, 0.f, arowA, x[0], x[1], nz); sp_partial<SP_MODE_ONE>(S, p.r2, p.c2, 0u, 0.f, arowB, x[2], x[3], nz); }
-            else if (p.type == 'D') sp_partial<SP_MODE_CH>(S, p.r1, p.c1, 0u, -1.f * m1, arowA, x[0], x[1], nz);
-            else if (two) sp_partial<SP_MODE_SAME>(S, p.r1, p.c1, p.c2, 0.f, arowA, x[0], x[1], nz);
-            else sp_partial<SP_MODE_ONE>(S, p.r1, p.c1, 0u, 0.f, arowA, x[0], x[1], nz);
+            if (diff) { sp_partial_balanced<SP_MODE_ONE>(S, p.r1, p.c1, 0u, 0.f, arowA, bal, x[0], x[1], nz); sp_partial_balanced<SP_MODE_ONE>(S, p.r2, p.c2, 0u, 0.f, arowB, bal, x[2], x[3], nz); }
+            else if (p.type == 'D') sp_partial_balanced<SP_MODE_CH>(S, p.r1, p.c1, 0u, -1.f * m1, arowA, bal, x[0], x[1], nz);
+            else if (two) sp_partial_balanced<SP_MODE_SAME>(S, p.r1, p.c1, p.c2, 0.f, arowA, bal, x[0], x[1], nz);
+            else sp_partial_balanced<SP_MODE_ONE>(S, p.r1, p.c1, 0u, 0.f, arowA, bal, x[0], x[1], nz);
             if (nz) cg_atomic_add_u32(&nzShared, nz);
 #pragma unroll
             for (int c = 0; c < 4; ++c) x[c] = cg_wave_allsum_f32(x[c]);

@@ -192,3 +192,10 @@ def test_batched_chains_equal_single_sessions(emul_lib, gist):
     check([gist[:150], gist[150:300]], [dict(seed=1), dict(seed=2)], nPatterns=3, nIterations=10, outputFrequency=5, whichMatrixFixed="P", fixedPatterns=fp)
     with pytest.raises(RuntimeError, match="launch shape"):
         _capi.run_batch([pu.synthetic(6000, 8), pu.synthetic(300, 8)], lib=lib, nPatterns=3, nIterations=4)
+
+
+def test_sparse_balanced_list_overflow(emul_lib):
+    """a data vector whose round of flag words holds more common non-zeros than the lane-balancing list (SP_BAL_CAP = 2048): 8000
+    genes, 70 % non-zero -- the owners' fallback loop; and a case that mixes both within one evaluation (two rounds of words)"""
+    pu.run_stepwise(emul_lib(256), pu.synthetic_counts(8000, 10, zeros=0.3, seed=2), 4, trace=False, nPatterns=3, seed=5, total_iter=10, check_every=2, sparseOptimization=True)
+    pu.run_stepwise(emul_lib(256), pu.synthetic_counts(20000, 6, zeros=0.85, seed=3), 3, trace=False, nPatterns=3, seed=6, total_iter=10, check_every=3, sparseOptimization=True)
