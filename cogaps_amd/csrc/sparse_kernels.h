@@ -158,8 +158,24 @@ CG_DEVICE void sp_bal_term(const SamplerDev &S, uint32_t col, float ch, const fl
     sp_term_vals<MODE>(d, v, v2, ex, ap, ch, ts, tm, tm2);
 }
 
+// the words of round 0 (word index = thread index), loaded by the caller together with the matrix rows so that they travel in the
+// same memory trip: data flags, the (or-ed) column flags, the number of packed values before the word
+struct SpPre { unsigned long long dfl, fv; uint32_t dbase; };
+CG_DEVICE SpPre sp_preload(const SamplerDev &S, uint32_t row, uint32_t col, uint32_t col2, bool same)
+{
+    SpPre o; o.dfl = 0ull; o.fv = 0ull; o.dbase = 0u;
+    const uint32_t w = cg_tid();
+    if (w < S.Wn) {
+        o.dfl = S.dflags[(size_t)row * S.Wn + w];
+        o.fv = S.oflags[(size_t)col * S.oMw + w];
+        if (same) o.fv |= S.oflags[(size_t)col2 * S.oMw + w];
+        o.dbase = S.dprefix[(size_t)row * S.Wn + w];
+    }
+    return o;
+}
+
 template <int MODE>
-CG_DEVICE void sp_partial_balanced(const SamplerDev &S, uint32_t row, uint32_t col, uint32_t col2, float ch, const float *arow, SpBal &bal, float &ps, float &pm, uint32_t &visited)
+CG_DEVICE void sp_partial_balanced(const SamplerDev &S, uint32_t row, uint32_t col, uint32_t col2, float ch, const float *arow, SpBal &bal, const SpPre &pre0, float &ps, float &pm, uint32_t &visited)
 {
     const uint32_t BS = cg_bdim(), t = cg_tid();
     const unsigned long long *fD = S.dflags + (size_t)row * S.Wn;
@@ -174,9 +190,12 @@ CG_DEVICE void sp_partial_balanced(const SamplerDev &S, uint32_t row, uint32_t c
         cg_sync();
         unsigned long long dfl = 0ull, common = 0ull; uint32_t base = 0, cnt = 0, dbase = 0;
         if (w < S.Wn) {
-            dfl = fD[w];
-            common = dfl & (MODE == SP_MODE_SAME ? (fV[w] | fV2[w]) : fV[w]);
-            dbase = pre[w];
+            if (w0 == 0u) { dfl = pre0.dfl; common = dfl & pre0.fv; dbase = pre0.dbase; }
+            else {
+                dfl = fD[w];
+                common = dfl & (MODE == SP_MODE_SAME ? (fV[w] | fV2[w]) : fV[w]);
+                dbase = pre[w];
+            }
             cnt = (uint32_t)cg_popc64(common);
             visited += cnt;
             if (cnt) {
@@ -279,32 +298,40 @@ CG_DEVICE void sp_alpha_seq(const SamplerDev &S, uint32_t row, uint32_t col, uin
 // HybridMatrix::add (HybridMatrix.cpp:25-31) / set (:33-39) on entry (row, col): the row copy, the column copy with
 // its epsilon rule (HybridVector.cpp:55-86) and flag word, and the count of flagged entries per column (canUseGibbs =
 // "the column has a flagged entry", VectorMath.cpp:125-128).  One thread per entry; rows are proposal-exclusive.
-CG_DEVICE void sp_store_col(const SamplerDev &S, uint32_t row, uint32_t col, float newCol, bool zero)
+// The entry's current column-copy value and flag bit are read when the proposal's record arrives (SpCell), not when the decision is
+// made: the row belongs to this proposal alone for the whole batch, so neither can change in between, and the update is then
+// stores and non-returning atomics only -- no dependent memory trip after the decision.
+struct SpCell { float colv; bool flagged; };
+CG_DEVICE SpCell sp_cell_load(const SamplerDev &S, uint32_t row, uint32_t col)
+{
+    SpCell c;
+    c.colv = S.mat[(size_t)col * S.Mpad + row];
+    c.flagged = ((S.mflags[(size_t)col * S.Mw + (row >> 6)] >> (row & 63u)) & 1ull) != 0ull;
+    return c;
+}
+CG_DEVICE void sp_store_col(const SamplerDev &S, uint32_t row, uint32_t col, float newCol, bool zero, bool wasFlagged)
 {
     unsigned long long *f = S.mflags + (size_t)col * S.Mw + (row >> 6);
     const unsigned long long bit = 1ull << (row & 63u);
     if (zero) {
-        const unsigned long long old = cg_atomic_and_u64(f, ~bit);
+        if (wasFlagged) { (void)cg_atomic_and_u64(f, ~bit); (void)cg_atomic_sub_u32(&S.colPos[col], 1u); }
         S.mat[(size_t)col * S.Mpad + row] = 0.f;
-        if (old & bit) cg_atomic_sub_u32(&S.colPos[col], 1u);
     } else {
-        const unsigned long long old = cg_atomic_or_u64(f, bit);
+        if (!wasFlagged) { (void)cg_atomic_or_u64(f, bit); (void)cg_atomic_add_u32(&S.colPos[col], 1u); }
         S.mat[(size_t)col * S.Mpad + row] = newCol;
-        if (!(old & bit)) cg_atomic_add_u32(&S.colPos[col], 1u);
     }
 }
-CG_DEVICE void sp_change_matrix(const SamplerDev &S, uint32_t row, uint32_t col, float oldRow, float delta)     // SparseNormalModel.cpp:110-114
+CG_DEVICE void sp_change_matrix(const SamplerDev &S, uint32_t row, uint32_t col, float oldRow, float delta, const SpCell &cell)     // SparseNormalModel.cpp:110-114
 {
     S.rows[(size_t)row * S.Kpad + col] = oldRow + delta;
-    const float c = S.mat[(size_t)col * S.Mpad + row];
-    const bool zero = c + delta < GAPS_EPSILON;
-    sp_store_col(S, row, col, c + delta, zero);
+    const bool zero = cell.colv + delta < GAPS_EPSILON;
+    sp_store_col(S, row, col, cell.colv + delta, zero, cell.flagged);
 }
-CG_DEVICE void sp_safely_change_matrix(const SamplerDev &S, uint32_t row, uint32_t col, float oldRow, float delta)   // :116-122
+CG_DEVICE void sp_safely_change_matrix(const SamplerDev &S, uint32_t row, uint32_t col, float oldRow, float delta, const SpCell &cell)   // :116-122
 {
     const float newVal = gm_max(oldRow + delta, 0.f);
     S.rows[(size_t)row * S.Kpad + col] = newVal;
-    sp_store_col(S, row, col, newVal, newVal < GAPS_EPSILON);
+    sp_store_col(S, row, col, newVal, newVal < GAPS_EPSILON, cell.flagged);
 }
 
 // One workgroup of W = cogaps_sparse_width(N) threads per queued proposal (AsynchronousGibbsSampler.h:127-219 over the
@@ -339,6 +366,13 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
         float s = 0.f, smu = 0.f;
         uint32_t nz = 0;
         if (t == 0) nzShared = 0u;
+        // Everything the record addresses goes out in ONE memory trip: the cells the decision will rewrite (writer), the table terms'
+        // Z1 entries, the first round of flag words, and below the matrix rows / Z2 columns for LDS.
+        SpCell cell1, cell2; cell1.colv = 0.f; cell1.flagged = false; cell2 = cell1;
+        if (t == 0u) { cell1 = sp_cell_load(S, p.r1, p.c1); if (two) cell2 = sp_cell_load(S, p.r2, p.c2); }
+        const float z1a = need ? S.Z1[p.c1] : 0.f, z1b = (need && two) ? S.Z1[p.c2] : 0.f;
+        SpPre preA, preB; preA.dfl = preA.fv = 0ull; preA.dbase = 0u; preB = preA;
+        if (!SEQ && need) { preA = sp_preload(S, p.r1, p.c1, p.c2, two && !diff); if (diff) preB = sp_preload(S, p.r2, p.c2, 0u, false); }
         if (need) {
             // this sampler's matrix row(s), read by every lane for the K-length dots
             // (the row copy is zero-padded to Kpad, a multiple of 4: sp_row_dot reads whole chunks)
@@ -353,12 +387,12 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
                 uint32_t vis = 0;
                 if (diff) {
                     float sa, ma, sb, mb;
-                    sp_alpha_seq<SP_MODE_ONE>(S, p.r1, p.c1, 0u, 0.f, arowA, S.Z1[p.c1], -1.f * sp_dot(arowA, z2A, K), seqCnt, seqBc, sa, ma, vis);
-                    sp_alpha_seq<SP_MODE_ONE>(S, p.r2, p.c2, 0u, 0.f, arowB, S.Z1[p.c2], -1.f * sp_dot(arowB, z2B, K), seqCnt, seqBc, sb, mb, vis);
+                    sp_alpha_seq<SP_MODE_ONE>(S, p.r1, p.c1, 0u, 0.f, arowA, z1a, -1.f * sp_dot(arowA, z2A, K), seqCnt, seqBc, sa, ma, vis);
+                    sp_alpha_seq<SP_MODE_ONE>(S, p.r2, p.c2, 0u, 0.f, arowB, z1b, -1.f * sp_dot(arowB, z2B, K), seqCnt, seqBc, sb, mb, vis);
                     sa = sa * beta; ma = ma * beta; sb = sb * beta; mb = mb * beta;
                     s = sa + sb; smu = ma - mb;
                 } else if (two) {
-                    const float s0 = S.Z1[p.c1] - 2.f * z2B[p.c1] + S.Z1[p.c2];
+                    const float s0 = z1a - 2.f * z2B[p.c1] + z1b;
                     float d0 = 0.f;
                     for (uint32_t k = 0; k < K; ++k) d0 += arowA[k] * (z2A[k] - z2B[k]);
                     sp_alpha_seq<SP_MODE_SAME>(S, p.r1, p.c1, p.c2, 0.f, arowA, s0, -1.f * d0, seqCnt, seqBc, s, smu, vis);
@@ -367,19 +401,19 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
                     const float ch = -1.f * m1;
                     float m0 = -1.f * sp_dot(arowA, z2A, K);
                     m0 -= ch * z2A[p.c1];
-                    sp_alpha_seq<SP_MODE_CH>(S, p.r1, p.c1, 0u, ch, arowA, S.Z1[p.c1], m0, seqCnt, seqBc, s, smu, vis);
+                    sp_alpha_seq<SP_MODE_CH>(S, p.r1, p.c1, 0u, ch, arowA, z1a, m0, seqCnt, seqBc, s, smu, vis);
                     s = s * beta; smu = smu * beta;
                 } else {
-                    sp_alpha_seq<SP_MODE_ONE>(S, p.r1, p.c1, 0u, 0.f, arowA, S.Z1[p.c1], -1.f * sp_dot(arowA, z2A, K), seqCnt, seqBc, s, smu, vis);
+                    sp_alpha_seq<SP_MODE_ONE>(S, p.r1, p.c1, 0u, 0.f, arowA, z1a, -1.f * sp_dot(arowA, z2A, K), seqCnt, seqBc, s, smu, vis);
                     s = s * beta; smu = smu * beta;
                 }
                 if (t == 0) nzShared = vis;
             } else {
             float x[4] = {0.f, 0.f, 0.f, 0.f};
-            if (diff) { sp_partial_balanced<SP_MODE_ONE>(S, p.r1, p.c1, 0u, 0.f, arowA, bal, x[0], x[1], nz); sp_partial_balanced<SP_MODE_ONE>(S, p.r2, p.c2, 0u, 0.f, arowB, bal, x[2], x[3], nz); }
-            else if (p.type == 'D') sp_partial_balanced<SP_MODE_CH>(S, p.r1, p.c1, 0u, -1.f * m1, arowA, bal, x[0], x[1], nz);
-            else if (two) sp_partial_balanced<SP_MODE_SAME>(S, p.r1, p.c1, p.c2, 0.f, arowA, bal, x[0], x[1], nz);
-            else sp_partial_balanced<SP_MODE_ONE>(S, p.r1, p.c1, 0u, 0.f, arowA, bal, x[0], x[1], nz);
+            if (diff) { sp_partial_balanced<SP_MODE_ONE>(S, p.r1, p.c1, 0u, 0.f, arowA, bal, preA, x[0], x[1], nz); sp_partial_balanced<SP_MODE_ONE>(S, p.r2, p.c2, 0u, 0.f, arowB, bal, preB, x[2], x[3], nz); }
+            else if (p.type == 'D') sp_partial_balanced<SP_MODE_CH>(S, p.r1, p.c1, 0u, -1.f * m1, arowA, bal, preA, x[0], x[1], nz);
+            else if (two) sp_partial_balanced<SP_MODE_SAME>(S, p.r1, p.c1, p.c2, 0.f, arowA, bal, preA, x[0], x[1], nz);
+            else sp_partial_balanced<SP_MODE_ONE>(S, p.r1, p.c1, 0u, 0.f, arowA, bal, preA, x[0], x[1], nz);
             if (nz) cg_atomic_add_u32(&nzShared, nz);
 #pragma unroll
             for (int c = 0; c < 4; ++c) x[c] = cg_wave_allsum_f32(x[c]);
@@ -392,11 +426,11 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
             if (scalarLane) {
                 // table terms (SparseNormalModel.cpp:160-161, 205-207, 256-258), then beta
                 if (diff) {
-                    const float sa = (S.Z1[p.c1] + tot[0]) * beta, ma = (-1.f * sp_dot(arowA, z2A, K) + tot[1]) * beta;
-                    const float sb = (S.Z1[p.c2] + tot[2]) * beta, mb = (-1.f * sp_dot(arowB, z2B, K) + tot[3]) * beta;
+                    const float sa = (z1a + tot[0]) * beta, ma = (-1.f * sp_dot(arowA, z2A, K) + tot[1]) * beta;
+                    const float sb = (z1b + tot[2]) * beta, mb = (-1.f * sp_dot(arowB, z2B, K) + tot[3]) * beta;
                     s = sa + sb; smu = ma - mb;                                    // AlphaParameters.cpp:11-14
                 } else if (two) {
-                    float s0 = S.Z1[p.c1] - 2.f * z2B[p.c1] + S.Z1[p.c2];
+                    float s0 = z1a - 2.f * z2B[p.c1] + z1b;
                     float d0 = 0.f;
                     for (uint32_t k = 0; k < K; ++k) d0 += arowA[k] * (z2A[k] - z2B[k]);   // dot_diff, VectorMath.h:137-155
                     float m0 = -1.f * d0;
@@ -404,7 +438,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
                 } else {
                     float m0 = -1.f * sp_dot(arowA, z2A, K);
                     if (p.type == 'D') m0 -= (-1.f * m1) * z2A[p.c1];
-                    s = (S.Z1[p.c1] + tot[0]) * beta; smu = (m0 + tot[1]) * beta;
+                    s = (z1a + tot[0]) * beta; smu = (m0 + tot[1]) * beta;
                 }
             }
             }
@@ -420,7 +454,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
             }
             SP_BCAST(bv, bhas);
             if (bhas != 0u && bv >= GAPS_EPSILON) {
-                if (writer) { S.atoms[p.h1].mass = bv; sp_change_matrix(S, p.r1, p.c1, old1, bv); }
+                if (writer) { S.atoms[p.h1].mass = bv; sp_change_matrix(S, p.r1, p.c1, old1, bv, cell1); }
             } else if (writer) eval_cache_erase(S, p.h1);
         } else if (p.type == 'D') {
             float rebirth = m1; uint32_t acc = 0;
@@ -431,8 +465,8 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
             }
             SP_BCAST(rebirth, acc);
             if (writer) {
-                if (acc != 0u) { if (rebirth != m1) { sp_safely_change_matrix(S, p.r1, p.c1, old1, rebirth - m1); S.atoms[p.h1].mass = rebirth; } }
-                else { sp_safely_change_matrix(S, p.r1, p.c1, old1, -1.f * m1); eval_cache_erase(S, p.h1); }
+                if (acc != 0u) { if (rebirth != m1) { sp_safely_change_matrix(S, p.r1, p.c1, old1, rebirth - m1, cell1); S.atoms[p.h1].mass = rebirth; } }
+                else { sp_safely_change_matrix(S, p.r1, p.c1, old1, -1.f * m1, cell1); eval_cache_erase(S, p.h1); }
             }
         } else if (p.type == 'M') {
             uint32_t acc = 0; float unused = 0.f;
@@ -440,8 +474,8 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
             SP_BCAST(unused, acc);
             if (acc && writer) {
                 eval_domain_move(S, p.h1, curPos, p.pos);
-                sp_safely_change_matrix(S, p.r1, p.c1, old1, -m1);
-                sp_change_matrix(S, p.r2, p.c2, old2, m1);
+                sp_safely_change_matrix(S, p.r1, p.c1, old1, -m1, cell1);
+                sp_change_matrix(S, p.r2, p.c2, old2, m1, cell2);
             }
         } else if (need) {
             float gv = 0.f; uint32_t gh = 0;
@@ -449,8 +483,8 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
             SP_BCAST(gv, gh);
             const float n1 = m1 + gv, n2 = m2 - gv;
             if (gh != 0u && n1 > GAPS_EPSILON && n2 > GAPS_EPSILON && writer) {
-                sp_safely_change_matrix(S, p.r1, p.c1, old1, n1 - m1);
-                sp_safely_change_matrix(S, p.r2, p.c2, old2, n2 - m2);
+                sp_safely_change_matrix(S, p.r1, p.c1, old1, n1 - m1, cell1);
+                sp_safely_change_matrix(S, p.r2, p.c2, old2, n2 - m2, cell2);
                 S.atoms[p.h1].mass = n1; S.atoms[p.h2].mass = n2;
             }
         }
