@@ -396,7 +396,7 @@ static void timing_resolve(cogaps_session *s, uint64_t realBatches)
 static void launch_gen(cogaps_session *s, HostSampler &h)
 {
     const int slot = timing_slot(s, h, 0, h.genLaunches);
-    LAUNCH_MAYBE_TIMED(slot, gen_kernel<GEN_WIN>, 1, GEN_WIN, h.d);
+    LAUNCH_MAYBE_TIMED(slot, gen_kernel<GEN_WIN>, 1, GEN_WIN, h.d.lcgMul, h.d.lcgInc, h.d.gs, (const uint32_t *)h.d.eraseList, (const uint32_t *)h.d.queueUnits, h.d.eraseCap, h.d.queueCap, h.d);
     h.genLaunches++;
 }
 static void launch_eval(cogaps_session *s, HostSampler &h)
@@ -405,14 +405,14 @@ static void launch_eval(cogaps_session *s, HostSampler &h)
     if (h.d.seq) {
         // verification mode: one workgroup per proposal whatever the vector length, sums in the reference's order
         if (h.d.sparse) LAUNCH_MAYBE_TIMED(slot, eval_sparse_seq_kernel, std::min<uint32_t>(h.d.queueCap, SEQ_SPARSE_GRID), cogaps_sparse_width(h.d.N), h.d);
-        else LAUNCH_MAYBE_TIMED(slot, eval_kernel<EVAL_SEQ>, std::min<uint32_t>(h.d.queueCap, 512u), EVAL_SEQ_BS, h.d, 1u);
+        else LAUNCH_MAYBE_TIMED(slot, eval_kernel<EVAL_SEQ>, std::min<uint32_t>(h.d.queueCap, 512u), EVAL_SEQ_BS, (const PropRec *)h.d.queue, (const GenScalars *)h.d.gs, h.d.queueCap, 1u, h.d);
     } else if (h.d.sparse) {
         const uint32_t grid = std::min<uint32_t>(h.d.queueCap, 1024u);
         LAUNCH_MAYBE_TIMED(slot, eval_sparse_kernel, grid, cogaps_sparse_width(h.d.N), h.d);
     } else if (h.d.redW <= 1024u) {
         // one workgroup of W threads per proposal
         const uint32_t grid = std::min<uint32_t>(h.d.queueCap, 512u);
-        LAUNCH_MAYBE_TIMED(slot, eval_kernel<EVAL_FUSED>, grid, h.d.redW, h.d, 1u);
+        LAUNCH_MAYBE_TIMED(slot, eval_kernel<EVAL_FUSED>, grid, h.d.redW, (const PropRec *)h.d.queue, (const GenScalars *)h.d.gs, h.d.queueCap, 1u, h.d);
     } else {
         // long data vectors: `slices` workgroups of `bs` threads per proposal, alpha kernel then apply kernel
         // (512 threads fill the machine a little better than 1024; at most 16 slices fit the partials record)
@@ -422,8 +422,8 @@ static void launch_eval(cogaps_session *s, HostSampler &h)
         const uint32_t grid = std::min<uint32_t>(h.d.queueCap, perWave) * slices;
         int slot2 = -1;
         if (slot >= 0 && s->evUsed < s->evPool.size()) { slot2 = (int)s->evUsed++; s->evKind[slot2] = 3; s->evOwner[slot2] = &h; s->evOrd[slot2] = h.updLaunches; }
-        LAUNCH_MAYBE_TIMED(slot, eval_kernel<EVAL_ALPHA>, grid, bs, h.d, slices);
-        LAUNCH_MAYBE_TIMED(slot2, eval_kernel<EVAL_APPLY>, grid, bs, h.d, slices);
+        LAUNCH_MAYBE_TIMED(slot, eval_kernel<EVAL_ALPHA>, grid, bs, (const PropRec *)h.d.queue, (const GenScalars *)h.d.gs, h.d.queueCap, slices, h.d);
+        LAUNCH_MAYBE_TIMED(slot2, eval_kernel<EVAL_APPLY>, grid, bs, (const PropRec *)h.d.queue, (const GenScalars *)h.d.gs, h.d.queueCap, slices, h.d);
     }
     h.evalLaunches++;
 }
@@ -640,7 +640,7 @@ cogaps_session *cogaps_session_create(const float *data, uint32_t nrow, uint32_t
         // GapsRandomState(seed): seeder + lookup tables (Cogaps.cpp:158, Random.cpp:264-267)
         s->seeder.init(p.seed);
         std::vector<float> e, ei, qg; build_luts(e, ei, qg);
-        s->dErf = dalloc<float>(e.size()); s->dErfinv = dalloc<float>(ei.size()); s->dQgamma = dalloc<float>(qg.size());
+        s->dErf = dalloc<float>(e.size() + 8); s->dErfinv = dalloc<float>(ei.size() + 8); s->dQgamma = dalloc<float>(qg.size() + 8);      // (read as whole float4 chunks by the evaluation kernel's LDS staging)
         rt_h2d(s->dErf, e.data(), e.size() * 4, s->stream); rt_h2d(s->dErfinv, ei.data(), ei.size() * 4, s->stream); rt_h2d(s->dQgamma, qg.data(), qg.size() * 4, s->stream);
         std::vector<uint64_t> lm(2 * GEN_WIN + 2), li(2 * GEN_WIN + 2);
         for (uint32_t k = 0; k < lm.size(); ++k) pcg_jump_coeffs(k, lm[k], li[k]);

@@ -83,8 +83,13 @@ CG_DEVICE void eval_vfinish(const float *lds, float (&tot)[NC])
     const uint32_t t = cg_tid(), nw = cg_bdim() >> 6;
     if (t < 64u) {
         const uint32_t i = t < (uint32_t)NV ? t : 0u;
+        // all sixteen slots are read at once (one wait instead of one per wave) and the ones past the last wave masked afterwards:
+        // the scratch has 16 * NV floats whatever the workgroup size, stale words are never added
         float y[16];
-        for (uint32_t w = 0; w < 16; ++w) y[w] = w < nw ? lds[w * NV + i] : 0.f;
+#pragma unroll
+        for (uint32_t w = 0; w < 16; ++w) y[w] = lds[w * NV + i];
+#pragma unroll
+        for (uint32_t w = 0; w < 16; ++w) y[w] = w < nw ? y[w] : 0.f;
         for (uint32_t stride = 1; stride < nw; stride <<= 1)
             for (uint32_t k = 0; k + stride < 16; k += 2 * stride) y[k] = y[k] + y[k + stride];
         float z = y[0];
@@ -295,12 +300,24 @@ CG_DEVICE void eval_domain_move(const SamplerDev &S, uint32_t h, uint64_t oldPos
 // bits of the butterfly), repeats the (deterministic) decision and updates its own slice of AP.
 // vbid / vgdim: this workgroup's index and the number of workgroups that serve THIS sampler's queue (the grid itself, or
 // one chain's share of a batched multi-chain launch)
-template <int PHASE>
-CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vbid, const uint32_t vgdim)
+// hot: the three values a workgroup's first memory trip needs, passed as leading scalar kernel arguments so that the dispatcher preloads
+// them into SGPRs (-amdgpu-kernarg-preload-count): the queue record is requested at once, the by-value SamplerDev's
+// kernel-argument lines (WARM bytes, 0 = the caller warmed them) come in under the same trip.
+struct EvalHot { const PropRec *queue; const GenScalars *gs; uint32_t queueCap; };
+template <int PHASE, int WARM>
+CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vbid, const uint32_t vgdim, const EvalHot hot)
 {
 #if defined(GEN_TIMELINE) && !defined(COGAPS_EMUL)
     unsigned long long ets[11]; uint32_t ets_n = 0;
 #endif
+    // the first record's trip starts before anything else is computed: its address needs only preloaded kernel arguments and the
+    // workgroup index; the by-value SamplerDev's kernel-argument lines come in under it
+    const uint32_t qFirst = (PHASE == EVAL_FUSED || PHASE == EVAL_SEQ) ? vbid : vbid / slices;
+    PropRec pNext = hot.queue[qFirst < hot.queueCap ? qFirst : 0u];
+    const uint32_t qlen = hot.gs->qlen;
+    const float T = hot.gs->annealTemp;
+    cg_sched_fence();
+    if (WARM > 0) cg_kernarg_warm<(WARM > 0 ? WARM : 4)>();
     CG_SHARED float lds[16 * 4];
     CG_SHARED float decf; CG_SHARED uint32_t deci;     // decision of wave 0, broadcast to the other waves
     CG_SHARED float seqTerm[PHASE == EVAL_SEQ ? 4 * 4 * EVAL_SEQ_BS : 1];
@@ -325,11 +342,9 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
     const uint32_t chunk0 = slice * BS, stride = WHOLE ? BS : S.redW;
     const bool writer = slice == 0u && t == 0u;          // the one thread that stores the proposal's scalar results
 #define EVAL_BCAST(F0, I0) do { if (multiWave) { if (t == 0) { decf = (F0); deci = (I0); } cg_sync(); (F0) = decf; (I0) = deci; } } while (0)
-    for (uint32_t q = WHOLE ? vbid : vbid / slices; ; q += qStep) {
+    for (uint32_t q = qFirst; ; q += qStep) {
         // one trip: the record (slot q always exists: q < queueCap), the queue length, the annealing temperature
-        const PropRec p = S.queue[q < S.queueCap ? q : 0u];
-        const uint32_t qlen = S.gs->qlen;
-        const float T = S.gs->annealTemp;
+        const PropRec p = pNext;
         if (q >= qlen) break;
         { uint32_t ty_ = p.type; EVAL_PIN(ty_); }
         EVAL_TS(1);
@@ -391,10 +406,10 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
             s = diff ? tot[0] + tot[2] : tot[0]; smu = diff ? tot[1] - tot[3] : tot[1];        // AlphaParameters.cpp:11-14
         }
         EVAL_PIN(s); EVAL_TS(3);
-        if (PHASE == EVAL_ALPHA) { if (q + qStep >= qlen) break; cg_sync(); continue; }
+        if (PHASE == EVAL_ALPHA) { if (q + qStep >= qlen) break; { const uint32_t qn_ = q + qStep; pNext = hot.queue[qn_ < hot.queueCap ? qn_ : 0u]; } cg_sync(); continue; }
         s = s * T; smu = smu * T;
 #if defined(GEN_PROFILE)
-        if (S.dbg & 8u) { if (q + qStep >= qlen) break; cg_sync(); continue; }    // timing experiment: stop before the scalar step
+        if (S.dbg & 8u) { if (q + qStep >= qlen) break; { const uint32_t qn_ = q + qStep; pNext = hot.queue[qn_ < hot.queueCap ? qn_ : 0u]; } cg_sync(); continue; }    // timing experiment: stop before the scalar step
 #endif
         if (p.type == 'B') {
             // ---------------------------------------------------------------- birth (:127-144)
@@ -485,13 +500,18 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
             S.queueUnits[q] = units;
         }
         if (q + qStep >= qlen) break;   // last proposal of this workgroup
+        { const uint32_t qn_ = q + qStep; pNext = hot.queue[qn_ < hot.queueCap ? qn_ : 0u]; }
         cg_sync();   // the LDS scratch is reused by the next proposal
     }
 }
 
 // the split kernels are built for two resident 1024-thread workgroups per compute unit (<= 64 VGPRs)
 template <int PHASE>
-CG_KERNEL void CG_LAUNCH_BOUNDS2((PHASE == EVAL_SEQ ? EVAL_SEQ_BS : 1024), (PHASE == EVAL_FUSED || PHASE == EVAL_SEQ ? 4 : 8)) eval_kernel(SamplerDev S, uint32_t slices) { cg_kernarg_warm<sizeof(SamplerDev) + 4>(); eval_body<PHASE>(S, slices, cg_bid(), cg_gdim()); }
+CG_KERNEL void CG_LAUNCH_BOUNDS2((PHASE == EVAL_SEQ ? EVAL_SEQ_BS : 1024), (PHASE == EVAL_FUSED || PHASE == EVAL_SEQ ? 4 : 8)) eval_kernel(const PropRec *hotQueue, const GenScalars *hotGs, uint32_t hotCap, uint32_t slices, SamplerDev S)
+{
+    EvalHot hot; hot.queue = hotQueue; hot.gs = hotGs; hot.queueCap = hotCap;
+    eval_body<PHASE, (int)sizeof(SamplerDev) + 24>(S, slices, cg_bid(), cg_gdim(), hot);
+}
 
 // Batched multi-chain launch: the samplers of C independent chains (GWCoGAPS / scCoGAPS shards on one GPU) stepped in lock-step by
 // one stream.  `arr` is a device array of their SamplerDev records read through the constant address space (scalar loads, as the
@@ -502,5 +522,7 @@ CG_KERNEL void CG_LAUNCH_BOUNDS2(1024, (PHASE == EVAL_FUSED ? 4 : 8)) eval_kerne
     const uint32_t chain = cg_bid() / wgPerChain;
     const SamplerDev CG_CONSTANT *sp = arr + chain;
     cg_const_warm<sizeof(SamplerDev)>(sp);
-    eval_body<PHASE>(*(const SamplerDev *)sp, slices, cg_bid() - chain * wgPerChain, wgPerChain);
+    const SamplerDev &S = *(const SamplerDev *)sp;
+    EvalHot hot; hot.queue = S.queue; hot.gs = S.gs; hot.queueCap = S.queueCap;
+    eval_body<PHASE, 0>(S, slices, cg_bid() - chain * wgPerChain, wgPerChain, hot);
 }

@@ -89,31 +89,48 @@ CG_DEVICE void gen_flush_parallel(const SamplerDev &S, GenShared<WIN> &sh, const
     cg_sync();
 }
 
-template <int WIN>
-CG_DEVICE void gen_body(const SamplerDev &S)
+// hot: what the launch's first memory trip reads, passed as leading scalar kernel arguments so that the dispatcher preloads them into
+// SGPRs (-amdgpu-kernarg-preload-count): the trip starts at once and the by-value SamplerDev's kernel-argument lines (WARM
+// bytes; 0 = the caller warmed them) come in under it instead of before it.
+struct GenHot { const uint64_t *lcgMul, *lcgInc; GenScalars *gs; const uint32_t *eraseList, *queueUnits; uint32_t eraseCap, queueCap; };
+template <int WIN, int WARM>
+CG_DEVICE void gen_body(const SamplerDev &S, const GenHot hot)
 {
     CG_SHARED GenShared<WIN> sh;
     const unsigned t = cg_tid();
-    GenScalars *gs = S.gs;
+    GenScalars *gs = hot.gs;
 
     unsigned long long prof_last = cg_clock(), prof_acc[16] = {0}; (void)prof_last; (void)prof_acc;
     GEN_TS_INIT(); GEN_TS(0); GEN_TS(0);
     // k-step PCG jumps for this lane's (u1,u2): k = 2t, or 2(t-1) when attempt 0 replays cached values
-    const uint64_t jm0 = S.lcgMul[2u * t], ji0 = S.lcgInc[2u * t];
-    const uint64_t jm1 = S.lcgMul[t ? 2u * (t - 1u) : 0u], ji1 = S.lcgInc[t ? 2u * (t - 1u) : 0u];
+    const uint64_t jm0 = hot.lcgMul[2u * t], ji0 = hot.lcgInc[2u * t];
+    const uint64_t jm1 = hot.lcgMul[t ? 2u * (t - 1u) : 0u], ji1 = hot.lcgInc[t ? 2u * (t - 1u) : 0u];
     // first memory trip of the launch, everything independent: the scalars every lane needs (same address
     // for all lanes: one transaction), the erase cache and traffic-unit slots read speculatively, and lane
     // 0's copy of the generator's scalars into LDS, where they live for the whole launch
-    const uint32_t e_m = gs->eraseCount, e_n = gs->nAtoms, e_fc = gs->freeCount, e_prevQ = gs->qlen, e_nDone = gs->nDone, e_nSteps = gs->nSteps;
-    const uint32_t specH = (t < (unsigned)FLUSH_MAX && t < S.eraseCap) ? S.eraseList[t] : 0u;
-    uint32_t units = (t < S.queueCap) ? S.queueUnits[t] : 0u;
-    if (t == 0) { sh.g = *gs; sh.newFront = CG_KEEP; sh.unitSum = 0; }
+    cg_u32x16 gw; cg_uniform_load16(gs, gw);        // words 0..15 of GenScalars (one scalar load; read after the wait below)
+    const uint32_t specH = (t < (unsigned)FLUSH_MAX && t < hot.eraseCap) ? hot.eraseList[t] : 0u;
+    uint32_t units = (t < hot.queueCap) ? hot.queueUnits[t] : 0u;
+    const uint64_t jmW = hot.lcgMul[2 * WIN], jiW = hot.lcgInc[2 * WIN];
+    // the generator's scalars into LDS, one lane per word
+    constexpr uint32_t GSW = (uint32_t)(sizeof(GenScalars) / 4u);
+    static_assert(GSW <= 2u * (uint32_t)WIN, "at most two words of GenScalars per lane");
+    const uint32_t gword = (t < GSW) ? reinterpret_cast<const uint32_t *>(gs)[t] : 0u;
+    const uint32_t gword2 = (t + (uint32_t)WIN < GSW) ? reinterpret_cast<const uint32_t *>(gs)[t + (uint32_t)WIN] : 0u;
+    cg_sched_fence();
+    if (WARM > 0) cg_kernarg_warm<(WARM > 0 ? WARM : 4)>(); else cg_uniform_wait();
+    static_assert(offsetof(GenScalars, nAtoms) == 24 && offsetof(GenScalars, freeCount) == 32 && offsetof(GenScalars, nSteps) == 40 && offsetof(GenScalars, nDone) == 44
+                  && offsetof(GenScalars, qlen) == 48 && offsetof(GenScalars, eraseCount) == 56, "word indices below");
+    const uint32_t e_m = gw[14], e_n = gw[6], e_fc = gw[8], e_prevQ = gw[12], e_nDone = gw[11], e_nSteps = gw[10];
+    if (t < GSW) reinterpret_cast<uint32_t *>(&sh.g)[t] = gword;
+    if (t + (uint32_t)WIN < GSW) reinterpret_cast<uint32_t *>(&sh.g)[t + (uint32_t)WIN] = gword2;
+    if (t == 0) { sh.newFront = CG_KEEP; sh.unitSum = 0; }
     {   // empty conflict table
         // (keys only: whoever claims a slot initialises its value words)
         GenTabKeys none; none.k[0] = none.k[1] = none.k[2] = none.k[3] = GEN_TAB_EMPTY;
         for (uint32_t i = t; i < (uint32_t)GEN_TAB_NB; i += WIN) *(GenTabKeys *)&sh.bkey[4u * i] = none;
     }
-    if (t == 0) { sh.jmul[WIN] = S.lcgMul[2 * WIN]; sh.jinc[WIN] = S.lcgInc[2 * WIN]; }
+    if (t == 0) { sh.jmul[WIN] = jmW; sh.jinc[WIN] = jiW; }
     sh.jmul[t] = jm0; sh.jinc[t] = ji0;        // even-step PCG jumps, for the round bookkeeping
     cg_sync_lds();
     GEN_PROF(14);
@@ -701,12 +718,19 @@ CG_DEVICE void gen_body(const SamplerDev &S)
 }
 
 template <int WIN>
-CG_KERNEL void CG_LAUNCH_BOUNDS(WIN) gen_kernel(SamplerDev S) { cg_kernarg_warm<sizeof(SamplerDev)>(); gen_body<WIN>(S); }
+CG_KERNEL void CG_LAUNCH_BOUNDS(WIN) gen_kernel(const uint64_t *lcgMul, const uint64_t *lcgInc, GenScalars *gs, const uint32_t *eraseList, const uint32_t *queueUnits,
+                                               uint32_t eraseCap, uint32_t queueCap, SamplerDev S)
+{
+    GenHot hot; hot.lcgMul = lcgMul; hot.lcgInc = lcgInc; hot.gs = gs; hot.eraseList = eraseList; hot.queueUnits = queueUnits; hot.eraseCap = eraseCap; hot.queueCap = queueCap;
+    gen_body<WIN, (int)sizeof(SamplerDev) + 48>(S, hot);
+}
 // batched multi-chain launch (eval_kernel.h): one workgroup per chain
 template <int WIN>
 CG_KERNEL void CG_LAUNCH_BOUNDS(WIN) gen_kernel_multi(const SamplerDev CG_CONSTANT *arr)
 {
     const SamplerDev CG_CONSTANT *sp = arr + cg_bid();
     cg_const_warm<sizeof(SamplerDev)>(sp);
-    gen_body<WIN>(*(const SamplerDev *)sp);
+    const SamplerDev &S = *(const SamplerDev *)sp;
+    GenHot hot; hot.lcgMul = S.lcgMul; hot.lcgInc = S.lcgInc; hot.gs = S.gs; hot.eraseList = S.eraseList; hot.queueUnits = S.queueUnits; hot.eraseCap = S.eraseCap; hot.queueCap = S.queueCap;
+    gen_body<WIN, 0>(S, hot);
 }

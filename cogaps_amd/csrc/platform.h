@@ -67,6 +67,14 @@ CG_DEVICE void cg_const_warm(const T CG_CONSTANT *p)
     asm volatile("" :: "s"(acc));
 }
 
+// Sixteen consecutive dwords at a wave-uniform address into SGPRs with one scalar load that is NOT waited for here: the caller
+// issues its other loads and calls cg_uniform_wait() (or cg_kernarg_warm, which ends with the same wait) before touching `out`.
+// Only for memory no lane of this launch has written yet (the scalar cache is not coherent with vector stores).
+typedef uint32_t cg_u32x16 __attribute__((ext_vector_type(16)));
+CG_DEVICE void cg_uniform_load16(const void *p, cg_u32x16 &out) { asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(out) : "s"(p) : "memory"); }
+CG_DEVICE void cg_uniform_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// nothing is scheduled across this point: what was issued before it stays before
+CG_DEVICE void cg_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // keeps a loaded value (and so the load) alive without using it
 CG_DEVICE void cg_keep_f32(float x) { asm volatile("" :: "v"(x)); }
 

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <functional>
+#include <string.h>
 
 #define CG_HD inline
 #define CG_DEVICE inline
@@ -33,6 +34,10 @@ template <int BYTES> inline void cg_kernarg_warm() {}
 #define CG_CONSTANT
 template <int BYTES, class T> inline void cg_const_warm(const T *) {}
 inline void cg_keep_f32(float) {}
+inline void cg_sched_fence() {}
+struct cg_u32x16 { uint32_t v[16]; uint32_t operator[](int i) const { return v[i]; } };
+inline void cg_uniform_load16(const void *p, cg_u32x16 &out) { memcpy(out.v, p, 64); }
+inline void cg_uniform_wait() {}
 
 // fibers only switch at barriers / wave exchanges, so plain read-modify-write is atomic here
 inline uint32_t cg_atomic_add_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
