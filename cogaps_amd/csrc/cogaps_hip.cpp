@@ -303,7 +303,7 @@ static void build_sampler(cogaps_session *s, HostSampler &h, char name, const fl
     d.nWords0 = (uint32_t)((nBins + 63) / 64); d.nWords1 = (d.nWords0 + 63) / 64; d.nWords2 = (d.nWords1 + 63) / 64;
     d.bits0 = dalloc<unsigned long long>(d.nWords0); d.bits1 = dalloc<unsigned long long>(d.nWords1); d.bits2 = dalloc<unsigned long long>(d.nWords2);
     d.queueCap = d.M + 8; d.eraseCap = d.queueCap;
-    d.eraseList = dalloc<uint32_t>(d.eraseCap); d.queue = dalloc<PropRec>(d.queueCap); d.queueUnits = dalloc<uint32_t>(d.queueCap); d.partials = dalloc<float>((size_t)d.queueCap * 64);
+    d.eraseList = dalloc<unsigned long long>(d.eraseCap); d.queue = dalloc<PropRec>(d.queueCap); d.queueUnits = dalloc<uint32_t>(d.queueCap); d.partials = dalloc<float>((size_t)d.queueCap * 64);
     d.rowStamp = dalloc<unsigned long long>(d.M);
     d.atomStamp = dalloc<unsigned long long>(d.atomCap); d.gapStamp = dalloc<unsigned long long>((size_t)d.atomCap + 1);
     d.inlineStamp = dalloc<unsigned long long>(d.atomCap); d.atomDest = dalloc<uint64_t>(d.atomCap);
@@ -396,7 +396,7 @@ static void timing_resolve(cogaps_session *s, uint64_t realBatches)
 static void launch_gen(cogaps_session *s, HostSampler &h)
 {
     const int slot = timing_slot(s, h, 0, h.genLaunches);
-    LAUNCH_MAYBE_TIMED(slot, gen_kernel<GEN_WIN>, 1, GEN_WIN, h.d.lcgMul, h.d.lcgInc, h.d.gs, (const uint32_t *)h.d.eraseList, (const uint32_t *)h.d.queueUnits, h.d.eraseCap, h.d.queueCap, h.d);
+    LAUNCH_MAYBE_TIMED(slot, gen_kernel<GEN_WIN>, 1, GEN_WIN, h.d.lcgMul, h.d.lcgInc, h.d.gs, (const unsigned long long *)h.d.eraseList, (const uint32_t *)h.d.queueUnits, h.d.eraseCap, h.d.queueCap, h.d);
     h.genLaunches++;
 }
 static void launch_eval(cogaps_session *s, HostSampler &h)
@@ -408,7 +408,7 @@ static void launch_eval(cogaps_session *s, HostSampler &h)
         else LAUNCH_MAYBE_TIMED(slot, eval_kernel<EVAL_SEQ>, std::min<uint32_t>(h.d.queueCap, 512u), EVAL_SEQ_BS, (const PropRec *)h.d.queue, (const GenScalars *)h.d.gs, h.d.queueCap, 1u, h.d);
     } else if (h.d.sparse) {
         const uint32_t grid = std::min<uint32_t>(h.d.queueCap, 1024u);
-        LAUNCH_MAYBE_TIMED(slot, eval_sparse_kernel, grid, cogaps_sparse_width(h.d.N), h.d);
+        LAUNCH_MAYBE_TIMED(slot, eval_sparse_kernel, grid, cogaps_sparse_width(h.d.N), (const PropRec *)h.d.queue, (const GenScalars *)h.d.gs, h.d.queueCap, h.d);
     } else if (h.d.redW <= 1024u) {
         // one workgroup of W threads per proposal
         const uint32_t grid = std::min<uint32_t>(h.d.queueCap, 512u);

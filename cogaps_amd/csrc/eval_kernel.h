@@ -263,10 +263,10 @@ CG_DEVICE void eval_store_matrix(const SamplerDev &S, uint32_t row, uint32_t col
     const bool was = oldv > 0.f, is = newv > 0.f;
     if (was != is) { if (is) cg_atomic_add_u32(&S.colPos[col], 1u); else cg_atomic_sub_u32(&S.colPos[col], 1u); }
 }
-CG_DEVICE void eval_cache_erase(const SamplerDev &S, uint32_t h)     // ConcurrentAtomicDomain.cpp:62-69
+CG_DEVICE void eval_cache_erase(const SamplerDev &S, uint32_t h, uint32_t row, uint32_t col)     // ConcurrentAtomicDomain.cpp:62-69
 {
     const uint32_t k = cg_atomic_add_u32(&S.gs->eraseCount, 1u);
-    if (k < S.eraseCap) S.eraseList[k] = h; else S.gs->error = GAPS_ERR_ERASE_CAP;
+    if (k < S.eraseCap) S.eraseList[k] = ((unsigned long long)(row * S.K + col) << 32) | (unsigned long long)h; else S.gs->error = GAPS_ERR_ERASE_CAP;
 }
 // ConcurrentAtomicDomain.cpp:126-132 move() across bins: position + the bin-head index
 CG_DEVICE void eval_domain_move(const SamplerDev &S, uint32_t h, uint64_t oldPos, uint64_t newPos)
@@ -424,7 +424,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
             if (bhas != 0u && bv >= GAPS_EPSILON) {
                 eval_update_ap(S, p.r1, p.c1, bv, chunk0, stride); ++nUpd;                          // changeMatrix
                 if (writer) { S.atoms[p.h1].mass = bv; eval_store_matrix(S, p.r1, p.c1, old1, old1 + bv); }
-            } else if (writer) eval_cache_erase(S, p.h1);
+            } else if (writer) eval_cache_erase(S, p.h1, p.r1, p.c1);
         } else if (p.type == 'D') {
             // ---------------------------------------------------------------- death / rebirth (:148-180)
             float rebirth = m1;
@@ -451,7 +451,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
             } else {
                 const float nv = gm_max(old1 + (-1.f * m1), 0.f);
                 eval_update_ap(S, p.r1, p.c1, nv - old1, chunk0, stride); ++nUpd;
-                if (writer) { eval_store_matrix(S, p.r1, p.c1, old1, nv); eval_cache_erase(S, p.h1); }
+                if (writer) { eval_store_matrix(S, p.r1, p.c1, old1, nv); eval_cache_erase(S, p.h1, p.r1, p.c1); }
             }
             EVAL_PROF(3);
         } else if (p.type == 'M') {

@@ -93,7 +93,8 @@ struct SamplerDev {
     uint32_t *binHead; // [M*K] lowest-position atom of each bin or CG_NONE
     unsigned long long *bits0, *bits1, *bits2;  // occupancy bitmap: exact level 0, monotone hints above
     uint32_t nWords0, nWords1, nWords2;
-    uint32_t *eraseList; // [eraseCap] handles (mEraseCache)
+    unsigned long long *eraseList; // [eraseCap] mEraseCache: handle in the low word, the atom's bin (row * nPatterns + column) in the high word --
+                                   // so that the flush can ask for the bin's head in the same memory trip as for the atom's record
     uint32_t eraseCap;
     // ---- ProposalQueue -------------------------------------------------------------------------
     PropRec *queue;    // [queueCap]

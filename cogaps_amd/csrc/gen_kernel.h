@@ -98,7 +98,7 @@ struct GenShared {
     uint32_t wtotA[3][WIN / 64], wtotB[3][WIN / 64];
     // flush: erase cache sorted by position (handles, links, vector indices, bins), the tail of the unsorted
     // vector and the net writes of the swap-with-last replay
-    uint64_t fpos[FLUSH_MAX]; uint32_t fh[FLUSH_MAX], fl[FLUSH_MAX], fr[FLUSH_MAX], fidx[FLUSH_MAX], fbin[FLUSH_MAX], vt[FLUSH_MAX], lowSlot[FLUSH_MAX], lowH[FLUSH_MAX];
+    uint64_t fpos[FLUSH_MAX]; uint32_t fh[FLUSH_MAX], fl[FLUSH_MAX], fr[FLUSH_MAX], fidx[FLUSH_MAX], fbin[FLUSH_MAX], fhead[FLUSH_MAX], vt[FLUSH_MAX], lowSlot[FLUSH_MAX], lowH[FLUSH_MAX];
     uint32_t nLow, newFront, flushM, flushBase, unitSum, endBatch;
 #if defined(GEN_TIMELINE)
     unsigned long long ts[(WIN / 64) * 64]; uint32_t tsn[WIN / 64];

@@ -13,7 +13,7 @@
 // LDS); the swap-with-last sequence on the unsorted vector -- order dependent -- is replayed by one lane on
 // indices held in LDS (no memory traffic), and only its net effect (<= m slots) is written back.
 template <int WIN>
-CG_DEVICE void gen_flush_parallel(const SamplerDev &S, GenShared<WIN> &sh, const uint32_t m, const uint32_t n, const uint32_t fc0, const uint32_t specH)
+CG_DEVICE void gen_flush_parallel(const SamplerDev &S, GenShared<WIN> &sh, const uint32_t m, const uint32_t n, const uint32_t fc0, const unsigned long long specE)
 {
     const unsigned t = cg_tid();
     GenScalars &g = sh.g;
@@ -22,12 +22,12 @@ CG_DEVICE void gen_flush_parallel(const SamplerDev &S, GenShared<WIN> &sh, const
     if (m > (uint32_t)FLUSH_MAX) {           // rare: serial fallback, exactly the reference's procedure
         if (t == 0) {
             for (uint32_t i = 1; i < m; ++i) {
-                uint32_t h = S.eraseList[i]; uint64_t p = S.atoms[h].pos; uint32_t j = i;
-                while (j > 0 && S.atoms[S.eraseList[j - 1]].pos > p) { S.eraseList[j] = S.eraseList[j - 1]; --j; }
-                S.eraseList[j] = h;
+                const unsigned long long e = S.eraseList[i]; uint64_t p = S.atoms[(uint32_t)e].pos; uint32_t j = i;
+                while (j > 0 && S.atoms[(uint32_t)S.eraseList[j - 1]].pos > p) { S.eraseList[j] = S.eraseList[j - 1]; --j; }
+                S.eraseList[j] = e;
             }
             uint32_t nn = n, fc = g.freeCount, fr = g.front;
-            for (uint32_t i = 0; i < m; ++i) gen_erase_one(S, S.eraseList[i], nn, fc, fr);
+            for (uint32_t i = 0; i < m; ++i) gen_erase_one(S, (uint32_t)S.eraseList[i], nn, fc, fr);
             g.nAtoms = nn; g.freeCount = fc; g.front = fr; g.eraseCount = 0;
         }
         cg_sync();
@@ -35,13 +35,15 @@ CG_DEVICE void gen_flush_parallel(const SamplerDev &S, GenShared<WIN> &sh, const
     }
     // 1. fetch the erased atoms and the tail of the unsorted vector
     uint32_t myH = 0; AtomRec rec; rec.pos = 0; rec.left = CG_NONE; rec.right = CG_NONE; rec.mass = 0.f; rec.idx = 0;
-    if (t < m) { myH = specH; rec = S.atoms[myH]; sh.fpos[t] = rec.pos; sh.vt[t] = S.vec[n - m + t]; }
+    // (the bin travels with the handle in the erase cache: the bin's head is asked for in the same trip as the record)
+    uint32_t myBin = 0, myHead = CG_NONE;
+    if (t < m) { myH = (uint32_t)specE; myBin = (uint32_t)(specE >> 32); rec = S.atoms[myH]; myHead = S.binHead[myBin]; sh.fpos[t] = rec.pos; sh.vt[t] = S.vec[n - m + t]; }
     cg_sync_lds();
     // 2. rank sort by position (positions are unique)
     if (t < m) {
         uint32_t r = 0;
         for (uint32_t j = 0; j < m; ++j) r += (sh.fpos[j] < rec.pos) ? 1u : 0u;
-        sh.fh[r] = myH; sh.fl[r] = rec.left; sh.fr[r] = rec.right; sh.fidx[r] = rec.idx; sh.fbin[r] = gen_bin_of(S, rec.pos);
+        sh.fh[r] = myH; sh.fl[r] = rec.left; sh.fr[r] = rec.right; sh.fidx[r] = rec.idx; sh.fbin[r] = myBin; sh.fhead[r] = myHead;
     }
     cg_sync_lds();
     // 3. list surgery + bin heads (reads the pre-flush links only)
@@ -56,7 +58,7 @@ CG_DEVICE void gen_flush_parallel(const SamplerDev &S, GenShared<WIN> &sh, const
             if (R != CG_NONE) S.atoms[R].left = L;
         }
         const uint32_t b = sh.fbin[k];
-        if (S.binHead[b] == h) {              // the lowest atom of its bin goes: the next surviving atom of the bin takes over
+        if (sh.fhead[k] == h) {               // the lowest atom of its bin goes: the next surviving atom of the bin takes over
             uint32_t j = k;
             while (j + 1 < m && sh.fh[j + 1] == sh.fr[j]) ++j;
             const uint32_t cand = sh.fr[j];
@@ -92,7 +94,7 @@ CG_DEVICE void gen_flush_parallel(const SamplerDev &S, GenShared<WIN> &sh, const
 // hot: what the launch's first memory trip reads, passed as leading scalar kernel arguments so that the dispatcher preloads them into
 // SGPRs (-amdgpu-kernarg-preload-count): the trip starts at once and the by-value SamplerDev's kernel-argument lines (WARM
 // bytes; 0 = the caller warmed them) come in under it instead of before it.
-struct GenHot { const uint64_t *lcgMul, *lcgInc; GenScalars *gs; const uint32_t *eraseList, *queueUnits; uint32_t eraseCap, queueCap; };
+struct GenHot { const uint64_t *lcgMul, *lcgInc; GenScalars *gs; const unsigned long long *eraseList; const uint32_t *queueUnits; uint32_t eraseCap, queueCap; };
 template <int WIN, int WARM>
 CG_DEVICE void gen_body(const SamplerDev &S, const GenHot hot)
 {
@@ -109,7 +111,7 @@ CG_DEVICE void gen_body(const SamplerDev &S, const GenHot hot)
     // for all lanes: one transaction), the erase cache and traffic-unit slots read speculatively, and lane
     // 0's copy of the generator's scalars into LDS, where they live for the whole launch
     cg_u32x16 gw; cg_uniform_load16(gs, gw);        // words 0..15 of GenScalars (one scalar load; read after the wait below)
-    const uint32_t specH = (t < (unsigned)FLUSH_MAX && t < hot.eraseCap) ? hot.eraseList[t] : 0u;
+    const unsigned long long specE = (t < (unsigned)FLUSH_MAX && t < hot.eraseCap) ? hot.eraseList[t] : 0ull;
     uint32_t units = (t < hot.queueCap) ? hot.queueUnits[t] : 0u;
     const uint64_t jmW = hot.lcgMul[2 * WIN], jiW = hot.lcgInc[2 * WIN];
     // the generator's scalars into LDS, one lane per word
@@ -163,7 +165,7 @@ CG_DEVICE void gen_body(const SamplerDev &S, const GenHot hot)
             sh.u1c = sh.g.u1; sh.u2c = sh.g.u2; sh.updBase = e_nDone;
         }
     }
-    gen_flush_parallel<WIN>(S, sh, e_m, e_n, e_fc, specH);
+    gen_flush_parallel<WIN>(S, sh, e_m, e_n, e_fc, specE);
     GEN_PROF(0);
     GEN_TS(2);
     if (t == 0) sh.newFront = CG_NONE;        // (the commit phase's marker; barriers follow before it is used)
@@ -718,7 +720,7 @@ CG_DEVICE void gen_body(const SamplerDev &S, const GenHot hot)
 }
 
 template <int WIN>
-CG_KERNEL void CG_LAUNCH_BOUNDS(WIN) gen_kernel(const uint64_t *lcgMul, const uint64_t *lcgInc, GenScalars *gs, const uint32_t *eraseList, const uint32_t *queueUnits,
+CG_KERNEL void CG_LAUNCH_BOUNDS(WIN) gen_kernel(const uint64_t *lcgMul, const uint64_t *lcgInc, GenScalars *gs, const unsigned long long *eraseList, const uint32_t *queueUnits,
                                                uint32_t eraseCap, uint32_t queueCap, SamplerDev S)
 {
     GenHot hot; hot.lcgMul = lcgMul; hot.lcgInc = lcgInc; hot.gs = gs; hot.eraseList = eraseList; hot.queueUnits = queueUnits; hot.eraseCap = eraseCap; hot.queueCap = queueCap;

@@ -336,9 +336,15 @@ CG_DEVICE void sp_safely_change_matrix(const SamplerDev &S, uint32_t row, uint32
 
 // One workgroup of W = cogaps_sparse_width(N) threads per queued proposal (AsynchronousGibbsSampler.h:127-219 over the
 // sparse model).
-template <bool SEQ>
-CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const uint32_t vgdim)
+template <bool SEQ, int WARM>
+CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const uint32_t vgdim, const EvalHot hot)
 {
+    // (eval_kernel.h: the first record's trip starts from preloaded kernel arguments, the SamplerDev lines come in under it)
+    PropRec pNext = hot.queue[vbid < hot.queueCap ? vbid : 0u];
+    const uint32_t qlen = hot.gs->qlen;
+    const float T = hot.gs->annealTemp;
+    cg_sched_fence();
+    if (WARM > 0) cg_kernarg_warm<(WARM > 0 ? WARM : 4)>();
     CG_SHARED float lds[16 * 4];
     CG_SHARED float arowA[SP_KMAX], arowB[SP_KMAX];
     CG_SHARED float z2A[SP_KMAX], z2B[SP_KMAX];        // the Z2 columns of c1 / c2 (table terms)
@@ -352,9 +358,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
     const bool multiWave = BS > 64u;
     const bool scalarLane = !multiWave || t < 64u;
     for (uint32_t q = vbid; ; q += vgdim) {
-        const PropRec p = S.queue[q < S.queueCap ? q : 0u];
-        const uint32_t qlen = S.gs->qlen;
-        const float T = S.gs->annealTemp;
+        const PropRec p = pNext;
         if (q >= qlen) break;
         uint64_t rng = p.rng;
         const bool two = (p.type == 'M' || p.type == 'E');
@@ -455,7 +459,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
             SP_BCAST(bv, bhas);
             if (bhas != 0u && bv >= GAPS_EPSILON) {
                 if (writer) { S.atoms[p.h1].mass = bv; sp_change_matrix(S, p.r1, p.c1, old1, bv, cell1); }
-            } else if (writer) eval_cache_erase(S, p.h1);
+            } else if (writer) eval_cache_erase(S, p.h1, p.r1, p.c1);
         } else if (p.type == 'D') {
             float rebirth = m1; uint32_t acc = 0;
             if (scalarLane) {
@@ -466,7 +470,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
             SP_BCAST(rebirth, acc);
             if (writer) {
                 if (acc != 0u) { if (rebirth != m1) { sp_safely_change_matrix(S, p.r1, p.c1, old1, rebirth - m1, cell1); S.atoms[p.h1].mass = rebirth; } }
-                else { sp_safely_change_matrix(S, p.r1, p.c1, old1, -1.f * m1, cell1); eval_cache_erase(S, p.h1); }
+                else { sp_safely_change_matrix(S, p.r1, p.c1, old1, -1.f * m1, cell1); eval_cache_erase(S, p.h1, p.r1, p.c1); }
             }
         } else if (p.type == 'M') {
             uint32_t acc = 0; float unused = 0.f;
@@ -497,18 +501,30 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
             S.queueUnits[q] = bytes;
         }
         if (q + vgdim >= qlen) break;
+        { const uint32_t qn_ = q + vgdim; pNext = hot.queue[qn_ < hot.queueCap ? qn_ : 0u]; }
         cg_sync();
     }
 }
-CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_kernel(SamplerDev S) { cg_kernarg_warm<sizeof(SamplerDev)>(); eval_sparse_body<false>(S, cg_bid(), cg_gdim()); }
+CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_kernel(const PropRec *hotQueue, const GenScalars *hotGs, uint32_t hotCap, SamplerDev S)
+{
+    EvalHot hot; hot.queue = hotQueue; hot.gs = hotGs; hot.queueCap = hotCap;
+    eval_sparse_body<false, (int)sizeof(SamplerDev) + 24>(S, cg_bid(), cg_gdim(), hot);
+}
 CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_kernel_multi(const SamplerDev CG_CONSTANT *arr, uint32_t wgPerChain)
 {
     const uint32_t chain = cg_bid() / wgPerChain;
     const SamplerDev CG_CONSTANT *sp = arr + chain;
     cg_const_warm<sizeof(SamplerDev)>(sp);
-    eval_sparse_body<false>(*(const SamplerDev *)sp, cg_bid() - chain * wgPerChain, wgPerChain);
+    const SamplerDev &S = *(const SamplerDev *)sp;
+    EvalHot hot; hot.queue = S.queue; hot.gs = S.gs; hot.queueCap = S.queueCap;
+    eval_sparse_body<false, 0>(S, cg_bid() - chain * wgPerChain, wgPerChain, hot);
 }
-CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_seq_kernel(SamplerDev S) { cg_kernarg_warm<sizeof(SamplerDev)>(); eval_sparse_body<true>(S, cg_bid(), cg_gdim()); }
+CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_seq_kernel(SamplerDev S)
+{
+    cg_kernarg_warm<sizeof(SamplerDev)>();
+    EvalHot hot; hot.queue = S.queue; hot.gs = S.gs; hot.queueCap = S.queueCap;
+    eval_sparse_body<true, 0>(S, cg_bid(), cg_gdim(), hot);
+}
 
 // SparseNormalModel::generateLookupTables (SparseNormalModel.cpp:294-311): Z1[i] = sum_k other(k,i)^2 through the
 // other matrix's ROW copy, Z2(i,j) = dot of its column copies.  One workgroup per (i, j >= i) pair plus one per i;
