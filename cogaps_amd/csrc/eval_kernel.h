@@ -90,8 +90,13 @@ CG_DEVICE void eval_vfinish(const float *lds, float (&tot)[NC])
         for (uint32_t w = 0; w < 16; ++w) y[w] = lds[w * NV + i];
 #pragma unroll
         for (uint32_t w = 0; w < 16; ++w) y[w] = w < nw ? y[w] : 0.f;
-        for (uint32_t stride = 1; stride < nw; stride <<= 1)
-            for (uint32_t k = 0; k + stride < 16; k += 2 * stride) y[k] = y[k] + y[k + stride];
+        // the whole sixteen-slot tree, statically: above the last wave it adds +0 to sums that cannot be -0 (they start from +0), which
+        // changes no bit, and the registers are indexed by constants (a run-time bound made every access an indexed move)
+#pragma unroll
+        for (uint32_t stride = 1; stride < 16u; stride <<= 1) {
+#pragma unroll
+            for (uint32_t k = 0; k + stride < 16u; k += 2u * stride) y[k] = y[k] + y[k + stride];
+        }
         float z = y[0];
         for (int off = 1; off < V; off <<= 1) z = z + cg_shfl_xor_f32(z, off);     // lanes c*V .. c*V+V-1: the V slots of component c
 #pragma unroll

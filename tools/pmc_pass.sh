@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM-traffic counters for the bench command, as the MI355X guide prescribes: separate --pmc passes, no trace domains.
-cd /tmp; export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/pmc; mkdir -p $O
+cd /tmp; export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r2_pmc; mkdir -p $O
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$C
   ( time COGAPS_NO_GRAPH=1 timeout -k 5 1200 rocprofv3 --pmc $C --output-format csv -d /tmp/pmc_$C -- python $R/bench.py --no-cpu > $O/bench_$C.json 2> $O/$C.err ) 2>&1 | grep real
