@@ -411,7 +411,8 @@ static void launch_eval(cogaps_session *s, HostSampler &h)
         LAUNCH_MAYBE_TIMED(slot, eval_sparse_kernel, grid, cogaps_sparse_width(h.d.N), (const PropRec *)h.d.queue, (const GenScalars *)h.d.gs, h.d.queueCap, h.d);
     } else if (h.d.redW <= 1024u) {
         // one workgroup of W threads per proposal
-        const uint32_t grid = std::min<uint32_t>(h.d.queueCap, 512u);
+        static const uint32_t fusedGrid = getenv("COGAPS_FUSED_GRID") ? (uint32_t)atoi(getenv("COGAPS_FUSED_GRID")) : 512u;      // dev: A/B of the launch size
+        const uint32_t grid = std::min<uint32_t>(h.d.queueCap, fusedGrid);
         LAUNCH_MAYBE_TIMED(slot, eval_kernel<EVAL_FUSED>, grid, h.d.redW, (const PropRec *)h.d.queue, (const GenScalars *)h.d.gs, h.d.queueCap, 1u, h.d);
     } else {
         // long data vectors: `slices` workgroups of `bs` threads per proposal, alpha kernel then apply kernel
