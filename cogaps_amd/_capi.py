@@ -494,18 +494,20 @@ def run_batch(datas, uncs=None, lib=None, kws=None, **common):
     L = lib if lib is not None else load()
     kws = kws or [{} for _ in datas]
     uncs = uncs or [None] * len(datas)
-    ss = [Session(d, unc=u, lib=L, **dict(common, **k)) for d, u, k in zip(datas, uncs, kws)]
-    n_iter = {int(s.p.nIterations) for s in ss}
-    if len(n_iter) != 1:
-        raise ValueError("the chains of a batch need the same nIterations")
-    n_iter = n_iter.pop()
-    b = Batch(ss)
+    ss, b = [], None
     try:
+        for d, u, k in zip(datas, uncs, kws):
+            ss.append(Session(d, unc=u, lib=L, **dict(common, **k)))
+        n_iter = {int(s.p.nIterations) for s in ss}
+        if len(n_iter) != 1:
+            raise ValueError("the chains of a batch need the same nIterations")
+        n_iter = n_iter.pop()
+        b = Batch(ss)
         b.run_iterations(1, 0, n_iter)
         b.run_iterations(2, 0, n_iter)
-        out = [s.finish() for s in ss]
+        return [s.finish() for s in ss]
     finally:
-        b.close()
+        if b is not None:
+            b.close()
         for s in ss:
             s.close()
-    return out

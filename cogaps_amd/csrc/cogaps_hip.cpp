@@ -590,11 +590,8 @@ void cogaps_default_params(cogaps_params *p)
 const char *cogaps_last_error(void) { return g_last_error.c_str(); }
 const char *cogaps_build_report(void)
 {
-#if defined(COGAPS_EMUL)
-    return "cogaps-amd TEST-ONLY emulator build (not a product library)";
-#else
-    return "cogaps-amd 0.1 | HIP gfx950 (MI355X) | asynchronous Gibbs sampler, dense normal model | checkpoints: no";
-#endif
+    static const std::string rep = std::string("cogaps-amd 0.2 | ") + CG_PLATFORM_NAME + " | asynchronous Gibbs sampler, dense and sparse normal model | checkpoints: no";
+    return rep.c_str();
 }
 int cogaps_checkpoints_enabled(void) { return 0; }
 int cogaps_compiled_with_openmp(void) { return 0; }
@@ -870,7 +867,7 @@ struct cogaps_batch {
     rt_graph graph[2]; bool graphValid[2] = {false, false};
     GenScalars *hGs = nullptr;                          // pinned, [C]
     bool sparse = false; char fixed = 'N';
-    uint64_t launches[2] = {0, 0}, stepsWithWork[2] = {0, 0};
+    uint64_t launches[2] = {0, 0};
     // HIP-event samples of the plain-launch remainder of each chunk
     bool timing = false; std::vector<rt_event_pair> ev; std::vector<int> evKind; std::vector<uint64_t> evOrd; size_t evUsed = 0;
     double genMs[2] = {0, 0}, evalMs[2] = {0, 0}; uint64_t genTimed[2] = {0, 0}, evalTimed[2] = {0, 0};
@@ -1067,10 +1064,8 @@ int cogaps_batch_run_iterations(cogaps_batch *b, int phase, uint32_t firstIter, 
         std::vector<uint32_t> nA(C), nP(C);
         const char f = b->fixed;
         for (uint32_t it = firstIter; it < firstIter + n; ++it) {
-            for (uint32_t c = 0; c < C; ++c) {
-                if (it >= b->ss[c]->p.nIterations && phase == 1) { /* a chain with fewer equilibration iterations keeps its last temperature */ }
+            for (uint32_t c = 0; c < C; ++c)
                 if (iteration_head(b->ss[c], phase, it, &nA[c], &nP[c])) return 1;
-            }
             // updateSampler (GapsRunner.cpp:201-222), every chain at once
             if (f != 'A') { if (run_update_multi(b, 0, nA)) return 1; if (f != 'P') for (cogaps_session *s : b->ss) do_sync(s, s->P, s->A); }
             if (f != 'P') { if (run_update_multi(b, 1, nP)) return 1; if (f != 'A') for (cogaps_session *s : b->ss) do_sync(s, s->A, s->P); }

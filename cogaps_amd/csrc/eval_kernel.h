@@ -22,25 +22,11 @@
 #include "gaps_state.h"
 #include "gen_kernel.h"   // gen_bin_of, bm_set, bm_clear
 
-#if defined(COGAPS_EMUL)
-struct cg_f4 { float x, y, z, w; };
-#else
-typedef float4 cg_f4;
-#endif
-
+// (cg_f4, cg_ld4_stream: platform.h)
 CG_DEVICE cg_f4 ld4(const float *base, uint32_t j) { return reinterpret_cast<const cg_f4 *>(base)[j]; }
 // streaming read (data / uncertainty rows are used once per batch): keeps them from displacing the lookup tables,
 // the queue and the atom records in L2
-#if defined(COGAPS_EMUL)
-CG_DEVICE cg_f4 ld4_stream(const float *base, uint32_t j) { return ld4(base, j); }
-#else
-typedef float cg_v4f __attribute__((ext_vector_type(4)));
-CG_DEVICE cg_f4 ld4_stream(const float *base, uint32_t j)
-{
-    const cg_v4f v = __builtin_nontemporal_load(reinterpret_cast<const cg_v4f *>(base) + j);
-    cg_f4 o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w; return o;
-}
-#endif
+CG_DEVICE cg_f4 ld4_stream(const float *base, uint32_t j) { return cg_ld4_stream(base, j); }
 CG_DEVICE void st4(float *base, uint32_t j, cg_f4 v) { reinterpret_cast<cg_f4 *>(base)[j] = v; }
 CG_DEVICE cg_f4 f4_zero() { cg_f4 z; z.x = 0.f; z.y = 0.f; z.z = 0.f; z.w = 0.f; return z; }
 CG_DEVICE cg_f4 f4_one() { cg_f4 z; z.x = 1.f; z.y = 1.f; z.z = 1.f; z.w = 1.f; return z; }
@@ -55,7 +41,7 @@ struct EvalAcc { float s, m; };
 #define EVAL_MODE_CH 1       // ... with the change ch*v added to AP (death)
 #define EVAL_MODE_SAME 2     // v = other[:,c1] - other[:,c2], one row (DenseNormalModel.cpp:200-212)
 
-#if defined(GEN_TIMELINE) && !defined(COGAPS_EMUL)
+#if defined(GEN_TIMELINE)
 // dev: timestamps of the first 16 workgroups of a launch (lane 0 of the first and of the last wave)
 __device__ unsigned long long g_eval_timeline[2 * 16 * 2 * 12];     // [narrow | wide workgroups]
 #define EVAL_TS(id) do { if ((t & 63u) == 0u && ets_n < 11u) { ets[ets_n++] = ((unsigned long long)cg_clock() << 8) | (unsigned long long)(id); } } while (0)
@@ -312,7 +298,7 @@ struct EvalHot { const PropRec *queue; const GenScalars *gs; uint32_t queueCap; 
 template <int PHASE, int WARM>
 CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vbid, const uint32_t vgdim, const EvalHot hot)
 {
-#if defined(GEN_TIMELINE) && !defined(COGAPS_EMUL)
+#if defined(GEN_TIMELINE)
     unsigned long long ets[11]; uint32_t ets_n = 0;
 #endif
     // the first record's trip starts before anything else is computed: its address needs only preloaded kernel arguments and the

@@ -329,11 +329,7 @@ CG_HD OptF gm_gibbs_mass(float s_, float s_mu, float a, float b, uint64_t &rng, 
     OptF o; o.v = 0.f; o.has = false;
     if (s_ > GAPS_EPSILON) {
         float mean = useLambda ? (s_mu - lambda) / s_ : s_mu / s_;
-#if defined(COGAPS_EMUL)
-        float sd = 1.f / __builtin_sqrtf(s_);
-#else
-        float sd = 1.f / sqrtf(s_);
-#endif
+        float sd = 1.f / cg_sqrtf(s_);
         return pcg_trunc_normal(rng, L, a, b, mean, sd);
     }
     return o;

@@ -30,7 +30,7 @@
 #define GEN_PROF(i) do { } while (0)
 #define GEN_PROF_FLUSH() do { } while (0)
 #endif
-#if defined(GEN_TIMELINE) && !defined(COGAPS_EMUL)
+#if defined(GEN_TIMELINE)
 // per-wave timeline of one typical launch (lane 0 of every wave records (clock << 8 | id)); dev tool only
 __device__ unsigned long long g_timeline[(GEN_WIN / 64) * 64];
 #define GEN_TS(id) do { if ((t & 63u) == 0u && ts_n < 64u) { sh.ts[(t & ~63u) + ts_n] = ((unsigned long long)cg_clock() << 8) | (unsigned long long)(id); ++ts_n; } } while (0)
