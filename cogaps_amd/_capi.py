@@ -78,7 +78,7 @@ EXPORTS = [
     "cogaps_session_finish", "cogaps_session_set_timing", "cogaps_session_perf",
     "cogaps_session_perf_sampler", "cogaps_session_get_rows", "cogaps_sparse_width", "cogaps_reduction_width", "cogaps_session_debug_prof", "cogaps_session_debug_replay",
     "cogaps_run_from_file", "cogaps_read_matrix_file", "cogaps_matrix_free", "cogaps_file_info", "cogaps_debug_math", "cogaps_current_device",
-    "cogaps_batch_create", "cogaps_batch_destroy", "cogaps_batch_run_iterations", "cogaps_batch_set_timing", "cogaps_batch_perf",
+    "cogaps_session_debug_check_domain", "cogaps_batch_create", "cogaps_batch_destroy", "cogaps_batch_run_iterations", "cogaps_batch_set_timing", "cogaps_batch_perf",
 ]
 
 REDUCE_LANES, REDUCE_SEQ = 0, 1                              # cogaps_params.reductionMode
@@ -133,6 +133,7 @@ def bind(L):
     L.cogaps_file_info.argtypes = [C.c_char_p, u32p, u32p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.cogaps_debug_math.argtypes = [C.c_int, C.c_int, fp, fp, C.c_uint32, C.c_int]
     L.cogaps_current_device.argtypes = [C.POINTER(C.c_int)]
+    L.cogaps_session_debug_check_domain.argtypes = [vp, C.c_char, u32p]
     L.cogaps_batch_create.restype = vp
     L.cogaps_batch_create.argtypes = [C.POINTER(vp), C.c_uint32]
     L.cogaps_batch_destroy.argtypes = [vp]
@@ -368,6 +369,12 @@ class Session:
         us = C.c_double()
         self._ck(self.L.cogaps_session_debug_replay(self.h, which.encode(), kind, n, flags, C.byref(us)))
         return us.value
+
+    def check_domain(self, which):
+        """number of broken invariants of the atomic domain's redundant state (0 = consistent)"""
+        v = C.c_uint32()
+        self._ck(self.L.cogaps_session_debug_check_domain(self.h, which.encode(), C.byref(v)))
+        return v.value
 
     def debug_prof(self, which):
         out = (C.c_uint64 * 16)()

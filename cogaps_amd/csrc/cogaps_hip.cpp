@@ -1157,6 +1157,31 @@ int cogaps_session_get_atoms(cogaps_session *s, char which, uint64_t *pos, float
     SESSION_END
 }
 
+// test hook: the atomic domain's redundant state -- links symmetric, vec / idx inverse of each other, every record's cached neighbour
+// positions and right-neighbour mass equal to the neighbours' own -- *violations = number of broken invariants
+int cogaps_session_debug_check_domain(cogaps_session *s, char which, uint32_t *violations)
+{
+    SESSION_TRY
+    HostSampler &h = pick(s, which);
+    read_gs(s, h);
+    const uint32_t n = s->hGs->nAtoms;
+    std::vector<uint32_t> vec(n); std::vector<AtomRec> atoms(h.d.atomCap);
+    if (n) rt_d2h(vec.data(), h.d.vec, (size_t)n * 4, s->stream);
+    rt_d2h(atoms.data(), h.d.atoms, (size_t)h.d.atomCap * sizeof(AtomRec), s->stream); rt_sync(s->stream);
+    uint32_t bad = 0, fronts = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t hd = vec[i];
+        if (hd >= h.d.atomCap) { ++bad; continue; }
+        const AtomRec &a = atoms[hd];
+        if (a.idx != i) ++bad;
+        if (a.left != CG_NONE) { const AtomRec &l = atoms[a.left]; if (l.right != hd || a.lpos != l.pos || !(l.pos < a.pos)) ++bad; } else { ++fronts; if (s->hGs->front != hd) ++bad; }
+        if (a.right != CG_NONE) { const AtomRec &r = atoms[a.right]; if (r.left != hd || a.rpos != r.pos || gm_f2u(a.rmass) != gm_f2u(r.mass)) ++bad; }
+    }
+    if (n && fronts != 1) ++bad;
+    *violations = bad;
+    SESSION_END
+}
+
 int cogaps_session_finish(cogaps_session *s, cogaps_result *out)
 {
     SESSION_TRY

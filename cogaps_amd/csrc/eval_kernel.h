@@ -259,18 +259,30 @@ CG_DEVICE void eval_cache_erase(const SamplerDev &S, uint32_t h, uint32_t row, u
     const uint32_t k = cg_atomic_add_u32(&S.gs->eraseCount, 1u);
     if (k < S.eraseCap) S.eraseList[k] = ((unsigned long long)(row * S.K + col) << 32) | (unsigned long long)h; else S.gs->error = GAPS_ERR_ERASE_CAP;
 }
-// ConcurrentAtomicDomain.cpp:126-132 move() across bins: position + the bin-head index
-CG_DEVICE void eval_domain_move(const SamplerDev &S, uint32_t h, uint64_t oldPos, uint64_t newPos)
+// ConcurrentAtomicDomain.cpp:126-132 move() across bins: position (+ the copies the neighbours cache) + the bin-head index.  `a` is the
+// atom's own record as the evaluation found it (fetched with the rows): its links and the neighbours' positions it caches are current --
+// births queued after the move may have changed the links, nothing moves next to a moving atom (ProposalQueue.cpp:167,218) -- so the
+// only dependent read left is the old bin's head.
+CG_DEVICE void eval_domain_move(const SamplerDev &S, const PropRec &p, const AtomRec &a)
 {
-    const uint32_t b1 = gen_bin_of(S, oldPos), b2 = gen_bin_of(S, newPos);
-    const uint32_t l = S.atoms[h].left, r = S.atoms[h].right;
-    S.atoms[h].pos = newPos;
-    if (S.binHead[b1] == h) {
-        if (r != CG_NONE && gen_bin_of(S, S.atoms[r].pos) == b1) S.binHead[b1] = r;
+    const uint32_t h = p.h1, l = a.left, r = a.right;
+    const uint32_t b1 = gen_bin_of(S, p.curPos), b2 = gen_bin_of(S, p.pos);
+    const uint32_t head1 = S.binHead[b1];
+    atom_set_pos(S, h, l, r, p.pos);
+    if (head1 == h) {
+        if (r != CG_NONE && gen_bin_of(S, a.rpos) == b1) S.binHead[b1] = r;
         else { S.binHead[b1] = CG_NONE; bm_clear(S, b1); }
     }
-    if (l == CG_NONE || gen_bin_of(S, S.atoms[l].pos) != b2) S.binHead[b2] = h;
+    if (l == CG_NONE || gen_bin_of(S, a.lpos) != b2) S.binHead[b2] = h;
     bm_set(S, b2);
+}
+// the writer thread's view of the atoms it may rewrite, requested when the queue record arrives and used after the decision
+struct EvalAtoms { AtomRec a1; uint32_t left2; };
+CG_DEVICE EvalAtoms eval_atoms_load(const SamplerDev &S, const PropRec &p, bool writer)
+{
+    EvalAtoms e; e.a1.pos = 0; e.a1.lpos = 0; e.a1.rpos = 0; e.a1.left = CG_NONE; e.a1.right = CG_NONE; e.a1.mass = 0.f; e.a1.rmass = 0.f; e.a1.idx = 0; e.a1.pad0 = 0; e.left2 = CG_NONE;
+    if (writer) { e.a1 = S.atoms[p.h1]; if (p.type == 'E') e.left2 = S.atoms[p.h2].left; }
+    return e;
 }
 
 #if defined(GEN_PROFILE) && !defined(GEN_SUBMARKS) && !defined(GEN_ROUNDMARKS)
@@ -340,9 +352,9 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
         { uint32_t ty_ = p.type; EVAL_PIN(ty_); }
         EVAL_TS(1);
         uint64_t rng = p.rng; uint32_t nUpd = 0;
+        EvalAtoms ea = eval_atoms_load(S, p, writer && (PHASE == EVAL_FUSED || PHASE == EVAL_SEQ));      // (split evaluation: requested after the slices' totals, below)
         const bool two = (p.type == 'M' || p.type == 'E');
         const float m1 = p.m1, m2 = p.m2, old1 = p.old1, old2 = p.old2;
-        const uint64_t curPos = p.curPos;
         const bool gibbs1 = (p.gibbs & 1u) != 0u, gibbs2 = (p.gibbs & 2u) != 0u;
         EVAL_PROF(0);
         EVAL_TS(2);
@@ -397,6 +409,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
             s = diff ? tot[0] + tot[2] : tot[0]; smu = diff ? tot[1] - tot[3] : tot[1];        // AlphaParameters.cpp:11-14
         }
         EVAL_PIN(s); EVAL_TS(3);
+        if (PHASE == EVAL_APPLY) ea = eval_atoms_load(S, p, writer);
         if (PHASE == EVAL_ALPHA) { if (q + qStep >= qlen) break; { const uint32_t qn_ = q + qStep; pNext = hot.queue[qn_ < hot.queueCap ? qn_ : 0u]; } cg_sync(); continue; }
         s = s * T; smu = smu * T;
 #if defined(GEN_PROFILE)
@@ -414,7 +427,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
             EVAL_TS(5);
             if (bhas != 0u && bv >= GAPS_EPSILON) {
                 eval_update_ap(S, p.r1, p.c1, bv, chunk0, stride); ++nUpd;                          // changeMatrix
-                if (writer) { S.atoms[p.h1].mass = bv; eval_store_matrix(S, p.r1, p.c1, old1, old1 + bv); }
+                if (writer) { atom_set_mass(S, p.h1, ea.a1.left, bv); eval_store_matrix(S, p.r1, p.c1, old1, old1 + bv); }
             } else if (writer) eval_cache_erase(S, p.h1, p.r1, p.c1);
         } else if (p.type == 'D') {
             // ---------------------------------------------------------------- death / rebirth (:148-180)
@@ -437,7 +450,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
                 if (rebirth != m1) {
                     const float nv = gm_max(old1 + (rebirth - m1), 0.f);            // safelyChangeMatrix
                     eval_update_ap(S, p.r1, p.c1, nv - old1, chunk0, stride); ++nUpd;
-                    if (writer) { eval_store_matrix(S, p.r1, p.c1, old1, nv); S.atoms[p.h1].mass = rebirth; }
+                    if (writer) { eval_store_matrix(S, p.r1, p.c1, old1, nv); atom_set_mass(S, p.h1, ea.a1.left, rebirth); }
                 }
             } else {
                 const float nv = gm_max(old1 + (-1.f * m1), 0.f);
@@ -457,7 +470,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
                 eval_update_ap(S, p.r1, p.c1, nv1 - old1, chunk0, stride); ++nUpd;
                 eval_update_ap(S, p.r2, p.c2, m1, chunk0, stride); ++nUpd;              // changeMatrix(r2,c2,+m); same thread owns the same elements
                 if (writer) {
-                    eval_domain_move(S, p.h1, curPos, p.pos);
+                    eval_domain_move(S, p, ea.a1);
                     eval_store_matrix(S, p.r1, p.c1, old1, nv1);
                     eval_store_matrix(S, p.r2, p.c2, old2, old2 + m1);
                 }
@@ -478,7 +491,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
                 if (writer) {
                     eval_store_matrix(S, p.r1, p.c1, old1, nv1);
                     eval_store_matrix(S, p.r2, p.c2, old2, nv2);
-                    S.atoms[p.h1].mass = n1; S.atoms[p.h2].mass = n2;
+                    atom_set_mass(S, p.h1, ea.a1.left, n1); atom_set_mass(S, p.h2, ea.left2, n2);
                 }
             }
         }

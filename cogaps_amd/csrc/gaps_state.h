@@ -10,12 +10,21 @@
 // One atom.  Addressed by HANDLE (stable for the atom's life, like the reference's heap pointer);
 // `vec` (index -> handle) restates the unsorted mAtoms vector used for uniform random picks
 // (ConcurrentAtomicDomain.cpp:32-44) and `idx` is the back pointer (ConcurrentAtom::mIndex).
-struct alignas(32) AtomRec {
+// The record also CACHES what the generator would otherwise fetch from the neighbours' records in a further dependent memory trip:
+// their positions (a move's bounds, an exchange partner's bin, the bin-head decisions of erase / move / insert) and the right
+// neighbour's mass (an exchange's partner).  Whoever changes an atom's position or mass rewrites the copies its neighbours hold
+// (atom_set_pos / atom_set_mass in gen_kernel.h; insert and erase splice them like the links): one proposal owns one atom, adjacent
+// atoms never move in the same batch (ProposalQueue.cpp:218), and the copies are separate words, so the writers never collide.  The
+// evaluation looks the holders up when it runs (the atom's own record, fetched with the rows): a birth queued later in the same batch
+// may have become the atom's neighbour after the proposal was drawn.
+struct alignas(16) AtomRec {
     uint64_t pos;
+    uint64_t lpos, rpos;    // cached: positions of the left / right neighbour (meaningless where left / right is CG_NONE)
     uint32_t left, right;   // neighbour handles in position order, CG_NONE at the ends
     float mass;
+    float rmass;            // cached: mass of the right neighbour
     uint32_t idx;
-    uint32_t pad0, pad1;
+    uint32_t pad0;
 };
 
 // One queued proposal (ProposalQueue.h:15-28) plus every scalar its evaluation starts from, so that the

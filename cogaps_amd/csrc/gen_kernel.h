@@ -98,7 +98,7 @@ struct GenShared {
     uint32_t wtotA[3][WIN / 64], wtotB[3][WIN / 64];
     // flush: erase cache sorted by position (handles, links, vector indices, bins), the tail of the unsorted
     // vector and the net writes of the swap-with-last replay
-    uint64_t fpos[FLUSH_MAX]; uint32_t fh[FLUSH_MAX], fl[FLUSH_MAX], fr[FLUSH_MAX], fidx[FLUSH_MAX], fbin[FLUSH_MAX], fhead[FLUSH_MAX], vt[FLUSH_MAX], lowSlot[FLUSH_MAX], lowH[FLUSH_MAX];
+    uint64_t fpos[FLUSH_MAX], flpos[FLUSH_MAX], frpos[FLUSH_MAX]; float frmass[FLUSH_MAX]; uint32_t fh[FLUSH_MAX], fl[FLUSH_MAX], fr[FLUSH_MAX], fidx[FLUSH_MAX], fbin[FLUSH_MAX], fhead[FLUSH_MAX], vt[FLUSH_MAX], lowSlot[FLUSH_MAX], lowH[FLUSH_MAX];
     uint32_t nLow, newFront, flushM, flushBase, unitSum, endBatch;
 #if defined(GEN_TIMELINE)
     unsigned long long ts[(WIN / 64) * 64]; uint32_t tsn[WIN / 64];
@@ -225,6 +225,19 @@ CG_DEVICE uint32_t bm_next_bin(const SamplerDev &S, uint32_t bin)   // smallest 
     }
 }
 
+// An atom's position / mass together with the copies its neighbours cache (gaps_state.h).  hl / hr: its neighbours' handles.
+CG_DEVICE void atom_set_pos(const SamplerDev &S, uint32_t h, uint32_t hl, uint32_t hr, uint64_t p)
+{
+    S.atoms[h].pos = p;
+    if (hl != CG_NONE) S.atoms[hl].rpos = p;
+    if (hr != CG_NONE) S.atoms[hr].lpos = p;
+}
+CG_DEVICE void atom_set_mass(const SamplerDev &S, uint32_t h, uint32_t hl, float m)
+{
+    S.atoms[h].mass = m;
+    if (hl != CG_NONE) S.atoms[hl].rmass = m;
+}
+
 // full search for the position-order neighbours a new atom at `p` (bin b) would get
 // (the std::map lookups of ConcurrentAtomicDomain.cpp:46-54 and :82-106); *newHead = it becomes the
 // lowest atom of its bin; *occupied = some atom already sits at p
@@ -259,12 +272,12 @@ CG_DEVICE void gen_find_gap(const SamplerDev &S, uint64_t p, uint32_t b, uint32_
 CG_DEVICE void gen_erase_one(const SamplerDev &S, uint32_t h, uint32_t &n, uint32_t &freeCount, uint32_t &front)
 {
     AtomRec rec = S.atoms[h];
-    if (rec.left != CG_NONE) S.atoms[rec.left].right = rec.right; else front = rec.right;
-    if (rec.right != CG_NONE) S.atoms[rec.right].left = rec.left;
+    if (rec.left != CG_NONE) { S.atoms[rec.left].right = rec.right; S.atoms[rec.left].rpos = rec.rpos; S.atoms[rec.left].rmass = rec.rmass; } else front = rec.right;
+    if (rec.right != CG_NONE) { S.atoms[rec.right].left = rec.left; S.atoms[rec.right].lpos = rec.lpos; }
     uint32_t b = gen_bin_of(S, rec.pos);
     if (S.binHead[b] == h) {
         uint32_t nxt = rec.right;
-        if (nxt != CG_NONE && gen_bin_of(S, S.atoms[nxt].pos) == b) S.binHead[b] = nxt;
+        if (nxt != CG_NONE && gen_bin_of(S, rec.rpos) == b) S.binHead[b] = nxt;
         else { S.binHead[b] = CG_NONE; bm_clear(S, b); }
     }
     uint32_t last = S.vec[n - 1];

@@ -34,7 +34,7 @@ CG_DEVICE void gen_flush_parallel(const SamplerDev &S, GenShared<WIN> &sh, const
         return;
     }
     // 1. fetch the erased atoms and the tail of the unsorted vector
-    uint32_t myH = 0; AtomRec rec; rec.pos = 0; rec.left = CG_NONE; rec.right = CG_NONE; rec.mass = 0.f; rec.idx = 0;
+    uint32_t myH = 0; AtomRec rec; rec.pos = 0; rec.lpos = 0; rec.rpos = 0; rec.left = CG_NONE; rec.right = CG_NONE; rec.mass = 0.f; rec.rmass = 0.f; rec.idx = 0;
     // (the bin travels with the handle in the erase cache: the bin's head is asked for in the same trip as the record)
     uint32_t myBin = 0, myHead = CG_NONE;
     if (t < m) { myH = (uint32_t)specE; myBin = (uint32_t)(specE >> 32); rec = S.atoms[myH]; myHead = S.binHead[myBin]; sh.fpos[t] = rec.pos; sh.vt[t] = S.vec[n - m + t]; }
@@ -44,6 +44,7 @@ CG_DEVICE void gen_flush_parallel(const SamplerDev &S, GenShared<WIN> &sh, const
         uint32_t r = 0;
         for (uint32_t j = 0; j < m; ++j) r += (sh.fpos[j] < rec.pos) ? 1u : 0u;
         sh.fh[r] = myH; sh.fl[r] = rec.left; sh.fr[r] = rec.right; sh.fidx[r] = rec.idx; sh.fbin[r] = myBin; sh.fhead[r] = myHead;
+        sh.flpos[r] = rec.lpos; sh.frpos[r] = rec.rpos; sh.frmass[r] = rec.rmass;
     }
     cg_sync_lds();
     // 3. list surgery + bin heads (reads the pre-flush links only)
@@ -54,15 +55,16 @@ CG_DEVICE void gen_flush_parallel(const SamplerDev &S, GenShared<WIN> &sh, const
             uint32_t j = k;
             while (j + 1 < m && sh.fh[j + 1] == sh.fr[j]) ++j;
             const uint32_t L = sh.fl[k], R = sh.fr[j];
-            if (L != CG_NONE) S.atoms[L].right = R; else sh.newFront = R;
-            if (R != CG_NONE) S.atoms[R].left = L;
+            // (the run's survivors take over each other's cached position / mass: the first erased atom knows L's, the last R's)
+            if (L != CG_NONE) { S.atoms[L].right = R; S.atoms[L].rpos = sh.frpos[j]; S.atoms[L].rmass = sh.frmass[j]; } else sh.newFront = R;
+            if (R != CG_NONE) { S.atoms[R].left = L; S.atoms[R].lpos = sh.flpos[k]; }
         }
         const uint32_t b = sh.fbin[k];
         if (sh.fhead[k] == h) {               // the lowest atom of its bin goes: the next surviving atom of the bin takes over
             uint32_t j = k;
             while (j + 1 < m && sh.fh[j + 1] == sh.fr[j]) ++j;
             const uint32_t cand = sh.fr[j];
-            if (cand != CG_NONE && gen_bin_of(S, S.atoms[cand].pos) == b) S.binHead[b] = cand;
+            if (cand != CG_NONE && gen_bin_of(S, sh.frpos[j]) == b) S.binHead[b] = cand;      // (the survivor's position is cached in the run's last record: no trip)
             else { S.binHead[b] = CG_NONE; bm_clear(S, b); }
         }
         S.freeHandles[fc0 + k] = h;           // pushed in erase order
@@ -285,7 +287,7 @@ CG_DEVICE void gen_body(const SamplerDev &S, const GenHot hot)
                 if (m) headBin = (bin & ~63u) + (uint32_t)cg_ctz64(m); else slowB = true;
             }
         }
-        uint32_t v2 = CG_NONE; AtomRec a; a.pos = 0; a.left = CG_NONE; a.right = CG_NONE; a.mass = 0.f; a.idx = 0;
+        uint32_t v2 = CG_NONE; AtomRec a; a.pos = 0; a.lpos = 0; a.rpos = 0; a.left = CG_NONE; a.right = CG_NONE; a.mass = 0.f; a.rmass = 0.f; a.idx = 0;
         if (isB && !slowB) v2 = S.binHead[headBin];
         if (pick) { h1 = v1; a = S.atoms[h1]; }
 #if defined(GEN_SUBMARKS)
@@ -295,45 +297,68 @@ CG_DEVICE void gen_body(const SamplerDev &S, const GenHot hot)
         GEN_TS(12);
         GEN_SUBS(11);
         // stage 3 ---------------------------------------------------------------------------------
-        AtomRec b3; b3.pos = 0; b3.left = CG_NONE; b3.right = CG_NONE; b3.mass = 0.f; b3.idx = 0;
+        // A picked atom's record carries its neighbours' positions and the right neighbour's mass (gaps_state.h): a move's bounds and
+        // an exchange's partner need no trip to the neighbours' records -- every pick goes from its record straight to the matrix
+        // entries.  (The one exception: the highest atom's exchange partner is front(), whose record is fetched.)
+        AtomRec b3; b3.pos = 0; b3.lpos = 0; b3.rpos = 0; b3.left = CG_NONE; b3.right = CG_NONE; b3.mass = 0.f; b3.rmass = 0.f; b3.idx = 0;
         uint64_t lp = 0, rp = 0;
+        float m2x = 0.f;                        // exchange: the partner's mass
+        bool frontE = false;                    // exchange of the highest atom: the partner is front()
         if (pick) {
             cpos = a.pos;
             const uint32_t b1 = gen_bin_of(S, cpos);
             r1 = gen_div_k(S, b1); c1 = b1 - r1 * K;
-            if (type == 'M') { hl = a.left; hr = a.right; }
-            else if (type == 'E') { hr = a.right; h2 = (hr != CG_NONE) ? hr : sh.g.front; }
+            hl = a.left;
+            if (type == 'M') { hr = a.right; lp = a.lpos; rp = a.rpos; }
+            else if (type == 'E') {
+                hr = a.right;
+                if (hr != CG_NONE) { h2 = hr; rbpos = a.rpos; m2x = a.rmass; }
+                else { h2 = sh.g.front; frontE = true; }
+            }
         }
         if (isB && !slowB) b3 = S.atoms[v2];
-        if (pick && type == 'M') { if (hl != CG_NONE) lp = S.atoms[hl].pos; if (hr != CG_NONE) rp = S.atoms[hr].pos; }
-        if (pick && type == 'E') b3 = S.atoms[h2];
-#if defined(GEN_SUBMARKS)
-        if (b3.pos == 12345678u || lp == 0x123456789ull || rp == 0x123456789ull) flags |= 0x80000000u;
-#endif
+        if (frontE) b3 = S.atoms[h2];
         // the scalars the evaluation starts from travel in the queue record (consumed at commit)
         float old1 = 0.f, old2 = 0.f; uint32_t gib1 = 0, gib2 = 0;
         if (isB || pick) { old1 = S.sparse ? S.rows[(size_t)r1 * S.Kpad + c1] : S.mat[(size_t)c1 * S.Mpad + r1]; gib1 = S.otherColPos[c1]; }
+        if (pick && type == 'M') {
+            if (hl != CG_NONE) { flags |= GEN_F_HASLEFT; lbpos = lp; } else lbpos = 0;
+            if (hr != CG_NONE) { flags |= GEN_F_HASRIGHT; rbpos = rp; } else rbpos = S.rboundNone;
+            pos = pcg_uniform64(rng, lbpos + 1ull, rbpos - 1ull);
+            const uint32_t bin2 = gen_bin_of(S, pos);
+            r2 = gen_div_k(S, bin2); c2 = bin2 - r2 * K;
+            if (r1 == r2 && c1 == c2) flags |= GEN_F_INLINE;
+        }
+        if (pick && type == 'E' && !frontE) {
+            flags |= GEN_F_HASRIGHT;
+            const uint32_t bin2 = gen_bin_of(S, rbpos);
+            r2 = gen_div_k(S, bin2); c2 = bin2 - r2 * K;
+        }
+        if (pick && (type == 'M' || (type == 'E' && !frontE))) { old2 = S.sparse ? S.rows[(size_t)r2 * S.Kpad + c2] : S.mat[(size_t)c2 * S.Mpad + r2]; gib2 = S.otherColPos[c2]; }
+#if defined(GEN_SUBMARKS)
+        if (b3.pos == 12345678u || lp == 0x123456789ull || rp == 0x123456789ull) flags |= 0x80000000u;
+#endif
         GEN_PIN(b3.pos); GEN_PIN(lp); GEN_PIN(rp);
         GEN_TS(13);
         GEN_SUBS(12);
         // finish ----------------------------------------------------------------------------------
+        uint64_t lposB = 0, rposB = 0; float rmassB = 0.f;        // birth: what the new atom's record caches of its neighbours
         if (isB) {
             if (!slowB) {
-                if (flags & GEN_F_BINEMPTY) { hr = v2; hl = b3.left; flags |= GEN_F_NEWHEAD; }
-                else if (b3.pos > pos) { hr = v2; hl = b3.left; flags |= GEN_F_NEWHEAD; }
+                if ((flags & GEN_F_BINEMPTY) || b3.pos > pos) { hr = v2; hl = b3.left; lposB = b3.lpos; rposB = b3.pos; rmassB = b3.mass; flags |= GEN_F_NEWHEAD; }
                 else if (b3.pos == pos) slowB = true;      // position already taken: the retry loop below
                 else {
-                    // the bin's lowest atom lies below pos: go on to the right from the record already in hand
-                    // (a bin holds 1.3 atoms on average: usually one more trip)
-                    uint32_t cur = v2, nxt = b3.right;
+                    // the bin's lowest atom lies below pos: go on to the right; the record in hand knows its right neighbour's
+                    // position, so the usual case (a bin holds 1.3 atoms on average) needs no further trip
+                    uint32_t cur = v2, nxt = b3.right; uint64_t curPos = b3.pos, nxtPos = b3.rpos; float nxtMass = b3.rmass;
                     for (;;) {
                         if (nxt == CG_NONE) break;
-                        const uint64_t np_ = S.atoms[nxt].pos;
-                        if (np_ == pos) { slowB = true; break; }
-                        if (np_ > pos) break;
-                        cur = nxt; nxt = S.atoms[nxt].right;
+                        if (nxtPos == pos) { slowB = true; break; }
+                        if (nxtPos > pos) break;
+                        const AtomRec w = S.atoms[nxt];
+                        cur = nxt; curPos = nxtPos; nxt = w.right; nxtPos = w.rpos; nxtMass = w.rmass;
                     }
-                    hl = cur; hr = nxt;
+                    hl = cur; hr = nxt; lposB = curPos; rposB = nxtPos; rmassB = nxtMass;
                 }
             }
             if (slowB) {
@@ -348,31 +373,24 @@ CG_DEVICE void gen_body(const SamplerDev &S, const GenHot hot)
                 if (nh) flags |= GEN_F_NEWHEAD;
                 if (S.binHead[bin] == CG_NONE) { flags |= GEN_F_BINEMPTY; if (S.bits0[bin >> 6] == 0ull) flags |= GEN_F_WORDZERO; }
                 old1 = S.sparse ? S.rows[(size_t)r1 * S.Kpad + c1] : S.mat[(size_t)c1 * S.Mpad + r1]; gib1 = S.otherColPos[c1];      // the retry may have moved the birth to another bin
+                lposB = (hl != CG_NONE) ? S.atoms[hl].pos : 0ull;
+                if (hr != CG_NONE) { rposB = S.atoms[hr].pos; rmassB = S.atoms[hr].mass; } else { rposB = 0ull; rmassB = 0.f; }
             }
-        } else if (pick) {
-            if (type == 'M') {
-                if (hl != CG_NONE) { flags |= GEN_F_HASLEFT; lbpos = lp; } else lbpos = 0;
-                if (hr != CG_NONE) { flags |= GEN_F_HASRIGHT; rbpos = rp; } else rbpos = S.rboundNone;
-                pos = pcg_uniform64(rng, lbpos + 1ull, rbpos - 1ull);
-                const uint32_t bin2 = gen_bin_of(S, pos);
-                r2 = gen_div_k(S, bin2); c2 = bin2 - r2 * K;
-                if (r1 == r2 && c1 == c2) flags |= GEN_F_INLINE;
-            } else if (type == 'E') {
-                if (hr != CG_NONE) flags |= GEN_F_HASRIGHT;
-                rbpos = b3.pos; i2 = b3.idx;
+        } else if (pick && type == 'E') {
+            if (frontE) {
+                rbpos = b3.pos; m2x = b3.mass;
                 const uint32_t bin2 = gen_bin_of(S, rbpos);
                 r2 = gen_div_k(S, bin2); c2 = bin2 - r2 * K;
-                old2 = S.sparse ? S.rows[(size_t)r2 * S.Kpad + c2] : S.mat[(size_t)c2 * S.Mpad + r2]; gib2 = S.otherColPos[c2];   // in flight under the table lookups below
-                if (r1 == r2 && c1 == c2) {
-                    flags |= GEN_F_INLINE;
-                    const float m1 = a.mass, m2 = b3.mass;
-                    const float newMass = pcg_trunc_gamma_upper(rng, S.luts, m1 + m2, 1.f / S.lambda, S.mathMode);
-                    const float delta = (m1 > m2) ? newMass - m1 : m2 - newMass;
-                    if (m1 + delta > GAPS_EPSILON && m2 - delta > GAPS_EPSILON) { flags |= GEN_F_APPLY; nm1 = m1 + delta; nm2 = m2 - delta; }
-                }
+                old2 = S.sparse ? S.rows[(size_t)r2 * S.Kpad + c2] : S.mat[(size_t)c2 * S.Mpad + r2]; gib2 = S.otherColPos[c2];
+            }
+            if (r1 == r2 && c1 == c2) {
+                flags |= GEN_F_INLINE;
+                const float m1 = a.mass, m2 = m2x;
+                const float newMass = pcg_trunc_gamma_upper(rng, S.luts, m1 + m2, 1.f / S.lambda, S.mathMode);
+                const float delta = (m1 > m2) ? newMass - m1 : m2 - newMass;
+                if (m1 + delta > GAPS_EPSILON && m2 - delta > GAPS_EPSILON) { flags |= GEN_F_APPLY; nm1 = m1 + delta; nm2 = m2 - delta; }
             }
         }
-        if (pick && type == 'M') { old2 = S.sparse ? S.rows[(size_t)r2 * S.Kpad + c2] : S.mat[(size_t)c2 * S.Mpad + r2]; gib2 = S.otherColPos[c2]; }
         GEN_PIN(pos); GEN_PIN(flags); GEN_PIN(r2); GEN_PIN(c2); GEN_PIN(rbpos); GEN_PIN(nm1);
         GEN_TS(14);
         GEN_PROF_R(2, 9);
@@ -466,7 +484,9 @@ CG_DEVICE void gen_body(const SamplerDev &S, const GenHot hot)
             key[0] = GEN_TAB_ROW | r1; use[0] = 1u;
             key[1] = GEN_TAB_ROW | r2; use[1] = tM | tE;
             key[2] = ((tM | tB) & hasL) ? hl : GEN_TAB_FRONT; use[2] = tM | tB | (tE & noRight);
-            key[3] = hr; use[3] = (tM | tB) & hasR;
+            // (same-bin exchange: the gap LEFT of the centre -- a birth there earlier in this window is the holder of the centre's cached mass)
+            const uint32_t eInl = tE & (uint32_t)(inl != 0u);
+            key[3] = eInl ? (hasL ? hl : GEN_TAB_FRONT) : hr; use[3] = ((tM | tB) & hasR) | eInl;
             const uint32_t tD = type == 'D';
             key[4] = h1; use[4] = tM | tE | tD;
             key[5] = h2; use[5] = tE;
@@ -501,6 +521,9 @@ CG_DEVICE void gen_body(const SamplerDev &S, const GenHot hot)
             // death / exchange: the masses in the queue record were read before an earlier same-bin exchange of
             // this window rewrote them
             haz |= (tE | tD) & (GEN_E(4, inl) | GEN_E(5, inl));
+            // same-bin exchange: it rewrites the copy of the centre's mass that the centre's left neighbour caches, and an earlier birth
+            // of this window between the two has become that neighbour
+            haz |= eInl & GEN_E(3, gap);
             if (tB) {
                 // mProposedMoves.overlap(pos): a neighbour has a queued move whose interval covers pos
                 const uint32_t uL = GEN_E(2, used), uR = GEN_E(3, used);
@@ -518,7 +541,7 @@ CG_DEVICE void gen_body(const SamplerDev &S, const GenHot hot)
         } else if (live) {
             const bool tB = type == 'B', tM = type == 'M', tE = type == 'E', inl = (flags & GEN_F_INLINE) != 0;
             const uint32_t keyL = (hl == CG_NONE) ? 0u : hl + 1u;
-            uint32_t pk[9], pid[9]; bool pu[9];
+            uint32_t pk[10], pid[10]; bool pu[10];
             pk[0] = GEN_K_ROW; pid[0] = r1; pu[0] = true;
             pk[1] = GEN_K_ROW; pid[1] = r2; pu[1] = tM || tE;
             pk[2] = GEN_K_ATOM; pid[2] = hl; pu[2] = (tM || tB) && hl != CG_NONE;
@@ -529,12 +552,13 @@ CG_DEVICE void gen_body(const SamplerDev &S, const GenHot hot)
             pk[6] = GEN_K_INL; pid[6] = tB ? hl : h1; pu[6] = tM || (tB && hl != CG_NONE) || tE || tD;
             pk[7] = GEN_K_INL; pid[7] = tM ? hl : (tB ? hr : h2); pu[7] = (tM && hl != CG_NONE) || (tB && hr != CG_NONE) || tE;
             pk[8] = GEN_K_INL; pid[8] = hr; pu[8] = tM && hr != CG_NONE;
-            int res[9]; uint32_t rix[9]; uint64_t d9 = 0, d10 = 0;
+            pk[9] = GEN_K_GAP; pid[9] = keyL; pu[9] = tE && inl;       // same-bin exchange: a birth of this window left of the centre (see the LDS round)
+            int res[10]; uint32_t rix[10]; uint64_t d9 = 0, d10 = 0;
             {
-                unsigned long long v[9];
-                for (int k = 0; k < 9; ++k) v[k] = cg_load_l2_u64(pu[k] ? gen_stamp_ptr(S, pk[k], pid[k]) : &S.gapStamp[0]);
+                unsigned long long v[10];
+                for (int k = 0; k < 10; ++k) v[k] = cg_load_l2_u64(pu[k] ? gen_stamp_ptr(S, pk[k], pid[k]) : &S.gapStamp[0]);
                 d9 = (tB && hl != CG_NONE) ? S.atomDest[hl] : 0ull; d10 = (tB && hr != CG_NONE) ? S.atomDest[hr] : 0ull;
-                for (int k = 0; k < 9; ++k) { rix[k] = 0; res[k] = pu[k] ? gen_probe(v[k], batchEpoch, roundNo, ct, &rix[k]) : 0; }
+                for (int k = 0; k < 10; ++k) { rix[k] = 0; res[k] = pu[k] ? gen_probe(v[k], batchEpoch, roundNo, ct, &rix[k]) : 0; }
             }
             GEN_SUB(8);
             bool fail = res[0] != 0, haz = false;                                        // row r1 in use
@@ -564,6 +588,7 @@ CG_DEVICE void gen_body(const SamplerDev &S, const GenHot hot)
                 if (res[4] == 2 || res[5] == 2) fail = true;
                 // the masses in the queue record were read before an earlier same-bin exchange of this window rewrote them
                 if (res[6] == 2 || res[7] == 2) haz = true;
+                if (res[9] == 2) haz = true;
             } else if (tD) {
                 if (res[6] == 2) haz = true;
             }
@@ -609,11 +634,12 @@ CG_DEVICE void gen_body(const SamplerDev &S, const GenHot hot)
                 const uint32_t idx = nR + bRank;
                 if (hb >= S.atomCap || idx >= S.atomCap) { gs->error = GAPS_ERR_ATOM_CAP; hb = 0; }
                 S.vec[idx] = hb;
-                AtomRec n; n.pos = pos; n.left = hl; n.right = hr; n.mass = 0.f; n.idx = idx; n.pad0 = 0; n.pad1 = 0;
+                AtomRec n; n.pos = pos; n.lpos = lposB; n.rpos = rposB; n.left = hl; n.right = hr; n.mass = 0.f; n.rmass = rmassB; n.idx = idx; n.pad0 = 0;
                 S.atoms[hb] = n;
                 h1 = hb;
-                if (hl != CG_NONE) S.atoms[hl].right = hb; else sh.newFront = hb;
-                if (hr != CG_NONE) S.atoms[hr].left = hb;
+                // splice: the neighbours' links and the copies they cache of the new atom (its mass is 0 until the evaluation sets it)
+                if (hl != CG_NONE) { S.atoms[hl].right = hb; S.atoms[hl].rpos = pos; S.atoms[hl].rmass = 0.f; } else sh.newFront = hb;
+                if (hr != CG_NONE) { S.atoms[hr].left = hb; S.atoms[hr].lpos = pos; }
                 if (flags & GEN_F_NEWHEAD) S.binHead[bin] = hb;
                 if (flags & GEN_F_BINEMPTY) {
                     cg_atomic_or_u64(&S.bits0[bin >> 6], 1ull << (bin & 63u));
@@ -623,21 +649,22 @@ CG_DEVICE void gen_body(const SamplerDev &S, const GenHot hot)
             } else if (type == 'D') {
                 if (more) { S.rowStamp[r1] = done; S.atomStamp[h1] = done; S.atomDest[h1] = 0ull; }
             } else if (type == 'M') {
-                if (flags & GEN_F_INLINE) S.atoms[h1].pos = pos;                  // domain.move, same bin
+                if (flags & GEN_F_INLINE) atom_set_pos(S, h1, hl, hr, pos);       // domain.move, same bin
                 else if (more) { S.rowStamp[r1] = done; S.rowStamp[r2] = done; S.atomStamp[h1] = done; S.atomDest[h1] = pos; }
             } else {
-                if (flags & GEN_F_INLINE) { if (flags & GEN_F_APPLY) { S.atoms[h1].mass = nm1; S.atoms[h2].mass = nm2; } }
+                if (flags & GEN_F_INLINE) { if (flags & GEN_F_APPLY) { atom_set_mass(S, h1, hl, nm1); atom_set_mass(S, h2, (hr != CG_NONE) ? h1 : CG_NONE, nm2); } }
                 else if (more) { S.rowStamp[r1] = done; S.rowStamp[r2] = done; }
             }
             if (queued) {
                 const uint32_t slot = sh.qlen + qBefore;
                 if (slot >= S.queueCap) gs->error = GAPS_ERR_QUEUE_CAP;
                 else {
+                    if (sh.g.traceOn && type == 'E') i2 = S.atoms[h2].idx;         // the partner's index: traces only
                     PropRec p; p.pos = (type == 'M') ? pos : 0ull; p.rng = rng; p.h1 = h1; p.h2 = h2; p.i1 = i1; p.i2 = i2;
                     p.r1 = r1; p.c1 = c1; p.r2 = r2; p.c2 = c2; p.type = type; p.batch = 0; p.pad[0] = p.pad[1] = p.pad[2] = 0;
                     const bool two = type == 'M' || type == 'E';
                     p.gibbs = (gib1 > 0u ? 1u : 0u) | ((two && gib2 > 0u) ? 2u : 0u);
-                    p.m1 = (type == 'B') ? 0.f : a.mass; p.m2 = (type == 'E') ? b3.mass : 0.f;
+                    p.m1 = (type == 'B') ? 0.f : a.mass; p.m2 = (type == 'E') ? m2x : 0.f;
                     p.old1 = old1; p.old2 = two ? old2 : 0.f; p.curPos = (type == 'M') ? cpos : 0ull;
                     S.queue[slot] = p;
                     if (sh.g.traceOn) { const uint32_t ti = sh.g.traceCount + slot; if (ti < sh.g.traceCap) { p.batch = sh.g.nBatches; S.trace[ti] = p; } }

@@ -361,9 +361,9 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
         const PropRec p = pNext;
         if (q >= qlen) break;
         uint64_t rng = p.rng;
+        const EvalAtoms ea = eval_atoms_load(S, p, t == 0u);
         const bool two = (p.type == 'M' || p.type == 'E');
         const float m1 = p.m1, m2 = p.m2, old1 = p.old1, old2 = p.old2;     // old1/old2: the ROW copy (mMatrix(r,c))
-        const uint64_t curPos = p.curPos;
         const bool gibbs1 = (p.gibbs & 1u) != 0u, gibbs2 = (p.gibbs & 2u) != 0u;
         const bool need = (p.type == 'B') ? gibbs1 : ((p.type == 'D' || p.type == 'M') ? true : (gibbs1 || gibbs2));
         const bool diff = two && p.r1 != p.r2;
@@ -458,7 +458,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
             }
             SP_BCAST(bv, bhas);
             if (bhas != 0u && bv >= GAPS_EPSILON) {
-                if (writer) { S.atoms[p.h1].mass = bv; sp_change_matrix(S, p.r1, p.c1, old1, bv, cell1); }
+                if (writer) { atom_set_mass(S, p.h1, ea.a1.left, bv); sp_change_matrix(S, p.r1, p.c1, old1, bv, cell1); }
             } else if (writer) eval_cache_erase(S, p.h1, p.r1, p.c1);
         } else if (p.type == 'D') {
             float rebirth = m1; uint32_t acc = 0;
@@ -469,7 +469,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
             }
             SP_BCAST(rebirth, acc);
             if (writer) {
-                if (acc != 0u) { if (rebirth != m1) { sp_safely_change_matrix(S, p.r1, p.c1, old1, rebirth - m1, cell1); S.atoms[p.h1].mass = rebirth; } }
+                if (acc != 0u) { if (rebirth != m1) { sp_safely_change_matrix(S, p.r1, p.c1, old1, rebirth - m1, cell1); atom_set_mass(S, p.h1, ea.a1.left, rebirth); } }
                 else { sp_safely_change_matrix(S, p.r1, p.c1, old1, -1.f * m1, cell1); eval_cache_erase(S, p.h1, p.r1, p.c1); }
             }
         } else if (p.type == 'M') {
@@ -477,7 +477,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
             if (scalarLane) { const float deltaLL = -1.f * m1 * (smu + s * m1 / 2.f); acc = (gm_logf_m(pcg_uniform(rng), mm) < deltaLL) ? 1u : 0u; }
             SP_BCAST(unused, acc);
             if (acc && writer) {
-                eval_domain_move(S, p.h1, curPos, p.pos);
+                eval_domain_move(S, p, ea.a1);
                 sp_safely_change_matrix(S, p.r1, p.c1, old1, -m1, cell1);
                 sp_change_matrix(S, p.r2, p.c2, old2, m1, cell2);
             }
@@ -489,7 +489,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
             if (gh != 0u && n1 > GAPS_EPSILON && n2 > GAPS_EPSILON && writer) {
                 sp_safely_change_matrix(S, p.r1, p.c1, old1, n1 - m1, cell1);
                 sp_safely_change_matrix(S, p.r2, p.c2, old2, n2 - m2, cell2);
-                S.atoms[p.h1].mass = n1; S.atoms[p.h2].mass = n2;
+                atom_set_mass(S, p.h1, ea.a1.left, n1); atom_set_mass(S, p.h2, ea.left2, n2);
             }
         }
         if (writer) {

@@ -215,6 +215,8 @@ int cogaps_batch_perf(cogaps_batch *b, int side, double *genUs, double *evalUs, 
 /* development aid: per-phase cycle counters of the generator kernel (all zero unless built with -DGEN_PROFILE) */
 int cogaps_session_debug_prof(cogaps_session *s, char which, uint64_t *out16);
 int cogaps_session_debug_replay(cogaps_session *s, char which, int kind, uint32_t n, uint32_t dbgFlags, double *usPerLaunch);
+/* test hook: counts broken invariants of the atomic domain's redundant state (links, index vector, cached neighbour positions / masses) */
+int cogaps_session_debug_check_domain(cogaps_session *s, char which, uint32_t *violations);
 
 /* test hook for the math modes: y[i] = fn(x[i]) with fn 0 = logf, 1 = expf in math mode `mathMode`, evaluated by a kernel on
  * the current device (on_device != 0) or by the same source compiled for the host */

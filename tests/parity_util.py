@@ -45,6 +45,7 @@ def assert_state_equal(S, O, tag, chisq=True):
         assert np.array_equal(S.rows(w), O.rows(w)), "%s %s: factor matrix (HybridMatrix row copy) differs" % (tag, w)
         assert np.array_equal(S.ap(w), O.ap(w)), "%s %s: AP cache differs" % (tag, w)
         assert S.avg_queue(w) == O.avg_queue(w), "%s %s: average queue length differs" % (tag, w)
+        assert S.check_domain(w) == 0, "%s %s: the atomic domain's cached neighbour positions / masses or links are inconsistent" % (tag, w)
         if chisq:
             assert S.chisq(w) == O.chisq(w), "%s %s: chi2 differs" % (tag, w)
 
