@@ -112,7 +112,6 @@ CG_DEVICE void gen_body(const SamplerDev &S, const GenHot hot)
     // first memory trip of the launch, everything independent: the scalars every lane needs (same address
     // for all lanes: one transaction), the erase cache and traffic-unit slots read speculatively, and lane
     // 0's copy of the generator's scalars into LDS, where they live for the whole launch
-    cg_u32x16 gw; cg_uniform_load16(gs, gw);        // words 0..15 of GenScalars (one scalar load; read after the wait below)
     const unsigned long long specE = (t < (unsigned)FLUSH_MAX && t < hot.eraseCap) ? hot.eraseList[t] : 0ull;
     uint32_t units = (t < hot.queueCap) ? hot.queueUnits[t] : 0u;
     const uint64_t jmW = hot.lcgMul[2 * WIN], jiW = hot.lcgInc[2 * WIN];
@@ -122,10 +121,7 @@ CG_DEVICE void gen_body(const SamplerDev &S, const GenHot hot)
     const uint32_t gword = (t < GSW) ? reinterpret_cast<const uint32_t *>(gs)[t] : 0u;
     const uint32_t gword2 = (t + (uint32_t)WIN < GSW) ? reinterpret_cast<const uint32_t *>(gs)[t + (uint32_t)WIN] : 0u;
     cg_sched_fence();
-    if (WARM > 0) cg_kernarg_warm<(WARM > 0 ? WARM : 4)>(); else cg_uniform_wait();
-    static_assert(offsetof(GenScalars, nAtoms) == 24 && offsetof(GenScalars, freeCount) == 32 && offsetof(GenScalars, nSteps) == 40 && offsetof(GenScalars, nDone) == 44
-                  && offsetof(GenScalars, qlen) == 48 && offsetof(GenScalars, eraseCount) == 56, "word indices below");
-    const uint32_t e_m = gw[14], e_n = gw[6], e_fc = gw[8], e_prevQ = gw[12], e_nDone = gw[11], e_nSteps = gw[10];
+    if (WARM > 0) cg_kernarg_warm<(WARM > 0 ? WARM : 4)>();
     if (t < GSW) reinterpret_cast<uint32_t *>(&sh.g)[t] = gword;
     if (t + (uint32_t)WIN < GSW) reinterpret_cast<uint32_t *>(&sh.g)[t + (uint32_t)WIN] = gword2;
     if (t == 0) { sh.newFront = CG_KEEP; sh.unitSum = 0; }
@@ -137,6 +133,9 @@ CG_DEVICE void gen_body(const SamplerDev &S, const GenHot hot)
     if (t == 0) { sh.jmul[WIN] = jmW; sh.jinc[WIN] = jiW; }
     sh.jmul[t] = jm0; sh.jinc[t] = ji0;        // even-step PCG jumps, for the round bookkeeping
     cg_sync_lds();
+    // the scalars every lane needs, from the LDS copy (wave-uniform: kept in scalar registers)
+    const uint32_t e_m = cg_uniform_u32(sh.g.eraseCount), e_n = cg_uniform_u32(sh.g.nAtoms), e_fc = cg_uniform_u32(sh.g.freeCount), e_prevQ = cg_uniform_u32(sh.g.qlen),
+                   e_nDone = cg_uniform_u32(sh.g.nDone), e_nSteps = cg_uniform_u32(sh.g.nSteps);
     GEN_PROF(14);
     GEN_TS(1);
     // second trip (addresses from the first), in flight while the flush runs: this round's seeds

@@ -67,22 +67,8 @@ CG_DEVICE void cg_const_warm(const T CG_CONSTANT *p)
     asm volatile("" :: "s"(acc));
 }
 
-// Sixteen consecutive dwords at a wave-uniform address into SGPRs with one scalar load that is NOT waited for here: the caller
-// issues its other loads and calls cg_uniform_wait() (or cg_kernarg_warm, which ends with the same wait) before touching `out`.
-// Only for memory no lane of this launch has written yet (the scalar cache is not coherent with vector stores).
-typedef uint32_t cg_u32x16 __attribute__((ext_vector_type(16)));
-CG_DEVICE void cg_uniform_load16(const void *p, cg_u32x16 &out) { asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(out) : "s"(p) : "memory"); }
-CG_DEVICE void cg_uniform_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-// four packed floats; a read of four that bypasses the caches' retention (non-temporal: rows used once per batch)
-typedef float4 cg_f4;
-typedef float cg_v4f __attribute__((ext_vector_type(4)));
-CG_DEVICE cg_f4 cg_ld4_stream(const float *base, uint32_t j)
-{
-    const cg_v4f v = __builtin_nontemporal_load(reinterpret_cast<const cg_v4f *>(base) + j);
-    cg_f4 o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w; return o;
-}
-CG_HD float cg_sqrtf(float x) { return sqrtf(x); }        // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt)
-#define CG_PLATFORM_NAME "HIP gfx950 (MI355X)"
+// a value every lane of the wave holds alike, moved to a scalar register
+CG_DEVICE uint32_t cg_uniform_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 // nothing is scheduled across this point: what was issued before it stays before
 CG_DEVICE void cg_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // keeps a loaded value (and so the load) alive without using it

@@ -35,13 +35,11 @@ template <int BYTES> inline void cg_kernarg_warm() {}
 template <int BYTES, class T> inline void cg_const_warm(const T *) {}
 inline void cg_keep_f32(float) {}
 inline void cg_sched_fence() {}
+inline uint32_t cg_uniform_u32(uint32_t x) { return x; }
 struct cg_f4 { float x, y, z, w; };
 inline cg_f4 cg_ld4_stream(const float *base, uint32_t j) { return reinterpret_cast<const cg_f4 *>(base)[j]; }
 inline float cg_sqrtf(float x) { return __builtin_sqrtf(x); }
 #define CG_PLATFORM_NAME "TEST-ONLY emulator"
-struct cg_u32x16 { uint32_t v[16]; uint32_t operator[](int i) const { return v[i]; } };
-inline void cg_uniform_load16(const void *p, cg_u32x16 &out) { memcpy(out.v, p, 64); }
-inline void cg_uniform_wait() {}
 
 // fibers only switch at barriers / wave exchanges, so plain read-modify-write is atomic here
 inline uint32_t cg_atomic_add_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
