@@ -67,6 +67,16 @@ CG_DEVICE void cg_const_warm(const T CG_CONSTANT *p)
     asm volatile("" :: "s"(acc));
 }
 
+// four packed floats; a read of four that bypasses the caches' retention (non-temporal: rows used once per batch)
+typedef float4 cg_f4;
+typedef float cg_v4f __attribute__((ext_vector_type(4)));
+CG_DEVICE cg_f4 cg_ld4_stream(const float *base, uint32_t j)
+{
+    const cg_v4f v = __builtin_nontemporal_load(reinterpret_cast<const cg_v4f *>(base) + j);
+    cg_f4 o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w; return o;
+}
+CG_HD float cg_sqrtf(float x) { return sqrtf(x); }        // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt)
+#define CG_PLATFORM_NAME "HIP gfx950 (MI355X)"
 // a value every lane of the wave holds alike, moved to a scalar register
 CG_DEVICE uint32_t cg_uniform_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 // nothing is scheduled across this point: what was issued before it stays before
