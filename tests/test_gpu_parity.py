@@ -608,6 +608,35 @@ def test_configs4_shard_invariants(hip_lib):
     last.close()
 
 
+def test_configs3_eight_shards_on_one_gpu(hip_lib):
+    """BASELINE configs[3] on the one GPU a test has: synthetic dense 160000 x 2000, GWCoGAPS nSets = 8, nPatterns = 50 -- eight
+    gene-wise shards of the headline shape, which a rank with eight shards runs as ONE batch of lock-stepped chains
+    (cogaps_batch_*; on the 8-GPU node each rank has one).  Few iterations; checked: a shard's chain inside the batch is
+    bit-identical to the same shard run alone through cogaps_run, in the first pass and in the fixed-pattern second pass
+    (callInternalCoGAPS, DistributedCogaps.R:12-35), and the stitched result has the reference's layout (:226-278)"""
+    import bench
+    from cogaps_amd import CogapsParams, _capi
+    from cogaps_amd.distributed import distributedCogaps
+    data = bench.synthetic_dense(160000, 2000)
+    p = CogapsParams(nPatterns=50, seed=42, nIterations=3)
+    p.distributed = "genome-wide"
+    p.setDistributedParams(nSets=8, minNS=2, cut=50)
+    r = distributedCogaps(data, p, outputFrequency=1000)
+    sets, cons = r["subsets"], r["consensus"]
+    assert len(sets) == 8 and all(len(st) == 20000 for st in sets) and np.array_equal(np.sort(np.concatenate(sets)), np.arange(1, 160001))
+    k2 = cons.shape[1]
+    assert cons.shape[0] == 2000 and k2 >= 1 and r["Amean"].shape == (160000, k2) and not r["Pmean"].any()
+    kw = dict(nIterations=3, seed=42, outputFrequency=1000, runningDistributed=True, lib=hip_lib)
+    for i in (0, 5):
+        shard = np.ascontiguousarray(data[sets[i] - 1])
+        one = _capi.run(shard, nPatterns=50, workerID=i + 1, **kw)
+        for key in ("Amean", "Pmean", "Asd", "Psd"):
+            assert np.array_equal(one[key], r["firstPass"][i][key]), "first pass, shard %d, %s" % (i, key)
+        assert one["totalUpdates"] == r["firstPass"][i]["totalUpdates"] and one["meanChiSq"] == r["firstPass"][i]["meanChiSq"]
+        two = _capi.run(shard, nPatterns=k2, workerID=i + 1, whichMatrixFixed="P", fixedPatterns=cons, **kw)
+        assert np.array_equal(two["Amean"], r["Amean"][sets[i] - 1]), "second pass, shard %d" % i
+
+
 def test_distributed_with_transposed_input(hip_lib, gist):
     """transposeData: the gene-wise shards of a samples x genes file are its column blocks (SubsetData.R:85-116); the
     result is the one of the untransposed run"""

@@ -1,22 +1,26 @@
-"""Timeline analysis of a rocprofv3 --kernel-trace CSV: kernel time vs gaps between consecutive dispatches."""
-import csv, glob, sys, collections
+"""Idle time between consecutive kernels of a rocprofv3 --kernel-trace CSV: where a stream of launches is not busy.
+
+usage: prof_gaps.py <rocprof output dir>
+Prints, per (previous kernel -> next kernel) pair: count, mean / median / p90 gap (us), total gap (ms); and busy / idle totals."""
+import csv, glob, sys, collections, statistics
 files = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)
-rows = []
+ev = []
 for f in files:
     for r in csv.DictReader(open(f)):
-        rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0][:28], r.get('Workgroup_Size_X') or r.get('Workgroup_Size')))
-rows.sort()
-skip = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-rows = rows[skip:]
-gap = collections.defaultdict(list); dur = collections.defaultdict(list)
-for i in range(len(rows) - 1):
-    a, b = rows[i], rows[i + 1]
-    gap[(a[2] + '/' + str(a[3]), b[2] + '/' + str(b[3]))].append((b[0] - a[1]) / 1e3)
-    dur[a[2] + '/' + str(a[3])].append((a[1] - a[0]) / 1e3)
-span = (rows[-1][1] - rows[0][0]) / 1e6
-ktot = sum(sum(v) for v in dur.values()) / 1e3
-print('span %.1f ms, kernel time %.1f ms (%.1f%%), dispatches %d' % (span, ktot, 100 * ktot / span, len(rows)))
-for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1]))[:6]:
-    v.sort(); print('  kernel %-36s n=%7d mean %7.2f med %7.2f p90 %7.2f us total %8.1f ms' % (k, len(v), sum(v) / len(v), v[len(v) // 2], v[int(len(v) * .9)], sum(v) / 1e3))
-for k, v in sorted(gap.items(), key=lambda kv: -sum(kv[1]))[:8]:
-    v.sort(); print('  gap %-58s n=%7d mean %7.2f med %7.2f p90 %7.2f us total %8.1f ms' % (k[0] + ' -> ' + k[1], len(v), sum(v) / len(v), v[len(v) // 2], v[int(len(v) * .9)], sum(v) / 1e3))
+        ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0].split('<')[0][-28:]))
+ev.sort()
+gaps = collections.defaultdict(list)
+busy = 0; idle = 0; end = None; prev = None
+for s, e, n in ev:
+    if end is not None:
+        g = (s - end) / 1e3
+        if g < 2000: gaps[(prev, n)].append(g)     # (longer pauses: host phases between updates, listed separately)
+        else: gaps[('(pause > 2 ms)', n)].append(g)
+        idle += max(0, s - end)
+    busy += e - s
+    end = max(end or 0, e); prev = n
+print('kernels %d  busy %.1f ms  idle %.1f ms  busy fraction %.3f' % (len(ev), busy / 1e6, idle / 1e6, busy / max(1, busy + idle)))
+print('%-30s -> %-30s %8s %9s %9s %9s %10s' % ('previous', 'next', 'count', 'mean_us', 'med_us', 'p90_us', 'total_ms'))
+for k, v in sorted(gaps.items(), key=lambda kv: -sum(kv[1])):
+    v.sort()
+    print('%-30s -> %-30s %8d %9.2f %9.2f %9.2f %10.2f' % (k[0], k[1], len(v), statistics.mean(v), v[len(v) // 2], v[int(len(v) * 0.9)], sum(v) / 1e3))
