@@ -155,6 +155,16 @@ def load():
             raise RuntimeError(
                 "cogaps_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        # One HIP / HSA runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64; when the library
+        # is loaded first it brings /opt/rocm's copies in, a later `import torch` adds the bundled ones, and whichever runtime touches
+        # the device second finds it taken ("no ROCm-capable device is detected" -- in torch.cuda / RCCL, or here).  With torch
+        # imported first the loader resolves this library's dependencies to the copies torch uses, so the front-end (device
+        # tensors, torch.distributed over RCCL) and the sampler share one runtime.  Without PyTorch (a plain C / R client) the
+        # library runs on the ROCm installation's runtime alone.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = bind(C.CDLL(LIB_PATH))
     return _lib
 

@@ -77,7 +77,8 @@ inline void rt_d2d(void *d, const void *sr, size_t n, rt_stream_t s) { RT_CHECK(
 inline void rt_memset(void *d, int v, size_t n, rt_stream_t s) { RT_CHECK(hipMemsetAsync(d, v, n, s)); }
 inline void rt_sync(rt_stream_t s) { RT_CHECK(hipStreamSynchronize(s)); }
 inline void rt_set_device(int d) { if (d >= 0) RT_CHECK(hipSetDevice(d)); }
-inline int rt_get_device() { int d = 0; RT_CHECK(hipGetDevice(&d)); return d; }
+// (hipGetDevice as a process's FIRST runtime call reports "no ROCm-capable device" on ROCm 7.2: initialise explicitly)
+inline int rt_get_device() { int d = 0; RT_CHECK(hipInit(0)); RT_CHECK(hipGetDevice(&d)); return d; }
 inline rt_stream_t rt_stream_create() { hipStream_t s; RT_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); return s; }
 inline void rt_stream_destroy(rt_stream_t s) { (void)hipStreamDestroy(s); }
 #define RT_LAUNCH(kernel, grid, block, stream, ...) do { hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (stream), __VA_ARGS__); RT_CHECK(hipGetLastError()); } while (0)

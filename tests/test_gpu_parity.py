@@ -608,6 +608,29 @@ def test_configs4_shard_invariants(hip_lib):
     last.close()
 
 
+def test_current_device_as_the_first_runtime_call():
+    """cogaps_current_device is what distributedCogaps asks before it hands a device ordinal to its shard threads -- in a process
+    that has made no other HIP call yet (no torch.cuda, no session) it must still answer"""
+    import subprocess, sys
+    out = subprocess.run([sys.executable, "-c", "from cogaps_amd import _capi; print('device', _capi.current_device())"],
+                         cwd=os.path.join(os.path.dirname(__file__), ".."), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "device 0" in out.stdout, out.stderr[-2000:]
+
+
+def test_one_runtime_with_pytorch_in_either_import_order():
+    """PyTorch's wheel bundles its own HIP / HSA runtime; the library must end up on the same one whichever is imported first
+    (a process with two runtimes loses the device in the second: `no ROCm-capable device is detected`): load the library, then
+    use torch.cuda, then run a session -- and the other way round"""
+    import subprocess, sys
+    body = ("import numpy as np\n%s\nprint(torch.ones(3, device='cuda').sum().item())\n"
+            "S = _capi.Session(np.random.rand(50, 20).astype('f4'), nPatterns=3, nIterations=10, seed=1); S.run_iterations(1, 0, 5); print('session ok', _capi.current_device())\n"
+            "print(sorted({l.split()[-1].split('/')[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}))")
+    for order in ("from cogaps_amd import _capi; _capi.load(); import torch", "import torch; torch.cuda.is_available(); from cogaps_amd import _capi"):
+        out = subprocess.run([sys.executable, "-c", body % order], cwd=os.path.join(os.path.dirname(__file__), ".."), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "session ok 0" in out.stdout and "3.0" in out.stdout, out.stderr[-2000:]
+        assert out.stdout.strip().splitlines()[-1].count("libamdhip64") == 1, out.stdout       # one HIP runtime mapped
+
+
 def test_configs3_eight_shards_on_one_gpu(hip_lib):
     """BASELINE configs[3] on the one GPU a test has: synthetic dense 160000 x 2000, GWCoGAPS nSets = 8, nPatterns = 50 -- eight
     gene-wise shards of the headline shape, which a rank with eight shards runs as ONE batch of lock-stepped chains
