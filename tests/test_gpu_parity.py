@@ -634,14 +634,14 @@ def test_one_runtime_with_pytorch_in_either_import_order():
 def test_configs3_eight_shards_on_one_gpu(hip_lib):
     """BASELINE configs[3] on the one GPU a test has: synthetic dense 160000 x 2000, GWCoGAPS nSets = 8, nPatterns = 50 -- eight
     gene-wise shards of the headline shape, which a rank with eight shards runs as ONE batch of lock-stepped chains
-    (cogaps_batch_*; on the 8-GPU node each rank has one).  Few iterations; checked: a shard's chain inside the batch is
+    (cogaps_batch_*; on the 8-GPU node each rank has one).  30 + 30 iterations (the patterns need some variance for the matching step, DistributedCogaps.R:197-217); checked: a shard's chain inside the batch is
     bit-identical to the same shard run alone through cogaps_run, in the first pass and in the fixed-pattern second pass
     (callInternalCoGAPS, DistributedCogaps.R:12-35), and the stitched result has the reference's layout (:226-278)"""
     import bench
     from cogaps_amd import CogapsParams, _capi
     from cogaps_amd.distributed import distributedCogaps
     data = bench.synthetic_dense(160000, 2000)
-    p = CogapsParams(nPatterns=50, seed=42, nIterations=3)
+    p = CogapsParams(nPatterns=50, seed=42, nIterations=30)
     p.distributed = "genome-wide"
     p.setDistributedParams(nSets=8, minNS=2, cut=50)
     r = distributedCogaps(data, p, outputFrequency=1000)
@@ -649,7 +649,7 @@ def test_configs3_eight_shards_on_one_gpu(hip_lib):
     assert len(sets) == 8 and all(len(st) == 20000 for st in sets) and np.array_equal(np.sort(np.concatenate(sets)), np.arange(1, 160001))
     k2 = cons.shape[1]
     assert cons.shape[0] == 2000 and k2 >= 1 and r["Amean"].shape == (160000, k2) and not r["Pmean"].any()
-    kw = dict(nIterations=3, seed=42, outputFrequency=1000, runningDistributed=True, lib=hip_lib)
+    kw = dict(nIterations=30, seed=42, outputFrequency=1000, runningDistributed=True, lib=hip_lib)
     for i in (0, 5):
         shard = np.ascontiguousarray(data[sets[i] - 1])
         one = _capi.run(shard, nPatterns=50, workerID=i + 1, **kw)
