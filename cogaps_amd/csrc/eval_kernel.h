@@ -511,7 +511,10 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
 
 // the split kernels are built for two resident 1024-thread workgroups per compute unit (<= 64 VGPRs)
 template <int PHASE>
-CG_KERNEL void CG_LAUNCH_BOUNDS2((PHASE == EVAL_SEQ ? EVAL_SEQ_BS : 1024), (PHASE == EVAL_FUSED || PHASE == EVAL_SEQ ? 4 : 8)) eval_kernel(const PropRec *hotQueue, const GenScalars *hotGs, uint32_t hotCap, uint32_t slices, SamplerDev S)
+#ifndef EVAL_APPLY_WAVES
+#define EVAL_APPLY_WAVES 6       // 70 VGPRs, nothing spilled (8 waves: 64 VGPRs and 12-20 bytes of scratch per lane; split evaluation 10.85 -> 10.40 us)
+#endif
+CG_KERNEL void CG_LAUNCH_BOUNDS2((PHASE == EVAL_SEQ ? EVAL_SEQ_BS : 1024), (PHASE == EVAL_FUSED || PHASE == EVAL_SEQ ? 4 : (PHASE == EVAL_APPLY ? EVAL_APPLY_WAVES : 8))) eval_kernel(const PropRec *hotQueue, const GenScalars *hotGs, uint32_t hotCap, uint32_t slices, SamplerDev S)
 {
     EvalHot hot; hot.queue = hotQueue; hot.gs = hotGs; hot.queueCap = hotCap;
     eval_body<PHASE, (int)sizeof(SamplerDev) + 24>(S, slices, cg_bid(), cg_gdim(), hot);
@@ -521,7 +524,10 @@ CG_KERNEL void CG_LAUNCH_BOUNDS2((PHASE == EVAL_SEQ ? EVAL_SEQ_BS : 1024), (PHAS
 // one stream.  `arr` is a device array of their SamplerDev records read through the constant address space (scalar loads, as the
 // by-value kernel argument of the one-chain kernels is); workgroups [c * wgPerChain, (c + 1) * wgPerChain) serve chain c's queue.
 template <int PHASE>
-CG_KERNEL void CG_LAUNCH_BOUNDS2(1024, (PHASE == EVAL_FUSED ? 4 : 8)) eval_kernel_multi(const SamplerDev CG_CONSTANT *arr, uint32_t slices, uint32_t wgPerChain)
+#ifndef EVAL_MULTI_FUSED_WAVES
+#define EVAL_MULTI_FUSED_WAVES 6      // 80 VGPRs: three 512-thread workgroups per compute unit instead of two (8 chains: +3.5 %); 8 waves would spill
+#endif
+CG_KERNEL void CG_LAUNCH_BOUNDS2(1024, (PHASE == EVAL_FUSED ? EVAL_MULTI_FUSED_WAVES : (PHASE == EVAL_APPLY ? EVAL_APPLY_WAVES : 8))) eval_kernel_multi(const SamplerDev CG_CONSTANT *arr, uint32_t slices, uint32_t wgPerChain)
 {
     const uint32_t chain = cg_bid() / wgPerChain;
     const SamplerDev CG_CONSTANT *sp = arr + chain;
