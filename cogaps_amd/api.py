@@ -56,8 +56,8 @@ def CoGAPS(data, params=None, nPatterns=None, nThreads=1, messages=True, outputF
     if params.distributed is not None:
         from .distributed import distributedCogaps
         # BPPARAM: the reference hands the subsets to that many BiocParallel workers (R/DistributedCogaps.R:60-63); here: shards in
-        # flight per GPU, run as one batch of lock-stepped chains (an int, or an object with a `workers` attribute; default 8)
-        in_flight = 8 if BPPARAM is None else int(getattr(BPPARAM, "workers", BPPARAM))
+        # flight per GPU, run as batches of lock-stepped chains (an int, or an object with a `workers` attribute; default 16 = two batches of eight)
+        in_flight = 16 if BPPARAM is None else int(getattr(BPPARAM, "workers", BPPARAM))
         raw = distributedCogaps(data, params, unc, messages=messages, outputFrequency=outputFrequency, transposeData=transposeData, device=device,
                                 shardsInFlight=in_flight, nSnapshots=nSnapshots, snapshotPhase=snapshotPhase)
     else:
