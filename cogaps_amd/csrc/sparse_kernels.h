@@ -357,9 +357,14 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
     const float lambda = S.lambda, beta = S.beta;
     const bool multiWave = BS > 64u;
     const bool scalarLane = !multiWave || t < 64u;
+#if defined(GEN_TIMELINE)
+    unsigned long long ets[11]; uint32_t ets_n = 0;
+#endif
+    EVAL_TS(0);
     for (uint32_t q = vbid; ; q += vgdim) {
         const PropRec p = pNext;
         if (q >= qlen) break;
+        EVAL_TS(1);
         uint64_t rng = p.rng;
         const EvalAtoms ea = eval_atoms_load(S, p, t == 0u);
         const bool two = (p.type == 'M' || p.type == 'E');
@@ -386,6 +391,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
                 if (k < K) { z2A[k] = S.Z2[(size_t)p.c1 * K + k]; if (two) z2B[k] = S.Z2[(size_t)p.c2 * K + k]; }
             }
             cg_sync();
+            EVAL_TS(2);
             if (SEQ) {
                 // table terms first, then the common non-zeros in index order (SparseNormalModel.cpp:160-161, 205-207, 256-258)
                 uint32_t vis = 0;
@@ -418,6 +424,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
             else if (p.type == 'D') sp_partial_balanced<SP_MODE_CH>(S, p.r1, p.c1, 0u, -1.f * m1, arowA, bal, preA, x[0], x[1], nz);
             else if (two) sp_partial_balanced<SP_MODE_SAME>(S, p.r1, p.c1, p.c2, 0.f, arowA, bal, preA, x[0], x[1], nz);
             else sp_partial_balanced<SP_MODE_ONE>(S, p.r1, p.c1, 0u, 0.f, arowA, bal, preA, x[0], x[1], nz);
+            EVAL_TS(3);
             if (nz) cg_atomic_add_u32(&nzShared, nz);
 #pragma unroll
             for (int c = 0; c < 4; ++c) x[c] = cg_wave_allsum_f32(x[c]);
@@ -427,6 +434,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
                 cg_sync();
                 eval_vfinish<4, 1>(lds, tot);
             }
+            EVAL_TS(4);
             if (scalarLane) {
                 // table terms (SparseNormalModel.cpp:160-161, 205-207, 256-258), then beta
                 if (diff) {
@@ -447,6 +455,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
             }
             }
         }
+        EVAL_PIN(s); EVAL_TS(5);
         s = s * T; smu = smu * T;
         const bool writer = t == 0u;
 #define SP_BCAST(F0, I0) do { if (multiWave) { if (t == 0) { decf = (F0); deci = (I0); } cg_sync(); (F0) = decf; (I0) = deci; } } while (0)
@@ -492,6 +501,14 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
                 atom_set_mass(S, p.h1, ea.a1.left, n1); atom_set_mass(S, p.h2, ea.left2, n2);
             }
         }
+        EVAL_TS(6);
+#if defined(GEN_TIMELINE)
+        if (cg_bid() < 16u && (t & 63u) == 0u && ((t >> 6) == 0u || (t >> 6) == ((BS - 1u) >> 6)) && qlen >= 20u) {
+            unsigned long long *o_ = &g_eval_timeline[((S.N > 4096u ? 16u : 0u) * 2u + cg_bid() * 2u + ((t >> 6) ? 1u : 0u)) * 12u];
+            o_[0] = (unsigned long long)(p.type | ((need ? 1u : 0u) << 8) | ((p.r1 == p.r2 ? 1u : 0u) << 16));
+            for (uint32_t i_ = 0; i_ < 11u; ++i_) o_[1 + i_] = i_ < ets_n ? ets[i_] : 0ull;
+        }
+#endif
         if (writer) {
             // roofline bookkeeping in bytes (sparse): per alpha call the flag words of the data vector and of the
             // column(s), this matrix row and a Z2 column; per common non-zero the data value, the column entry and a row of

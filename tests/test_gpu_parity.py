@@ -40,6 +40,27 @@ def test_sparse_model_stepwise(hip_lib, genes, samples, k, iters, zeros):
     pu.run_stepwise(hip_lib, data, iters, trace=genes * samples < 50000, nPatterns=k, seed=11, total_iter=max(iters, 40), check_every=5, sparseOptimization=True)
 
 
+def _random_case(i):
+    """shape, pattern count, sparsity and seeds of random case i (fixed generator: the cases are the same on every run)"""
+    rng = np.random.Generator(np.random.MT19937(20260 + i))
+    genes = int(rng.choice([rng.integers(20, 90), rng.integers(90, 700), rng.integers(700, 5000)]))
+    samples = int(rng.choice([rng.integers(5, 40), rng.integers(40, 400), rng.integers(400, 1500)]))
+    if genes * samples > 1500000:
+        samples = max(5, 1500000 // genes)
+    k = int(rng.integers(2, min(12, genes, samples) + 1))
+    return genes, samples, k, bool(i % 3 == 2), int(rng.integers(1, 10000)), float(rng.choice([0.5, 0.8, 0.93]))
+
+
+@pytest.mark.parametrize("case", range(40))
+def test_random_shapes_stepwise(hip_lib, case):
+    """Forty random problem shapes (ragged lengths, one- to many-wave reductions, a third of them through the sparse model),
+    each stepwise against the oracle: proposal traces where the problem is small, atoms, matrices, A*P, chi2 after every check"""
+    genes, samples, k, sparse, seed, zeros = _random_case(case)
+    data = pu.synthetic_counts(genes, samples, zeros=zeros, seed=seed) if sparse else pu.synthetic(genes, samples, seed=seed)
+    iters = 80 if genes * samples < 200000 else 30
+    pu.run_stepwise(hip_lib, data, iters, trace=genes * samples < 60000, nPatterns=k, seed=seed, total_iter=2 * iters, check_every=3, sparseOptimization=sparse)
+
+
 def test_sparse_model_full_run(hip_lib, oracle):
     from cogaps_amd import _capi
     data = pu.synthetic_counts(400, 60, zeros=0.85, seed=33)

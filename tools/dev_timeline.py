@@ -4,7 +4,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cogaps_amd import _capi
 from bench import synthetic_dense
 PL = _capi.bind(ctypes.CDLL(os.path.join(os.path.dirname(_capi.LIB_PATH), 'libcogaps_hip_PROFILE_DEV.so')))
-S = _capi.Session(synthetic_dense(20000, 2000), lib=PL, nPatterns=50, nIterations=100, seed=42)
+SPARSE = "--sparse" in sys.argv
+if SPARSE: sys.argv.remove("--sparse")
+data = synthetic_dense(20000, 2000)
+if SPARSE: data *= (np.random.Generator(np.random.MT19937(777)).random(data.shape) >= 0.95)
+S = _capi.Session(data, lib=PL, nPatterns=50, nIterations=100, seed=42, sparseOptimization=SPARSE)
 S.run_iterations(1, 0, int(sys.argv[1]) if len(sys.argv) > 1 else 40)
 names = {0: 'entry', 1: 'entry loads+sync', 2: 'flush', 4: 'round set-up sync', 5: 'A1 pcg+guess', 6: 'A1 count3 #1', 7: 'A1 exact decide', 8: 'A1 count3 #2+perm',
          9: 'A1 sync', 10: 'A2 stage1 rng/addr', 11: 'A2 stage2 (vec/bits0 used)', 12: 'A2 stage3 (atoms/binHead used)', 13: 'A2 neighbour loads issued', 14: 'A2 finish',
@@ -36,6 +40,7 @@ PL.cogaps_debug_eval_timeline.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert PL.cogaps_debug_eval_timeline(ebuf, 2 * 16 * 2 * 12) == 0
 ea = np.array(ebuf).reshape(2, 16, 2, 12)
 en = {0: 'entry', 1: 'record', 2: 'scalars', 3: 'reduced', 4: 'scalar math', 5: 'broadcast', 6: 'AP update', 10: 'partials', 11: 'parked', 12: 'barrier'}
+if SPARSE: en = {0: 'entry', 1: 'record', 2: 'rows in LDS', 3: 'terms folded', 4: 'totals', 5: 's, s_mu', 6: 'decision + update'}
 for which, e in (('narrow workgroups (A sampler)', ea[0]), ('wide workgroups (P sampler)', ea[1])):
     print()
     print('evaluation kernel, %s, cycles since workgroup entry:' % which)
