@@ -145,6 +145,17 @@ def test_verification_mode_stepwise(hip_lib, gist):
     pu.run_stepwise(hip_lib, pu.synthetic_counts(900, 20, zeros=0.8, seed=9), 20, nPatterns=6, seed=12, total_iter=40, check_every=5, sparseOptimization=True, **SEQ)
 
 
+@pytest.mark.parametrize("case", range(40, 56))
+def test_random_shapes_verification_mode(hip_lib, case):
+    """sixteen more random shapes in the verification mode (the reference's scalar order, glibc's logf / expf) against the oracle
+    in the same arithmetic, stepwise; the odd cases with glibc's non-fused (SSE2) variants"""
+    genes, samples, k, sparse, seed, zeros = _random_case(case)
+    data = pu.synthetic_counts(genes, samples, zeros=zeros, seed=seed) if sparse else pu.synthetic(genes, samples, seed=seed)
+    iters = 40 if genes * samples < 200000 else 12
+    pu.run_stepwise(hip_lib, data, iters, trace=genes * samples < 60000, nPatterns=k, seed=seed, total_iter=2 * iters, check_every=4, sparseOptimization=sparse,
+                    reductionMode="seq", mathMode="glibc-sse2" if case % 2 else "glibc-fma")
+
+
 def test_user_uncertainty_stepwise(hip_lib, gist, modsim):
     """an uncertainty matrix given by the caller (DenseNormalModel.h:90-96): the kernels read S*S instead of recomputing it from D;
     fused evaluation (modsim, GIST A side) and the P side's 1363-element vectors, lane order, against the oracle"""
