@@ -77,7 +77,7 @@ EXPORTS = [
     "cogaps_session_get_atoms", "cogaps_session_dims", "cogaps_session_avg_queue",
     "cogaps_session_finish", "cogaps_session_set_timing", "cogaps_session_perf",
     "cogaps_session_perf_sampler", "cogaps_session_get_rows", "cogaps_sparse_width", "cogaps_reduction_width", "cogaps_session_debug_prof", "cogaps_session_debug_replay",
-    "cogaps_run_from_file", "cogaps_read_matrix_file", "cogaps_matrix_free", "cogaps_file_info", "cogaps_debug_math", "cogaps_current_device",
+    "cogaps_run_from_file", "cogaps_read_matrix_file", "cogaps_matrix_free", "cogaps_file_info", "cogaps_debug_math", "cogaps_current_device", "cogaps_device_memory",
     "cogaps_session_debug_check_domain", "cogaps_batch_create", "cogaps_batch_destroy", "cogaps_batch_run_iterations", "cogaps_batch_set_timing", "cogaps_batch_perf",
 ]
 
@@ -133,6 +133,7 @@ def bind(L):
     L.cogaps_file_info.argtypes = [C.c_char_p, u32p, u32p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.cogaps_debug_math.argtypes = [C.c_int, C.c_int, fp, fp, C.c_uint32, C.c_int]
     L.cogaps_current_device.argtypes = [C.POINTER(C.c_int)]
+    L.cogaps_device_memory.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.cogaps_session_debug_check_domain.argtypes = [vp, C.c_char, u32p]
     L.cogaps_batch_create.restype = vp
     L.cogaps_batch_create.argtypes = [C.POINTER(vp), C.c_uint32]
@@ -453,6 +454,15 @@ def debug_math(fn, x, mathMode="portable", on_device=False, lib=None):
     if L.cogaps_debug_math({"log": 0, "exp": 1}[fn], _MATH[mathMode] if isinstance(mathMode, str) else int(mathMode), _fp(xs), _fp(ys), xs.size, int(on_device)):
         raise RuntimeError(L.cogaps_last_error().decode())
     return ys
+
+
+def device_memory(device=-1, lib=None):
+    """(free, total) bytes of HBM on `device` (-1: the calling thread's current one)"""
+    L = lib if lib is not None else load()
+    f, t = C.c_uint64(0), C.c_uint64(0)
+    if L.cogaps_device_memory(int(device), C.byref(f), C.byref(t)):
+        raise RuntimeError(L.cogaps_last_error().decode())
+    return int(f.value), int(t.value)
 
 
 def current_device(lib=None):

@@ -580,6 +580,19 @@ int cogaps_current_device(int *device)
     try { if (!device) return fail("null argument"); *device = rt_get_device(); return 0; } catch (const std::exception &e) { return fail(e.what()); }
 }
 
+int cogaps_device_memory(int device, uint64_t *freeBytes, uint64_t *totalBytes)
+{
+    try {
+        if (!freeBytes || !totalBytes) return fail("null argument");
+        const int before = rt_get_device();
+        if (device >= 0) rt_set_device(device);
+        size_t f = 0, t = 0; rt_mem_info(&f, &t);
+        if (device >= 0) rt_set_device(before);
+        *freeBytes = (uint64_t)f; *totalBytes = (uint64_t)t;
+        return 0;
+    } catch (const std::exception &e) { return fail(e.what()); }
+}
+
 void cogaps_default_params(cogaps_params *p)
 {
     memset(p, 0, sizeof(*p));

@@ -25,6 +25,7 @@ inline void rt_memset(void *d, int v, size_t n, rt_stream_t) { memset(d, v, n); 
 inline void rt_sync(rt_stream_t) {}
 inline void rt_set_device(int) {}
 inline int rt_get_device() { return 0; }
+inline void rt_mem_info(size_t *freeB, size_t *totalB) { *freeB = *totalB = (size_t)1 << 40; }
 inline rt_stream_t rt_stream_create() { return 0; }
 inline void rt_stream_destroy(rt_stream_t) {}
 #define RT_LAUNCH(kernel, grid, block, stream, ...) cgemu::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })
@@ -79,6 +80,7 @@ inline void rt_sync(rt_stream_t s) { RT_CHECK(hipStreamSynchronize(s)); }
 inline void rt_set_device(int d) { if (d >= 0) RT_CHECK(hipSetDevice(d)); }
 // (hipGetDevice as a process's FIRST runtime call reports "no ROCm-capable device" on ROCm 7.2: initialise explicitly)
 inline int rt_get_device() { int d = 0; RT_CHECK(hipInit(0)); RT_CHECK(hipGetDevice(&d)); return d; }
+inline void rt_mem_info(size_t *freeB, size_t *totalB) { RT_CHECK(hipMemGetInfo(freeB, totalB)); }
 inline rt_stream_t rt_stream_create() { hipStream_t s; RT_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); return s; }
 inline void rt_stream_destroy(rt_stream_t s) { (void)hipStreamDestroy(s); }
 #define RT_LAUNCH(kernel, grid, block, stream, ...) do { hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (stream), __VA_ARGS__); RT_CHECK(hipGetLastError()); } while (0)

@@ -241,6 +241,14 @@ def _run_shards(spec, ids, in_flight, run_fn):
         return {i: run_fn(spec(i)[0], unc=spec(i)[1], **spec(i)[2]) for i in ids}
     if run_fn is _capi.run:
         out = {}
+        # no more shards in flight than the GPU holds: a session keeps ~9 matrices of its shard's size resident (data, A*P cache,
+        # uncertainty, for both samplers) -- counted as 10 (13 with an uncertainty matrix) against 85 % of the free HBM
+        d0, u0, k0 = spec(ids[0])
+        per_shard = (13 if u0 is not None else 10) * 4 * int(np.asarray(d0).size) + (64 << 20)
+        free_bytes, _ = _capi.device_memory(k0.get("device", -1))
+        in_flight = max(1, min(in_flight, int(0.85 * free_bytes // per_shard)))
+        if in_flight == 1:
+            return {i: run_fn(spec(i)[0], unc=spec(i)[1], **spec(i)[2]) for i in ids}
 
         def batch(grp):
             sp = [spec(i) for i in grp]

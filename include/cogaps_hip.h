@@ -126,6 +126,9 @@ const char *cogaps_last_error(void);
 
 /* the HIP device ordinal that is current for the calling host thread (what cogaps_params.device = -1 resolves to) */
 int cogaps_current_device(int *device);
+/* free and total bytes of HBM on `device` (-1: the calling thread's current one); what a caller that keeps several sessions per GPU
+ * sizes its batches by (cogaps_amd/distributed.py) */
+int cogaps_device_memory(int device, uint64_t *freeBytes, uint64_t *totalBytes);
 
 /* the three trivial exports next to cogaps_cpp (src/Cogaps.cpp:217-246) */
 const char *cogaps_build_report(void);

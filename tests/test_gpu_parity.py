@@ -649,6 +649,14 @@ def test_current_device_as_the_first_runtime_call():
     assert out.returncode == 0 and "device 0" in out.stdout, out.stderr[-2000:]
 
 
+def test_device_memory(hip_lib):
+    """cogaps_device_memory: what distributed.py sizes a rank's batches by (an MI355X has 288 GB of HBM3E)"""
+    from cogaps_amd import _capi
+    free, total = _capi.device_memory(-1, lib=hip_lib)
+    assert 0 < free <= total and total > 200e9
+    assert _capi.device_memory(0, lib=hip_lib)[1] == total
+
+
 def test_one_runtime_with_pytorch_in_either_import_order():
     """PyTorch's wheel bundles its own HIP / HSA runtime; the library must end up on the same one whichever is imported first
     (a process with two runtimes loses the device in the second: `no ROCm-capable device is detected`): load the library, then
