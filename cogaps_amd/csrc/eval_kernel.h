@@ -247,6 +247,48 @@ CG_DEVICE void eval_update_ap(const SamplerDev &S, uint32_t row, uint32_t col, f
     }
 }
 
+// The two updates of an accepted move / exchange, AP[:,r1] += d1 * other[:,c1] then AP[:,r2] += d2 * other[:,c2], with all their loads in
+// one trip (two calls of eval_update_ap pay the trip twice, one after the other, and the launch lasts as long as its slowest workgroup --
+// a two-site one).  r1 == r2: the second update continues from the first one's result in registers -- the same additions in the same
+// order as the stored-and-reloaded form.
+CG_DEVICE void eval_update_ap2(const SamplerDev &S, uint32_t r1, uint32_t c1, float d1, uint32_t r2, uint32_t c2, float d2, uint32_t chunk0, uint32_t stride)
+{
+    constexpr int UN = 2;
+    const uint32_t nq = S.Npad >> 2, t = cg_tid();
+    float *AP1 = S.AP + (size_t)r1 * S.Npad, *AP2 = S.AP + (size_t)r2 * S.Npad;
+    const float *V1 = S.other + (size_t)c1 * S.Npad, *V2 = S.other + (size_t)c2 * S.Npad;
+    const bool same = r1 == r2;
+#if defined(GEN_PROFILE)
+    if (S.dbg & 2u) return;
+#endif
+    for (uint32_t j0 = chunk0 + t; j0 < nq; j0 += UN * stride) {
+        cg_f4 v1[UN], v2[UN], p1[UN], p2[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const uint32_t j = j0 + (uint32_t)u * stride;
+            if (j < nq) { v1[u] = ld4(V1, j); v2[u] = ld4(V2, j); p1[u] = ld4(AP1, j); p2[u] = same ? f4_zero() : ld4(AP2, j); }
+            else { v1[u] = f4_zero(); v2[u] = f4_zero(); p1[u] = f4_zero(); p2[u] = f4_zero(); }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const uint32_t j = j0 + (uint32_t)u * stride;
+            if (j < nq) {
+                cg_f4 q = p1[u];
+                q.x = q.x + d1 * v1[u].x; q.y = q.y + d1 * v1[u].y; q.z = q.z + d1 * v1[u].z; q.w = q.w + d1 * v1[u].w;
+                if (same) {
+                    q.x = q.x + d2 * v2[u].x; q.y = q.y + d2 * v2[u].y; q.z = q.z + d2 * v2[u].z; q.w = q.w + d2 * v2[u].w;
+                    st4(AP1, j, q);
+                } else {
+                    st4(AP1, j, q);
+                    cg_f4 w = p2[u];
+                    w.x = w.x + d2 * v2[u].x; w.y = w.y + d2 * v2[u].y; w.z = w.z + d2 * v2[u].z; w.w = w.w + d2 * v2[u].w;
+                    st4(AP2, j, w);
+                }
+            }
+        }
+    }
+}
+
 // mMatrix(row,col) = newv, keeping the per-column count of positive entries (canUseGibbs) current
 CG_DEVICE void eval_store_matrix(const SamplerDev &S, uint32_t row, uint32_t col, float oldv, float newv)
 {
@@ -467,8 +509,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
             EVAL_TS(5);
             if (acc) {
                 const float nv1 = gm_max(old1 + (-m1), 0.f);                    // safelyChangeMatrix(r1,c1,-m)
-                eval_update_ap(S, p.r1, p.c1, nv1 - old1, chunk0, stride); ++nUpd;
-                eval_update_ap(S, p.r2, p.c2, m1, chunk0, stride); ++nUpd;              // changeMatrix(r2,c2,+m); same thread owns the same elements
+                eval_update_ap2(S, p.r1, p.c1, nv1 - old1, p.r2, p.c2, m1, chunk0, stride); nUpd += 2;      // ... then changeMatrix(r2,c2,+m); same thread owns the same elements
                 if (writer) {
                     eval_domain_move(S, p, ea.a1);
                     eval_store_matrix(S, p.r1, p.c1, old1, nv1);
@@ -485,9 +526,8 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
             const float n1 = m1 + gv, n2 = m2 - gv;
             if (gh != 0u && n1 > GAPS_EPSILON && n2 > GAPS_EPSILON) {
                 const float nv1 = gm_max(old1 + (n1 - m1), 0.f);
-                eval_update_ap(S, p.r1, p.c1, nv1 - old1, chunk0, stride); ++nUpd;
                 const float nv2 = gm_max(old2 + (n2 - m2), 0.f);
-                eval_update_ap(S, p.r2, p.c2, nv2 - old2, chunk0, stride); ++nUpd;
+                eval_update_ap2(S, p.r1, p.c1, nv1 - old1, p.r2, p.c2, nv2 - old2, chunk0, stride); nUpd += 2;
                 if (writer) {
                     eval_store_matrix(S, p.r1, p.c1, old1, nv1);
                     eval_store_matrix(S, p.r2, p.c2, old2, nv2);
