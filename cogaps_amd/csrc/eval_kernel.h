@@ -289,6 +289,41 @@ CG_DEVICE void eval_update_ap2(const SamplerDev &S, uint32_t r1, uint32_t c1, fl
     }
 }
 
+// The fused evaluation of ONE chain (a launch is as long as its slowest workgroup's dependent chain) asks for the chunk its thread
+// will rewrite -- the A*P row(s) and the other matrix's column(s) the record names -- BEFORE the scalar step and uses it after the
+// decision: the update's trip runs under the table lookups and the logarithm instead of after them.  (One chunk per thread there: the
+// fused form has at least as many threads as chunks.)  A rejected proposal has read 16-32 KB for nothing, from L2 mostly.
+struct EvalPre { cg_f4 v1, p1, v2, p2; };
+// (j = chunk0 + t is the thread's first chunk; a vector longer than the reduction is wide has further chunks, done the usual way)
+CG_DEVICE void eval_update_pre1(const SamplerDev &S, uint32_t row, uint32_t col, float delta, uint32_t chunk0, uint32_t stride, const cg_f4 &v, const cg_f4 &p)
+{
+    const uint32_t j = chunk0 + cg_tid(), nq = S.Npad >> 2;
+    if (j < nq) {
+        cg_f4 q = p;
+        q.x = q.x + delta * v.x; q.y = q.y + delta * v.y; q.z = q.z + delta * v.z; q.w = q.w + delta * v.w;
+        st4(S.AP + (size_t)row * S.Npad, j, q);
+    }
+    if (nq > stride) eval_update_ap(S, row, col, delta, chunk0 + stride, stride);
+}
+CG_DEVICE void eval_update_pre2(const SamplerDev &S, uint32_t r1, uint32_t c1, float d1, uint32_t r2, uint32_t c2, float d2, uint32_t chunk0, uint32_t stride, const EvalPre &e)
+{
+    const uint32_t j = chunk0 + cg_tid(), nq = S.Npad >> 2;
+    if (j < nq) {
+        cg_f4 q = e.p1;
+        q.x = q.x + d1 * e.v1.x; q.y = q.y + d1 * e.v1.y; q.z = q.z + d1 * e.v1.z; q.w = q.w + d1 * e.v1.w;
+        if (r1 == r2) {
+            q.x = q.x + d2 * e.v2.x; q.y = q.y + d2 * e.v2.y; q.z = q.z + d2 * e.v2.z; q.w = q.w + d2 * e.v2.w;
+            st4(S.AP + (size_t)r1 * S.Npad, j, q);
+        } else {
+            st4(S.AP + (size_t)r1 * S.Npad, j, q);
+            cg_f4 w = e.p2;
+            w.x = w.x + d2 * e.v2.x; w.y = w.y + d2 * e.v2.y; w.z = w.z + d2 * e.v2.z; w.w = w.w + d2 * e.v2.w;
+            st4(S.AP + (size_t)r2 * S.Npad, j, w);
+        }
+    }
+    if (nq > stride) eval_update_ap2(S, r1, c1, d1, r2, c2, d2, chunk0 + stride, stride);
+}
+
 // mMatrix(row,col) = newv, keeping the per-column count of positive entries (canUseGibbs) current
 CG_DEVICE void eval_store_matrix(const SamplerDev &S, uint32_t row, uint32_t col, float oldv, float newv)
 {
@@ -411,6 +446,14 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
 #endif
         const bool diff = two && p.r1 != p.r2;
         float s = 0.f, smu = 0.f;          // un-annealed sums, valid in wave 0
+        // the one-chain fused launch only: the batched one is throughput bound and at its register budget, and the split form's APPLY
+        // launch got slower with it (10.3 -> 12 us: 80 KB rows fetched for every rejected proposal, registers at the launch bound)
+        constexpr bool PRE = PHASE == EVAL_FUSED && WARM > 0;
+        EvalPre pre; pre.v1 = f4_zero(); pre.p1 = f4_zero(); pre.v2 = f4_zero(); pre.p2 = f4_zero();
+        const uint32_t jPre = chunk0 + t;
+#define EVAL_PREFETCH() do { if (PRE && jPre < (S.Npad >> 2)) { \
+            pre.v1 = ld4(S.other + (size_t)p.c1 * S.Npad, jPre); pre.p1 = ld4(S.AP + (size_t)p.r1 * S.Npad, jPre); \
+            if (two) { pre.v2 = ld4(S.other + (size_t)p.c2 * S.Npad, jPre); if (p.r1 != p.r2) pre.p2 = ld4(S.AP + (size_t)p.r2 * S.Npad, jPre); } } } while (0)
         if (need) {
             float tot[4] = {0.f, 0.f, 0.f, 0.f};
             if (PHASE == EVAL_SEQ) {
@@ -451,6 +494,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
             s = diff ? tot[0] + tot[2] : tot[0]; smu = diff ? tot[1] - tot[3] : tot[1];        // AlphaParameters.cpp:11-14
         }
         EVAL_PIN(s); EVAL_TS(3);
+        if (PHASE == EVAL_FUSED) EVAL_PREFETCH();                    // (after the reduction: the registers are free again)
         if (PHASE == EVAL_APPLY) ea = eval_atoms_load(S, p, writer);
         if (PHASE == EVAL_ALPHA) { if (q + qStep >= qlen) break; { const uint32_t qn_ = q + qStep; pNext = hot.queue[qn_ < hot.queueCap ? qn_ : 0u]; } cg_sync(); continue; }
         s = s * T; smu = smu * T;
@@ -468,7 +512,8 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
             EVAL_BCAST(bv, bhas);
             EVAL_TS(5);
             if (bhas != 0u && bv >= GAPS_EPSILON) {
-                eval_update_ap(S, p.r1, p.c1, bv, chunk0, stride); ++nUpd;                          // changeMatrix
+                if (PRE) eval_update_pre1(S, p.r1, p.c1, bv, chunk0, stride, pre.v1, pre.p1); else eval_update_ap(S, p.r1, p.c1, bv, chunk0, stride);
+                ++nUpd;                          // changeMatrix
                 if (writer) { atom_set_mass(S, p.h1, ea.a1.left, bv); eval_store_matrix(S, p.r1, p.c1, old1, old1 + bv); }
             } else if (writer) eval_cache_erase(S, p.h1, p.r1, p.c1);
         } else if (p.type == 'D') {
@@ -491,12 +536,14 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
             if (acc != 0u) {
                 if (rebirth != m1) {
                     const float nv = gm_max(old1 + (rebirth - m1), 0.f);            // safelyChangeMatrix
-                    eval_update_ap(S, p.r1, p.c1, nv - old1, chunk0, stride); ++nUpd;
+                    if (PRE) eval_update_pre1(S, p.r1, p.c1, nv - old1, chunk0, stride, pre.v1, pre.p1); else eval_update_ap(S, p.r1, p.c1, nv - old1, chunk0, stride);
+                    ++nUpd;
                     if (writer) { eval_store_matrix(S, p.r1, p.c1, old1, nv); atom_set_mass(S, p.h1, ea.a1.left, rebirth); }
                 }
             } else {
                 const float nv = gm_max(old1 + (-1.f * m1), 0.f);
-                eval_update_ap(S, p.r1, p.c1, nv - old1, chunk0, stride); ++nUpd;
+                if (PRE) eval_update_pre1(S, p.r1, p.c1, nv - old1, chunk0, stride, pre.v1, pre.p1); else eval_update_ap(S, p.r1, p.c1, nv - old1, chunk0, stride);
+                ++nUpd;
                 if (writer) { eval_store_matrix(S, p.r1, p.c1, old1, nv); eval_cache_erase(S, p.h1, p.r1, p.c1); }
             }
             EVAL_PROF(3);
@@ -509,7 +556,8 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
             EVAL_TS(5);
             if (acc) {
                 const float nv1 = gm_max(old1 + (-m1), 0.f);                    // safelyChangeMatrix(r1,c1,-m)
-                eval_update_ap2(S, p.r1, p.c1, nv1 - old1, p.r2, p.c2, m1, chunk0, stride); nUpd += 2;      // ... then changeMatrix(r2,c2,+m); same thread owns the same elements
+                if (PRE) eval_update_pre2(S, p.r1, p.c1, nv1 - old1, p.r2, p.c2, m1, chunk0, stride, pre); else eval_update_ap2(S, p.r1, p.c1, nv1 - old1, p.r2, p.c2, m1, chunk0, stride);
+                nUpd += 2;      // ... then changeMatrix(r2,c2,+m); same thread owns the same elements
                 if (writer) {
                     eval_domain_move(S, p, ea.a1);
                     eval_store_matrix(S, p.r1, p.c1, old1, nv1);
@@ -527,7 +575,8 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
             if (gh != 0u && n1 > GAPS_EPSILON && n2 > GAPS_EPSILON) {
                 const float nv1 = gm_max(old1 + (n1 - m1), 0.f);
                 const float nv2 = gm_max(old2 + (n2 - m2), 0.f);
-                eval_update_ap2(S, p.r1, p.c1, nv1 - old1, p.r2, p.c2, nv2 - old2, chunk0, stride); nUpd += 2;
+                if (PRE) eval_update_pre2(S, p.r1, p.c1, nv1 - old1, p.r2, p.c2, nv2 - old2, chunk0, stride, pre); else eval_update_ap2(S, p.r1, p.c1, nv1 - old1, p.r2, p.c2, nv2 - old2, chunk0, stride);
+                nUpd += 2;
                 if (writer) {
                     eval_store_matrix(S, p.r1, p.c1, old1, nv1);
                     eval_store_matrix(S, p.r2, p.c2, old2, nv2);

@@ -27,7 +27,7 @@ def test_gist_stepwise(hip_lib, gist):
     assert props > 100000
 
 
-@pytest.mark.parametrize("genes,samples,k", [(4100, 12, 3), (17000, 8, 3), (3000, 300, 5), (257, 129, 4)])
+@pytest.mark.parametrize("genes,samples,k", [(4100, 12, 3), (17000, 8, 3), (3000, 300, 5), (257, 129, 4), (70001, 6, 2)])
 def test_wide_reductions(hip_lib, genes, samples, k):
     """evaluation workgroups of 256 / 1024 / 128 lanes and ragged vector lengths (N not a multiple of 4)"""
     pu.run_stepwise(hip_lib, pu.synthetic(genes, samples), 25, trace=(genes < 5000), nPatterns=k, seed=123, total_iter=50, check_every=5)
