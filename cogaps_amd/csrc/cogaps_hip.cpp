@@ -636,6 +636,7 @@ cogaps_session *cogaps_session_create(const float *data, uint32_t nrow, uint32_t
         rt_set_device(p.device);
         s = new cogaps_session();
         s->p = p;
+        s->p.device = rt_get_device();            // (-1 resolved: later calls from other host threads select the same GPU)
         s->startTime = now_s();
         if (p.printMessages) { printf("Loading Data..."); fflush(stdout); }                  // GapsRunner.cpp:399
         if (p.subsetData && p.dataIndicesSubset) s->subset.assign(p.dataIndicesSubset, p.dataIndicesSubset + p.nSubset);
@@ -730,7 +731,8 @@ void cogaps_session_destroy(cogaps_session *s)
     delete s;
 }
 
-#define SESSION_TRY try { rt_alloc_scope allocOn_(s->stream);      // allocations made on behalf of a session fill on its stream
+// (the HIP current device belongs to the calling host thread: a session used from another thread than its creator's selects its GPU again)
+#define SESSION_TRY try { rt_set_device(s->p.device); rt_alloc_scope allocOn_(s->stream);      // allocations made on behalf of a session fill on its stream
 #define SESSION_END } catch (const std::exception &e) { return fail(e.what()); } return 0;
 
 static HostSampler &pick(cogaps_session *s, char w) { return w == 'A' ? s->A : s->P; }
@@ -1069,6 +1071,7 @@ void cogaps_batch_destroy(cogaps_batch *b)
 int cogaps_batch_run_iterations(cogaps_batch *b, int phase, uint32_t firstIter, uint32_t n, uint64_t *updates)
 {
     try {
+        rt_set_device(b->ss[0]->p.device);
         rt_alloc_scope allocOn(b->stream);
         const uint32_t C = (uint32_t)b->ss.size();
         const double t0 = now_s();
