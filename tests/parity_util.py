@@ -91,3 +91,34 @@ def synthetic_counts(genes, samples, zeros=0.85, rank=4, seed=7):
     p0 = rng.gamma(2.0, 0.5, (samples, rank)) * (rng.random((samples, rank)) > 0.4)
     d = np.ceil((a0 @ p0.T) * (0.9 + 0.2 * rng.random((genes, samples)))) * (rng.random((genes, samples)) > zeros)
     return d.astype(np.float32)
+
+
+def option_cases():
+    """combinations of the run options cogaps_cpp forwards (Cogaps.cpp:64-139): transposed input, a subset in either dimension, a fixed
+    factor, an uncertainty matrix, the sparse model, nPatterns from 1 up"""
+    cases, i = [], 0
+    for sparse in (False, True):
+        for transpose in (False, True):
+            for fixed in ("N", "A", "P"):
+                for subset in (0, 1, 2):
+                    i += 1
+                    cases.append((sparse, transpose, fixed, subset, 1 + (i % 6), bool(i % 2) and not sparse))
+    return cases
+
+
+def run_option_case(lib, sparse, transpose, fixed, subset, k, with_unc):
+    genes, samples = 83, 37
+    base = synthetic_counts(genes, samples, zeros=0.6, seed=5 + k) if sparse else synthetic(genes, samples, seed=5 + k)
+    data = np.ascontiguousarray(base.T) if transpose else base          # transposeData: the file holds samples x genes
+    kw = dict(nPatterns=k, seed=100 + k, total_iter=40, check_every=5, transposeData=transpose, sparseOptimization=sparse)
+    n_genes, n_samples = genes, samples
+    if subset == 1:
+        kw.update(subsetIndices=np.arange(3, 3 + 50, dtype=np.uint32), subsetDim=1); n_genes = 50
+    elif subset == 2:
+        kw.update(subsetIndices=np.arange(2, 2 + 20, dtype=np.uint32), subsetDim=2); n_samples = 20
+    if fixed != "N":
+        rows = n_genes if fixed == "A" else n_samples
+        kw.update(whichMatrixFixed=fixed, fixedPatterns=np.abs(np.random.default_rng(k).normal(size=(rows, k))).astype(np.float32))
+    if with_unc:
+        kw.update(unc=np.maximum(data * np.float32(0.2), np.float32(0.3)).astype(np.float32))
+    run_stepwise(lib, data, 40, trace=(fixed == "N"), **kw)

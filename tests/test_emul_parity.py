@@ -42,6 +42,12 @@ def test_split_evaluation(emul_lib, genes, iters):
     pu.run_stepwise(emul_lib(256), data, iters, trace=False, nPatterns=3, seed=7, total_iter=10)
 
 
+@pytest.mark.parametrize("sparse,transpose,fixed,subset,k,with_unc", pu.option_cases()[1::3])
+def test_option_combinations_stepwise(emul_lib, sparse, transpose, fixed, subset, k, with_unc):
+    """a third of the 36 option combinations the GPU suite runs (parity_util.option_cases), on the emulator"""
+    pu.run_option_case(emul_lib(win=256), sparse, transpose, fixed, subset, k, with_unc)
+
+
 def test_transposed_and_uncertainty(emul_lib, modsim):
     unc = (np.maximum(modsim * 0.2, 0.05)).astype(np.float32)
     S, O = pu.make_pair(emul_lib(256), np.ascontiguousarray(modsim.T), unc=None, nPatterns=3, seed=4, nIterations=20, transposeData=True)

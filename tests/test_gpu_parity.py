@@ -266,6 +266,13 @@ def test_transpose_uncertainty_subset_fixed(hip_lib, gist, modsim):
                     whichMatrixFixed="P", fixedPatterns=fixedP, check_every=10)
 
 
+@pytest.mark.parametrize("sparse,transpose,fixed,subset,k,with_unc", pu.option_cases())
+def test_option_combinations_stepwise(hip_lib, sparse, transpose, fixed, subset, k, with_unc):
+    """all 36 combinations of {dense, sparse model} x {transposed input} x {no / A / P fixed} x {no subset, gene subset, sample subset},
+    nPatterns 1..6, half of the dense ones with an uncertainty matrix: stepwise against the oracle"""
+    pu.run_option_case(hip_lib, sparse, transpose, fixed, subset, k, with_unc)
+
+
 @pytest.mark.parametrize("name,k", [("gist", 7), ("modsim", 3)])
 def test_full_run_golden_lane_order(hip_lib, gist, modsim, name, k):
     """cogaps_run vs the committed oracle output in the kernels' reduction order: everything bit-exact"""
