@@ -407,14 +407,8 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
     unsigned long long eprof_last = cg_clock(); (void)eprof_last;
     const float lambda = S.lambda;
     EVAL_TS(0);
-    if (PHASE == EVAL_APPLY) {
-        // (every slice workgroup of the split form repeats the scalar step.)  The scalar step makes two dependent lookups in the normal-distribution tables (12 + 20 KB).  After a kernel
-        // boundary they come from the Infinity Cache; touching every 128-byte line now, under the record's trip,
-        // leaves them in this XCD's L2 by the time the step needs them.
-        float touch = 0.f;
-        for (uint32_t i = t; i < 94u + 157u; i += BS) touch += (i < 94u) ? S.luts.erf[i * 32u] : S.luts.erfinv[(i - 94u) * 32u];
-        cg_keep_f32(touch);
-    }
+    // (every slice workgroup of the split form repeats the scalar step and its two dependent table lookups; touching the tables' lines at
+    // entry, which paid in round 1, costs 0.7 % since the launch prologues were shortened and is gone)
     const bool multiWave = BS > 64u;
     const bool scalarLane = !multiWave || t < 64u;       // the per-proposal scalar math (LUTs, fp64 log) runs in wave 0 only
     const uint32_t slice = WHOLE ? 0u : vbid % slices;
