@@ -56,7 +56,7 @@ typedef struct cogaps_params {
     uint32_t fixedRows;
     uint32_t workerID;
     int32_t runningDistributed;
-    int32_t device;                /* HIP device ordinal, -1 = current */
+    int32_t device;                /* HIP device ordinal, -1 = the creating thread's current one (resolved at session creation; every later call on the session selects that GPU for its calling thread) */
     int (*interrupt)(void *);      /* polled once per iteration (GapsRunner.cpp:280); non-zero aborts */
     void *interruptArg;
     int32_t snapshotPhase;         /* 0 = all phases (GAPS_ALL_PHASES, the default of GapsParameters.h:98), 1 = equilibration, 2 = sampling */
