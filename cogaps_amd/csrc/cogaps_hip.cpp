@@ -24,6 +24,18 @@
 #ifndef GEN_WIN
 #define GEN_WIN 256
 #endif
+// A sampler whose batches are short takes half the window: every wave with live lanes costs a generator launch 0.4-0.9 us, a second
+// round of a batch that outgrows the window ~3.5 us (profiles/r02_ab_generator_window.txt: the headline shape's P sampler, ~94 attempts
+// per batch, is 0.75 us per launch faster with 128 lanes; its A sampler, ~157, needs the 256).  Any window gives the same batches.
+#define GEN_WIN_HALF (GEN_WIN / 2 >= 64 ? GEN_WIN / 2 : GEN_WIN)
+static uint32_t gen_window_for(uint32_t current, float stepsPerBatch)
+{
+    if (GEN_WIN_HALF == GEN_WIN || stepsPerBatch <= 1.f) return current;
+    if (current == (uint32_t)GEN_WIN && stepsPerBatch < 0.85f * (float)GEN_WIN_HALF) return (uint32_t)GEN_WIN_HALF;
+    if (current == (uint32_t)GEN_WIN_HALF && stepsPerBatch > 0.95f * (float)GEN_WIN_HALF) return (uint32_t)GEN_WIN;
+    return current;
+}
+
 
 static thread_local std::string g_last_error;
 static int fail(const std::string &m) { g_last_error = m; return 1; }
@@ -148,6 +160,7 @@ struct HostSampler {
     float avgQueue = 0.f;
     float dataSparsity = 0.f;     // DenseNormalModel::dataSparsity
     float stepsPerBatch = 0.f;
+    uint32_t genWin = GEN_WIN;    // lanes of the generator launch (gen_window_for)
     float anneal = 1.f;           // annealing temperature of the next update
     rt_graph graph;               // GRAPH_PAIRS (generate, evaluate) pairs, replayed while the kernel parameters stay the same
     SamplerDev graphKey; bool graphValid = false;    // proposals per batch in the last update (chunk-size predictor)
@@ -396,7 +409,8 @@ static void timing_resolve(cogaps_session *s, uint64_t realBatches)
 static void launch_gen(cogaps_session *s, HostSampler &h)
 {
     const int slot = timing_slot(s, h, 0, h.genLaunches);
-    LAUNCH_MAYBE_TIMED(slot, gen_kernel<GEN_WIN>, 1, GEN_WIN, h.d.lcgMul, h.d.lcgInc, h.d.gs, (const unsigned long long *)h.d.eraseList, (const uint32_t *)h.d.queueUnits, h.d.eraseCap, h.d.queueCap, h.d);
+    if (h.genWin == (uint32_t)GEN_WIN) LAUNCH_MAYBE_TIMED(slot, gen_kernel<GEN_WIN>, 1, GEN_WIN, h.d.lcgMul, h.d.lcgInc, h.d.gs, (const unsigned long long *)h.d.eraseList, (const uint32_t *)h.d.queueUnits, h.d.eraseCap, h.d.queueCap, h.d);
+    else LAUNCH_MAYBE_TIMED(slot, gen_kernel<GEN_WIN_HALF>, 1, GEN_WIN_HALF, h.d.lcgMul, h.d.lcgInc, h.d.gs, (const unsigned long long *)h.d.eraseList, (const uint32_t *)h.d.queueUnits, h.d.eraseCap, h.d.queueCap, h.d);
     h.genLaunches++;
 }
 static void launch_eval(cogaps_session *s, HostSampler &h)
@@ -516,6 +530,8 @@ static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool t
     }
     h.nAtoms = s->hGs->nAtoms; h.avgQueue = s->hGs->avgQueue; h.batches += s->hGs->nBatches;
     if (s->hGs->nBatches >= 8u) h.stepsPerBatch = (float)nSteps / (float)s->hGs->nBatches;
+    const uint32_t win = gen_window_for(h.genWin, h.stepsPerBatch);
+    if (win != h.genWin) { h.genWin = win; if (h.graphValid) { rt_graph_destroy(h.graph); h.graphValid = false; } }      // (the captured launches carry the window)
     return 0;
 }
 
@@ -887,6 +903,7 @@ struct cogaps_batch {
     bool timing = false; std::vector<rt_event_pair> ev; std::vector<int> evKind; std::vector<uint64_t> evOrd; size_t evUsed = 0;
     double genMs[2] = {0, 0}, evalMs[2] = {0, 0}; uint64_t genTimed[2] = {0, 0}, evalTimed[2] = {0, 0};
     uint64_t ord = 0;
+    uint32_t genWin[2] = {GEN_WIN, GEN_WIN};           // per side, from the chain with the longest batches
 };
 
 static HostSampler &bpick(cogaps_batch *b, uint32_t c, int w) { return w == 0 ? b->ss[c]->A : b->ss[c]->P; }
@@ -913,7 +930,8 @@ static void multi_launch_pair(cogaps_batch *b, int w, const MultiGeom &g, int sl
     const uint32_t C = (uint32_t)b->ss.size();
     const SamplerDev CG_CONSTANT *arr = (const SamplerDev CG_CONSTANT *)b->dev[w];
 #define MLAUNCH(slot, KERNEL, grid, block, ...) do { if ((slot) >= 0) RT_LAUNCH_TIMED(KERNEL, grid, block, b->stream, b->ev[slot], __VA_ARGS__); else RT_LAUNCH(KERNEL, grid, block, b->stream, __VA_ARGS__); } while (0)
-    MLAUNCH(slotGen, gen_kernel_multi<GEN_WIN>, C, GEN_WIN, arr);
+    if (b->genWin[w] == (uint32_t)GEN_WIN) MLAUNCH(slotGen, gen_kernel_multi<GEN_WIN>, C, GEN_WIN, arr);
+    else MLAUNCH(slotGen, gen_kernel_multi<GEN_WIN_HALF>, C, GEN_WIN_HALF, arr);
     if (b->sparse) MLAUNCH(slotEval, eval_sparse_kernel_multi, C * g.wgPerChain, g.block, arr, g.wgPerChain);
     else if (g.fused) MLAUNCH(slotEval, eval_kernel_multi<EVAL_FUSED>, C * g.wgPerChain, g.block, arr, 1u, g.wgPerChain);
     else {
@@ -1012,6 +1030,9 @@ static int run_update_multi(cogaps_batch *b, int w, const std::vector<uint32_t> 
         h.nAtoms = g.nAtoms; h.avgQueue = g.avgQueue; h.batches += g.nBatches;
         if (g.nBatches >= 8u) h.stepsPerBatch = (float)nSteps[c] / (float)g.nBatches;
     }
+    float spb = 0.f; for (uint32_t c = 0; c < C; ++c) spb = std::max(spb, bpick(b, c, w).stepsPerBatch);
+    const uint32_t win = gen_window_for(b->genWin[w], spb);
+    if (win != b->genWin[w]) { b->genWin[w] = win; if (b->graphValid[w]) { rt_graph_destroy(b->graph[w]); b->graphValid[w] = false; } }
     return 0;
 }
 
