@@ -332,8 +332,8 @@ def main():
         kernels = [
             kernel_line(ev_name(fusedA), "A", kt["A"]["evalMs"], kt["A"]["timedBatches"], kt["A"]["evalBytes"], kt["A"]["evalTimed"]),
             kernel_line(ev_name(fusedP), "P", kt["P"]["evalMs"], kt["P"]["timedBatches"], kt["P"]["evalBytes"], kt["P"]["evalTimed"]),
-            kernel_line("gen_kernel<256>", "A", kt["A"]["genMs"], kt["A"]["timedBatches"], 0, kt["A"]["genTimed"]),
-            kernel_line("gen_kernel<256>", "P", kt["P"]["genMs"], kt["P"]["timedBatches"], 0, kt["P"]["genTimed"]),
+            kernel_line("gen_kernel", "A", kt["A"]["genMs"], kt["A"]["timedBatches"], 0, kt["A"]["genTimed"]),
+            kernel_line("gen_kernel", "P", kt["P"]["genMs"], kt["P"]["timedBatches"], 0, kt["P"]["genTimed"]),
             kernel_line("sparse_tables_kernel (not timed)" if args.sparse else "transpose_kernel (sync)", "A+P", tot["syncMs"], tot["syncTimed"], tot["syncBytes"], tot["syncTimed"]),
         ]
         gen_ms = kt["A"]["genMs"] + kt["P"]["genMs"]

@@ -12,7 +12,9 @@ def per_kernel(d, counter):
     for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         for r in csv.DictReader(open(f)):
             if r['Counter_Name'] == counter:
-                rows[r['Kernel_Name'].split('(')[0]].append((int(r['Dispatch_Id']), float(r['Counter_Value'])))
+                name = r['Kernel_Name'].split('(')[0]
+                if 'gen_kernel<' in name: name = 'gen_kernel'          # (both window instantiations: one generator)
+                rows[name].append((int(r['Dispatch_Id']), float(r['Counter_Value'])))
     for v in rows.values():
         v.sort()
     return rows
@@ -22,7 +24,7 @@ fetch, write = per_kernel(sys.argv[1], 'FETCH_SIZE'), per_kernel(sys.argv[2], 'W
 bench = json.load(open(sys.argv[3]))
 ks = bench['roofline']['kernels']        # [evaluation A, evaluation P, generator A, generator P, sync]
 want = {'eval_kernel<0>': ks[0]['launches'], 'eval_kernel<1>': ks[1]['launches'], 'eval_kernel<2>': ks[1]['launches'],
-        'gen_kernel<256>': ks[2]['launches'] + ks[3]['launches']}
+        'gen_kernel': ks[2]['launches'] + ks[3]['launches']}
 out = {}
 for name, n in want.items():
     fk = [k for k in fetch if name in k]; wk = [k for k in write if name in k]
