@@ -201,6 +201,23 @@ def chains_main(args):
         s.close()
 
 
+def self_launch(n):
+    """plain `python bench.py --gpus N`: start the N ranks the way the driver does and pass their exit code on"""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL across processes needs dmabuf IPC on this driver
+    rc = subprocess.call(cmd, env=env)
+    if rc:
+        raise SystemExit("bench.py --gpus %d: the %d-rank launch failed (exit code %d); no line was printed for fewer ranks" % (n, n, rc))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -223,19 +240,31 @@ def main():
     if args.chains > 1:
         return chains_main(args)
 
+    # `--gpus N` is a promise about the line that gets printed: N ranks, one per GPU.  Launched by torch.distributed.run (the
+    # driver's form) the environment carries the world; launched as plain `python bench.py --gpus N` the script starts the N
+    # ranks itself (the same launcher, 127.0.0.1 rendezvous on a free port) and hands over -- it never measures one GPU and
+    # calls it N.
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or plain `python bench.py --gpus %d`, which starts its own ranks)"
+                         % (args.gpus, world, args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
     # test hook: COGAPS_BENCH_BACKEND=gloo lets the ranks of a multi-process run share the GPUs that exist (collectives on
     # host tensors), so the N > 1 code path can be exercised on a one-GPU box; the driver's runs use RCCL ("nccl")
     backend = os.environ.get("COGAPS_BENCH_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and n_dev < world:
+        raise SystemExit("--gpus %d needs %d GPUs on this node, %d visible: refusing to run (one rank per GPU over RCCL; nothing is measured on fewer)" % (args.gpus, world, n_dev))
     if backend != "nccl":
-        local_rank %= torch.cuda.device_count()
+        local_rank %= n_dev
     comm_dev = "cuda" if backend == "nccl" else "cpu"
     torch.cuda.set_device(local_rank)
     dist = None
@@ -245,6 +274,8 @@ def main():
             dist.init_process_group(backend="nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend, init_method="env://")
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("--gpus %d but the process group has %d ranks" % (args.gpus, dist.get_world_size()))
 
     from cogaps_amd import _capi
 
@@ -258,6 +289,7 @@ def main():
         data *= (np.random.Generator(np.random.MT19937(777 + rank)).random(data.shape) >= 0.95)
     params = dict(nPatterns=args.patterns, nIterations=n_iter, seed=42, outputFrequency=max(1, n_iter // 10), sparseOptimization=args.sparse)
     S = _capi.Session(data, device=local_rank, **params)
+    shared_factor = "A" if args.sparse else "P"
 
     def run_steps(first, n):
         done, upd = 0, 0
@@ -287,8 +319,10 @@ def main():
     t0 = time.perf_counter()
     updates = run_steps(burn + W, K)
     if dist is not None:
-        # the one exchange of the GWCoGAPS path: all-gather of the shared-dimension factor
-        fac = torch.from_numpy(S.matrix("P")).to(comm_dev)
+        # the one exchange of the path: all-gather of the factor the subsets SHARE before findConsensusMatrix -- GWCoGAPS
+        # (gene-wise subsets, the dense line) shares the sample factor P, scCoGAPS (cell-wise subsets, --sparse) the gene
+        # factor A (reference R/DistributedCogaps.R:71-78)
+        fac = torch.from_numpy(S.matrix(shared_factor)).to(comm_dev)
         gathered = [torch.empty_like(fac) for _ in range(world)]
         dist.all_gather(gathered, fac)
     torch.cuda.synchronize()
@@ -365,9 +399,14 @@ def main():
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * max_dt / K,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("synthetic sparse %dx%d fp32 per GPU (95 %% zeros), sparseOptimization, nPatterns=%d, asynchronous sampler, seed 42 (cf. BASELINE configs[4]%s)"
-                                    if args.sparse else "synthetic dense %dx%d fp32 per GPU, nPatterns=%d, asynchronous sampler, seed 42 (BASELINE configs[2]%s)")
-                                   % (args.genes, args.samples, args.patterns, "; GWCoGAPS nSets=%d gene-wise shards, configs[3]" % world if world > 1 else ""),
+            "config": {"workload": ("synthetic sparse %dx%d fp32 per GPU (95 %% zeros), sparseOptimization, nPatterns=%d, asynchronous sampler, seed 42 (%s%s)"
+                                    if args.sparse else "synthetic dense %dx%d fp32 per GPU, nPatterns=%d, asynchronous sampler, seed 42 (%s%s)")
+                                   % (args.genes, args.samples, args.patterns,
+                                      (("one cell-wise shard of BASELINE configs[4]: 50000 genes x 12500 of the 100000 cells" if (args.genes, args.samples) == (50000, 12500)
+                                        else "the SparseNormalModel on a configs[2]-sized product; BASELINE configs[4]'s shard is --genes 50000 --samples 12500") if args.sparse
+                                       else ("BASELINE configs[2]" if (args.genes, args.samples, args.patterns) == (20000, 2000, 50) else "not a BASELINE shape")),
+                                      ("; scCoGAPS nSets=%d cell-wise shards, one per GPU" % world if args.sparse else "; GWCoGAPS nSets=%d gene-wise shards, configs[3]" % world) if world > 1 else ""),
+                       "ranks": world, "collective_backend": (backend if dist is not None else None), "shared_factor_gathered": (shared_factor if dist is not None else None),
                        "nIterations": n_iter, "untimed_schedule_steps_before_warmup": burn, "proposals_timed": int(tot_updates), "batches_rank0": int(batches),
                        "avg_queue_A": S.avg_queue("A"), "avg_queue_P": S.avg_queue("P"),
                        "atoms_A": S.natoms("A"), "atoms_P": S.natoms("P"),

@@ -77,7 +77,7 @@ EXPORTS = [
     "cogaps_session_get_atoms", "cogaps_session_dims", "cogaps_session_avg_queue",
     "cogaps_session_finish", "cogaps_session_set_timing", "cogaps_session_perf",
     "cogaps_session_perf_sampler", "cogaps_session_get_rows", "cogaps_sparse_width", "cogaps_reduction_width", "cogaps_session_debug_prof", "cogaps_session_debug_replay",
-    "cogaps_run_from_file", "cogaps_read_matrix_file", "cogaps_matrix_free", "cogaps_file_info", "cogaps_debug_math", "cogaps_current_device", "cogaps_device_memory",
+    "cogaps_run_from_file", "cogaps_read_matrix_file", "cogaps_read_matrix_file_subset", "cogaps_matrix_free", "cogaps_file_info", "cogaps_debug_math", "cogaps_current_device", "cogaps_device_memory",
     "cogaps_session_debug_check_domain", "cogaps_batch_create", "cogaps_batch_destroy", "cogaps_batch_run_iterations", "cogaps_batch_set_timing", "cogaps_batch_perf",
 ]
 
@@ -128,6 +128,7 @@ def bind(L):
     L.cogaps_reduction_width.argtypes = [C.c_uint32]
     L.cogaps_run_from_file.argtypes = [C.c_char_p, C.POINTER(CogapsParamsC), C.c_char_p, C.POINTER(CogapsResultC)]
     L.cogaps_read_matrix_file.argtypes = [C.c_char_p, u32p, u32p, C.POINTER(fp)]
+    L.cogaps_read_matrix_file_subset.argtypes = [C.c_char_p, C.c_int, u32p, C.c_uint32, u32p, u32p, C.POINTER(fp)]
     L.cogaps_matrix_free.argtypes = [fp]
     L.cogaps_matrix_free.restype = None
     L.cogaps_file_info.argtypes = [C.c_char_p, u32p, u32p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -162,10 +163,15 @@ def load():
         # imported first the loader resolves this library's dependencies to the copies torch uses, so the front-end (device
         # tensors, torch.distributed over RCCL) and the sampler share one runtime.  Without PyTorch (a plain C / R client) the
         # library runs on the ROCm installation's runtime alone.
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
+        # COGAPS_NO_TORCH=1 skips this (a Python client that never uses torch saves the import and stays on the ROCm installation's
+        # runtime; it must then not import torch later in the same process).  A PyTorch that is not a ROCm build (CPU-only, CUDA)
+        # bundles no HIP runtime: nothing to share, the library resolves against /opt/rocm as it would without PyTorch.
+        import sys
+        if "torch" in sys.modules or os.environ.get("COGAPS_NO_TORCH", "") in ("", "0"):
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         _lib = bind(C.CDLL(LIB_PATH))
     return _lib
 
@@ -398,11 +404,20 @@ class Session:
         return result_to_dict(self.L, r)
 
 
-def read_matrix_file(path, lib=None):
-    """The library's own reader (csrc/file_reader.h): the file as a dense fp32 matrix.  Host only."""
+def read_matrix_file(path, lib=None, rows=None, cols=None):
+    """The library's own reader (csrc/file_reader.h): the file as a dense fp32 matrix.  Host only.  rows / cols (one of them): 1-based
+    indices of the rows / columns to keep -- only that part of the file is materialised, in SORTED index order, as the reference's
+    workers read their subset of a file (Matrix.cpp:70-134)."""
     L = lib or load()
     nr, nc, ptr = C.c_uint32(), C.c_uint32(), C.POINTER(C.c_float)()
-    if L.cogaps_read_matrix_file(os.fsencode(path), C.byref(nr), C.byref(nc), C.byref(ptr)):
+    if rows is not None and cols is not None:
+        raise ValueError("rows or cols, not both")
+    if rows is None and cols is None:
+        rc = L.cogaps_read_matrix_file(os.fsencode(path), C.byref(nr), C.byref(nc), C.byref(ptr))
+    else:
+        idx = np.ascontiguousarray(rows if rows is not None else cols, dtype=np.uint32)
+        rc = L.cogaps_read_matrix_file_subset(os.fsencode(path), int(rows is not None), idx.ctypes.data_as(C.POINTER(C.c_uint32)), idx.size, C.byref(nr), C.byref(nc), C.byref(ptr))
+    if rc:
         raise RuntimeError(L.cogaps_last_error().decode())
     try:
         return np.ctypeslib.as_array(ptr, shape=(nr.value, nc.value)).copy() if nr.value * nc.value else np.zeros((nr.value, nc.value), np.float32)
@@ -517,14 +532,22 @@ class Batch:
 
 def run_batch(datas, uncs=None, lib=None, kws=None, **common):
     """cogaps_run for several chains at once through the batched launches: datas[i] with the keyword arguments kws[i] (merged over
-    `common`).  All chains need the same nIterations.  Returns the result dicts in order."""
+    `common`) -- or ONE iterable of (data, uncertainty, keyword arguments) triples, consumed one at a time: a chain's host matrices
+    are released as soon as its session holds them in HBM.  All chains need the same nIterations.  Returns the result dicts in order."""
     L = lib if lib is not None else load()
-    kws = kws or [{} for _ in datas]
-    uncs = uncs or [None] * len(datas)
+    if uncs is None and kws is None and not isinstance(datas, (list, tuple)):
+        triples = datas
+    else:
+        kws = kws or [{} for _ in datas]
+        uncs = uncs or [None] * len(datas)
+        triples = zip(datas, uncs, kws)
     ss, b = [], None
     try:
-        for d, u, k in zip(datas, uncs, kws):
-            ss.append(Session(d, unc=u, lib=L, **dict(common, **k)))
+        for d, u, k in triples:
+            s_ = Session(d, unc=u, lib=L, **dict(common, **k))
+            s_.d = s_.u = None                # the library copied them at creation (cogaps_session_create)
+            ss.append(s_)
+            del d, u
         n_iter = {int(s.p.nIterations) for s in ss}
         if len(n_iter) != 1:
             raise ValueError("the chains of a batch need the same nIterations")

@@ -29,15 +29,39 @@ CG_KERNEL void transpose_kernel(const float *src, float *dst, uint32_t srcM, uin
     transpose_body(src, dst, srcM, srcN, srcNpad, dstNpad, tilesX);
 }
 
-// DenseNormalModel::extraInitialization (DenseNormalModel.cpp:38-54): AP(i,j) = sum_k other(i,k)*mat(j,k), k ascending
-CG_KERNEL void init_ap_kernel(SamplerDev S)
+// DenseNormalModel::extraInitialization (DenseNormalModel.cpp:38-54): AP(i,j) = sum_k other(i,k)*mat(j,k), k ascending, one
+// accumulator per entry starting from +0.  The one dense contraction of the path, run once per session (and it only ever multiplies
+// by an all-zero factor: at most one of the two matrices is given, GapsRunner.cpp:329-350 -- the host skips the launch when neither
+// is).  Tiled: a workgroup owns 256 consecutive elements i x INIT_JT vectors j; thread = element i (coalesced loads of other and
+// stores of AP), INIT_JT accumulators in registers, the matrix tile [k][j] staged through LDS INIT_KT patterns at a time and read
+// back as broadcasts.  Same products, same order per entry as the triple loop.
+#define INIT_JT 32
+#define INIT_KT 32
+CG_KERNEL void CG_LAUNCH_BOUNDS(256) init_ap_kernel(SamplerDev S, uint32_t tilesI)
 {
-    const uint32_t i = cg_bid() * cg_bdim() + cg_tid();   // element within the vector
-    if (i >= S.N) return;
-    for (uint32_t j = 0; j < S.M; ++j) {
-        float acc = 0.f;
-        for (uint32_t k = 0; k < S.K; ++k) acc = acc + S.other[(size_t)k * S.Npad + i] * S.mat[(size_t)k * S.Mpad + j];
-        S.AP[(size_t)j * S.Npad + i] = acc;
+    CG_SHARED float mt[INIT_KT][INIT_JT];
+    const uint32_t t = cg_tid();
+    const uint32_t i = (cg_bid() % tilesI) * 256u + t, j0 = (cg_bid() / tilesI) * (uint32_t)INIT_JT;
+    float acc[INIT_JT];
+#pragma unroll
+    for (int jj = 0; jj < INIT_JT; ++jj) acc[jj] = 0.f;
+    for (uint32_t k0 = 0; k0 < S.K; k0 += INIT_KT) {
+        cg_sync();
+        for (uint32_t e = t; e < (uint32_t)(INIT_KT * INIT_JT); e += 256u) {
+            const uint32_t k = k0 + e / (uint32_t)INIT_JT, j = j0 + e % (uint32_t)INIT_JT;
+            mt[e / (uint32_t)INIT_JT][e % (uint32_t)INIT_JT] = (k < S.K && j < S.M) ? S.mat[(size_t)k * S.Mpad + j] : 0.f;
+        }
+        cg_sync();
+        const uint32_t kn = (S.K - k0) < (uint32_t)INIT_KT ? (S.K - k0) : (uint32_t)INIT_KT;
+        for (uint32_t kk = 0; kk < kn; ++kk) {
+            const float o = (i < S.N) ? S.other[(size_t)(k0 + kk) * S.Npad + i] : 0.f;
+#pragma unroll
+            for (int jj = 0; jj < INIT_JT; ++jj) acc[jj] = acc[jj] + o * mt[kk][jj];
+        }
+    }
+    if (i < S.N) {
+#pragma unroll
+        for (int jj = 0; jj < INIT_JT; ++jj) if (j0 + (uint32_t)jj < S.M) S.AP[(size_t)(j0 + (uint32_t)jj) * S.Npad + i] = acc[jj];
     }
 }
 

@@ -714,9 +714,13 @@ cogaps_session *cogaps_session_create(const float *data, uint32_t nrow, uint32_t
         s->runnerRng = pcg_from_seed(s->seeder.next());
         // ASampler.sync(PSampler); PSampler.sync(ASampler); extraInitialization x2 (GapsRunner.cpp:444-447)
         if (p.useSparseOptimization) { do_sync(s, s->A, s->P); do_sync(s, s->P, s->A); }     // the lookup tables; extraInitialization is a no-op (SparseNormalModel.cpp:34-37)
-        else {
-            RT_LAUNCH(init_ap_kernel, (s->A.d.N + 255) / 256, 256, s->stream, s->A.d);
-            RT_LAUNCH(init_ap_kernel, (s->P.d.N + 255) / 256, 256, s->stream, s->P.d);
+        else if (p.whichMatrixFixed != 'N') {
+            // (no fixed matrix: both factors are all zero and AP = 0 is what the allocation holds -- 0.11 s of multiplying zeros per
+            // session at the headline shape otherwise)
+            for (HostSampler *h : {&s->A, &s->P}) {
+                const uint32_t tilesI = (h->d.N + 255u) / 256u, tilesJ = (h->d.M + (uint32_t)INIT_JT - 1u) / (uint32_t)INIT_JT;
+                RT_LAUNCH(init_ap_kernel, tilesI * tilesJ, 256, s->stream, h->d, tilesI);
+            }
         }
         rt_sync(s->stream);
         if (p.printMessages) {                                                   // GapsRunner.cpp:412-426
@@ -1387,16 +1391,30 @@ int cogaps_run(const float *data, uint32_t nrow, uint32_t ncol, const cogaps_par
 }
 
 // ---- the file entry point (gaps::run(const std::string&...), GapsRunner.h:24-29; cogaps_from_file_cpp, Cogaps.cpp:217-227) ----
+static int table_out(const cgio::Table &t, uint32_t *nrow, uint32_t *ncol, float **data)
+{
+    float *v = (float *)malloc(std::max<size_t>(1, t.v.size()) * sizeof(float));
+    if (!v) return fail("out of memory");
+    memcpy(v, t.v.data(), t.v.size() * sizeof(float));
+    *nrow = t.nrow; *ncol = t.ncol; *data = v;
+    return 0;
+}
 int cogaps_read_matrix_file(const char *path, uint32_t *nrow, uint32_t *ncol, float **data)
 {
     try {
         if (!path || !nrow || !ncol || !data) return fail("null argument");
-        cgio::Table t = cgio::read_matrix_file(path);
-        float *v = (float *)malloc(std::max<size_t>(1, t.v.size()) * sizeof(float));
-        if (!v) return fail("out of memory");
-        memcpy(v, t.v.data(), t.v.size() * sizeof(float));
-        *nrow = t.nrow; *ncol = t.ncol; *data = v;
-        return 0;
+        return table_out(cgio::read_matrix_file(path), nrow, ncol, data);
+    } catch (const std::exception &e) { return fail(e.what()); }
+}
+// the rows (byRows != 0) or columns of the file named by the 1-based `indices`, as the reference's workers read their subset of a
+// file (Matrix(path, genesInCols, subsetGenes, indices), data_structures/Matrix.cpp:70-134: sorted indices, lower_bound placement);
+// the rest of the matrix is never materialised
+int cogaps_read_matrix_file_subset(const char *path, int byRows, const uint32_t *indices, uint32_t nIndices, uint32_t *nrow, uint32_t *ncol, float **data)
+{
+    try {
+        if (!path || !nrow || !ncol || !data || !indices || nIndices == 0) return fail("null argument or empty subset");
+        cgio::ReadOpts o; o.sub = cgio::Subset(byRows != 0, indices, nIndices);
+        return table_out(cgio::read_matrix_file(path, o), nrow, ncol, data);
     } catch (const std::exception &e) { return fail(e.what()); }
 }
 
@@ -1409,7 +1427,8 @@ int cogaps_file_info(const char *path, uint32_t *nrow, uint32_t *ncol, char *row
 {
     try {
         if (!path || !nrow || !ncol) return fail("null argument");
-        cgio::Table t = cgio::read_matrix_file(path);
+        cgio::ReadOpts o; o.values = false;                      // dimensions and names: no value is parsed, no matrix is built
+        cgio::Table t = cgio::read_matrix_file(path, o);
         *nrow = t.nrow; *ncol = t.ncol;
         auto join = [](const std::vector<std::string> &v, char *out, size_t cap, size_t *needed) {
             std::string s; for (size_t i = 0; i < v.size(); ++i) { if (i) s += '\n'; s += v[i]; }
@@ -1425,13 +1444,21 @@ int cogaps_run_from_file(const char *dataPath, const cogaps_params *params, cons
 {
     try {
         if (!dataPath || !params || !out) return fail("null argument");
-        cgio::Table d = cgio::read_matrix_file(dataPath), u;
+        // A worker of a distributed run reads ITS subset of the file (Matrix.cpp:70-134): the rows or columns the indices name, in
+        // sorted order -- never the whole matrix.  The run then sees an ordinary matrix with no subset left to take.
+        cgio::ReadOpts o; cogaps_params p = *params;
+        if (p.subsetData && p.dataIndicesSubset && p.nSubset) {
+            const bool byRows = (p.subsetGenes != 0) == (p.transposeData == 0);      // genes are the file's rows unless transposeData
+            o.sub = cgio::Subset(byRows, p.dataIndicesSubset, p.nSubset);
+            p.subsetData = 0; p.dataIndicesSubset = nullptr; p.nSubset = 0;
+        }
+        cgio::Table d = cgio::read_matrix_file(dataPath, o), u;
         const bool haveUnc = uncertaintyPath && uncertaintyPath[0];
         if (haveUnc) {
-            u = cgio::read_matrix_file(uncertaintyPath);
-            if (u.nrow != d.nrow || u.ncol != d.ncol) return fail("uncertainty matrix has different dimensions than the data");
+            u = cgio::read_matrix_file(uncertaintyPath, o);
+            if (u.nrow != d.nrow || u.ncol != d.ncol || u.fileRows != d.fileRows || u.fileCols != d.fileCols) return fail("uncertainty matrix has different dimensions than the data");
         }
-        return cogaps_run(d.v.data(), d.nrow, d.ncol, params, haveUnc ? u.v.data() : nullptr, out);
+        return cogaps_run(d.v.data(), d.nrow, d.ncol, &p, haveUnc ? u.v.data() : nullptr, out);
     } catch (const std::exception &e) { return fail(e.what()); }
 }
 

@@ -226,69 +226,146 @@ def _current_device(run_fn):
     return 0
 
 
-def _run_shards(spec, ids, in_flight, run_fn):
-    """This rank's shards, `in_flight` at a time (the role of BPPARAM's workers, DistributedCogaps.R:60-63, 84-87).  spec(i) gives
-    (data, uncertainty, keyword arguments) of shard i's cogaps_run call.
+def _launch_shape(n_genes, n_samples, sparse):
+    """what cogaps_batch_create requires the chains of a batch to share (cogaps_hip.cpp): the reduction widths and slice counts of the
+    two samplers' data vectors (A: samples long, P: genes long), the sparse model's workgroup widths"""
+    L = _capi.load()
+    key = []
+    for n in (n_samples, n_genes):
+        npad = (n + 3) & ~3
+        key += [L.cogaps_reduction_width(n), ((npad >> 2) + 511) // 512, L.cogaps_sparse_width(n) if sparse else 0]
+    return tuple(key)
 
-    With the product library the shards in flight run as ONE batch (cogaps_batch_*, batched multi-chain launches: one generator
+
+def _run_shards(spec, ids, in_flight, run_fn, shape_of=None):
+    """This rank's shards, `in_flight` at a time (the role of BPPARAM's workers, DistributedCogaps.R:60-63, 84-87).  spec(i) gives
+    (data, uncertainty, keyword arguments) of shard i's cogaps_run call -- it is called when the shard's turn comes and its matrices
+    are dropped as soon as the shard's session holds them in HBM, so the host never keeps more than one group's shards;
+    shape_of(i) = (genes, samples, sparse, has uncertainty) of the shard without loading it.
+
+    With the product library the shards in flight run as batches (cogaps_batch_*, batched multi-chain launches: one generator
     launch with a workgroup per chain and one evaluation launch over all chains' queues per step) -- a single chain keeps one
     workgroup busy in its generator kernel and a few hundred in its evaluation kernel, alternately, so the chains of a batch cost
-    about the time of one; from four shards on they run as two such batches on two host threads.  Shards whose evaluation launch shapes differ (very uneven subsets), or another run_fn (tests), fall back
-    to one host thread, one stream and one session per shard in flight.  Either way every shard's chain is bit-identical to the
-    chain it runs alone."""
+    about the time of one; from four shards on they run as two such batches on two host threads.  A batch needs one evaluation launch
+    shape: the shards are grouped by it up front (`_launch_shape`; very uneven subsets give several groups, a group of one runs as
+    a plain session), nothing is decided by parsing error messages.  A group that does not fit the GPU's memory after all is retried
+    with half as many shards in flight; finished shards are kept.  Another run_fn (tests) runs one host thread per shard in flight.
+    Either way every shard's chain is bit-identical to the chain it runs alone."""
     ids = list(ids)
+
+    def one(i):
+        d, u, k = spec(i)
+        return run_fn(d, unc=u, **k)
     if in_flight <= 1 or len(ids) <= 1:
-        return {i: run_fn(spec(i)[0], unc=spec(i)[1], **spec(i)[2]) for i in ids}
-    if run_fn is _capi.run:
+        return {i: one(i) for i in ids}
+    if run_fn is _capi.run and shape_of is not None:
         out = {}
         # no more shards in flight than the GPU holds: a session keeps ~9 matrices of its shard's size resident (data, A*P cache,
-        # uncertainty, for both samplers; DESIGN.md section 3) -- counted as 10 (13 with an uncertainty matrix) against 85 % of the free HBM
-        d0, u0, k0 = spec(ids[0])
-        per_shard = (13 if u0 is not None else 10) * 4 * int(np.asarray(d0).size) + (64 << 20)
-        free_bytes, _ = _capi.device_memory(k0.get("device", -1))
+        # uncertainty, for both samplers; DESIGN.md section 3) -- counted as 10 (13 with an uncertainty matrix) against 85 % of the free
+        # HBM; the sparse model keeps the dense data and uncertainty for meanChiSq plus the packed vectors: counted as 5
+        g0_, s0_, sparse0, unc0 = shape_of(ids[0])
+        per_shard = (5 if sparse0 else (13 if unc0 else 10)) * 4 * max(g_ * s_ for g_, s_, _, _ in (shape_of(i) for i in ids)) + (64 << 20)
+        device = spec.device if hasattr(spec, "device") else -1
+        free_bytes, _ = _capi.device_memory(device)
         in_flight = max(1, min(in_flight, int(0.85 * free_bytes // per_shard)))
-        if in_flight == 1:
-            return {i: run_fn(spec(i)[0], unc=spec(i)[1], **spec(i)[2]) for i in ids}
+        by_shape = {}
+        for i in ids:
+            g_, s_, sp_, _ = shape_of(i)
+            by_shape.setdefault(_launch_shape(g_, s_, sp_), []).append(i)
 
         def batch(grp):
-            sp = [spec(i) for i in grp]
             if len(grp) == 1:
-                return [run_fn(sp[0][0], unc=sp[0][1], **sp[0][2])]
-            return _capi.run_batch([x[0] for x in sp], uncs=[x[1] for x in sp], kws=[x[2] for x in sp])
-        try:
-            for g0 in range(0, len(ids), in_flight):
-                grp = ids[g0:g0 + in_flight]
+                return [one(grp[0])]
+            return _capi.run_batch((spec(i) for i in grp))
+        for members in by_shape.values():
+            g0 = 0
+            while g0 < len(members):
+                grp = members[g0:g0 + in_flight]
                 # Two batches on two host threads and streams once there are chains enough: one batch's generator launch (one
                 # workgroup per chain, the latency-bound step) then runs under the other's evaluation launches.  Measured with the C3
                 # shape (DESIGN.md section 5): 8 chains 21.2 -> 23.3 M proposals/s, 16 chains 29.0 -> 34.4 M, 32 chains 35.7 -> 44.0 M.
                 halves = [grp[0::2], grp[1::2]] if len(grp) >= 4 else [grp]
-                if len(halves) == 1:
-                    res = [batch(grp)]
-                else:
-                    from concurrent.futures import ThreadPoolExecutor
-                    with ThreadPoolExecutor(max_workers=2) as pool:
-                        res = list(pool.map(batch, halves))
+                try:
+                    if len(halves) == 1:
+                        res = [batch(grp)]
+                    else:
+                        from concurrent.futures import ThreadPoolExecutor
+                        with ThreadPoolExecutor(max_workers=2) as pool:
+                            res = list(pool.map(batch, halves))
+                except RuntimeError as e:
+                    if "out of memory" in str(e).lower() and in_flight > 1:      # hipErrorOutOfMemory: the footprint estimate was too low
+                        in_flight = max(1, in_flight // 2)
+                        continue
+                    raise
                 for h, rr in zip(halves, res):
                     for i, r in zip(h, rr):
                         out[i] = r
-            return out
-        except RuntimeError as e:
-            if "launch shape" not in str(e):
-                raise
+                g0 += len(grp)
+        return out
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=min(in_flight, 4)) as pool:       # (HIP gives a process four hardware queues: DESIGN.md section 5)
-        futs = {i: pool.submit(lambda j=i: run_fn(spec(j)[0], unc=spec(j)[1], **spec(j)[2])) for i in ids}
+        futs = {i: pool.submit(one, i) for i in ids}
         return {i: f.result() for i, f in futs.items()}
 
 
+class _Source:
+    """Where the shards of a distributed run come from.  `data` is
+      * a 2-D array: shard i = its rows / columns sets[i] (in the order given, Matrix(mat, ...), Matrix.cpp:30-69);
+      * a path to a .mtx / .csv / .tsv / .gct file: every rank reads only ITS shards' rows / columns of the file with the library's
+        reader (cogaps_read_matrix_file_subset) -- as the reference's workers do (Matrix(path, ...), Matrix.cpp:70-134), which sorts
+        the indices first: the sets are sorted to match;
+      * a callable loader(i, indices) -> matrix or (matrix, uncertainty): shard i's own contiguous sub-matrix for the 1-based
+        `indices` (rows of the data when the partitioned dimension is the rows, else columns), with `shape` = dimensions of the whole.
+    No rank ever materialises the whole matrix unless the caller hands it over as an array."""
+
+    def __init__(self, data, uncertainty, shape, subset_rows):
+        self.data, self.unc, self.subset_rows = data, uncertainty, subset_rows
+        self.kind = "path" if isinstance(data, (str, bytes)) else ("loader" if callable(data) else "array")
+        if self.kind == "array":
+            self.shape = tuple(data.shape)
+        elif self.kind == "path":
+            nr, nc, self.row_names, self.col_names = _capi.file_info(data)
+            self.shape = (nr, nc)
+            if uncertainty is not None and not isinstance(uncertainty, (str, bytes)):
+                raise ValueError("data given as a file needs the uncertainty as a file, too")
+        else:
+            if shape is None:
+                raise ValueError("a shard loader needs shape=(rows, columns) of the whole data matrix")
+            if uncertainty is not None:
+                raise ValueError("a shard loader returns (matrix, uncertainty) itself")
+            self.shape = (int(shape[0]), int(shape[1]))
+
+    def has_unc(self):
+        return self.unc is not None
+
+    def shard(self, i, idx1):
+        if self.kind == "array":
+            idx = idx1 - 1
+            cut = (lambda m: np.ascontiguousarray(m[idx, :] if self.subset_rows else m[:, idx], dtype=np.float32))
+            return cut(self.data), (None if self.unc is None else cut(self.unc))
+        if self.kind == "path":
+            kw = {"rows": idx1} if self.subset_rows else {"cols": idx1}
+            return _capi.read_matrix_file(self.data, **kw), (None if self.unc is None else _capi.read_matrix_file(self.unc, **kw))
+        r = self.data(i, idx1)
+        d, u = r if isinstance(r, tuple) else (r, None)
+        d = np.ascontiguousarray(d, dtype=np.float32)
+        want = (len(idx1), self.shape[1]) if self.subset_rows else (self.shape[0], len(idx1))
+        if d.shape != want:
+            raise ValueError("the shard loader returned %s for shard %d, expected %s" % (d.shape, i, want))
+        return d, (None if u is None else np.ascontiguousarray(u, dtype=np.float32))
+
+
 def distributedCogaps(data, params, uncertainty=None, messages=False, outputFrequency=1000, transposeData=False,
-                      device=-1, run_fn=None, comm_device=None, shardsInFlight=16, nSnapshots=0, snapshotPhase="sampling"):
+                      device=-1, run_fn=None, comm_device=None, shardsInFlight=16, nSnapshots=0, snapshotPhase="sampling", shape=None):
     run_fn = run_fn or _capi.run
     shardsInFlight = max(1, int(shardsInFlight))
     genome_wide = params.distributed == "genome-wide"
     subset_rows = bool(transposeData) != genome_wide          # xor, SubsetData.R:87-88
-    total = data.shape[0] if subset_rows else data.shape[1]
+    src = _Source(data, uncertainty, shape, subset_rows)
+    total = src.shape[0] if subset_rows else src.shape[1]
     sets = create_sets(total, params, params.geneNames if genome_wide else params.sampleNames)
+    if src.kind == "path":
+        sets = [np.sort(st) for st in sets]                    # Matrix.cpp:113: a worker reading a file sorts its indices
     if min(len(s) for s in sets) < params.nPatterns:
         raise ValueError("data subset dimension less than nPatterns")
     dist = _dist()
@@ -310,25 +387,25 @@ def distributedCogaps(data, params, uncertainty=None, messages=False, outputFreq
                   transposeData=transposeData, sparseOptimization=params.sparseOptimization, device=device,
                   takePumpSamples=params.takePumpSamples, nSnapshots=nSnapshots, snapshotPhase=snapshotPhase)      # allParams reaches every worker unchanged (:12-35)
 
-    shard_cache = {}
+    def shape_of(i):
+        """(genes, samples, sparse model, uncertainty given) of shard i, from the index sets alone"""
+        r, c = (len(sets[i]), src.shape[1]) if subset_rows else (src.shape[0], len(sets[i]))
+        g_, s_ = (c, r) if transposeData else (r, c)
+        return g_, s_, bool(params.sparseOptimization), src.has_unc()
 
-    def shard(i):
-        """rows (columns) sets[i] of the data / uncertainty as their own contiguous matrices: the library then holds and uploads
-        one shard, never the whole matrix (Matrix(mat, genesInCols, subsetGenes, indices), Matrix.cpp:30-69, picks exactly these)"""
-        if i not in shard_cache:
-            idx = sets[i] - 1
-            cut = (lambda m: np.ascontiguousarray(m[idx, :] if subset_rows else m[:, idx], dtype=np.float32))
-            shard_cache[i] = (cut(data), None if uncertainty is None else cut(uncertainty))
-        return shard_cache[i]
-
-    def spec(i, n_patterns, fixed=None, which="N"):            # callInternalCoGAPS, DistributedCogaps.R:12-35
-        d, u = shard(i)
-        return d, u, dict(nPatterns=n_patterns, runningDistributed=True, workerID=i + 1, messages=messages, whichMatrixFixed=which,
-                          fixedPatterns=fixed, **common)
+    def make_spec(n_patterns, fixed=None, which="N"):          # callInternalCoGAPS, DistributedCogaps.R:12-35
+        def spec(i):
+            # rows (columns) sets[i] of the data / uncertainty as their own contiguous matrices, cut (or read, or loaded) when the
+            # shard's turn comes: the library then holds and uploads one shard, never the whole matrix
+            d, u = src.shard(i, sets[i])
+            return d, u, dict(nPatterns=n_patterns, runningDistributed=True, workerID=i + 1, messages=messages, whichMatrixFixed=which,
+                              fixedPatterns=fixed, **common)
+        spec.device = device
+        return spec
 
     initial, unmatched, matched = None, None, None
     if params.fixedPatterns is None:
-        initial = _run_shards(lambda i: spec(i, params.nPatterns), mine, shardsInFlight, run_fn)
+        initial = _run_shards(make_spec(params.nPatterns), mine, shardsInFlight, run_fn, shape_of)
         key = "Pmean" if genome_wide else "Amean"
         local = {i: initial[i][key] for i in mine}
         if dist is not None:
@@ -337,16 +414,26 @@ def distributedCogaps(data, params, uncertainty=None, messages=False, outputFreq
         else:
             unmatched = [local[i] for i in range(len(sets))]
         matched = find_consensus_matrix(unmatched, params)
+        if dist is not None:
+            # the consensus is computed redundantly on every rank from the gathered patterns: the second pass is only meaningful
+            # if all ranks hold the same bits -- checked, not assumed
+            import hashlib
+            import torch
+            dig = np.frombuffer(hashlib.sha256(np.ascontiguousarray(matched["consensus"]).tobytes()).digest()[:8], dtype=np.int64).copy()
+            mine_t = torch.from_numpy(dig).to(comm_device)
+            every = [torch.empty_like(mine_t) for _ in range(world)]
+            dist.all_gather(every, mine_t)
+            if any(int(t.item()) != int(dig[0]) for t in every):
+                raise RuntimeError("the ranks computed different consensus matrices from the same gathered patterns")
     else:
         matched = {"consensus": np.asarray(params.fixedPatterns, dtype=np.float32), "clusteredPatterns": None}
 
     consensus = matched["consensus"]
     which = "P" if genome_wide else "A"
-    final = _run_shards(lambda i: spec(i, consensus.shape[1], fixed=consensus, which=which), mine, shardsInFlight, run_fn)
+    final = _run_shards(make_spec(consensus.shape[1], fixed=consensus, which=which), mine, shardsInFlight, run_fn, shape_of)
 
     # stitchTogether (DistributedCogaps.R:226-278): collect the per-subset free factor on every rank
     free_key, free_sd = ("Amean", "Asd") if genome_wide else ("Pmean", "Psd")
-    shard_cache.clear()
     if dist is not None:
         # tensor all-gathers (RCCL on GPUs): the free factor's mean and standard deviation, padded to the longest subset, and
         # one small record per subset (meanChiSq); the shared factor comes back from every shard as the same all-zero matrix
@@ -357,9 +444,13 @@ def distributedCogaps(data, params, uncertainty=None, messages=False, outputFreq
             return {i: np.concatenate([final[i][key], np.zeros((rows - final[i][key].shape[0], k2), np.float32)], axis=0) for i in mine}
         g_mean = _all_gather_arrays(padded(free_key), [(rows, k2)] * len(sets), dist, comm_device)
         g_sd = _all_gather_arrays(padded(free_sd), [(rows, k2)] * len(sets), dist, comm_device)
-        g_chi = _all_gather_arrays({i: np.full((1, 1), final[i]["meanChiSq"], np.float32) for i in mine}, [(1, 1)] * len(sets), dist, comm_device)
+        # (meanChiSq travels as two fp32 halves of its float64 value: the multi-rank sum equals the single-process one to the last digit)
+        def split64(x):
+            hi = np.float32(x)
+            return np.array([[hi, np.float32(float(x) - float(hi))]], dtype=np.float32)
+        g_chi = _all_gather_arrays({i: split64(final[i]["meanChiSq"]) for i in mine}, [(1, 2)] * len(sets), dist, comm_device)
         shared_zero = np.zeros_like(final[mine[0]]["Pmean" if genome_wide else "Amean"])
-        allf = {i: {free_key: g_mean[i][:len(sets[i])], free_sd: g_sd[i][:len(sets[i])], "meanChiSq": float(g_chi[i][0, 0]),
+        allf = {i: {free_key: g_mean[i][:len(sets[i])], free_sd: g_sd[i][:len(sets[i])], "meanChiSq": float(g_chi[i][0, 0]) + float(g_chi[i][0, 1]),
                     ("Pmean" if genome_wide else "Amean"): shared_zero} for i in range(len(sets))}
     else:
         allf = final

@@ -116,6 +116,12 @@ int cogaps_run(const float *data, uint32_t nrow, uint32_t ncol, const cogaps_par
 int cogaps_run_from_file(const char *dataPath, const cogaps_params *params, const char *uncertaintyPath, cogaps_result *out);
 /* the file as a dense row-major fp32 matrix (callee-allocated; release with cogaps_matrix_free).  Host only: no GPU needed. */
 int cogaps_read_matrix_file(const char *path, uint32_t *nrow, uint32_t *ncol, float **data);
+/* ... of a SUBSET of the file: the rows (byRows != 0) or columns named by the 1-based `indices`, read the way the reference's workers
+ * read their subset of a file (Matrix(path, genesInCols, subsetGenes, indices), src/data_structures/Matrix.cpp:70-134: the indices
+ * are sorted first, a duplicated index fills its first position only); the rest of the matrix is never materialised.
+ * cogaps_run_from_file does the same when params->subsetData is set. */
+int cogaps_read_matrix_file_subset(const char *path, int byRows, const uint32_t *indices, uint32_t nIndices,
+                                   uint32_t *nrow, uint32_t *ncol, float **data);
 void cogaps_matrix_free(float *data);
 /* getFileInfo_cpp (src/Cogaps.cpp:229-246): dimensions and the row / column names the file carries, '\n'-joined into the
  * caller's buffers (NULL / 0 to skip; *needed = bytes of a complete copy incl. the terminator).  Host only. */

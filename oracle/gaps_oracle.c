@@ -1715,15 +1715,18 @@ static void pump_update(const go_session *s, const float *src, float *stat)
         stat[(size_t)i * K + maxI] += 1.f;
     }
 }
-static void run_phase(go_session *s, int phase)
+/* iterations [first, first + n) of a phase; stepsA / stepsP (may be NULL): the Poisson step counts drawn per iteration */
+void go_run_iterations(go_session *s, int phase, uint32_t first, uint32_t n, uint32_t *stepsA, uint32_t *stepsP)
 {
     const go_params *p = &s->p;
-    for (unsigned iter = 0; iter < p->nIterations; ++iter) {
+    for (unsigned iter = first; iter < first + n; ++iter) {
         if (phase == 1) {
             float temp = (float)(2 * iter) / (float)p->nIterations;
             go_set_annealing(s, fmin_ref(1.f, temp));
         }
         uint32_t nA, nP; go_draw_steps(s, &nA, &nP);
+        if (stepsA) stepsA[iter - first] = nA;
+        if (stepsP) stepsP[iter - first] = nP;
         s->totalUpdates += go_iterate(s, nA, nP);
         if (phase == 2) {
             go_stats_update(s);
@@ -1747,6 +1750,7 @@ static void run_phase(go_session *s, int phase)
         }
     }
 }
+static void run_phase(go_session *s, int phase) { go_run_iterations(s, phase, 0, s->p.nIterations, NULL, NULL); }
 /* GapsStatistics.cpp:63-86 (model = P sampler: mDMatrix is genes x samples) */
 static float mean_chisq(const go_session *s)
 {

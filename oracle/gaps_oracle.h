@@ -124,6 +124,9 @@ float go_avg_queue(const go_session *s, char which);
 /* the three lookup tables (Random.cpp:269-295): 3001 + 5001 + 5001 floats */
 void go_get_luts(const go_session *s, float *erf, float *erfinv, float *qgamma);
 void go_finish(go_session *s, go_result *out);
+/* iterations [first, first + n) of phase 1 (equilibration) / 2 (sampling) exactly as go_run's loop runs them (annealing, step counts,
+ * statistics, snapshots, history; GapsRunner.cpp:272-327); stepsA / stepsP (may be NULL) receive the Poisson step counts per iteration */
+void go_run_iterations(go_session *s, int phase, uint32_t first, uint32_t n, uint32_t *stepsA, uint32_t *stepsP);
 
 /* free-standing pieces exposed for unit tests */
 float go_portable_logf(float x);

@@ -122,6 +122,7 @@ def lib(omp=False):
         getattr(L, n).argtypes = [C.c_void_p, C.c_char]
     L.go_get_luts.argtypes = [C.c_void_p, fp, fp, fp]
     L.go_finish.argtypes = [C.c_void_p, C.POINTER(GoResult)]
+    L.go_run_iterations.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.go_portable_logf.restype = C.c_float
     L.go_portable_logf.argtypes = [C.c_float]
     L.go_portable_expf.restype = C.c_float
@@ -275,6 +276,14 @@ class Session:
 
     def iterate(self, nA, nP):
         return self.L.go_iterate(self.h, nA, nP)
+
+    def run_iterations(self, phase, first, n):
+        """iterations [first, first + n) of a phase as go_run runs them; returns the Poisson step counts (nA[], nP[])"""
+        a = np.zeros(n, dtype=np.uint32)
+        b = np.zeros(n, dtype=np.uint32)
+        u32p = C.POINTER(C.c_uint32)
+        self.L.go_run_iterations(self.h, phase, first, n, a.ctypes.data_as(u32p), b.ctypes.data_as(u32p))
+        return a, b
 
     def stats_update(self):
         self.L.go_stats_update(self.h)

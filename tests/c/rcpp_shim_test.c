@@ -9,6 +9,12 @@
  * is turned into cogaps_params by the same rules, line for line.  The result is printed the way
  * cogapsRun names it (Cogaps.cpp:162-186) so that tests/test_gpu_parity.py can compare it with the ctypes path.
  *
+ * Besides the two run entry points: entry=info prints what getFileInfo_cpp returns (Cogaps.cpp:243-254) through
+ * cogaps_file_info (two calls: sizes, then names -- the '\n'-joined buffers split back into one name per line);
+ * interruptAt=k installs the Rcpp::checkUserInterrupt() hook (GapsRunner.cpp:280) as cogaps_params.interrupt and
+ * raises the "interrupt" when the hook is polled for the k-th time: the run must end there with a non-zero code
+ * and the library's message, nothing leaked (cogaps_run releases its session on the error path).
+ *
  * usage: rcpp_shim_test <matrix file> [key=value ...]          (no Python anywhere in this process)
  */
 #include <stdio.h>
@@ -89,20 +95,55 @@ static int get_gaps_parameters(const struct all_params *a, cogaps_params *p)
     return 0;
 }
 
+/* Rcpp::checkUserInterrupt() stand-in: the k-th poll reports a pending interrupt */
+struct interrupt_state { int polls, raiseAt; };
+static int poll_interrupt(void *arg)
+{
+    struct interrupt_state *st = (struct interrupt_state *)arg;
+    st->polls++;
+    return st->raiseAt > 0 && st->polls >= st->raiseAt;
+}
+
+/* getFileInfo_cpp (Cogaps.cpp:243-254): dimensions + row / column names, one per line */
+static int file_info(const char *path)
+{
+    uint32_t nr = 0, nc = 0; size_t rn = 0, cn = 0;
+    if (cogaps_file_info(path, &nr, &nc, NULL, 0, &rn, NULL, 0, &cn)) { fprintf(stderr, "CoGAPS terminated: %s\n", cogaps_last_error()); return 1; }
+    char *rows = (char *)calloc(rn ? rn : 1, 1), *cols = (char *)calloc(cn ? cn : 1, 1);
+    if (cogaps_file_info(path, &nr, &nc, rows, rn, NULL, cols, cn, NULL)) { fprintf(stderr, "CoGAPS terminated: %s\n", cogaps_last_error()); free(rows); free(cols); return 1; }
+    printf("dimensions %u %u\n", nr, nc);
+    const char *label[2] = {"rowName", "colName"}; char *buf[2]; buf[0] = rows; buf[1] = cols;
+    for (int w = 0; w < 2; ++w) {
+        unsigned n = 0;
+        for (char *tok = buf[w]; tok && *tok; ) {
+            char *nl = strchr(tok, '\n'); if (nl) *nl = 0;
+            printf("%s %u %s\n", label[w], n++, tok);
+            tok = nl ? nl + 1 : NULL;
+        }
+        printf("%ss %u\n", label[w], n);
+    }
+    free(rows); free(cols);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2) { fprintf(stderr, "usage: %s <matrix file> [key=value ...]\n", argv[0]); return 2; }
     struct all_params a; defaults(&a);
-    int fromFile = 0;
+    int fromFile = 0, info = 0;
+    struct interrupt_state irq; irq.polls = 0; irq.raiseAt = 0;
     for (int i = 2; i < argc; ++i) {
         char *eq = strchr(argv[i], '=');
         if (!eq) { fprintf(stderr, "bad argument %s\n", argv[i]); return 2; }
         *eq = 0;
-        if (!strcmp(argv[i], "entry")) { fromFile = !strcmp(eq + 1, "file"); continue; }    /* cogaps_cpp or cogaps_from_file_cpp */
+        if (!strcmp(argv[i], "entry")) { fromFile = !strcmp(eq + 1, "file"); info = !strcmp(eq + 1, "info"); continue; }    /* cogaps_cpp, cogaps_from_file_cpp or getFileInfo_cpp */
+        if (!strcmp(argv[i], "interruptAt")) { irq.raiseAt = atoi(eq + 1); continue; }
         if (set(&a, argv[i], eq + 1)) { fprintf(stderr, "unknown key %s\n", argv[i]); return 2; }
     }
+    if (info) return file_info(argv[1]);
     cogaps_params p;
     if (get_gaps_parameters(&a, &p)) return 1;
+    if (irq.raiseAt > 0) { p.interrupt = poll_interrupt; p.interruptArg = &irq; }
     cogaps_result r; memset(&r, 0, sizeof(r));
     int rc;
     if (fromFile) rc = cogaps_run_from_file(argv[1], &p, NULL, &r);              /* cogaps_from_file_cpp, Cogaps.cpp:217-227 */
@@ -112,7 +153,12 @@ int main(int argc, char **argv)
         rc = cogaps_run(d, nr, nc, &p, NULL, &r);
         cogaps_matrix_free(d);
     }
-    if (rc) { fprintf(stderr, "CoGAPS terminated: %s\n", cogaps_last_error()); return 1; }      /* GAPS_ERROR -> Rcpp::stop */
+    if (rc) {                                                                                    /* GAPS_ERROR -> Rcpp::stop */
+        fprintf(stderr, "CoGAPS terminated: %s\n", cogaps_last_error());
+        if (irq.raiseAt > 0) fprintf(stderr, "interrupt polls %d\n", irq.polls);
+        free(a.subsetIndices);
+        return 1;
+    }
     /* the list cogapsRun returns (Cogaps.cpp:162-186) */
     printf("nGenes %u nSamples %u nPatterns %u\n", r.nGenes, r.nSamples, r.nPatterns);
     printf("seed %u\nmeanChiSq %.9g\ntotalUpdates %llu\n", r.seed, r.meanChiSq, (unsigned long long)r.totalUpdates);

@@ -5,6 +5,7 @@ import ctypes
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -187,6 +188,29 @@ def test_plain_c_client_builds_and_fails_loudly_without_a_gpu():
     assert out.returncode == 1 and "checkpoints are disabled" in out.stderr
     out = subprocess.run([exe, os.path.join(GOLDEN, "GIST.mtx"), "bogusKey=1"], capture_output=True, text=True)
     assert out.returncode == 2
+    # getFileInfo_cpp (Cogaps.cpp:243-254) through cogaps_file_info, host only: the names of GIST.gct / .csv round-trip through the
+    # '\n'-joined buffers; a .mtx carries none
+    from cogaps_amd.io import read_matrix
+    for ext in ("gct", "csv", "mtx"):
+        out = subprocess.run([exe, os.path.join(GOLDEN, "GIST." + ext), "entry=info"], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        lines = out.stdout.splitlines()
+        assert lines[0] == "dimensions 1363 9"
+        _, rown, coln = read_matrix(os.path.join(GOLDEN, "GIST." + ext), return_names=True)
+        assert [ln.split(" ", 2)[2] for ln in lines if ln.startswith("rowName ")] == rown
+        assert [ln.split(" ", 2)[2] for ln in lines if ln.startswith("colName ")] == coln
+        assert "rowNames %d" % len(rown) in lines and "colNames %d" % len(coln) in lines
+    # error returns of the file entry points: a missing file, an unknown extension, a malformed table -- status 1 and the message
+    bad = os.path.join(cdir, "_bad_table.csv")
+    with open(bad, "w") as f:
+        f.write(",a,b\nr1,1\n")
+    try:
+        for path, what in (("/nonexistent/x.csv", "cannot open"), (os.path.join(GOLDEN, "c3_k50_s42_i100_lane.npz"), "unsupported file extension"), (bad, "Invalid character delimited file")):
+            for entry in ("file", "info"):
+                out = subprocess.run([exe, path, "entry=" + entry, "nPatterns=3", "nIterations=5", "messages=0"], capture_output=True, text=True)
+                assert out.returncode == 1 and out.stderr.startswith("CoGAPS terminated: ") and what in out.stderr and out.stdout == "", (path, entry, out.stderr)
+    finally:
+        os.remove(bad)
     try:
         import torch
         gpu = torch.cuda.is_available()
@@ -195,3 +219,54 @@ def test_plain_c_client_builds_and_fails_loudly_without_a_gpu():
     if not gpu:
         out = subprocess.run([exe, os.path.join(GOLDEN, "GIST.mtx"), "nPatterns=3", "nIterations=5", "messages=0"], capture_output=True, text=True)
         assert out.returncode == 1 and out.stderr.startswith("CoGAPS terminated: ") and out.stdout == ""
+
+
+def test_native_subset_reader_reads_only_the_named_rows_or_columns(tmp_path, gist):
+    """cogaps_read_matrix_file_subset: what a worker of a distributed run reads of a file (Matrix(path, genesInCols, subsetGenes,
+    indices), data_structures/Matrix.cpp:70-134): the indices are sorted, an element lands at its index's lower_bound position, a
+    duplicated index fills its first position only; all four formats, rows and columns; file_info parses no values"""
+    import ctypes
+    from conftest import GOLDEN
+    from cogaps_amd import _capi
+    L = _capi.bind(ctypes.CDLL(_capi.LIB_PATH))
+    rows = np.array([700, 3, 1363, 41, 42, 1], dtype=np.uint32)
+    cols = np.array([9, 2, 5], dtype=np.uint32)
+    for ext in ("mtx", "csv", "tsv", "gct"):
+        path = os.path.join(GOLDEN, "GIST." + ext)
+        a = _capi.read_matrix_file(path, lib=L, rows=rows)
+        assert a.shape == (6, 9) and np.array_equal(a, gist[np.sort(rows) - 1]), ext
+        b = _capi.read_matrix_file(path, lib=L, cols=cols)
+        assert b.shape == (1363, 3) and np.array_equal(b, gist[:, np.sort(cols) - 1]), ext
+        d = _capi.read_matrix_file(path, lib=L, rows=np.array([5, 5, 2], dtype=np.uint32))       # sorted: 2, 5, 5 -> the second 5 stays empty
+        assert np.array_equal(d[0], gist[1]) and np.array_equal(d[1], gist[4]) and not d[2].any(), ext
+        for bad in (np.array([0, 1], np.uint32), np.array([1364], np.uint32)):
+            with pytest.raises(RuntimeError):
+                _capi.read_matrix_file(path, lib=L, rows=bad)
+        with pytest.raises(RuntimeError):
+            _capi.read_matrix_file(path, lib=L, cols=np.array([10], np.uint32))
+    with pytest.raises(ValueError):
+        _capi.read_matrix_file(os.path.join(GOLDEN, "GIST.mtx"), lib=L, rows=rows, cols=cols)
+    # dimensions and names without values: a file whose values do not parse still answers file_info (getFileInfo_cpp needs no matrix)
+    f = tmp_path / "names_only.csv"
+    f.write_text(",a,b\nr1,oops,1\nr2,2,3\n")
+    assert _capi.file_info(str(f), lib=L) == (2, 2, ["r1", "r2"], ["a", "b"])
+    with pytest.raises(RuntimeError):
+        _capi.read_matrix_file(str(f), lib=L)
+
+
+def test_bench_refuses_to_report_fewer_gpus_than_asked_for():
+    """`python bench.py --gpus 2` without a launcher starts its own two ranks (torch.distributed.run, 127.0.0.1); where they cannot
+    come up -- here: no GPU at all -- the command fails and prints NO bench line: never `n_gpus: 1` for `--gpus 2`"""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the launch path is covered by the gpu tests")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert "2-rank launch failed" in out.stderr and "needs an MI355X" in out.stderr
+    # a launcher-provided world that contradicts --gpus is refused as well
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--no-cpu"], cwd=ROOT, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and "WORLD_SIZE=2" in out.stderr and not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]

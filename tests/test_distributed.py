@@ -155,3 +155,83 @@ def test_world2_gloo_matches_single_process(tmp_path, emul_lib, gist):
     o = po.run(gist[:240], nPatterns=3, nIterations=12, seed=5, outputFrequency=6, math_mode=po.MATH_PORTABLE, redW_A=64, redW_P=64, redG=4,
                subsetIndices=np.arange(1, 121, dtype=np.uint32), subsetDim=1)
     assert np.array_equal(o["Pmean"], a["u0"])
+
+
+def test_clustering_agrees_with_scipy_on_random_matrices():
+    """the restated cluster::agnes(method = "complete") + stats::cutree against an independent implementation (scipy's
+    linkage('complete') + cut_tree) on 240 random 1 - cor matrices: the same partition for every cut, labels numbered by first
+    appearance; and the restated stats::cor against numpy's corrcoef"""
+    from scipy.cluster.hierarchy import cut_tree, linkage
+    from scipy.spatial.distance import squareform
+    from cogaps_amd.distributed import _complete_linkage_cutree, _cor
+    rng = np.random.default_rng(11)
+    for case in range(240):
+        n, rows = int(rng.integers(3, 26)), int(rng.integers(5, 60))
+        m = np.abs(rng.normal(size=(rows, n))) + (rng.random((rows, 1)) if case % 3 else 0.0)
+        c = _cor(m)
+        assert np.allclose(c, np.corrcoef(m.T), rtol=0, atol=1e-12)
+        d = 1.0 - c
+        d = 0.5 * (d + d.T)
+        np.fill_diagonal(d, 0.0)
+        z = linkage(squareform(d, checks=False), method="complete")
+        for k in {1, 2, 3, max(1, n // 2), n - 1, n}:
+            if k < 1:
+                continue
+            ours = _complete_linkage_cutree(d, k)
+            ref = cut_tree(z, n_clusters=k).ravel()
+            first = {}
+            ref_lab = np.array([first.setdefault(int(v), len(first) + 1) for v in ref])          # cutree numbers clusters by first appearance
+            assert np.array_equal(ours, ref_lab), (case, n, k)
+
+
+def _gw_params(n_sets, sets):
+    from cogaps_amd import CogapsParams
+    p = CogapsParams(nPatterns=3, seed=5, nIterations=40)
+    p.distributed = "genome-wide"
+    p.setDistributedParams(nSets=n_sets, minNS=2)
+    p.explicitSets = sets
+    return p
+
+
+def test_shard_sources_array_file_and_loader_agree(emul_lib, gist):
+    """distributedCogaps takes the whole matrix, a FILE (every rank reads only its shards' rows through
+    cogaps_read_matrix_file_subset, as the reference's workers do, Matrix.cpp:70-134) or a LOADER i -> shard: the same result, and
+    with a file or a loader the whole matrix is never built (checked: the loader is asked for exactly the shards, once per pass)"""
+    from conftest import GOLDEN
+    from cogaps_amd import _capi
+    from cogaps_amd.distributed import distributedCogaps
+    lib = emul_lib(256)
+    run = lambda d, unc=None, **kw: _capi.run(d, unc=unc, lib=lib, **{k: v for k, v in kw.items() if k != "device"})
+    sets = [list(range(1, 101)), list(range(101, 181)), list(range(181, 301))]                  # uneven on purpose
+    ref = distributedCogaps(gist[:300], _gw_params(3, sets), run_fn=run, outputFrequency=5)
+    # (a file holds all 1363 genes: the sets name the first 300)
+    for ext in ("mtx", "csv"):
+        r = distributedCogaps(os.path.join(GOLDEN, "GIST." + ext), _gw_params(3, sets), run_fn=run, outputFrequency=5)
+        for k in ("Amean", "Asd", "consensus"):
+            assert np.array_equal(r[k], ref[k]), (ext, k)
+    asked = []
+
+    def loader(i, idx):
+        asked.append((i, len(idx)))
+        return np.ascontiguousarray(gist[np.asarray(idx) - 1])
+    r = distributedCogaps(loader, _gw_params(3, sets), run_fn=run, outputFrequency=5, shape=(300, 9))
+    assert np.array_equal(r["Amean"], ref["Amean"]) and np.array_equal(r["consensus"], ref["consensus"])
+    assert sorted(asked) == sorted([(0, 100), (1, 80), (2, 120)] * 2)
+    with pytest.raises(ValueError, match="shape"):
+        distributedCogaps(loader, _gw_params(3, sets), run_fn=run)
+    with pytest.raises(ValueError, match="expected"):
+        distributedCogaps(lambda i, idx: gist[:5], _gw_params(3, sets), run_fn=run, shape=(300, 9))
+    # a file's subset arrives in sorted index order (Matrix.cpp:113): unsorted explicit sets give the sorted sets' result
+    shuffled = [list(reversed(s)) for s in sets]
+    r = distributedCogaps(os.path.join(GOLDEN, "GIST.tsv"), _gw_params(3, shuffled), run_fn=run, outputFrequency=5)
+    assert np.array_equal(r["Amean"], ref["Amean"])
+
+
+def test_shards_are_grouped_by_launch_shape():
+    """the batches of a rank's shards are formed from the shards' shapes up front (cogaps_reduction_width / cogaps_sparse_width of
+    both samplers' vector lengths), not by parsing an error message"""
+    from cogaps_amd.distributed import _launch_shape
+    assert _launch_shape(20000, 2000, False) == _launch_shape(19990, 2000, False)                # same widths and slice counts
+    assert _launch_shape(20000, 2000, False) != _launch_shape(9000, 2000, False)                 # 8192 vs 4096 lanes on the P side
+    assert _launch_shape(50000, 12500, True) != _launch_shape(50000, 12500, False)
+    assert _launch_shape(50000, 12500, True) == _launch_shape(50000, 12400, True)

@@ -250,6 +250,20 @@ def test_plain_c_client_equals_the_ctypes_path(hip_lib, gist):
     assert "worker 2 is starting!" in out.stdout and "worker 2 is finished!" in out.stdout      # GapsRunner.cpp:428-433, 494-500
     bad = subprocess.run([exe, mtx, "nPatterns=3", "nIterations=10", "asynchronousUpdates=0"], capture_output=True, text=True, timeout=600)
     assert bad.returncode == 1 and "asynchronousUpdates=FALSE" in bad.stderr
+    # a worker reading its subset from the FILE (cogaps_from_file_cpp with subsetIndices): only rows 1..300 are ever read (Matrix.cpp:70-134)
+    out = subprocess.run([exe, mtx, "entry=file", "nPatterns=3", "nIterations=40", "seed=5", "outputFrequency=20", "subsetDim=1", "subsetIndices=1:300", "asynchronousUpdates=0",
+                          "workerID=2"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    d2 = parse(out.stdout)
+    assert d2["nGenes"].split()[0] == "300" and int(d2["totalUpdates"]) == r["totalUpdates"] and d2["atomsA"] == d["atomsA"] and d2["sumAmean"] == d["sumAmean"]
+    # Rcpp::checkUserInterrupt() (GapsRunner.cpp:280) as the interrupt callback: raised at the 25th poll of a 40 + 40 iteration run, the
+    # run ends there -- exactly 25 polls, status 1, the library's message, no result -- through both entry points; a later run in a
+    # fresh process is unaffected (nothing leaks on the error path: cogaps_run destroys its session)
+    for entry in ("matrix", "file"):
+        out = subprocess.run([exe, mtx, "entry=" + entry, "nPatterns=3", "nIterations=40", "seed=5", "messages=0", "interruptAt=25"], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 1 and "CoGAPS terminated: interrupted" in out.stderr and "interrupt polls 25" in out.stderr and "atomsA" not in out.stdout
+    out = subprocess.run([exe, mtx, "nPatterns=3", "nIterations=40", "seed=5", "messages=0", "interruptAt=1000"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "atomsA" in out.stdout
 
 
 def test_tiny_domain(hip_lib):
@@ -721,3 +735,128 @@ def test_distributed_with_transposed_input(hip_lib, gist):
     a, b = go(gist[:300], False), go(np.ascontiguousarray(gist[:300].T), True)
     assert np.array_equal(a.featureLoadings, b.featureLoadings) and np.array_equal(a.loadingStdDev, b.loadingStdDev)
     assert np.array_equal(a.metadata["diagnostics"]["consensus"], b.metadata["diagnostics"]["consensus"])
+
+
+def test_benchmarked_chain_end_to_end_against_the_golden(hip_lib):
+    """The chain bench.py times -- BASELINE configs[2], 20000 x 2000, K = 50, seed 42, 100 + 100 iterations -- from its first iteration
+    to its last against tests/golden/c3_k50_s42_i100_lane.npz (the lane-order oracle's run, tools/make_golden_c3.py; loop =
+    runOnePhase, src/GapsRunner.cpp:272-327): the proposals of EVERY iteration and the domain sizes after it (so the timed window,
+    iterations 181-200 of the schedule, is covered step by step), the atom / chi2 histories, totalUpdates (5.3e7), the queue
+    lengths, meanChiSq, the four statistics matrices (sha256 + a 1 % sample to locate a mismatch) and the final chain state (atoms,
+    factor matrices, A*P caches) -- all bit for bit."""
+    import hashlib
+    import bench
+    from cogaps_amd import _capi
+    g = np.load(os.path.join(GOLDEN, "c3_k50_s42_i100_lane.npz"))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    S = _capi.Session(bench.synthetic_dense(20000, 2000), lib=hip_lib, nPatterns=50, nIterations=100, seed=42, outputFrequency=10)
+    k = 0
+    for phase in (1, 2):
+        for it in range(100):
+            upd = S.run_iterations(phase, it, 1)
+            assert upd == int(g["stepsA"][k]) + int(g["stepsP"][k]), "proposals of schedule step %d" % k
+            assert (S.natoms("A"), S.natoms("P")) == (int(g["natomsA"][k]), int(g["natomsP"][k])), "atoms after schedule step %d" % k
+            k += 1
+    for w in "AP":
+        a = S.atoms(w)
+        assert sha(a["pos"]) == str(g["sha256_atoms_pos_" + w]) and sha(a["mass"]) == str(g["sha256_atoms_mass_" + w]), "final atoms " + w
+        assert sha(S.matrix(w)) == str(g["sha256_matrix_" + w]), "final factor matrix " + w
+        assert sha(S.ap(w)) == str(g["sha256_ap_" + w]), "final A*P cache " + w
+        assert S.check_domain(w) == 0
+    r = S.finish()
+    S.close()
+    assert r["totalUpdates"] == int(g["totalUpdates"]) == 52906603
+    for f in ("atomsA", "atomsP", "chisq"):
+        assert np.array_equal(r[f], g[f]), f
+    assert r["averageQueueLengthA"] == float(g["avgQueueA"]) and r["averageQueueLengthP"] == float(g["avgQueueP"]) and r["meanChiSq"] == float(g["meanChiSq"])
+    for f in ("Amean", "Pmean", "Asd", "Psd"):
+        flat = r[f].ravel()
+        assert np.array_equal(flat[g["sample_idx_" + f]], g["sample_" + f]), f + " (sample)"
+        assert sha(r[f]) == str(g["sha256_" + f]), f
+
+
+@pytest.mark.parametrize("name", ["gist_tsv_k3", "modsim_sparse_k4", "gist_csv_sparse_k6", "k50_dense", "k50_sparse", "shard_round1", "shard_round2"])
+def test_judge_round2_fingerprints_on_the_gpu(hip_lib, gist, modsim, name, _judge_cache={}):
+    """the six further reference-printed configurations of tests/test_oracle_pin.py::JUDGE_R2 -- K = 50 dense and sparse, the two-round
+    shard flow among them -- reproduced digit for digit by cogaps_run on the GPU in the verification mode"""
+    from cogaps_amd import _capi
+    from test_oracle_pin import JUDGE_R2, check_judge_case, run_judge_case
+    r = run_judge_case(lambda d, **kw: _capi.run(d, lib=hip_lib, **SEQ, **kw), name, gist, modsim, _judge_cache)
+    check_judge_case(r, JUDGE_R2[name])
+
+
+def test_bench_starts_its_own_ranks_and_never_reports_fewer():
+    """plain `python bench.py --gpus 2` (no launcher): the script starts its two ranks itself.  With the gloo test hook they share this
+    box's GPU and the line says n_gpus = 2, ranks = 2; over RCCL two ranks need two GPUs -- on a one-GPU box the command fails and
+    prints no line at all (never n_gpus = 1 for --gpus 2).  --sparse gathers the factor scCoGAPS shares (A), the dense line P."""
+    import json, subprocess, sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    small = ["--steps", "8", "--warmup", "2", "--genes", "4000", "--samples", "400", "--patterns", "10", "--no-cpu"]
+    for extra, shared in (([], "P"), (["--sparse"], "A")):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + small + extra, env=dict(base, COGAPS_BENCH_BACKEND="gloo"), cwd=root,
+                             capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, out.stdout[-2000:]
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["config"]["collective_backend"] == "gloo" and d["config"]["shared_factor_gathered"] == shared and d["value"] > 0
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + small, env=base, cwd=root, capture_output=True, text=True, timeout=900)
+        assert out.returncode != 0 and not [ln for ln in out.stdout.splitlines() if ln.startswith("{")], out.stdout[-1000:]
+        assert "needs 2 GPUs" in out.stderr
+
+
+def test_configs4_eight_sparse_shards_on_one_gpu(hip_lib):
+    """BASELINE configs[4] as a whole workload on the one GPU a test has: synthetic sparse 50000 genes x 100000 cells (95 % zeros),
+    sparseOptimization, scCoGAPS nSets = 8, nPatterns = 50 -- eight cell-wise shards of 50000 x 12500, which a rank that holds all of
+    them runs as batches of lock-stepped chains (on the 8-GPU node each rank has one).  The data never exist as one 20 GB matrix: a
+    shard LOADER builds each 50000 x 12500 block when its turn comes (distributedCogaps(loader, shape = ...)).  Few iterations (the
+    patterns need some variance for the matching step); checked: two shards' chains inside the batches are bit-identical to the same
+    shards run alone through cogaps_run, in the first pass and in the fixed-pattern second pass (callInternalCoGAPS,
+    DistributedCogaps.R:12-35), and the stitched result has the reference's layout (:226-278)"""
+    import bench
+    from cogaps_amd import CogapsParams, _capi
+    from cogaps_amd.distributed import distributedCogaps
+    G, CELLS, NSETS = 50000, 100000, 8
+    per = CELLS // NSETS
+
+    def block(i):
+        # the bench's recipe -- rank-10 product, multiplicative noise, 95 % of the entries zeroed i.i.d. -- evaluated only where an entry
+        # survives (positions from geometric gaps: the same distribution as an i.i.d. 5 % mask): a 50000 x 12500 block is built 18
+        # times in this test
+        rng = np.random.Generator(np.random.PCG64(12345 + i))
+        a0 = (rng.gamma(2.0, 0.5, size=(G, 10)) * (rng.random((G, 10)) >= 0.7)).astype(np.float32)
+        p0 = (rng.gamma(2.0, 0.5, size=(per, 10)) * (rng.random((per, 10)) >= 0.5)).astype(np.float32)
+        pos = np.cumsum(rng.geometric(0.05, size=int(G * per * 0.05 * 1.02) + 4096)) - 1
+        pos = pos[pos < G * per]
+        rr, cc = np.divmod(pos, per)
+        vals = np.einsum("ij,ij->i", a0[rr], p0[cc]) * (np.float32(0.9) + np.float32(0.2) * rng.random(pos.size, dtype=np.float32))
+        d = np.zeros((G, per), dtype=np.float32)
+        d.ravel()[pos] = vals
+        return d
+    asked = []
+
+    def loader(i, idx):
+        assert len(idx) == per and idx[0] == 1 + i * per and idx[-1] == (i + 1) * per       # contiguous explicit sets: block i
+        asked.append(i)
+        return block(i)
+    p = CogapsParams(nPatterns=50, seed=42, nIterations=20, sparseOptimization=True)
+    p.distributed = "single-cell"
+    p.setDistributedParams(nSets=NSETS, minNS=2, cut=50)
+    p.explicitSets = [np.arange(1 + i * per, 1 + (i + 1) * per) for i in range(NSETS)]
+    r = distributedCogaps(loader, p, outputFrequency=1000, shape=(G, CELLS))
+    assert sorted(asked) == sorted(list(range(NSETS)) * 2)
+    cons = r["consensus"]
+    k2 = cons.shape[1]
+    assert cons.shape[0] == G and k2 >= 1 and r["Pmean"].shape == (CELLS, k2) and not r["Amean"].any()
+    kw = dict(nIterations=20, seed=42, outputFrequency=1000, runningDistributed=True, sparseOptimization=True, lib=hip_lib)
+    for i in (1, 6):
+        shard = block(i)
+        one = _capi.run(shard, nPatterns=50, workerID=i + 1, **kw)
+        for key in ("Amean", "Pmean", "Asd", "Psd"):
+            assert np.array_equal(one[key], r["firstPass"][i][key]), "first pass, shard %d, %s" % (i, key)
+        assert one["totalUpdates"] == r["firstPass"][i]["totalUpdates"] and one["meanChiSq"] == r["firstPass"][i]["meanChiSq"]
+        two = _capi.run(shard, nPatterns=k2, workerID=i + 1, whichMatrixFixed="A", fixedPatterns=cons, **kw)
+        assert np.array_equal(two["Pmean"], r["Pmean"][i * per:(i + 1) * per]), "second pass, shard %d" % i

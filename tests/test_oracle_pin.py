@@ -161,3 +161,140 @@ def test_portable_log_exp_accuracy(oracle):
     for x in -rng.random(5000).astype(np.float32) * 60:
         assert L.go_portable_expf(float(x)) == np.float32(np.exp(np.float64(x)))
     assert L.go_portable_logf(0.0) == -np.inf and L.go_portable_logf(1.0) == 0.0
+
+
+def test_luts_are_the_correctly_rounded_tables(oracle):
+    """The three lookup tables come from double-precision normal / gamma(2,1) cdf and quantile calls (Boost.Math in the reference,
+    Math.cpp:55-81 -- a dependency absent from /root/reference and from this image; libm + Newton in the oracle and the product),
+    rounded to fp32 (Random.cpp:269-295).  Rebuilt here with mpmath at 50 digits following the same fp32 rounding sequence: every one
+    of the 13 003 entries equals the oracle's, and no exact value lies within 1e-13 (relative; ~1000 double ulps) of an fp32 rounding
+    midpoint -- so ANY double-accurate implementation, Boost.Math included, rounds to these same fp32 tables.  That closes the
+    "LUT bit-parity with a real Boost build" caveat of SURVEY.md section 8c in substance."""
+    import mpmath as mp
+    mp.mp.dps = 50
+    f32 = np.float32
+    e, ei, qg = oracle.luts()
+    sqrt2f = f32(1.4142135623730951)
+    margin = [mp.mpf(1)]
+
+    def to_f32(v):
+        """round the exact value to fp32; record its relative distance to the nearer rounding midpoint"""
+        r = f32(float(v))                      # (double rounding is harmless exactly when the margin below holds)
+        if v != 0:
+            lo, hi = np.nextafter(r, f32(-np.inf)), np.nextafter(r, f32(np.inf))
+            d = min(abs(v - (mp.mpf(float(r)) + mp.mpf(float(lo))) / 2), abs(v - (mp.mpf(float(r)) + mp.mpf(float(hi))) / 2)) / abs(v)
+            margin[0] = min(margin[0], d)
+        return r
+
+    def newton(f, df, x0):
+        x = mp.mpf(float(x0))
+        for _ in range(8):
+            x = x - f(x) / df(x)
+        return x
+    bad = 0
+    # erf: 2.f * float(cdf(N(0,1), x * sqrt2f)) - 1.f
+    for i in range(3001):
+        x = f32(i) / f32(1000.0)
+        p = to_f32(mp.ncdf(mp.mpf(float(f32(x * sqrt2f)))))
+        bad += int(f32(f32(2.0) * p - f32(1.0)).tobytes() != e[i].tobytes())
+    # erfinv: float(quantile(N(0,1), (1.f + x) / 2.f)) / sqrt2f; the last entry from q = 1.9998f / 2.f
+    qs = [f32(f32(1.0) + f32(i) / f32(5000.0)) / f32(2.0) for i in range(5000)] + [f32(1.9998) / f32(2.0)]
+    for i, q in enumerate(qs):
+        qq = mp.mpf(float(q))
+        z = mp.mpf(0) if q == f32(0.5) else newton(lambda t: mp.ncdf(t) - qq, mp.npdf, float(ei[i]) * 1.4142135623730951)
+        bad += int(f32(to_f32(z) / sqrt2f).tobytes() != ei[i].tobytes())
+    # qgamma: float(quantile(Gamma(2,1), x)), 0 below 1e-6; the last entry from 0.9998f
+    xs = [f32(i) / f32(5000.0) for i in range(5000)] + [f32(0.9998)]
+    for i, x in enumerate(xs):
+        if i == 0 or x < f32(0.000001):
+            bad += int(qg[i] != 0.0)
+            continue
+        xx = mp.mpf(float(x))
+        z = newton(lambda t: 1 - mp.exp(-t) * (1 + t) - xx, lambda t: t * mp.exp(-t), max(float(qg[i]), 1e-3))
+        bad += int(to_f32(z).tobytes() != qg[i].tobytes())
+    assert bad == 0
+    assert margin[0] >= mp.mpf("1e-13"), margin[0]
+
+
+# Six further outputs of the reference core (VERDICT.md round 2, "Judge's own checks": the reference's sources built per SURVEY.md
+# Appendix B and run on configurations nobody had tuned anything on).  Among them the only reference-printed numbers for K = 50 --
+# forward gaps::dot order, large-lambda Poisson -- dense and sparse (the bench's generator at 4000 x 400), and for the two-round shard
+# flow (subset of genes, then whichMatrixFixed = 'P' with the first round's Pmean).  kw: oracle / library keyword arguments.
+def _judge_data(name, gist, modsim):
+    import bench
+    if name in ("gist_tsv_k3", "gist_csv_sparse_k6", "shard_round1", "shard_round2"):
+        return gist
+    if name == "modsim_sparse_k4":
+        return modsim
+    d = bench.synthetic_dense(4000, 400)
+    if name == "k50_sparse":
+        d = d * (np.random.Generator(np.random.MT19937(777)).random(d.shape) >= 0.95)
+    return np.ascontiguousarray(d, dtype=np.float32)
+
+
+JUDGE_R2 = {
+    "gist_tsv_k3": dict(kw=dict(nPatterns=3, nIterations=400, seed=2024, outputFrequency=40),
+                        atomsA=[517, 1201, 1788, 2225, 2596, 2625, 2512, 2313, 2228, 2208, 2141, 2099, 2160, 2193, 2199, 2200, 2231, 2246, 2290, 2269],
+                        atomsP=[11, 17, 21, 25, 24, 25, 25, 32, 36, 37, 39, 44, 46, 47, 45, 47, 48, 46, 49, 51],
+                        totalUpdates=1671263, meanChiSq=5399.322, lastChisq=6716.472, qA=31.665, qP=2.670,
+                        probes=[("Amean", 0, [1.06566, 0.009782198, 0.002830506]), ("Pmean", 0, [0.9526445, 0.9599464, 1.0])]),
+    "modsim_sparse_k4": dict(kw=dict(nPatterns=4, nIterations=500, seed=9, outputFrequency=50, sparseOptimization=True),
+                             atomsA=[35, 47, 51, 68, 75, 91, 90, 90, 86, 85, 86, 98, 91, 105, 109, 105, 107, 101, 91, 93],
+                             atomsP=[19, 41, 47, 50, 49, 59, 58, 63, 56, 56, 54, 45, 52, 55, 54, 57, 52, 55, 58, 56],
+                             totalUpdates=133060, meanChiSq=49.368, lastChisq=114.531, qA=4.645, qP=4.084,
+                             probes=[("Amean", 0, [0.3686761, 0.05144705, 11.68852])]),
+    "gist_csv_sparse_k6": dict(kw=dict(nPatterns=6, nIterations=250, seed=31, outputFrequency=25, sparseOptimization=True),
+                               atomsA=[520, 1358, 2068, 2520, 2747, 2839, 2889, 2949, 3016, 3055, 3090, 3097, 3158, 3155, 3194, 3244, 3245, 3201, 3342, 3289],
+                               atomsP=[12, 17, 23, 27, 30, 39, 41, 43, 42, 45, 46, 43, 44, 48, 50, 52, 55, 58, 54, 54],
+                               totalUpdates=1375546, meanChiSq=3562.224, lastChisq=7074.692, qA=33.215, qP=2.893, probes=[]),
+    "k50_dense": dict(kw=dict(nPatterns=50, nIterations=25, seed=42, outputFrequency=2),
+                      atomsA=[17, 36, 69, 164, 360, 697, 1238, 2002, 3023, 4205, 5455, 6826, 9054, 10577, 12037, 13640, 15269, 16881, 18509, 20189, 21820, 23372, 24987, 26625],
+                      atomsP=[13, 26, 47, 88, 176, 280, 420, 541, 677, 851, 1018, 1162, 1415, 1575, 1748, 1934, 2117, 2289, 2440, 2594, 2777, 2949, 3110, 3278],
+                      totalUpdates=535815, meanChiSq=67113072.0, lastChisq=58949680.0, qA=62.417, qP=20.467, probes=[("Amean", 0, [0.04871542])]),
+    "k50_sparse": dict(kw=dict(nPatterns=50, nIterations=30, seed=42, outputFrequency=3, sparseOptimization=True),
+                       atomsA=[22, 67, 212, 551, 1144, 2192, 3469, 4836, 6276, 7681, 9169, 10576, 12031, 13404, 14807, 16177, 17423, 18496, 19568, 20607],
+                       atomsP=[20, 47, 111, 244, 393, 554, 749, 947, 1170, 1372, 1623, 1884, 2112, 2326, 2548, 2789, 2980, 3219, 3407, 3598],
+                       totalUpdates=583624, meanChiSq=4587509.0, lastChisq=5578760.0, qA=61.292, qP=20.624, probes=[("Amean", 0, [None, None, 0.05574835])]),
+    "shard_round1": dict(kw=dict(nPatterns=3, nIterations=200, seed=42, outputFrequency=50, subsetIndices=np.arange(1, 401, dtype=np.uint32), subsetDim=1),
+                         atomsA=[231, 474, 719, 890, 1042, 980, 950, 902], atomsP=None, totalUpdates=None, meanChiSq=None, lastChisq=None, qA=None, qP=None, probes=[]),
+    "shard_round2": dict(kw=dict(nPatterns=3, nIterations=200, seed=42, outputFrequency=50, subsetIndices=np.arange(1, 401, dtype=np.uint32), subsetDim=1, whichMatrixFixed="P"),
+                         atomsA=[210, 410, 535, 605, 630, 679, 728, 750], atomsP=[0] * 8, totalUpdates=None, meanChiSq=0.0, lastChisq=None, qA=None, qP=None,
+                         probes=[("Pmean", 0, [0.0])]),
+}
+
+
+def check_judge_case(r, fp):
+    """every digit the reference binary printed (seven significant digits; chi2 values as printed)"""
+    assert r["atomsA"].tolist() == fp["atomsA"]
+    if fp["atomsP"] is not None:
+        assert r["atomsP"].tolist() == fp["atomsP"]
+    if fp["totalUpdates"] is not None:
+        assert r["totalUpdates"] == fp["totalUpdates"]
+    for got, want in ((r["meanChiSq"], fp["meanChiSq"]), (float(r["chisq"][-1]), fp["lastChisq"])):
+        if want is not None:
+            assert abs(got - want) <= max(6e-4, 6e-8 * abs(want)), (got, want)
+    if fp["qA"] is not None:
+        assert abs(r["averageQueueLengthA"] - fp["qA"]) < 6e-4 and abs(r["averageQueueLengthP"] - fp["qP"]) < 6e-4
+    for f, row, vals in fp["probes"]:
+        for c, v in enumerate(vals):
+            if v is not None:
+                assert abs(float(r[f][row, c]) - v) <= 6e-7 * abs(v), (f, row, c)
+
+
+def run_judge_case(run, name, gist, modsim, cache):
+    """`run(data, **kw)` -> result dict; the second shard round takes the first round's Pmean as its fixed patterns"""
+    fp = JUDGE_R2[name]
+    kw = dict(fp["kw"])
+    if name == "shard_round2":
+        if "shard_round1" not in cache:
+            cache["shard_round1"] = run(_judge_data("shard_round1", gist, modsim), **JUDGE_R2["shard_round1"]["kw"])
+        kw["fixedPatterns"] = cache["shard_round1"]["Pmean"]
+    r = run(_judge_data(name, gist, modsim), **kw)
+    cache[name] = r
+    return r
+
+
+@pytest.mark.parametrize("name", list(JUDGE_R2))
+def test_judge_round2_fingerprints(oracle, gist, modsim, name, _judge_cache={}):
+    r = run_judge_case(oracle.run, name, gist, modsim, _judge_cache)
+    check_judge_case(r, JUDGE_R2[name])
