@@ -832,7 +832,12 @@ static int iteration_head(cogaps_session *s, int phase, uint32_t it, uint32_t *n
         const float temp = (float)(2 * it) / (float)s->p.nIterations;
         cogaps_session_set_annealing(s, gm_min(1.f, temp));
     }
-    return cogaps_session_draw_steps(s, nA, nP);
+    const int rc = cogaps_session_draw_steps(s, nA, nP);
+    // tests: COGAPS_TEST_ZERO_STEPS="<workerID>:<iteration>" turns that worker's A update of that equilibration iteration into
+    // update(0) -- what a Poisson draw of 0 (probability e^-10 per draw while a chain holds at most ten atoms) does -- after the
+    // draw, so the generators' sequences are unchanged
+    if (phase == 1) if (const char *z = getenv("COGAPS_TEST_ZERO_STEPS")) { unsigned wk = 0, zi = 0; if (sscanf(z, "%u:%u", &wk, &zi) == 2 && wk == s->p.workerID && zi == it) *nA = 0; }
+    return rc;
 }
 // ... and its tail (:314-325): snapshots, status line / histories
 static int iteration_tail(cogaps_session *s, int phase, uint32_t it)
@@ -896,7 +901,7 @@ int cogaps_session_run_iterations(cogaps_session *s, int phase, uint32_t firstIt
 // ================================================================================================================================
 struct cogaps_batch {
     std::vector<cogaps_session *> ss;
-    rt_stream_t stream;
+    rt_stream_t stream = rt_stream_t();
     SamplerDev *dev[2] = {nullptr, nullptr};            // [0] the A samplers' records, [1] the P samplers'
     std::vector<SamplerDev> host[2];                    // what the device arrays hold
     rt_graph graph[2]; bool graphValid[2] = {false, false};
@@ -967,10 +972,15 @@ static int run_update_multi(cogaps_batch *b, int w, const std::vector<uint32_t> 
         g.annealTemp = h.anneal;
         g.nSteps = n; g.nDone = 0; g.nBatches = 0; g.updateFlushed = 0; g.qlen = 0;
         g.traceOn = 0; g.traceCount = 0; g.traceCap = 0; g.traceBatchCount = 0;
+        // update(0) -- a Poisson draw of 0 has probability e^-10 while a chain holds at most 10 atoms -- is a no-op in the reference
+        // (AsynchronousGibbsSampler.h:94: the loop body never runs): the chain is done before the first launch and the lock-stepped
+        // batch never waits for it (its generator workgroup sees nDone >= nSteps and leaves at once)
+        if (n == 0) { g.updateFlushed = 1; done[c] = 1; }
         rt_h2d(h.d.gs, &g, sizeof(GenScalars), b->stream);
         avgq[c] = h.stepsPerBatch > 1.f ? h.stepsPerBatch : (g.avgQueue > 1.f ? g.avgQueue : 1.f);
         h.updLaunches = 0;
     }
+    if (std::all_of(done.begin(), done.end(), [](char d) { return d != 0; })) { rt_sync(b->stream); return 0; }
     // the records the kernels read: re-uploaded when a pointer in one of them changed (atom tables regrown, seed buffer moved);
     // the captured graph stays valid -- its kernels' arguments are the array's address and the launch geometry
     bool changed = false;
@@ -1064,18 +1074,24 @@ cogaps_batch *cogaps_batch_create(cogaps_session **sessions, uint32_t n)
         b->sparse = s0->p.useSparseOptimization != 0; b->fixed = s0->p.whichMatrixFixed;
         b->stream = rt_stream_create();
         rt_alloc_scope allocOn(b->stream);
-        for (cogaps_session *s : b->ss) {      // from here on the sessions run on the batch's stream, one after the other
-            rt_sync(s->stream);
+        // everything that can fail is done BEFORE a session is touched: a failed creation leaves every session as it was
+        b->hGs = (GenScalars *)rt_malloc_host(sizeof(GenScalars) * n);
+        for (int w = 0; w < 2; ++w) { b->dev[w] = dalloc<SamplerDev>(n); b->host[w].resize(n); memset(b->host[w].data(), 0, sizeof(SamplerDev) * n); }
+        for (cogaps_session *s : b->ss) rt_sync(s->stream);
+        for (cogaps_session *s : b->ss) {      // from here on the sessions run on the batch's stream, one after the other (nothing below throws)
             if (s->A.graphValid) { rt_graph_destroy(s->A.graph); s->A.graphValid = false; }
             if (s->P.graphValid) { rt_graph_destroy(s->P.graph); s->P.graphValid = false; }
             rt_stream_destroy(s->stream); s->stream = b->stream; s->ownsStream = false;
         }
-        b->hGs = (GenScalars *)rt_malloc_host(sizeof(GenScalars) * n);
-        for (int w = 0; w < 2; ++w) { b->dev[w] = dalloc<SamplerDev>(n); b->host[w].resize(n); memset(b->host[w].data(), 0, sizeof(SamplerDev) * n); }
         return b;
     } catch (const std::exception &e) {
         fail(e.what());
-        delete b;
+        if (b) {
+            for (int w = 0; w < 2; ++w) rt_free(b->dev[w]);
+            rt_free_host(b->hGs);
+            if (b->stream) rt_stream_destroy(b->stream);
+            delete b;
+        }
         return nullptr;
     }
 }

@@ -1658,6 +1658,19 @@ void go_debug_set_matrices(go_session *s, const float *A, const float *P)
     sampler_sync(&s->A, &s->P); sampler_sync(&s->P, &s->A);
     sampler_extra_init(&s->A); sampler_extra_init(&s->P);
 }
+/* bench hook: put a freshly created session into a given chain state -- the atoms of both domains (position, mass; inserted in the
+ * given order, which becomes the order of the unsorted vector) and the factor matrices (row-major [rows][K]); the A*P caches / lookup
+ * tables are rebuilt from the matrices.  Lets bench.py time the CPU port on the SAME iterations of the chain the GPU is timed on
+ * (the generators' states are the session's own: the same distribution of work, not the same draws). */
+int go_import_state(go_session *s, const uint64_t *posA, const float *massA, uint32_t nA, const float *A,
+                    const uint64_t *posP, const float *massP, uint32_t nP, const float *P)
+{
+    if (s->A.dom.n != 0 || s->P.dom.n != 0) return 1;
+    for (uint32_t i = 0; i < nA; ++i) dom_insert(&s->A.dom, posA[i], massA[i]);
+    for (uint32_t i = 0; i < nP; ++i) dom_insert(&s->P.dom, posP[i], massP[i]);
+    go_debug_set_matrices(s, A, P);
+    return 0;
+}
 void go_debug_alpha(const go_session *s, char which, int mode, uint32_t r1, uint32_t c1, uint32_t r2, uint32_t c2, float ch, float *out2)
 {
     const go_sampler *sm = pickc(s, which);

@@ -112,6 +112,9 @@ float go_chisq(const go_session *s, char which);
 /* copy-outs: matrix is row-major [rows][K]; AP is [M][N] (one contiguous vector per factor row) */
 void go_get_matrix(const go_session *s, char which, float *out);
 void go_debug_set_matrices(go_session *s, const float *A, const float *P);
+/* bench hook: a fresh session takes over a chain state (atoms in vector order + factor matrices, row-major); 0 on success */
+int go_import_state(go_session *s, const uint64_t *posA, const float *massA, uint32_t nA, const float *A,
+                    const uint64_t *posP, const float *massP, uint32_t nP, const float *P);
 void go_debug_alpha(const go_session *s, char which, int mode, uint32_t r1, uint32_t c1, uint32_t r2, uint32_t c2, float ch, float *out2);
 void go_get_rows(const go_session *s, char which, float *out); /* HybridMatrix row copy (sparse model); = go_get_matrix for the dense model */
 void go_get_ap(const go_session *s, char which, float *out);

@@ -114,6 +114,7 @@ def lib(omp=False):
     L.go_get_ap.argtypes = [C.c_void_p, C.c_char, fp]
     L.go_get_rows.argtypes = [C.c_void_p, C.c_char, fp]
     L.go_debug_set_matrices.argtypes = [C.c_void_p, fp, fp]
+    L.go_import_state.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), fp, C.c_uint32, fp, C.POINTER(C.c_uint64), fp, C.c_uint32, fp]
     L.go_debug_alpha.argtypes = [C.c_void_p, C.c_char, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, fp]
     L.go_get_atoms.argtypes = [C.c_void_p, C.c_char, C.POINTER(C.c_uint64), fp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.go_get_dims.argtypes = [C.c_void_p, C.c_char] + [C.POINTER(C.c_uint32)] * 3
@@ -305,6 +306,15 @@ class Session:
     def debug_set_matrices(self, A, P):
         a = np.ascontiguousarray(A, dtype=np.float32); b = np.ascontiguousarray(P, dtype=np.float32)
         self.L.go_debug_set_matrices(self.h, _fp(a), _fp(b))
+
+    def import_state(self, atomsA, A, atomsP, P):
+        """a fresh session takes over a chain state: atoms dicts (pos, mass in vector order) and the factor matrices [rows][K]"""
+        u64p = C.POINTER(C.c_uint64)
+        pa, ma = np.ascontiguousarray(atomsA["pos"], np.uint64), np.ascontiguousarray(atomsA["mass"], np.float32)
+        pp, mp = np.ascontiguousarray(atomsP["pos"], np.uint64), np.ascontiguousarray(atomsP["mass"], np.float32)
+        a, b = np.ascontiguousarray(A, np.float32), np.ascontiguousarray(P, np.float32)
+        if self.L.go_import_state(self.h, pa.ctypes.data_as(u64p), _fp(ma), pa.size, _fp(a), pp.ctypes.data_as(u64p), _fp(mp), pp.size, _fp(b)):
+            raise RuntimeError("go_import_state needs a fresh session")
 
     def debug_alpha(self, which, mode, r1, c1, r2=0, c2=0, ch=0.0):
         out = np.zeros(2, dtype=np.float32)

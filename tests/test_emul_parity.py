@@ -205,3 +205,33 @@ def test_sparse_balanced_list_overflow(emul_lib):
     genes, 70 % non-zero -- the owners' fallback loop; and a case that mixes both within one evaluation (two rounds of words)"""
     pu.run_stepwise(emul_lib(256), pu.synthetic_counts(8000, 10, zeros=0.3, seed=2), 4, trace=False, nPatterns=3, seed=5, total_iter=10, check_every=2, sparseOptimization=True)
     pu.run_stepwise(emul_lib(256), pu.synthetic_counts(20000, 6, zeros=0.85, seed=3), 3, trace=False, nPatterns=3, seed=6, total_iter=10, check_every=3, sparseOptimization=True)
+
+
+def test_update_of_zero_steps(emul_lib, gist, monkeypatch):
+    """update(0) -- a Poisson draw of 0 has probability e^-10 per draw while a chain holds at most ten atoms -- is a no-op
+    (AsynchronousGibbsSampler.h:94) for a single session (against the oracle) and inside a lock-stepped batch, which must not wait
+    for the chain that has nothing to do: the batched chains equal the same chains run alone, zero-step iteration included"""
+    from cogaps_amd import _capi
+    lib = emul_lib(256)
+    S, O = pu.make_pair(lib, gist[:200], nPatterns=3, seed=8, nIterations=20)
+    for it in range(6):
+        S.set_annealing(0.5), O.set_annealing(0.5)
+        nA, nP = S.draw_steps()
+        assert (nA, nP) == O.draw_steps()
+        if it in (0, 3):
+            nA = 0
+        if it == 4:
+            nP = 0
+        S.iterate(nA, nP), O.iterate(nA, nP)
+        pu.assert_state_equal(S, O, "it%d" % it)
+    S.close(), O.close()
+    monkeypatch.setenv("COGAPS_TEST_ZERO_STEPS", "2:3")
+    kws = [dict(workerID=w, runningDistributed=True) for w in (1, 2, 3)]
+    datas = [gist[:200], gist[200:400], gist[400:600]]
+    common = dict(nPatterns=3, seed=8, nIterations=12, outputFrequency=6)
+    batched = _capi.run_batch(datas, kws=kws, lib=lib, **common)
+    for d, k, b in zip(datas, kws, batched):
+        one = _capi.run(d, lib=lib, **dict(common, **k))
+        assert one["totalUpdates"] == b["totalUpdates"] and np.array_equal(one["Amean"], b["Amean"]) and np.array_equal(one["Psd"], b["Psd"])
+    monkeypatch.delenv("COGAPS_TEST_ZERO_STEPS")
+    assert _capi.run(datas[1], lib=lib, **dict(common, **kws[1]))["totalUpdates"] != batched[1]["totalUpdates"]      # the hook did change worker 2's run
