@@ -159,6 +159,8 @@ struct HostSampler {
     uint32_t nAtoms = 0;          // host copy after the last update
     float avgQueue = 0.f;
     float dataSparsity = 0.f;     // DenseNormalModel::dataSparsity
+    SamplerDev *dRecord = nullptr; SamplerDev recordHeld;   // `d` in device memory (the generator reads it through a pointer) and what that copy holds
+    bool recordValid = false;
     float stepsPerBatch = 0.f;
     uint32_t genWin = GEN_WIN;    // lanes of the generator launch (gen_window_for)
     float anneal = 1.f;           // annealing temperature of the next update
@@ -213,7 +215,7 @@ static void free_sampler(HostSampler &h)
     rt_free(d.bits0); rt_free(d.bits1); rt_free(d.bits2); rt_free(d.eraseList); rt_free(d.queue); rt_free(d.queueUnits); rt_free(d.partials);
     rt_free(d.rowStamp); rt_free(d.atomStamp); rt_free(d.gapStamp); rt_free(d.inlineStamp); rt_free(d.atomDest);
     rt_free(d.gs); rt_free(d.trace); rt_free(d.traceBatchNproc); rt_free(d.traceBatchQlen);
-    rt_free(h.Sraw); rt_free(h.seeds); rt_free_host(h.hSeeds); rt_free(h.partial);
+    rt_free(h.Sraw); rt_free(h.seeds); rt_free_host(h.hSeeds); rt_free(h.partial); rt_free(h.dRecord);
     rt_free((void *)d.dflags); rt_free((void *)d.dprefix); rt_free((void *)d.dptr); rt_free((void *)d.dvals); rt_free(d.rows); rt_free(d.mflags); rt_free(d.Z1); rt_free(d.Z2);
 }
 
@@ -406,11 +408,23 @@ static void timing_resolve(cogaps_session *s, uint64_t realBatches)
     s->evUsed = 0;
 }
 #define LAUNCH_MAYBE_TIMED(slot, KERNEL, grid, block, ...) do { if ((slot) >= 0) RT_LAUNCH_TIMED(KERNEL, grid, block, s->stream, s->evPool[slot], __VA_ARGS__); else RT_LAUNCH(KERNEL, grid, block, s->stream, __VA_ARGS__); } while (0)
+// The generator reads the sampler's record from device memory (gen_populate.h: a by-value SamplerDev made the compiler open the kernel
+// with seven serial scalar-cache misses).  The copy is refreshed, on the session's stream, whenever the host's record changed.
+static void sync_record(cogaps_session *s, HostSampler &h)
+{
+    if (!h.dRecord) h.dRecord = dalloc<SamplerDev>(1);
+    if (h.recordValid && memcmp(&h.recordHeld, &h.d, sizeof(SamplerDev)) == 0) return;
+    h.recordHeld = h.d;
+    rt_h2d(h.dRecord, &h.recordHeld, sizeof(SamplerDev), s->stream);
+    rt_sync(s->stream);
+    h.recordValid = true;
+}
 static void launch_gen(cogaps_session *s, HostSampler &h)
 {
     const int slot = timing_slot(s, h, 0, h.genLaunches);
-    if (h.genWin == (uint32_t)GEN_WIN) LAUNCH_MAYBE_TIMED(slot, gen_kernel<GEN_WIN>, 1, GEN_WIN, h.d.lcgMul, h.d.lcgInc, h.d.gs, (const unsigned long long *)h.d.eraseList, (const uint32_t *)h.d.queueUnits, h.d.eraseCap, h.d.queueCap, h.d);
-    else LAUNCH_MAYBE_TIMED(slot, gen_kernel<GEN_WIN_HALF>, 1, GEN_WIN_HALF, h.d.lcgMul, h.d.lcgInc, h.d.gs, (const unsigned long long *)h.d.eraseList, (const uint32_t *)h.d.queueUnits, h.d.eraseCap, h.d.queueCap, h.d);
+    const SamplerDev CG_CONSTANT *rec = (const SamplerDev CG_CONSTANT *)h.dRecord;
+    if (h.genWin == (uint32_t)GEN_WIN) LAUNCH_MAYBE_TIMED(slot, gen_kernel<GEN_WIN>, 1, GEN_WIN + 64, h.d.lcgMul, h.d.lcgInc, h.d.gs, (const unsigned long long *)h.d.eraseList, (const uint32_t *)h.d.queueUnits, h.d.eraseCap, h.d.queueCap, rec);
+    else LAUNCH_MAYBE_TIMED(slot, gen_kernel<GEN_WIN_HALF>, 1, GEN_WIN_HALF + 64, h.d.lcgMul, h.d.lcgInc, h.d.gs, (const unsigned long long *)h.d.eraseList, (const uint32_t *)h.d.queueUnits, h.d.eraseCap, h.d.queueCap, rec);
     h.genLaunches++;
 }
 static void launch_eval(cogaps_session *s, HostSampler &h)
@@ -493,6 +507,7 @@ static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool t
     rt_h2d(d.gs, s->hGs, sizeof(GenScalars), s->stream);
     rt_sync(s->stream);
     if (nSteps == 0) return 0;
+    sync_record(s, h);
     h.updLaunches = 0;
     // proposals per batch: the previous update of this sampler is the best predictor
     float avgq = h.stepsPerBatch > 1.f ? h.stepsPerBatch : (g.avgQueue > 1.f ? g.avgQueue : 1.f);
@@ -939,8 +954,8 @@ static void multi_launch_pair(cogaps_batch *b, int w, const MultiGeom &g, int sl
     const uint32_t C = (uint32_t)b->ss.size();
     const SamplerDev CG_CONSTANT *arr = (const SamplerDev CG_CONSTANT *)b->dev[w];
 #define MLAUNCH(slot, KERNEL, grid, block, ...) do { if ((slot) >= 0) RT_LAUNCH_TIMED(KERNEL, grid, block, b->stream, b->ev[slot], __VA_ARGS__); else RT_LAUNCH(KERNEL, grid, block, b->stream, __VA_ARGS__); } while (0)
-    if (b->genWin[w] == (uint32_t)GEN_WIN) MLAUNCH(slotGen, gen_kernel_multi<GEN_WIN>, C, GEN_WIN, arr);
-    else MLAUNCH(slotGen, gen_kernel_multi<GEN_WIN_HALF>, C, GEN_WIN_HALF, arr);
+    if (b->genWin[w] == (uint32_t)GEN_WIN) MLAUNCH(slotGen, gen_kernel_multi<GEN_WIN>, C, GEN_WIN + 64, arr);
+    else MLAUNCH(slotGen, gen_kernel_multi<GEN_WIN_HALF>, C, GEN_WIN_HALF + 64, arr);
     if (b->sparse) MLAUNCH(slotEval, eval_sparse_kernel_multi, C * g.wgPerChain, g.block, arr, g.wgPerChain);
     else if (g.fused) MLAUNCH(slotEval, eval_kernel_multi<EVAL_FUSED>, C * g.wgPerChain, g.block, arr, 1u, g.wgPerChain);
     else {
@@ -1318,11 +1333,13 @@ int cogaps_session_debug_replay(cogaps_session *s, char which, int kind, uint32_
         rt_h2d(h.seeds, sd.data(), sd.size() * 8, s->stream); h.d.seeds = h.seeds;
         g.nSteps = steps; g.nDone = 0; g.updateFlushed = 0; g.qlen = 0; g.traceOn = 0;
         *s->hGs = g; rt_h2d(h.d.gs, s->hGs, sizeof(GenScalars), s->stream);
+        sync_record(s, h);
         launch_gen(s, h);
         if (kind == 0 || kind == 3) launch_eval(s, h);
     }
     rt_sync(s->stream);
     h.d.dbg = dbgFlags;
+    sync_record(s, h);
     const double t0 = now_s();
     for (uint32_t i = 0; i < n; ++i) { if (kind == 0 || kind == 3) { launch_gen(s, h); launch_eval(s, h); } else if (kind == 2) launch_gen(s, h); else launch_eval(s, h); }
     rt_sync(s->stream);

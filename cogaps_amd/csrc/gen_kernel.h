@@ -23,37 +23,21 @@
 #pragma once
 #include "gaps_state.h"
 
-#if defined(GEN_PROFILE)
-#define GEN_PROF(i) do { if (t == 0) { unsigned long long now_ = cg_clock(); prof_acc[i] += now_ - prof_last; prof_last = now_; } } while (0)
-#define GEN_PROF_FLUSH() do { if (t == 0) { for (int i_ = 0; i_ < 16; ++i_) if (prof_acc[i_]) cg_atomic_add_u64(&gs->prof[i_], prof_acc[i_]); } } while (0)
-#else
-#define GEN_PROF(i) do { } while (0)
-#define GEN_PROF_FLUSH() do { } while (0)
-#endif
 #if defined(GEN_TIMELINE)
-// per-wave timeline of one typical launch (lane 0 of every wave records (clock << 8 | id)); dev tool only
-__device__ unsigned long long g_timeline[(GEN_WIN / 64) * 64];
+// per-wave timeline of one typical launch (lane 0 of every wave -- the attempt waves and the helper wave -- records (clock << 8 | id)); dev tool only
+__device__ unsigned long long g_timeline[(GEN_WIN / 64 + 1) * 64];
 #define GEN_TS(id) do { if ((t & 63u) == 0u && ts_n < 64u) { sh.ts[(t & ~63u) + ts_n] = ((unsigned long long)cg_clock() << 8) | (unsigned long long)(id); ++ts_n; } } while (0)
-#define GEN_TS_DUMP() do { if ((t & 63u) == 0u) sh.tsn[t >> 6] = ts_n; cg_sync(); if (sh.processed >= 100u && sh.roundNo == 1u) { for (uint32_t i_ = t; i_ < (uint32_t)(WIN / 64) * 64u; i_ += WIN) g_timeline[i_] = ((i_ & 63u) < sh.tsn[i_ >> 6]) ? sh.ts[i_] : 0ull; } } while (0)
+// every wave leaves its own marks when it ends (a launch that found a well filled queue: the populated chain)
+#define GEN_TS_DUMP_WAVE() do { if ((t & 63u) == 0u && e_prevQ >= 140u && (t >> 6) <= (unsigned)(GEN_WIN / 64)) { for (uint32_t i_ = 0; i_ < 64u; ++i_) g_timeline[(t & ~63u) + i_] = i_ < ts_n ? sh.ts[(t & ~63u) + i_] : 0ull; } } while (0)
 #define GEN_TS_INIT() uint32_t ts_n = 0
+#define GEN_TS_RESUME(k) ts_n = (k)
 #define GEN_PIN(x) asm volatile("" : "+v"(x) :: "memory")      // the value is computed before the next timestamp
 #else
 #define GEN_TS(id) do { } while (0)
 #define GEN_TS_INIT() do { } while (0)
+#define GEN_TS_RESUME(k) do { } while (0)
 #define GEN_PIN(x) do { } while (0)
-#define GEN_TS_DUMP() do { } while (0)
-#endif
-#if defined(GEN_ROUNDMARKS)
-#define GEN_PROF_R(i, j) do { if (roundNo > 1u) { GEN_PROF(j); if (t == 0 && (j) == 8) prof_acc[14] += 1ull << 40; } else GEN_PROF(i); } while (0)
-#else
-#define GEN_PROF_R(i, j) GEN_PROF(i)
-#endif
-#if defined(GEN_SUBMARKS)
-#define GEN_SUB(i) GEN_PROF(i)
-#define GEN_SUBS(i) do { cg_sync(); GEN_PROF(i); } while (0)
-#else
-#define GEN_SUB(i) do { } while (0)
-#define GEN_SUBS(i) do { } while (0)
+#define GEN_TS_DUMP_WAVE() do { } while (0)
 #endif
 
 #define GEN_T_NONE 0
@@ -99,9 +83,9 @@ struct GenShared {
     // flush: erase cache sorted by position (handles, links, vector indices, bins), the tail of the unsorted
     // vector and the net writes of the swap-with-last replay
     uint64_t fpos[FLUSH_MAX], flpos[FLUSH_MAX], frpos[FLUSH_MAX]; float frmass[FLUSH_MAX]; uint32_t fh[FLUSH_MAX], fl[FLUSH_MAX], fr[FLUSH_MAX], fidx[FLUSH_MAX], fbin[FLUSH_MAX], fhead[FLUSH_MAX], vt[FLUSH_MAX], lowSlot[FLUSH_MAX], lowH[FLUSH_MAX];
-    uint32_t nLow, newFront, flushM, flushBase, unitSum, endBatch;
+    uint32_t nLow, newFront, flushM, flushBase, unitSum, frontPending;
 #if defined(GEN_TIMELINE)
-    unsigned long long ts[(WIN / 64) * 64]; uint32_t tsn[WIN / 64];
+    unsigned long long ts[(WIN / 64 + 1) * 64];
 #endif
     alignas(16) uint32_t bkey[4 * GEN_TAB_NB];      // conflict sets of round 1: keys, bucket-major
     alignas(16) GenTabVal bval[4 * GEN_TAB_NB];     // ... and the ordinals registered under each key
@@ -110,7 +94,7 @@ struct GenShared {
     GenScalars g;                        // the generator's scalars, LDS-resident for the launch
     uint64_t qrngRound, batchEpoch;
     uint32_t roundNo, stopKey;
-    uint32_t nR, minAtoms, processed, qlen, skip, remaining, done, stopT, stopFail;
+    uint32_t nR, minAtoms, processed, qlen, skip, remaining;
     uint32_t nWork, updBase; float u1c, u2c;
 };
 

@@ -4,23 +4,46 @@
 // TYPE so that a wavefront executes (mostly) one of the birth/death, move or exchange code paths instead
 // of all four under divergence -- the attempt ordinal `ct` travels with the lane and is what the
 // conflict stamps compare.  Per-attempt prefix counts (queue slot, birth rank) come from LDS bit masks.
+//
+// Wave specialisation (round 3).  A launch has WIN attempt lanes (WIN / 64 waves) plus ONE HELPER WAVE (lanes WIN .. WIN + 63) that
+// owns the launch's serial chores, so that they run BESIDE the attempt waves instead of before and after them:
+//   * the flush of the erase cache (ConcurrentAtomicDomain.cpp:71-79) -- <= FLUSH_MAX atoms, one helper lane each, the steps of one
+//     wave need no workgroup barrier between them -- runs while the attempt waves classify their attempts (A1) and draw what needs
+//     only the window's scalars (first stage of A2); the two sides meet at one barrier before the first load that reads the domain;
+//   * the conflict table's value words are preset while the launch's first memory trip is in flight (so registration needs no
+//     opener / second barrier), and
+//   * the round bookkeeping (counts, generator state, queue-length mean) and the write-back of the generator's scalars run while the
+//     attempt lanes commit; a batch's last round ends without a closing barrier.
+// A workgroup barrier counts every wave, so the helper executes exactly the barriers the attempt waves execute (the same number, at
+// points chosen so that neither side waits long); what it does between them is its own.
 #pragma once
 
-// ---- flushEraseCache (ConcurrentAtomicDomain.cpp:71-79 + erase :109-124) --------------------------------
+// ---- flushEraseCache (ConcurrentAtomicDomain.cpp:71-79 + erase :109-124), by the helper wave --------------------------
 // The reference sorts the erase cache by position and erases one atom after the other.  Here: rank sort in
 // LDS; the list surgery and the bin-head index are done by one lane per erased atom (after the sort, an
 // erased neighbour of erased atom k can only be k-1 / k+1, so runs of adjacent erased atoms are walked in
 // LDS); the swap-with-last sequence on the unsorted vector -- order dependent -- is replayed by one lane on
 // indices held in LDS (no memory traffic), and only its net effect (<= m slots) is written back.
+// ht: helper lane 0..63.  The steps are separate functions because the caller interleaves them with the barriers it owes the
+// attempt waves; inside the one wave a step sees the previous step's LDS writes after cg_wave_sync().
+struct GenFlushRegs { uint32_t myH, myBin, myHead; AtomRec rec; uint32_t vtail; };
+// step 1: request the erased atoms' records, their bins' heads and the tail of the unsorted vector (no wait)
 template <int WIN>
-CG_DEVICE void gen_flush_parallel(const SamplerDev &S, GenShared<WIN> &sh, const uint32_t m, const uint32_t n, const uint32_t fc0, const unsigned long long specE)
+CG_DEVICE void gen_flush_fetch(const SamplerDev &S, GenFlushRegs &f, const unsigned ht, const uint32_t m, const uint32_t n, const unsigned long long specE)
 {
-    const unsigned t = cg_tid();
+    f.myH = 0; f.myBin = 0; f.myHead = CG_NONE; f.vtail = CG_NONE;
+    f.rec.pos = 0; f.rec.lpos = 0; f.rec.rpos = 0; f.rec.left = CG_NONE; f.rec.right = CG_NONE; f.rec.mass = 0.f; f.rec.rmass = 0.f; f.rec.idx = 0; f.rec.pad0 = 0;
+    // (the bin travels with the handle in the erase cache: the bin's head is asked for in the same trip as the record)
+    if (m <= (uint32_t)FLUSH_MAX && ht < m) { f.myH = (uint32_t)specE; f.myBin = (uint32_t)(specE >> 32); f.rec = S.atoms[f.myH]; f.myHead = S.binHead[f.myBin]; f.vtail = S.vec[n - m + ht]; }
+}
+// steps 2-4: sort, surgery, replay, write-back.  part 0: sort; part 1: list surgery + bin heads + index replay; part 2: write-back
+template <int WIN>
+CG_DEVICE void gen_flush_part(const SamplerDev &S, GenShared<WIN> &sh, const GenFlushRegs &f, const unsigned ht, const uint32_t m, const uint32_t n, const uint32_t fc0, const int part)
+{
     GenScalars &g = sh.g;
-    if (t == 0) { sh.flushM = 0; sh.flushBase = fc0; }
-    if (m == 0) return;                      // uniform across the block
-    if (m > (uint32_t)FLUSH_MAX) {           // rare: serial fallback, exactly the reference's procedure
-        if (t == 0) {
+    if (m == 0) return;                      // uniform across the wave
+    if (m > (uint32_t)FLUSH_MAX) {           // rare: serial fallback, exactly the reference's procedure (one lane, in the last part)
+        if (part == 2 && ht == 0) {
             for (uint32_t i = 1; i < m; ++i) {
                 const unsigned long long e = S.eraseList[i]; uint64_t p = S.atoms[(uint32_t)e].pos; uint32_t j = i;
                 while (j > 0 && S.atoms[(uint32_t)S.eraseList[j - 1]].pos > p) { S.eraseList[j] = S.eraseList[j - 1]; --j; }
@@ -30,735 +53,808 @@ CG_DEVICE void gen_flush_parallel(const SamplerDev &S, GenShared<WIN> &sh, const
             for (uint32_t i = 0; i < m; ++i) gen_erase_one(S, (uint32_t)S.eraseList[i], nn, fc, fr);
             g.nAtoms = nn; g.freeCount = fc; g.front = fr; g.eraseCount = 0;
         }
-        cg_sync();
         return;
     }
-    // 1. fetch the erased atoms and the tail of the unsorted vector
-    uint32_t myH = 0; AtomRec rec; rec.pos = 0; rec.lpos = 0; rec.rpos = 0; rec.left = CG_NONE; rec.right = CG_NONE; rec.mass = 0.f; rec.rmass = 0.f; rec.idx = 0;
-    // (the bin travels with the handle in the erase cache: the bin's head is asked for in the same trip as the record)
-    uint32_t myBin = 0, myHead = CG_NONE;
-    if (t < m) { myH = (uint32_t)specE; myBin = (uint32_t)(specE >> 32); rec = S.atoms[myH]; myHead = S.binHead[myBin]; sh.fpos[t] = rec.pos; sh.vt[t] = S.vec[n - m + t]; }
-    cg_sync_lds();
-    // 2. rank sort by position (positions are unique)
-    if (t < m) {
-        uint32_t r = 0;
-        for (uint32_t j = 0; j < m; ++j) r += (sh.fpos[j] < rec.pos) ? 1u : 0u;
-        sh.fh[r] = myH; sh.fl[r] = rec.left; sh.fr[r] = rec.right; sh.fidx[r] = rec.idx; sh.fbin[r] = myBin; sh.fhead[r] = myHead;
-        sh.flpos[r] = rec.lpos; sh.frpos[r] = rec.rpos; sh.frmass[r] = rec.rmass;
-    }
-    cg_sync_lds();
-    // 3. list surgery + bin heads (reads the pre-flush links only)
-    if (t < m) {
-        const uint32_t k = t, h = sh.fh[k];
-        const bool leftErased = (k > 0) && (sh.fh[k - 1] == sh.fl[k]);
-        if (!leftErased) {                    // head of a run of adjacent erased atoms
-            uint32_t j = k;
-            while (j + 1 < m && sh.fh[j + 1] == sh.fr[j]) ++j;
-            const uint32_t L = sh.fl[k], R = sh.fr[j];
-            // (the run's survivors take over each other's cached position / mass: the first erased atom knows L's, the last R's)
-            if (L != CG_NONE) { S.atoms[L].right = R; S.atoms[L].rpos = sh.frpos[j]; S.atoms[L].rmass = sh.frmass[j]; } else sh.newFront = R;
-            if (R != CG_NONE) { S.atoms[R].left = L; S.atoms[R].lpos = sh.flpos[k]; }
+    if (part == 0) {
+        if (ht < m) { sh.fpos[ht] = f.rec.pos; sh.vt[ht] = f.vtail; }
+        cg_wave_sync();
+        // rank sort by position (positions are unique)
+        if (ht < m) {
+            uint32_t r = 0;
+            for (uint32_t j = 0; j < m; ++j) r += (sh.fpos[j] < f.rec.pos) ? 1u : 0u;
+            sh.fh[r] = f.myH; sh.fl[r] = f.rec.left; sh.fr[r] = f.rec.right; sh.fidx[r] = f.rec.idx; sh.fbin[r] = f.myBin; sh.fhead[r] = f.myHead;
+            sh.flpos[r] = f.rec.lpos; sh.frpos[r] = f.rec.rpos; sh.frmass[r] = f.rec.rmass;
         }
-        const uint32_t b = sh.fbin[k];
-        if (sh.fhead[k] == h) {               // the lowest atom of its bin goes: the next surviving atom of the bin takes over
-            uint32_t j = k;
-            while (j + 1 < m && sh.fh[j + 1] == sh.fr[j]) ++j;
-            const uint32_t cand = sh.fr[j];
-            if (cand != CG_NONE && gen_bin_of(S, sh.frpos[j]) == b) S.binHead[b] = cand;      // (the survivor's position is cached in the run's last record: no trip)
-            else { S.binHead[b] = CG_NONE; bm_clear(S, b); }
-        }
-        S.freeHandles[fc0 + k] = h;           // pushed in erase order
+        cg_wave_sync();
+        return;
     }
-    // 4. swap-with-last replay on indices (mAtoms[idx] = mAtoms.back(); pop_back), one lane, LDS only
-    if (t == 0) {
-        uint32_t curN = n, nl = 0;
-        const uint32_t base = n - m;
-        for (uint32_t k = 0; k < m; ++k) {
-            const uint32_t i = sh.fidx[k];
-            const uint32_t hl = sh.vt[curN - 1u - base];           // occupant of the last slot
-            if (i >= base) sh.vt[i - base] = hl;
-            else {
-                uint32_t e = 0; while (e < nl && sh.lowSlot[e] != i) ++e;
-                sh.lowSlot[e] = i; sh.lowH[e] = hl; if (e == nl) ++nl;
+    if (part == 1) {
+        // list surgery + bin heads (reads the pre-flush links only)
+        if (ht < m) {
+            const uint32_t k = ht, h = sh.fh[k];
+            const bool leftErased = (k > 0) && (sh.fh[k - 1] == sh.fl[k]);
+            if (!leftErased) {                    // head of a run of adjacent erased atoms
+                uint32_t j = k;
+                while (j + 1 < m && sh.fh[j + 1] == sh.fr[j]) ++j;
+                const uint32_t L = sh.fl[k], R = sh.fr[j];
+                // (the run's survivors take over each other's cached position / mass: the first erased atom knows L's, the last R's)
+                if (L != CG_NONE) { S.atoms[L].right = R; S.atoms[L].rpos = sh.frpos[j]; S.atoms[L].rmass = sh.frmass[j]; } else sh.newFront = R;
+                if (R != CG_NONE) { S.atoms[R].left = L; S.atoms[R].lpos = sh.flpos[k]; }
             }
-            for (uint32_t q = k + 1; q < m; ++q) if (sh.fh[q] == hl) sh.fidx[q] = i;   // a later victim was moved
-            --curN;
+            const uint32_t b = sh.fbin[k];
+            if (sh.fhead[k] == h) {               // the lowest atom of its bin goes: the next surviving atom of the bin takes over
+                uint32_t j = k;
+                while (j + 1 < m && sh.fh[j + 1] == sh.fr[j]) ++j;
+                const uint32_t cand = sh.fr[j];
+                if (cand != CG_NONE && gen_bin_of(S, sh.frpos[j]) == b) S.binHead[b] = cand;      // (the survivor's position is cached in the run's last record: no trip)
+                else { S.binHead[b] = CG_NONE; bm_clear(S, b); }
+            }
+            S.freeHandles[fc0 + k] = h;           // pushed in erase order
         }
-        sh.nLow = nl; sh.flushM = m;
-        g.nAtoms = n - m; g.freeCount += m; g.eraseCount = 0;
+        // swap-with-last replay on indices (mAtoms[idx] = mAtoms.back(); pop_back), one lane, LDS only
+        if (ht == 0) {
+            uint32_t curN = n, nl = 0;
+            const uint32_t base = n - m;
+            for (uint32_t k = 0; k < m; ++k) {
+                const uint32_t i = sh.fidx[k];
+                const uint32_t hl = sh.vt[curN - 1u - base];           // occupant of the last slot
+                if (i >= base) sh.vt[i - base] = hl;
+                else {
+                    uint32_t e = 0; while (e < nl && sh.lowSlot[e] != i) ++e;
+                    sh.lowSlot[e] = i; sh.lowH[e] = hl; if (e == nl) ++nl;
+                }
+                for (uint32_t q = k + 1; q < m; ++q) if (sh.fh[q] == hl) sh.fidx[q] = i;   // a later victim was moved
+                --curN;
+            }
+            sh.nLow = nl; sh.flushM = m;
+            g.nAtoms = n - m; g.freeCount += m; g.eraseCount = 0;
+        }
+        cg_wave_sync();
+        return;
     }
-    cg_sync_lds();
-    if (t < sh.nLow) { const uint32_t slot = sh.lowSlot[t], h = sh.lowH[t]; S.vec[slot] = h; S.atoms[h].idx = slot; }
-    if (t == 0 && sh.newFront != CG_KEEP) { g.front = sh.newFront; }
-    cg_sync();
+    if (ht < sh.nLow) { const uint32_t slot = sh.lowSlot[ht], h = sh.lowH[ht]; S.vec[slot] = h; S.atoms[h].idx = slot; }
+    if (ht == 0 && sh.newFront != CG_KEEP) { g.front = sh.newFront; }
 }
 
 // hot: what the launch's first memory trip reads, passed as leading scalar kernel arguments so that the dispatcher preloads them into
 // SGPRs (-amdgpu-kernarg-preload-count): the trip starts at once and the by-value SamplerDev's kernel-argument lines (WARM
 // bytes; 0 = the caller warmed them) come in under it instead of before it.
 struct GenHot { const uint64_t *lcgMul, *lcgInc; GenScalars *gs; const unsigned long long *eraseList; const uint32_t *queueUnits; uint32_t eraseCap, queueCap; };
-template <int WIN, int WARM>
-CG_DEVICE void gen_body(const SamplerDev &S, const GenHot hot)
+
+// ---- the helper wave: flush, table presets, round bookkeeping, write-back.  Mirrors the attempt waves' barriers one for one. ----
+template <int WIN>
+CG_DEVICE void gen_helper(const SamplerDev &S, GenShared<WIN> &sh, GenScalars *gs, const unsigned ht, const unsigned long long specE,
+                          const uint32_t e_m, const uint32_t e_n, const uint32_t e_fc, const uint32_t e_prevQ, const uint32_t e_nDone, const uint32_t e_nSteps)
 {
-    CG_SHARED GenShared<WIN> sh;
-    const unsigned t = cg_tid();
-    GenScalars *gs = hot.gs;
-
-    unsigned long long prof_last = cg_clock(), prof_acc[16] = {0}; (void)prof_last; (void)prof_acc;
-    GEN_TS_INIT(); GEN_TS(0); GEN_TS(0);
-    // k-step PCG jumps for this lane's (u1,u2): k = 2t, or 2(t-1) when attempt 0 replays cached values
-    const uint64_t jm0 = hot.lcgMul[2u * t], ji0 = hot.lcgInc[2u * t];
-    const uint64_t jm1 = hot.lcgMul[t ? 2u * (t - 1u) : 0u], ji1 = hot.lcgInc[t ? 2u * (t - 1u) : 0u];
-    // first memory trip of the launch, everything independent: the scalars every lane needs (same address
-    // for all lanes: one transaction), the erase cache and traffic-unit slots read speculatively, and lane
-    // 0's copy of the generator's scalars into LDS, where they live for the whole launch
-    const unsigned long long specE = (t < (unsigned)FLUSH_MAX && t < hot.eraseCap) ? hot.eraseList[t] : 0ull;
-    uint32_t units = (t < hot.queueCap) ? hot.queueUnits[t] : 0u;
-    const uint64_t jmW = hot.lcgMul[2 * WIN], jiW = hot.lcgInc[2 * WIN];
-    // the generator's scalars into LDS, one lane per word
-    constexpr uint32_t GSW = (uint32_t)(sizeof(GenScalars) / 4u);
-    static_assert(GSW <= 2u * (uint32_t)WIN, "at most two words of GenScalars per lane");
-    const uint32_t gword = (t < GSW) ? reinterpret_cast<const uint32_t *>(gs)[t] : 0u;
-    const uint32_t gword2 = (t + (uint32_t)WIN < GSW) ? reinterpret_cast<const uint32_t *>(gs)[t + (uint32_t)WIN] : 0u;
-    cg_sched_fence();
-    if (WARM > 0) cg_kernarg_warm<(WARM > 0 ? WARM : 4)>();
-    if (t < GSW) reinterpret_cast<uint32_t *>(&sh.g)[t] = gword;
-    if (t + (uint32_t)WIN < GSW) reinterpret_cast<uint32_t *>(&sh.g)[t + (uint32_t)WIN] = gword2;
-    if (t == 0) { sh.newFront = CG_KEEP; sh.unitSum = 0; }
-    {   // empty conflict table
-        // (keys only: whoever claims a slot initialises its value words)
-        GenTabKeys none; none.k[0] = none.k[1] = none.k[2] = none.k[3] = GEN_TAB_EMPTY;
-        for (uint32_t i = t; i < (uint32_t)GEN_TAB_NB; i += WIN) *(GenTabKeys *)&sh.bkey[4u * i] = none;
+    const unsigned t = (unsigned)WIN + ht;
+    GEN_TS_INIT(); GEN_TS_RESUME(7);      // (marks 0, 0, 26-29, 1 were left by gen_body)
+    GenFlushRegs fr;
+    gen_flush_fetch<WIN>(S, fr, ht, e_m, e_n, specE);          // the flush's one memory trip: under the attempt waves' A1
+    const uint32_t n0 = e_n - e_m;                              // the domain holds this many atoms after the flush
+    const uint64_t batchEpoch = sh.g.batchEpoch + 1;
+    const uint32_t remaining = e_nSteps - e_nDone;
+    if (ht == 0) {
+        // the round scalars of round 1 (the attempt lanes derive the same values in registers and read these copies only later)
+        sh.batchEpoch = batchEpoch; sh.roundNo = 1; sh.stopKey = 0xFFFFFFFFu; sh.frontPending = 0;
+        sh.qrngRound = sh.g.qrng; sh.nR = n0; sh.minAtoms = n0; sh.processed = 0; sh.qlen = 0; sh.skip = sh.g.useCached ? 1u : 0u;
+        sh.remaining = remaining; sh.u1c = sh.g.u1; sh.u2c = sh.g.u2; sh.updBase = e_nDone;
+        sh.flushM = 0; sh.flushBase = e_fc; sh.nLow = 0;
     }
-    if (t == 0) { sh.jmul[WIN] = jmW; sh.jinc[WIN] = jiW; }
-    sh.jmul[t] = jm0; sh.jinc[t] = ji0;        // even-step PCG jumps, for the round bookkeeping
-    cg_sync_lds();
-    // the scalars every lane needs, from the LDS copy (wave-uniform: kept in scalar registers)
-    const uint32_t e_m = cg_uniform_u32(sh.g.eraseCount), e_n = cg_uniform_u32(sh.g.nAtoms), e_fc = cg_uniform_u32(sh.g.freeCount), e_prevQ = cg_uniform_u32(sh.g.qlen),
-                   e_nDone = cg_uniform_u32(sh.g.nDone), e_nSteps = cg_uniform_u32(sh.g.nSteps);
-    GEN_PROF(14);
-    GEN_TS(1);
-    // second trip (addresses from the first), in flight while the flush runs: this round's seeds
-    const uint64_t seed1 = (e_nDone + t < e_nSteps) ? S.seeds[e_nDone + t] : 0ull;
-    {   // roofline bookkeeping: add up the traffic units the evaluation kernel left per queue slot (this
-        // workgroup is the only writer of evalBytes / evalProps: plain LDS accumulation, written back at the end)
-        if (t >= e_prevQ) units = 0;
-        for (uint32_t q = t + WIN; q < e_prevQ; q += WIN) units += S.queueUnits[q];
-        if (units) cg_atomic_add_u32(&sh.unitSum, units);
-    }
-    // set-up of the first round, issued before the flush so that it runs under the flush's memory trips: after the
-    // flush the domain holds e_n - e_m atoms
-    const bool updateDone = e_nDone >= e_nSteps;
-    {
-        const uint32_t n0 = e_n - e_m;
-        // death probability (ProposalQueue::deathProb) for every atom count an attempt of this window can see:
-        // lane t fills the entries for t births / t deaths ahead of it
-        sh.dpHi[t] = gm_death_prob((double)((uint64_t)n0 + t), S.domainLenD, S.alphaD, S.numBins);
-        sh.dpLo[t] = (n0 >= t) ? gm_death_prob((double)(uint64_t)(n0 - t), S.domainLenD, S.alphaD, S.numBins) : 0.f;
-        if (t < (unsigned)(WIN / 64)) { sh.mq[t] = 0ull; sh.mb[t] = 0ull; sh.md[t] = 0ull; }
-        if (t == 0) {
-            sh.batchEpoch = sh.g.batchEpoch + 1;
-            sh.roundNo = 1; sh.stopKey = 0xFFFFFFFFu;
-            sh.qrngRound = sh.g.qrng;
-            sh.nR = n0; sh.minAtoms = n0;
-            sh.processed = 0; sh.qlen = 0; sh.skip = sh.g.useCached ? 1u : 0u;
-            sh.remaining = e_nSteps - e_nDone;
-            sh.u1c = sh.g.u1; sh.u2c = sh.g.u2; sh.updBase = e_nDone;
-        }
-    }
-    gen_flush_parallel<WIN>(S, sh, e_m, e_n, e_fc, specE);
-    GEN_PROF(0);
+    if (ht < (unsigned)(WIN / 64)) { sh.mq[ht] = 0ull; sh.mb[ht] = 0ull; sh.md[ht] = 0ull; }
     GEN_TS(2);
-    if (t == 0) sh.newFront = CG_NONE;        // (the commit phase's marker; barriers follow before it is used)
-    if (e_m == 0) cg_sync_lds();                   // the flush ended with a barrier otherwise
-    if (updateDone) {
-        if (t == 0) { gs->nAtoms = sh.g.nAtoms; gs->front = sh.g.front; gs->freeCount = sh.g.freeCount; gs->eraseCount = 0; gs->qlen = 0; gs->batchNproc = 0; gs->updateFlushed = 1;
-                      gs->evalBytes = sh.g.evalBytes + (unsigned long long)sh.unitSum * S.unitBytes; gs->evalProps = sh.g.evalProps + e_prevQ; }
-        GEN_PROF_FLUSH();
-        return;
-    }
-
-    const uint64_t batchEpoch = sh.batchEpoch;
-    const uint32_t updBase = e_nDone;           // attempts consumed by earlier batches of this update
-    const uint32_t K = S.K;
-
-    for (;;) {
-        GEN_TS(4);
-        const uint32_t roundNo = sh.roundNo;
-        const uint32_t nR = sh.nR, minR = sh.minAtoms, skip = sh.skip, processed = sh.processed;
-        const uint32_t left_ = sh.remaining - processed;
-        const uint32_t winN = left_ < (uint32_t)WIN ? left_ : (uint32_t)WIN;
-
-        // ------------------------------------------------------------------ A1 (lane = attempt): (u1,u2), B/D/M/E
-        {
-            // (0/1 words and selects instead of short-circuit logic: with one wave per SIMD a branch costs more
-            // than the arithmetic it would skip)
-            const uint32_t active = t < winN;
-            const uint32_t tt = active ? t : 0u;
-            const uint64_t mySeed = (processed == 0u) ? seed1 : S.seeds[updBase + processed + tt];      // round 1: prefetched
-            uint64_t s = (skip ? jm1 : jm0) * sh.qrngRound + (skip ? ji1 : ji0);
-            float u1 = pcg_uniform(s), u2 = pcg_uniform(s);
-            const uint32_t cached = (skip != 0u) & (uint32_t)(t == 0u);       // attempt 0 replays the cached pair
-            u1 = cached ? sh.u1c : u1; u2 = cached ? sh.u2c : u2;
-            uint32_t guess = gen_decide(u1, u2, minR, nR, sh.dpLo[0], sh.dpHi[0]);
-            guess = active ? guess : (uint32_t)GEN_T_NONE;
-            GEN_PIN(guess); GEN_PIN(u1); GEN_PIN(u2);
-            GEN_TS(5);
-            sh.u1[t] = u1; sh.u2[t] = u2;
-            uint32_t bBefore, dBefore, e3, tB, tD, t3;
-            gen_count3<WIN>(sh.wtotA, t, guess == 'B', guess == 'D', false, bBefore, dBefore, e3, tB, tD, t3);
-            GEN_TS(6);
-            // the exact B/D/indeterminate decision depends on how many births / deaths precede this attempt
-            const uint32_t exact = gen_decide(u1, u2, (uint64_t)minR - dBefore, (uint64_t)nR + bBefore, sh.dpLo[dBefore], sh.dpHi[bBefore]);
-            const uint32_t hazA = active & (uint32_t)(exact != guess);
-            const uint32_t failA = active & (hazA ^ 1u) & (uint32_t)(guess == GEN_T_NONE);   // indeterminate: batch ends, no seed used
-            uint32_t aflags = hazA ? GEN_F_HAZARD : (failA ? GEN_F_FAIL : 0u);
-            if (aflags) cg_atomic_min_u32(&sh.stopKey, 2u * t + (hazA ^ 1u));
-            GEN_PIN(aflags);
-            GEN_TS(7);
-            // sort the attempts that go on by code path: births+deaths | moves | exchanges
-            const uint32_t go = active & (uint32_t)(aflags == 0u);
-            const uint32_t k0 = go & ((uint32_t)(guess == 'B') | (uint32_t)(guess == 'D')), k1 = go & (uint32_t)(guess == 'M'), k2 = go & (uint32_t)(guess == 'E');
-            uint32_t e0, e1, e2, T0, T1, T2;
-            gen_count3<WIN>(sh.wtotB, t, k0 != 0u, k1 != 0u, k2 != 0u, e0, e1, e2, T0, T1, T2);
-            if (go) {
-                uint32_t slot = T0 + T1 + e2;
-                slot = k1 ? T0 + e1 : slot;
-                slot = k0 ? e0 : slot;
-                sh.perm[slot] = (uint16_t)t;
-                sh.info[t] = guess | (bBefore << 8);
-                sh.seed[t] = mySeed;                                     // consumed after the type sort
-            }
-            GEN_TS(8);
-            if (t == 0) sh.nWork = T0 + T1 + T2;
-        }
+    for (uint32_t roundNo = 1; ; ++roundNo) {
+        const bool first = roundNo == 1u;
+        const bool ldsRound = first;
+        // ---- A1's three barriers (gen_count3 twice, then the sorted slots); round 1: the flush goes on between them
         cg_sync_lds();
-        GEN_PROF_R(1, 8);
-        GEN_TS(9);
-
-        // ------------------------------------------------------------------ A2 (lane = sorted slot): populate-phase draws
-        const bool go = t < sh.nWork;
-        const uint32_t ct = go ? (uint32_t)sh.perm[t] : 0u;          // this lane's attempt ordinal in the window
-        const uint32_t info = go ? sh.info[ct] : 0u;
-        const uint32_t type = info & 0xFFu, bBefore = info >> 8;
-        uint32_t flags = 0;
-        const bool isB = go && type == 'B';
-        bool pick = go && type != 'B';                 // D/M/E: picks an existing atom
-        uint64_t rng = go ? pcg_from_seed(sh.seed[ct]) : 0ull;   // AtomicProposal ctor, ProposalQueue.cpp:12-15
-        const uint32_t nT = nR + bBefore;              // domain size this attempt sees
-        uint64_t pos = 0, cpos = 0, lbpos = 0, rbpos = 0;
-        uint32_t h1 = CG_NONE, h2 = CG_NONE, i1 = CG_NONE, i2 = CG_NONE, hl = CG_NONE, hr = CG_NONE;
-        uint32_t r1 = 0, c1 = 0, r2 = 0, c2 = 0; float nm1 = 0.f, nm2 = 0.f;
-        uint32_t bin = 0, headBin = 0; unsigned long long w0 = 0;
-
-        // stage 1 ---------------------------------------------------------------------------------
-        if (isB) {
-            // uniform64(1, L) (Random.cpp:105-123) with the constant range's iPart precomputed
-            uint64_t x = pcg_u64(rng);
-            while (x >= S.limitL) x = pcg_u64(rng);
-            pos = (S.iPartL == 1ull ? x : x / S.iPartL) + 1ull;
-            bin = gen_bin_of(S, pos); r1 = gen_div_k(S, bin); c1 = bin - r1 * K;
-            i1 = nT;
-        } else if (pick) {
-            i1 = pcg_uniform32(rng, 0u, nT - 1u);
-            if (i1 >= nR) { flags |= GEN_F_FAIL; pick = false; }   // an atom born earlier in this window: its row is in use
-        }
-        GEN_PIN(i1); GEN_PIN(bin); GEN_PIN(pos);
-        GEN_TS(10);
-        GEN_SUBS(9);
-        uint32_t v1 = CG_NONE;
-        if (isB) w0 = S.bits0[bin >> 6];
-        if (pick) v1 = S.vec[i1];
-#if defined(GEN_SUBMARKS)
-        if (v1 == 12345678u || w0 == 0x123456789ull) flags |= 0x80000000u;
-#endif
-        GEN_PIN(v1); GEN_PIN(w0);
-        GEN_TS(11);
-        GEN_SUBS(10);
-        // stage 2 ---------------------------------------------------------------------------------
-        bool slowB = false;
-        if (isB) {
-            const uint32_t bit = bin & 63u;
-            if ((w0 >> bit) & 1ull) headBin = bin;
-            else {
-                flags |= GEN_F_BINEMPTY; if (w0 == 0ull) flags |= GEN_F_WORDZERO;
-                const unsigned long long m = (bit == 63u) ? 0ull : (w0 & ~((2ull << bit) - 1ull));
-                if (m) headBin = (bin & ~63u) + (uint32_t)cg_ctz64(m); else slowB = true;
-            }
-        }
-        uint32_t v2 = CG_NONE; AtomRec a; a.pos = 0; a.lpos = 0; a.rpos = 0; a.left = CG_NONE; a.right = CG_NONE; a.mass = 0.f; a.rmass = 0.f; a.idx = 0;
-        if (isB && !slowB) v2 = S.binHead[headBin];
-        if (pick) { h1 = v1; a = S.atoms[h1]; }
-#if defined(GEN_SUBMARKS)
-        if (v2 == 12345678u || a.pos == 0x123456789ull) flags |= 0x80000000u;
-#endif
-        GEN_PIN(v2); GEN_PIN(a.pos); GEN_PIN(a.left);
-        GEN_TS(12);
-        GEN_SUBS(11);
-        // stage 3 ---------------------------------------------------------------------------------
-        // A picked atom's record carries its neighbours' positions and the right neighbour's mass (gaps_state.h): a move's bounds and
-        // an exchange's partner need no trip to the neighbours' records -- every pick goes from its record straight to the matrix
-        // entries.  (The one exception: the highest atom's exchange partner is front(), whose record is fetched.)
-        AtomRec b3; b3.pos = 0; b3.lpos = 0; b3.rpos = 0; b3.left = CG_NONE; b3.right = CG_NONE; b3.mass = 0.f; b3.rmass = 0.f; b3.idx = 0;
-        uint64_t lp = 0, rp = 0;
-        float m2x = 0.f;                        // exchange: the partner's mass
-        bool frontE = false;                    // exchange of the highest atom: the partner is front()
-        if (pick) {
-            cpos = a.pos;
-            const uint32_t b1 = gen_bin_of(S, cpos);
-            r1 = gen_div_k(S, b1); c1 = b1 - r1 * K;
-            hl = a.left;
-            if (type == 'M') { hr = a.right; lp = a.lpos; rp = a.rpos; }
-            else if (type == 'E') {
-                hr = a.right;
-                if (hr != CG_NONE) { h2 = hr; rbpos = a.rpos; m2x = a.rmass; }
-                else { h2 = sh.g.front; frontE = true; }
-            }
-        }
-        if (isB && !slowB) b3 = S.atoms[v2];
-        if (frontE) b3 = S.atoms[h2];
-        // the scalars the evaluation starts from travel in the queue record (consumed at commit)
-        float old1 = 0.f, old2 = 0.f; uint32_t gib1 = 0, gib2 = 0;
-        if (isB || pick) { old1 = S.sparse ? S.rows[(size_t)r1 * S.Kpad + c1] : S.mat[(size_t)c1 * S.Mpad + r1]; gib1 = S.otherColPos[c1]; }
-        if (pick && type == 'M') {
-            if (hl != CG_NONE) { flags |= GEN_F_HASLEFT; lbpos = lp; } else lbpos = 0;
-            if (hr != CG_NONE) { flags |= GEN_F_HASRIGHT; rbpos = rp; } else rbpos = S.rboundNone;
-            pos = pcg_uniform64(rng, lbpos + 1ull, rbpos - 1ull);
-            const uint32_t bin2 = gen_bin_of(S, pos);
-            r2 = gen_div_k(S, bin2); c2 = bin2 - r2 * K;
-            if (r1 == r2 && c1 == c2) flags |= GEN_F_INLINE;
-        }
-        if (pick && type == 'E' && !frontE) {
-            flags |= GEN_F_HASRIGHT;
-            const uint32_t bin2 = gen_bin_of(S, rbpos);
-            r2 = gen_div_k(S, bin2); c2 = bin2 - r2 * K;
-        }
-        if (pick && (type == 'M' || (type == 'E' && !frontE))) { old2 = S.sparse ? S.rows[(size_t)r2 * S.Kpad + c2] : S.mat[(size_t)c2 * S.Mpad + r2]; gib2 = S.otherColPos[c2]; }
-#if defined(GEN_SUBMARKS)
-        if (b3.pos == 12345678u || lp == 0x123456789ull || rp == 0x123456789ull) flags |= 0x80000000u;
-#endif
-        GEN_PIN(b3.pos); GEN_PIN(lp); GEN_PIN(rp);
-        GEN_TS(13);
-        GEN_SUBS(12);
-        // finish ----------------------------------------------------------------------------------
-        uint64_t lposB = 0, rposB = 0; float rmassB = 0.f;        // birth: what the new atom's record caches of its neighbours
-        if (isB) {
-            if (!slowB) {
-                if ((flags & GEN_F_BINEMPTY) || b3.pos > pos) { hr = v2; hl = b3.left; lposB = b3.lpos; rposB = b3.pos; rmassB = b3.mass; flags |= GEN_F_NEWHEAD; }
-                else if (b3.pos == pos) slowB = true;      // position already taken: the retry loop below
-                else {
-                    // the bin's lowest atom lies below pos: go on to the right; the record in hand knows its right neighbour's
-                    // position, so the usual case (a bin holds 1.3 atoms on average) needs no further trip
-                    uint32_t cur = v2, nxt = b3.right; uint64_t curPos = b3.pos, nxtPos = b3.rpos; float nxtMass = b3.rmass;
-                    for (;;) {
-                        if (nxt == CG_NONE) break;
-                        if (nxtPos == pos) { slowB = true; break; }
-                        if (nxtPos > pos) break;
-                        const AtomRec w = S.atoms[nxt];
-                        cur = nxt; curPos = nxtPos; nxt = w.right; nxtPos = w.rpos; nxtMass = w.rmass;
-                    }
-                    hl = cur; hr = nxt; lposB = curPos; rposB = nxtPos; rmassB = nxtMass;
-                }
-            }
-            if (slowB) {
-                bool occ, nh;
-                gen_find_gap(S, pos, bin, &hl, &hr, &occ, &nh);
-                while (occ) {           // randomFreePosition retry (ConcurrentAtomicDomain.cpp:46-54)
-                    pos = pcg_uniform64(rng, 1ull, S.domainLenU);
-                    bin = gen_bin_of(S, pos); r1 = gen_div_k(S, bin); c1 = bin - r1 * K;
-                    gen_find_gap(S, pos, bin, &hl, &hr, &occ, &nh);
-                }
-                flags &= ~(GEN_F_BINEMPTY | GEN_F_WORDZERO | GEN_F_NEWHEAD);
-                if (nh) flags |= GEN_F_NEWHEAD;
-                if (S.binHead[bin] == CG_NONE) { flags |= GEN_F_BINEMPTY; if (S.bits0[bin >> 6] == 0ull) flags |= GEN_F_WORDZERO; }
-                old1 = S.sparse ? S.rows[(size_t)r1 * S.Kpad + c1] : S.mat[(size_t)c1 * S.Mpad + r1]; gib1 = S.otherColPos[c1];      // the retry may have moved the birth to another bin
-                lposB = (hl != CG_NONE) ? S.atoms[hl].pos : 0ull;
-                if (hr != CG_NONE) { rposB = S.atoms[hr].pos; rmassB = S.atoms[hr].mass; } else { rposB = 0ull; rmassB = 0.f; }
-            }
-        } else if (pick && type == 'E') {
-            if (frontE) {
-                rbpos = b3.pos; m2x = b3.mass;
-                const uint32_t bin2 = gen_bin_of(S, rbpos);
-                r2 = gen_div_k(S, bin2); c2 = bin2 - r2 * K;
-                old2 = S.sparse ? S.rows[(size_t)r2 * S.Kpad + c2] : S.mat[(size_t)c2 * S.Mpad + r2]; gib2 = S.otherColPos[c2];
-            }
-            if (r1 == r2 && c1 == c2) {
-                flags |= GEN_F_INLINE;
-                const float m1 = a.mass, m2 = m2x;
-                const float newMass = pcg_trunc_gamma_upper(rng, S.luts, m1 + m2, 1.f / S.lambda, S.mathMode);
-                const float delta = (m1 > m2) ? newMass - m1 : m2 - newMass;
-                if (m1 + delta > GAPS_EPSILON && m2 - delta > GAPS_EPSILON) { flags |= GEN_F_APPLY; nm1 = m1 + delta; nm2 = m2 - delta; }
-            }
-        }
-        GEN_PIN(pos); GEN_PIN(flags); GEN_PIN(r2); GEN_PIN(c2); GEN_PIN(rbpos); GEN_PIN(nm1);
-        GEN_TS(14);
-        GEN_PROF_R(2, 9);
-
-        // ------------------------------------------------------------------ B1: register rows / atoms / gaps
-        // Round 1 of a batch (95 % of all rounds) keeps the conflict sets in an LDS hash table; later rounds,
-        // which must also see what earlier rounds of the batch committed, use the stamp tables in HBM.
-        const bool live = go && !(flags & GEN_F_FAIL);
-        const bool queuedM = live && type == 'M' && !(flags & GEN_F_INLINE);
-        const bool ldsRound = roundNo == 1u;
-        if (go) { sh.cpos[ct] = cpos; sh.pos[ct] = pos; sh.type[ct] = queuedM ? (uint8_t)'M' : (uint8_t)0; }
-        uint32_t rs0 = 0, rs1 = 0, rs2 = 0, rf0 = 0, rf1 = 0, rf2 = 0;
-        if (live && ldsRound) {
-            // up to three (key, field) registrations; an unused one repeats the first.  Predicates are 0/1 words
-            // combined with bit operations: every short-circuit would be a branch, and a branch costs more
-            // than the arithmetic it skips when one wave owns the SIMD
-            const uint32_t inl = flags & GEN_F_INLINE, tB = type == 'B', tD = type == 'D', tM = type == 'M';
-            const uint32_t k0 = inl ? h1 : (GEN_TAB_ROW | r1), f0 = inl << 1;
-            const uint32_t use1 = 1u ^ (inl & tM), use2 = tM & (inl ^ 1u);
-            const uint32_t hlKey = (hl == CG_NONE) ? GEN_TAB_FRONT : hl;
-            uint32_t k1 = GEN_TAB_ROW | r2;              // queued move / exchange: the second row
-            k1 = tD ? h1 : k1;                           // death: the atom
-            k1 = tB ? hlKey : k1;                        // birth: the gap right of the left neighbour
-            k1 = inl ? h2 : k1;                          // same-bin exchange: the partner
-            k1 = use1 ? k1 : k0;
-            uint32_t f1 = inl ? 2u : tB; f1 = use1 ? f1 : f0;
-            const uint32_t k2 = use2 ? h1 : k0, f2 = use2 ? 0u : f0;
-            // claim the three slots together: one compare-and-swap each per probe step (a placed key
-            // repeats the swap on its own slot, which changes nothing)
-            const uint32_t hh0 = gen_tab_hash(k0), hh1 = gen_tab_hash(k1), hh2 = gen_tab_hash(k2);
-            uint32_t b0 = gen_tab_bucket(hh0), b1_ = gen_tab_bucket(hh1), b2_ = gen_tab_bucket(hh2);
-            const uint32_t j0 = gen_tab_start(hh0), j1 = gen_tab_start(hh1), j2 = gen_tab_start(hh2);
-            uint32_t s0 = 0, s1 = 0, s2 = 0, d0 = 0, d1 = 0, d2 = 0, w0_ = 0, w1_ = 0, w2_ = 0;
-            for (uint32_t i = 0; ; ++i) {
-                const uint32_t p0 = d0 ? s0 : 4u * b0 + ((j0 + i) & 3u), p1 = d1 ? s1 : 4u * b1_ + ((j1 + i) & 3u), p2 = d2 ? s2 : 4u * b2_ + ((j2 + i) & 3u);
-                const uint32_t o0 = cg_atomic_cas_u32(&sh.bkey[p0], GEN_TAB_EMPTY, k0);
-                const uint32_t o1 = cg_atomic_cas_u32(&sh.bkey[p1], GEN_TAB_EMPTY, k1);
-                const uint32_t o2 = cg_atomic_cas_u32(&sh.bkey[p2], GEN_TAB_EMPTY, k2);
-                s0 = p0; s1 = p1; s2 = p2;
-                w0_ |= o0 == GEN_TAB_EMPTY; w1_ |= o1 == GEN_TAB_EMPTY; w2_ |= o2 == GEN_TAB_EMPTY;     // this lane opened the slot
-                d0 |= (uint32_t)(o0 == GEN_TAB_EMPTY) | (uint32_t)(o0 == k0);
-                d1 |= (uint32_t)(o1 == GEN_TAB_EMPTY) | (uint32_t)(o1 == k1);
-                d2 |= (uint32_t)(o2 == GEN_TAB_EMPTY) | (uint32_t)(o2 == k2);
-                if (d0 & d1 & d2) break;
-                const uint32_t wrap = (i & 3u) == 3u;      // bucket exhausted: the next one
-                b0 = (b0 + wrap) & (uint32_t)(GEN_TAB_NB - 1); b1_ = (b1_ + wrap) & (uint32_t)(GEN_TAB_NB - 1); b2_ = (b2_ + wrap) & (uint32_t)(GEN_TAB_NB - 1);
-            }
-            GenTabVal nobody; nobody.used = nobody.gap = nobody.inl = nobody.pad = GEN_TAB_EMPTY;
-            if (w0_) sh.bval[s0] = nobody;
-            if (w1_) sh.bval[s1] = nobody;
-            if (w2_) sh.bval[s2] = nobody;
-            rs0 = s0; rs1 = s1; rs2 = s2; rf0 = f0; rf1 = f1; rf2 = f2;
-        } else if (live) {
-            // up to three keys: (kind, id)
-            uint32_t rk[3], rid[3]; int nk = 0;
-            const bool inl = (flags & GEN_F_INLINE) != 0;
-            if (type == 'B') { rk[0] = GEN_K_ROW; rid[0] = r1; rk[1] = GEN_K_GAP; rid[1] = (hl == CG_NONE) ? 0u : hl + 1u; nk = 2; }
-            else if (type == 'D') { rk[0] = GEN_K_ROW; rid[0] = r1; rk[1] = GEN_K_ATOM; rid[1] = h1; nk = 2; }
-            else if (type == 'M') {
-                if (inl) { rk[0] = GEN_K_INL; rid[0] = h1; nk = 1; }
-                else { rk[0] = GEN_K_ROW; rid[0] = r1; rk[1] = GEN_K_ROW; rid[1] = r2; rk[2] = GEN_K_ATOM; rid[2] = h1; nk = 3; }
-            } else {
-                if (inl) { rk[0] = GEN_K_INL; rid[0] = h1; rk[1] = GEN_K_INL; rid[1] = h2; nk = 2; }
-                else { rk[0] = GEN_K_ROW; rid[0] = r1; rk[1] = GEN_K_ROW; rid[1] = r2; nk = 2; }
-            }
-            const unsigned long long st = gen_stamp(batchEpoch, roundNo, ct);
-            for (int k = 0; k < nk; ++k) cg_atomic_max_u64(gen_stamp_ptr(S, rk[k], rid[k]), st);
-        }
-        GEN_TS(15);
+        if (first) gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 0);
+        cg_sync_lds();
+        if (first) gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 1);
+        cg_sync_lds();
+        if (first) { gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 2); GEN_TS(3); cg_sync(); }      // the join: the flush's stores are acknowledged (vmcnt(0)) before any lane reads the domain
+        // ---- B1 / B2 barriers
         if (ldsRound) cg_sync_lds(); else cg_sync();
-        if (ldsRound) {
-            if (live) {
-                uint32_t *words = &sh.bval[0].used;       // word 0 = used, 1 = gap, 2 = inl
-                cg_atomic_min_u32(&words[4u * rs0 + rf0], ct);
-                cg_atomic_min_u32(&words[4u * rs1 + rf1], ct);
-                cg_atomic_min_u32(&words[4u * rs2 + rf2], ct);
-            }
-            cg_sync_lds();
-        }
-        GEN_PROF_R(3, 10);
-        GEN_TS(16);
-
-        // ------------------------------------------------------------------ B2: probe the sets (all probes of a lane
-        // are independent: issued together, then the per-type logic runs on registers)
-        if (live && ldsRound) {
-            // six bucket reads, then the six value reads of the matching slots; a key that is not in the table
-            // reads "nobody".  0/1 words and bit operations again (see B1).
-            const uint32_t tB = type == 'B', tM = type == 'M', tE = type == 'E', inl = flags & GEN_F_INLINE;
-            const uint32_t hasL = hl != CG_NONE, hasR = hr != CG_NONE, noRight = (flags & GEN_F_HASRIGHT) == 0u;
-            uint32_t key[6], use[6];
-            key[0] = GEN_TAB_ROW | r1; use[0] = 1u;
-            key[1] = GEN_TAB_ROW | r2; use[1] = tM | tE;
-            key[2] = ((tM | tB) & hasL) ? hl : GEN_TAB_FRONT; use[2] = tM | tB | (tE & noRight);
-            // (same-bin exchange: the gap LEFT of the centre -- a birth there earlier in this window is the holder of the centre's cached mass)
-            const uint32_t eInl = tE & (uint32_t)(inl != 0u);
-            key[3] = eInl ? (hasL ? hl : GEN_TAB_FRONT) : hr; use[3] = ((tM | tB) & hasR) | eInl;
-            const uint32_t tD = type == 'D';
-            key[4] = h1; use[4] = tM | tE | tD;
-            key[5] = h2; use[5] = tE;
-            uint32_t bk[6]; GenTabKeys kq[6];
-            for (int k = 0; k < 6; ++k) { bk[k] = gen_tab_bucket(gen_tab_hash(key[k])); kq[k] = *(const GenTabKeys *)&sh.bkey[4u * bk[k]]; }
-            uint32_t sl[6], hit[6], over = 0;
-            for (int k = 0; k < 6; ++k) {
-                const uint32_t *q4 = kq[k].k;
-                const uint32_t e1 = q4[1] == key[k], e2 = q4[2] == key[k], e3 = q4[3] == key[k];
-                const uint32_t found = (uint32_t)(q4[0] == key[k]) | e1 | e2 | e3;
-                const uint32_t hole = (uint32_t)(q4[0] == GEN_TAB_EMPTY) | (uint32_t)(q4[1] == GEN_TAB_EMPTY) | (uint32_t)(q4[2] == GEN_TAB_EMPTY) | (uint32_t)(q4[3] == GEN_TAB_EMPTY);
-                sl[k] = 4u * bk[k] + e1 + 2u * e2 + 3u * e3;
-                hit[k] = use[k] & found;
-                over |= use[k] & (found ^ 1u) & (hole ^ 1u);             // the key may have spilled into the next bucket
-            }
-            if (over) {                                                   // rare
-                for (int k = 0; k < 6; ++k) if (use[k]) { const uint32_t f = gen_tab_find<WIN>(sh, key[k]); hit[k] = f != GEN_TAB_EMPTY; sl[k] = hit[k] ? f : 0u; }
-            }
-            GenTabVal e[6];
-            for (int k = 0; k < 6; ++k) e[k] = sh.bval[hit[k] ? sl[k] : 0u];
-            // E(v) = 1 when an earlier attempt of this window registered under the word
-            #define GEN_E(k, w) (hit[k] & (uint32_t)(e[k].w < ct))
-            uint32_t fail = GEN_E(0, used) | GEN_E(1, used);                              // a row in use
-            // move: a neighbour in use (mUsedAtoms), or a birth earlier in this window inside (left, right)
-            fail |= tM & (GEN_E(2, used) | GEN_E(3, used) | GEN_E(2, gap) | GEN_E(4, gap));
-            // exchange: an earlier birth right of the centre is the true partner (or, for the last atom, a new front())
-            fail |= tE & (GEN_E(4, gap) | GEN_E(2, gap));
-            // birth: an earlier birth in the same gap; move / birth / same-bin exchange: an earlier same-bin
-            // move or exchange of this window touched an atom whose position this attempt relied on
-            uint32_t haz = tB & (GEN_E(2, gap) | GEN_E(2, inl) | GEN_E(3, inl));
-            haz |= tM & (GEN_E(4, inl) | GEN_E(2, inl) | GEN_E(3, inl));
-            // death / exchange: the masses in the queue record were read before an earlier same-bin exchange of
-            // this window rewrote them
-            haz |= (tE | tD) & (GEN_E(4, inl) | GEN_E(5, inl));
-            // same-bin exchange: it rewrites the copy of the centre's mass that the centre's left neighbour caches, and an earlier birth
-            // of this window between the two has become that neighbour
-            haz |= eInl & GEN_E(3, gap);
-            if (tB) {
-                // mProposedMoves.overlap(pos): a neighbour has a queued move whose interval covers pos
-                const uint32_t uL = GEN_E(2, used), uR = GEN_E(3, used);
-                const uint32_t iL = uL ? e[2].used : 0u, iR = uR ? e[3].used : 0u;
-                const uint64_t aL = sh.cpos[iL], bL = sh.pos[iL], aR = sh.cpos[iR], bR = sh.pos[iR];
-                const uint32_t mL = uL & (uint32_t)(sh.type[iL] == 'M'), mR = uR & (uint32_t)(sh.type[iR] == 'M');
-                const uint64_t loL = aL < bL ? aL : bL, hiL = aL < bL ? bL : aL, loR = aR < bR ? aR : bR, hiR = aR < bR ? bR : aR;
-                fail |= mL & (uint32_t)(loL < pos) & (uint32_t)(pos < hiL);
-                fail |= mR & (uint32_t)(loR < pos) & (uint32_t)(pos < hiR);
-            }
-            #undef GEN_E
-            GEN_PIN(flags);
-            GEN_TS(17);
-            flags |= haz ? GEN_F_HAZARD : (fail ? GEN_F_FAIL : 0u);
-        } else if (live) {
-            const bool tB = type == 'B', tM = type == 'M', tE = type == 'E', inl = (flags & GEN_F_INLINE) != 0;
-            const uint32_t keyL = (hl == CG_NONE) ? 0u : hl + 1u;
-            uint32_t pk[10], pid[10]; bool pu[10];
-            pk[0] = GEN_K_ROW; pid[0] = r1; pu[0] = true;
-            pk[1] = GEN_K_ROW; pid[1] = r2; pu[1] = tM || tE;
-            pk[2] = GEN_K_ATOM; pid[2] = hl; pu[2] = (tM || tB) && hl != CG_NONE;
-            pk[3] = GEN_K_ATOM; pid[3] = hr; pu[3] = (tM || tB) && hr != CG_NONE;
-            pk[4] = GEN_K_GAP; pid[4] = (tB || tM) ? keyL : h1 + 1u; pu[4] = tB || tM || tE;
-            pk[5] = GEN_K_GAP; pid[5] = tM ? h1 + 1u : 0u; pu[5] = tM || (tE && !(flags & GEN_F_HASRIGHT));
-            const bool tD = type == 'D';
-            pk[6] = GEN_K_INL; pid[6] = tB ? hl : h1; pu[6] = tM || (tB && hl != CG_NONE) || tE || tD;
-            pk[7] = GEN_K_INL; pid[7] = tM ? hl : (tB ? hr : h2); pu[7] = (tM && hl != CG_NONE) || (tB && hr != CG_NONE) || tE;
-            pk[8] = GEN_K_INL; pid[8] = hr; pu[8] = tM && hr != CG_NONE;
-            pk[9] = GEN_K_GAP; pid[9] = keyL; pu[9] = tE && inl;       // same-bin exchange: a birth of this window left of the centre (see the LDS round)
-            int res[10]; uint32_t rix[10]; uint64_t d9 = 0, d10 = 0;
-            {
-                unsigned long long v[10];
-                for (int k = 0; k < 10; ++k) v[k] = cg_load_l2_u64(pu[k] ? gen_stamp_ptr(S, pk[k], pid[k]) : &S.gapStamp[0]);
-                d9 = (tB && hl != CG_NONE) ? S.atomDest[hl] : 0ull; d10 = (tB && hr != CG_NONE) ? S.atomDest[hr] : 0ull;
-                for (int k = 0; k < 10; ++k) { rix[k] = 0; res[k] = pu[k] ? gen_probe(v[k], batchEpoch, roundNo, ct, &rix[k]) : 0; }
-            }
-            GEN_SUB(8);
-            bool fail = res[0] != 0, haz = false;                                        // row r1 in use
-            if (res[1] != 0) fail = true;                                                // row r2 in use
-            if (tB) {
-                if (res[4] == 2) haz = true;                                             // an earlier birth of this window in the same gap
-                const uint32_t nb[2] = {hl, hr}; const uint64_t dest[2] = {d9, d10};
-                for (int k = 0; k < 2; ++k) {
-                    if (nb[k] == CG_NONE) continue;
-                    // mProposedMoves.overlap(pos): the neighbour has a queued move whose interval covers pos
-                    const int u = res[2 + k]; const uint32_t ix = rix[2 + k];
-                    uint64_t ma = 0, mb = 0; bool mv = false;
-                    if (u == 1 && dest[k] != 0ull) { ma = S.atoms[nb[k]].pos; mb = dest[k]; mv = true; }
-                    else if (u == 2 && sh.type[ix] == 'M') { ma = sh.cpos[ix]; mb = sh.pos[ix]; mv = true; }
-                    if (mv) { const uint64_t lo = ma < mb ? ma : mb, hi = ma < mb ? mb : ma; if (lo < pos && pos < hi) fail = true; }
-                    // an earlier same-bin move of this window shifted the neighbour this gap search compared against
-                    if (res[6 + k] == 2) haz = true;
-                }
-            } else if (tM) {
-                if (res[2] != 0 || res[3] != 0) fail = true;                             // mUsedAtoms: a neighbour is in use
-                // a birth earlier in this window inside (left, right) is the true neighbour, and it is "used"
-                if (res[4] == 2 || res[5] == 2) fail = true;
-                // an earlier same-bin move/exchange of this window touched the centre or a neighbour: positions stale
-                if (res[6] == 2 || res[7] == 2 || res[8] == 2) haz = true;
-            } else if (tE) {
-                // an earlier birth right of the centre is the true partner (or, for the last atom, a new front())
-                if (res[4] == 2 || res[5] == 2) fail = true;
-                // the masses in the queue record were read before an earlier same-bin exchange of this window rewrote them
-                if (res[6] == 2 || res[7] == 2) haz = true;
-                if (res[9] == 2) haz = true;
-            } else if (tD) {
-                if (res[6] == 2) haz = true;
-            }
-            if (haz) flags |= GEN_F_HAZARD; else if (fail) flags |= GEN_F_FAIL;
-        }
-        GEN_TS(18);
-        if (go && (flags & (GEN_F_HAZARD | GEN_F_FAIL))) cg_atomic_min_u32(&sh.stopKey, 2u * ct + ((flags & GEN_F_HAZARD) ? 0u : 1u));
         if (ldsRound) cg_sync_lds(); else cg_sync();
-        GEN_PROF(4);
-        GEN_TS(19);
-
-        // ------------------------------------------------------------------ C: commit attempts [0, stopT)
+        // ---- C: masks complete behind this barrier; the attempt lanes commit, this wave keeps the books
+        const uint32_t nR = sh.nR, minR = sh.minAtoms, skip = sh.skip, processed = sh.processed;
+        const uint32_t left_ = remaining - processed;
+        const uint32_t winN = left_ < (uint32_t)WIN ? left_ : (uint32_t)WIN;
+        cg_sync_lds();
+        GEN_TS(20);
         const uint32_t stopKey = sh.stopKey;
         const uint32_t stopT = (stopKey == 0xFFFFFFFFu) ? winN : (stopKey >> 1);
         const bool stopFail = (stopKey != 0xFFFFFFFFu) && (stopKey & 1u);
-        const bool commit = go && ct < stopT;            // every such attempt is live
-        const bool queued = commit && (type == 'B' || type == 'D' || !(flags & GEN_F_INLINE));
-        if (commit) {
-            const unsigned long long bit = 1ull << (ct & 63u);
-            if (queued) cg_atomic_or_u64(&sh.mq[ct >> 6], bit);
-            if (type == 'B') cg_atomic_or_u64(&sh.mb[ct >> 6], bit);
-            if (type == 'D') cg_atomic_or_u64(&sh.md[ct >> 6], bit);
-        }
-        cg_sync_lds();
-        GEN_PROF(5);
-        GEN_TS(20);
-        if (commit) {
-            uint32_t qBefore = 0, bRank = 0;
-            {
-                const uint32_t wq = ct >> 6; const unsigned long long lt = (1ull << (ct & 63u)) - 1ull;
-                for (uint32_t w = 0; w < wq; ++w) { qBefore += (uint32_t)cg_popc64(sh.mq[w]); bRank += (uint32_t)cg_popc64(sh.mb[w]); }
-                qBefore += (uint32_t)cg_popc64(sh.mq[wq] & lt); bRank += (uint32_t)cg_popc64(sh.mb[wq] & lt);
-            }
-            const unsigned long long done = (batchEpoch << 24) | GEN_STAMP_COMMITTED;
-            const bool more = !stopFail && (processed + stopT < sh.remaining);   // another round of this batch follows: it reads these
-            if (type == 'B') {
-                // handle allocation: free stack first (deterministic by rank), then bump
-                const uint32_t fc = sh.g.freeCount;
-                // the top of the stack is what this launch's flush pushed, still in LDS
-                uint32_t hb;
-                if (bRank < fc) { const uint32_t fi = fc - 1u - bRank; hb = (fi >= sh.flushBase && fi - sh.flushBase < sh.flushM) ? sh.fh[fi - sh.flushBase] : S.freeHandles[fi]; }
-                else hb = sh.g.handleHi + (bRank - fc);
-                const uint32_t idx = nR + bRank;
-                if (hb >= S.atomCap || idx >= S.atomCap) { gs->error = GAPS_ERR_ATOM_CAP; hb = 0; }
-                S.vec[idx] = hb;
-                AtomRec n; n.pos = pos; n.lpos = lposB; n.rpos = rposB; n.left = hl; n.right = hr; n.mass = 0.f; n.rmass = rmassB; n.idx = idx; n.pad0 = 0;
-                S.atoms[hb] = n;
-                h1 = hb;
-                // splice: the neighbours' links and the copies they cache of the new atom (its mass is 0 until the evaluation sets it)
-                if (hl != CG_NONE) { S.atoms[hl].right = hb; S.atoms[hl].rpos = pos; S.atoms[hl].rmass = 0.f; } else sh.newFront = hb;
-                if (hr != CG_NONE) { S.atoms[hr].left = hb; S.atoms[hr].lpos = pos; }
-                if (flags & GEN_F_NEWHEAD) S.binHead[bin] = hb;
-                if (flags & GEN_F_BINEMPTY) {
-                    cg_atomic_or_u64(&S.bits0[bin >> 6], 1ull << (bin & 63u));
-                    if (flags & GEN_F_WORDZERO) { const uint32_t wa = bin >> 6, wb = wa >> 6, wc = wb >> 6; cg_atomic_or_u64(&S.bits1[wb], 1ull << (wa & 63u)); cg_atomic_or_u64(&S.bits2[wc], 1ull << (wb & 63u)); }
-                }
-                if (more) { S.rowStamp[r1] = done; S.atomStamp[hb] = done; S.atomDest[hb] = 0ull; }
-            } else if (type == 'D') {
-                if (more) { S.rowStamp[r1] = done; S.atomStamp[h1] = done; S.atomDest[h1] = 0ull; }
-            } else if (type == 'M') {
-                if (flags & GEN_F_INLINE) atom_set_pos(S, h1, hl, hr, pos);       // domain.move, same bin
-                else if (more) { S.rowStamp[r1] = done; S.rowStamp[r2] = done; S.atomStamp[h1] = done; S.atomDest[h1] = pos; }
-            } else {
-                if (flags & GEN_F_INLINE) { if (flags & GEN_F_APPLY) { atom_set_mass(S, h1, hl, nm1); atom_set_mass(S, h2, (hr != CG_NONE) ? h1 : CG_NONE, nm2); } }
-                else if (more) { S.rowStamp[r1] = done; S.rowStamp[r2] = done; }
-            }
-            if (queued) {
-                const uint32_t slot = sh.qlen + qBefore;
-                if (slot >= S.queueCap) gs->error = GAPS_ERR_QUEUE_CAP;
-                else {
-                    if (sh.g.traceOn && type == 'E') i2 = S.atoms[h2].idx;         // the partner's index: traces only
-                    PropRec p; p.pos = (type == 'M') ? pos : 0ull; p.rng = rng; p.h1 = h1; p.h2 = h2; p.i1 = i1; p.i2 = i2;
-                    p.r1 = r1; p.c1 = c1; p.r2 = r2; p.c2 = c2; p.type = type; p.batch = 0; p.pad[0] = p.pad[1] = p.pad[2] = 0;
-                    const bool two = type == 'M' || type == 'E';
-                    p.gibbs = (gib1 > 0u ? 1u : 0u) | ((two && gib2 > 0u) ? 2u : 0u);
-                    p.m1 = (type == 'B') ? 0.f : a.mass; p.m2 = (type == 'E') ? m2x : 0.f;
-                    p.old1 = old1; p.old2 = two ? old2 : 0.f; p.curPos = (type == 'M') ? cpos : 0ull;
-                    S.queue[slot] = p;
-                    if (sh.g.traceOn) { const uint32_t ti = sh.g.traceCount + slot; if (ti < sh.g.traceCap) { p.batch = sh.g.nBatches; S.trace[ti] = p; } }
-                }
-            }
-        }
-        GEN_TS(21);
-        cg_sync_lds();
-        GEN_PROF_R(6, 11);
-        GEN_TS(22);
-        // ------------------------------------------------------------------ round bookkeeping
-        if (t == 0) {
+        const bool endB = stopFail || (processed + stopT >= remaining);
+        const bool frontPending = sh.frontPending != 0u;
+        if (ht == 0) {
             uint32_t totQ = 0, totB = 0, totD = 0;
             for (uint32_t w = 0; w < (uint32_t)(WIN / 64); ++w) { totQ += (uint32_t)cg_popc64(sh.mq[w]); totB += (uint32_t)cg_popc64(sh.mb[w]); totD += (uint32_t)cg_popc64(sh.md[w]); }
             if (totB) { const uint32_t fc = sh.g.freeCount; if (totB <= fc) sh.g.freeCount = fc - totB; else { sh.g.freeCount = 0; sh.g.handleHi += totB - fc; } sh.g.nAtoms = nR + totB; }
-            if (sh.newFront != CG_NONE) { sh.g.front = sh.newFront; sh.newFront = CG_NONE; }
             sh.nR = nR + totB; sh.minAtoms = minR - totD;
-            sh.qlen += totQ; sh.processed = processed + stopT;
+            const uint32_t qlen = sh.qlen + totQ;
+            sh.qlen = qlen; sh.processed = processed + stopT;
             const uint32_t attempted = stopT + (stopFail ? 1u : 0u);
             const uint32_t draws = 2u * (attempted - ((skip && attempted) ? 1u : 0u));
             const uint64_t jm = sh.jmul[draws >> 1], ji = sh.jinc[draws >> 1];
-            sh.qrngRound = jm * sh.qrngRound + ji;
+            const uint64_t qr = jm * sh.qrngRound + ji;
+            sh.qrngRound = qr;
             if (attempted) sh.skip = 0;
-            sh.stopT = stopT; sh.stopFail = stopFail ? 1u : 0u;
-#if defined(GEN_PROFILE)
-            prof_acc[15] += 1ull;
-#endif
-            const bool endB = stopFail || (processed + stopT >= sh.remaining);
-            sh.endBatch = endB ? 1u : 0u;
             if (endB) {
-                // final values of the scalars the generator owns, in the LDS copy; the lanes write it back below
+                // final values of the scalars the generator owns, in the LDS copy; the lanes of this wave write it back below
                 GenScalars &g = sh.g;
-                g.qrng = sh.qrngRound;
+                g.qrng = qr;
                 if (stopFail) { g.useCached = 1; g.u1 = sh.u1[stopT]; g.u2 = sh.u2[stopT]; }
                 else g.useCached = 0;
-                const uint32_t nDone = updBase + processed + stopT;
+                const uint32_t nDone = e_nDone + processed + stopT;
                 g.nDone = nDone;
-                g.qlen = sh.qlen; g.batchNproc = processed + stopT;
+                g.qlen = qlen; g.batchNproc = processed + stopT;
                 g.batchEpoch = batchEpoch; g.eraseCount = 0;
                 if (nDone < g.nSteps) {           // n < nSteps: AsynchronousGibbsSampler.h:97-102
                     const float ns = g.nQueueSamples + 1.f;
                     float avg = g.avgQueue;
                     avg *= (ns - 1.f) / ns;
-                    avg += (float)sh.qlen / ns;
+                    avg += (float)qlen / ns;
                     g.nQueueSamples = ns; g.avgQueue = avg;
                 }
                 if (g.traceOn) {
                     const uint32_t bi = g.traceBatchCount;
-                    if (bi < g.traceCap) { S.traceBatchNproc[bi] = processed + stopT; S.traceBatchQlen[bi] = sh.qlen; }
-                    g.traceBatchCount = bi + 1; g.traceCount += sh.qlen;
+                    if (bi < g.traceCap) { S.traceBatchNproc[bi] = processed + stopT; S.traceBatchQlen[bi] = qlen; }
+                    g.traceBatchCount = bi + 1; g.traceCount += qlen;
                 }
                 g.nBatches += 1;
                 g.evalBytes = g.evalBytes + (unsigned long long)sh.unitSum * S.unitBytes; g.evalProps = g.evalProps + e_prevQ;
             }
         }
-        cg_sync_lds();
-        GEN_PROF_R(7, 12);
+        cg_wave_sync();
         GEN_TS(23);
-        if (sh.endBatch) {
-            // write back the leading words of GenScalars (everything the generator owns) one lane per word; the
-            // sticky error word is only ever written in place
-            if (t < GEN_GS_WORDS && t != GEN_GS_ERROR_WORD) reinterpret_cast<uint32_t *>(gs)[t] = reinterpret_cast<const uint32_t *>(&sh.g)[t];
+        if (endB) {
+            // write back the leading words of GenScalars (everything the generator owns) one lane per word; the sticky error word is
+            // only ever written in place, and a new front atom's handle is written by the birth that made it (it may still be on its way
+            // into the LDS copy)
+            const uint32_t frontWord = (uint32_t)(offsetof(GenScalars, front) / 4u);
+            for (uint32_t w = ht; w < GEN_GS_WORDS; w += 64u)
+                if (w != GEN_GS_ERROR_WORD && !(frontPending && w == frontWord)) reinterpret_cast<uint32_t *>(gs)[w] = reinterpret_cast<const uint32_t *>(&sh.g)[w];
             GEN_TS(24);
-            cg_sync_lds();
-            GEN_TS_DUMP();
-            GEN_PROF(13);
-            GEN_PROF_FLUSH();
+            GEN_TS_DUMP_WAVE();
             return;
         }
-        // ------------------------------------------------------------------ set-up of the next round of this batch
-        if (t == 0) { sh.roundNo += 1; sh.stopKey = 0xFFFFFFFFu; sh.newFront = CG_NONE; if (sh.roundNo >= 4094u) gs->error = GAPS_ERR_SPIN; }
-        if (t < (unsigned)(WIN / 64)) { sh.mq[t] = 0ull; sh.mb[t] = 0ull; sh.md[t] = 0ull; }
-        {   // sh.nR / sh.minAtoms were published before the barrier above
-            const uint32_t n0 = sh.nR, m0 = sh.minAtoms;
-            sh.dpHi[t] = gm_death_prob((double)((uint64_t)n0 + t), S.domainLenD, S.alphaD, S.numBins);
-            sh.dpLo[t] = (m0 >= t) ? gm_death_prob((double)(uint64_t)(m0 - t), S.domainLenD, S.alphaD, S.numBins) : 0.f;
-        }
+        // ---- another round of this batch: its set-up once every lane is done with this round's masks
+        cg_sync_lds();
+        if (ht == 0) { sh.roundNo = roundNo + 1u; sh.stopKey = 0xFFFFFFFFu; sh.frontPending = 0; if (roundNo + 1u >= 4094u) gs->error = GAPS_ERR_SPIN; }
+        if (ht < (unsigned)(WIN / 64)) { sh.mq[ht] = 0ull; sh.mb[ht] = 0ull; sh.md[ht] = 0ull; }
         cg_sync();
     }
 }
 
+// One round of a batch for the attempt lanes: the window's attempts are classified (A1), drawn (A2), checked against each other (B1, B2)
+// and committed up to the first one that ends the batch or has to be redrawn (C).  Returns whether the batch ends with this round.
+// FIRST: round 1, compiled as its own straight-line copy.  92 % of all launches are one round long; as the body of a loop the round
+// had every loop-invariant of its rare paths hoisted in front of it by the compiler -- the reciprocal of a 64-bit division that only
+// tiny domains perform, 1 / lambda and the glibc exponential's table for same-bin exchanges, four hundred instructions before the
+// first attempt was looked at, and the wait for the seeds at the loop's head -- and a dozen scalar registers spilled to carry them.
+struct GenRoundCtx {
+    unsigned t; uint64_t jm0, ji0, jm1, ji1, seed1, batchEpoch, g_qrng; uint32_t n0, updBase, remaining, K, g_skip, e_prevQ; float dp0, g_u1, g_u2; GenScalars *gs;
+};
+template <int WIN, bool FIRST>
+CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRoundCtx &c, const uint32_t roundNo)
+{
+    const unsigned t = c.t;
+    const uint64_t jm0 = c.jm0, ji0 = c.ji0, jm1 = c.jm1, ji1 = c.ji1, seed1 = c.seed1, batchEpoch = c.batchEpoch;
+    const uint32_t updBase = c.updBase, remaining = c.remaining, K = c.K;
+    GenScalars *gs = c.gs;
+    constexpr bool first = FIRST;
+    GEN_TS_INIT(); GEN_TS_RESUME(FIRST ? 7u : 40u);
+    GEN_TS(4);
+    const uint32_t nR = first ? c.n0 : sh.nR, minR = first ? c.n0 : sh.minAtoms, skip = first ? c.g_skip : sh.skip, processed = first ? 0u : sh.processed;
+    const uint64_t qrngRound = first ? c.g_qrng : sh.qrngRound;
+    const float u1c = first ? c.g_u1 : sh.u1c, u2c = first ? c.g_u2 : sh.u2c;
+    const float dpLo0 = first ? c.dp0 : sh.dpLo[0], dpHi0 = first ? c.dp0 : sh.dpHi[0];
+    const uint32_t left_ = remaining - processed;
+    const uint32_t winN = left_ < (uint32_t)WIN ? left_ : (uint32_t)WIN;
+
+    // ------------------------------------------------------------------ A1 (lane = attempt): (u1,u2), B/D/M/E
+    {
+        // (0/1 words and selects instead of short-circuit logic: with one wave per SIMD a branch costs more
+        // than the arithmetic it would skip)
+        const uint32_t active = t < winN;
+        const uint32_t tt = active ? t : 0u;
+        const uint64_t mySeed = (processed == 0u) ? seed1 : S.seeds[updBase + processed + tt];      // round 1: prefetched
+        uint64_t s = (skip ? jm1 : jm0) * qrngRound + (skip ? ji1 : ji0);
+        float u1 = pcg_uniform(s), u2 = pcg_uniform(s);
+        const uint32_t cached = (skip != 0u) & (uint32_t)(t == 0u);       // attempt 0 replays the cached pair
+        u1 = cached ? u1c : u1; u2 = cached ? u2c : u2;
+        uint32_t guess = gen_decide(u1, u2, minR, nR, dpLo0, dpHi0);
+        guess = active ? guess : (uint32_t)GEN_T_NONE;
+        GEN_PIN(guess); GEN_PIN(u1); GEN_PIN(u2);
+        GEN_TS(5);
+        sh.u1[t] = u1; sh.u2[t] = u2;
+        uint32_t bBefore, dBefore, e3, tB, tD, t3;
+        gen_count3<WIN>(sh.wtotA, t, guess == 'B', guess == 'D', false, bBefore, dBefore, e3, tB, tD, t3);
+        GEN_TS(6);
+        // the exact B/D/indeterminate decision depends on how many births / deaths precede this attempt
+        const uint32_t exact = gen_decide(u1, u2, (uint64_t)minR - dBefore, (uint64_t)nR + bBefore, sh.dpLo[dBefore], sh.dpHi[bBefore]);
+        const uint32_t hazA = active & (uint32_t)(exact != guess);
+        const uint32_t failA = active & (hazA ^ 1u) & (uint32_t)(guess == GEN_T_NONE);   // indeterminate: batch ends, no seed used
+        uint32_t aflags = hazA ? GEN_F_HAZARD : (failA ? GEN_F_FAIL : 0u);
+        if (aflags) cg_atomic_min_u32(&sh.stopKey, 2u * t + (hazA ^ 1u));
+        GEN_PIN(aflags);
+        GEN_TS(7);
+        // sort the attempts that go on by code path: births+deaths | moves | exchanges
+        const uint32_t go = active & (uint32_t)(aflags == 0u);
+        const uint32_t k0 = go & ((uint32_t)(guess == 'B') | (uint32_t)(guess == 'D')), k1 = go & (uint32_t)(guess == 'M'), k2 = go & (uint32_t)(guess == 'E');
+        uint32_t e0, e1, e2, T0, T1, T2;
+        gen_count3<WIN>(sh.wtotB, t, k0 != 0u, k1 != 0u, k2 != 0u, e0, e1, e2, T0, T1, T2);
+        if (go) {
+            uint32_t slot = T0 + T1 + e2;
+            slot = k1 ? T0 + e1 : slot;
+            slot = k0 ? e0 : slot;
+            sh.perm[slot] = (uint16_t)t;
+            sh.info[t] = guess | (bBefore << 8);
+            sh.seed[t] = mySeed;                                     // consumed after the type sort
+        }
+        GEN_TS(8);
+        if (t == 0) sh.nWork = T0 + T1 + T2;
+    }
+    cg_sync_lds();
+    GEN_TS(9);
+
+    // ------------------------------------------------------------------ A2 (lane = sorted slot): populate-phase draws
+    const bool go = t < sh.nWork;
+    const uint32_t ct = go ? (uint32_t)sh.perm[t] : 0u;          // this lane's attempt ordinal in the window
+    const uint32_t info = go ? sh.info[ct] : 0u;
+    const uint32_t type = info & 0xFFu, bBefore = info >> 8;
+    uint32_t flags = 0;
+    const bool isB = go && type == 'B';
+    bool pick = go && type != 'B';                 // D/M/E: picks an existing atom
+    uint64_t rng = go ? pcg_from_seed(sh.seed[ct]) : 0ull;   // AtomicProposal ctor, ProposalQueue.cpp:12-15
+    const uint32_t nT = nR + bBefore;              // domain size this attempt sees
+    uint64_t pos = 0, cpos = 0, lbpos = 0, rbpos = 0;
+    uint32_t h1 = CG_NONE, h2 = CG_NONE, i1 = CG_NONE, i2 = CG_NONE, hl = CG_NONE, hr = CG_NONE;
+    uint32_t r1 = 0, c1 = 0, r2 = 0, c2 = 0; float nm1 = 0.f, nm2 = 0.f;
+    uint32_t bin = 0, headBin = 0; unsigned long long w0 = 0;
+
+    // stage 1 ---------------------------------------------------------------------------------
+    if (isB) {
+        // uniform64(1, L) (Random.cpp:105-123) with the constant range's iPart precomputed
+        uint64_t x = pcg_u64(rng);
+        while (x >= S.limitL) x = pcg_u64(rng);
+        pos = (S.iPartL == 1ull ? x : x / S.iPartL) + 1ull;
+        bin = gen_bin_of(S, pos); r1 = gen_div_k(S, bin); c1 = bin - r1 * K;
+        i1 = nT;
+    } else if (pick) {
+        i1 = pcg_uniform32(rng, 0u, nT - 1u);
+        if (i1 >= nR) { flags |= GEN_F_FAIL; pick = false; }   // an atom born earlier in this window: its row is in use
+    }
+    GEN_PIN(i1); GEN_PIN(bin); GEN_PIN(pos);
+    GEN_TS(10);
+    // Everything above needed only the window's scalars.  From here on the lanes read the domain (index vector, records, bitmap,
+    // bin heads), which the helper wave's flush has been rewriting meanwhile: join it (its stores are acknowledged: cg_sync waits
+    // for every wave's own outstanding memory operations).  Later rounds of a batch ended with such a barrier already.
+    if (FIRST) cg_sync();
+    GEN_TS(25);
+    uint32_t v1 = CG_NONE;
+    if (isB) w0 = S.bits0[bin >> 6];
+    if (pick) v1 = S.vec[i1];
+#if defined(GEN_SUBMARKS)
+    if (v1 == 12345678u || w0 == 0x123456789ull) flags |= 0x80000000u;
+#endif
+    GEN_PIN(v1); GEN_PIN(w0);
+    GEN_TS(11);
+    // stage 2 ---------------------------------------------------------------------------------
+    bool slowB = false;
+    if (isB) {
+        const uint32_t bit = bin & 63u;
+        if ((w0 >> bit) & 1ull) headBin = bin;
+        else {
+            flags |= GEN_F_BINEMPTY; if (w0 == 0ull) flags |= GEN_F_WORDZERO;
+            const unsigned long long m = (bit == 63u) ? 0ull : (w0 & ~((2ull << bit) - 1ull));
+            if (m) headBin = (bin & ~63u) + (uint32_t)cg_ctz64(m); else slowB = true;
+        }
+    }
+    uint32_t v2 = CG_NONE; AtomRec a; a.pos = 0; a.lpos = 0; a.rpos = 0; a.left = CG_NONE; a.right = CG_NONE; a.mass = 0.f; a.rmass = 0.f; a.idx = 0;
+    if (isB && !slowB) v2 = S.binHead[headBin];
+    if (pick) { h1 = v1; a = S.atoms[h1]; }
+#if defined(GEN_SUBMARKS)
+    if (v2 == 12345678u || a.pos == 0x123456789ull) flags |= 0x80000000u;
+#endif
+    GEN_PIN(v2); GEN_PIN(a.pos); GEN_PIN(a.left);
+    GEN_TS(12);
+    // stage 3 ---------------------------------------------------------------------------------
+    // A picked atom's record carries its neighbours' positions and the right neighbour's mass (gaps_state.h): a move's bounds and
+    // an exchange's partner need no trip to the neighbours' records -- every pick goes from its record straight to the matrix
+    // entries.  (The one exception: the highest atom's exchange partner is front(), whose record is fetched.)
+    AtomRec b3; b3.pos = 0; b3.lpos = 0; b3.rpos = 0; b3.left = CG_NONE; b3.right = CG_NONE; b3.mass = 0.f; b3.rmass = 0.f; b3.idx = 0;
+    uint64_t lp = 0, rp = 0;
+    float m2x = 0.f;                        // exchange: the partner's mass
+    bool frontE = false;                    // exchange of the highest atom: the partner is front()
+    if (pick) {
+        cpos = a.pos;
+        const uint32_t b1 = gen_bin_of(S, cpos);
+        r1 = gen_div_k(S, b1); c1 = b1 - r1 * K;
+        hl = a.left;
+        if (type == 'M') { hr = a.right; lp = a.lpos; rp = a.rpos; }
+        else if (type == 'E') {
+            hr = a.right;
+            if (hr != CG_NONE) { h2 = hr; rbpos = a.rpos; m2x = a.rmass; }
+            else { h2 = sh.g.front; frontE = true; }
+        }
+    }
+    if (isB && !slowB) b3 = S.atoms[v2];
+    if (frontE) b3 = S.atoms[h2];
+    // the scalars the evaluation starts from travel in the queue record (consumed at commit)
+    float old1 = 0.f, old2 = 0.f; uint32_t gib1 = 0, gib2 = 0;
+    if (isB || pick) { old1 = S.sparse ? S.rows[(size_t)r1 * S.Kpad + c1] : S.mat[(size_t)c1 * S.Mpad + r1]; gib1 = S.otherColPos[c1]; }
+    if (pick && type == 'M') {
+        if (hl != CG_NONE) { flags |= GEN_F_HASLEFT; lbpos = lp; } else lbpos = 0;
+        if (hr != CG_NONE) { flags |= GEN_F_HASRIGHT; rbpos = rp; } else rbpos = S.rboundNone;
+        pos = pcg_uniform64(rng, lbpos + 1ull, rbpos - 1ull);
+        const uint32_t bin2 = gen_bin_of(S, pos);
+        r2 = gen_div_k(S, bin2); c2 = bin2 - r2 * K;
+        if (r1 == r2 && c1 == c2) flags |= GEN_F_INLINE;
+    }
+    if (pick && type == 'E' && !frontE) {
+        flags |= GEN_F_HASRIGHT;
+        const uint32_t bin2 = gen_bin_of(S, rbpos);
+        r2 = gen_div_k(S, bin2); c2 = bin2 - r2 * K;
+    }
+    if (pick && (type == 'M' || (type == 'E' && !frontE))) { old2 = S.sparse ? S.rows[(size_t)r2 * S.Kpad + c2] : S.mat[(size_t)c2 * S.Mpad + r2]; gib2 = S.otherColPos[c2]; }
+#if defined(GEN_SUBMARKS)
+    if (b3.pos == 12345678u || lp == 0x123456789ull || rp == 0x123456789ull) flags |= 0x80000000u;
+#endif
+    GEN_PIN(b3.pos); GEN_PIN(lp); GEN_PIN(rp);
+    GEN_TS(13);
+    // finish ----------------------------------------------------------------------------------
+    uint64_t lposB = 0, rposB = 0; float rmassB = 0.f;        // birth: what the new atom's record caches of its neighbours
+    if (isB) {
+        if (!slowB) {
+            if ((flags & GEN_F_BINEMPTY) || b3.pos > pos) { hr = v2; hl = b3.left; lposB = b3.lpos; rposB = b3.pos; rmassB = b3.mass; flags |= GEN_F_NEWHEAD; }
+            else if (b3.pos == pos) slowB = true;      // position already taken: the retry loop below
+            else {
+                // the bin's lowest atom lies below pos: go on to the right; the record in hand knows its right neighbour's
+                // position, so the usual case (a bin holds 1.3 atoms on average) needs no further trip
+                uint32_t cur = v2, nxt = b3.right; uint64_t curPos = b3.pos, nxtPos = b3.rpos; float nxtMass = b3.rmass;
+                for (;;) {
+                    if (nxt == CG_NONE) break;
+                    if (nxtPos == pos) { slowB = true; break; }
+                    if (nxtPos > pos) break;
+                    const AtomRec w = S.atoms[nxt];
+                    cur = nxt; curPos = nxtPos; nxt = w.right; nxtPos = w.rpos; nxtMass = w.rmass;
+                }
+                hl = cur; hr = nxt; lposB = curPos; rposB = nxtPos; rmassB = nxtMass;
+            }
+        }
+        if (slowB) {
+            bool occ, nh;
+            gen_find_gap(S, pos, bin, &hl, &hr, &occ, &nh);
+            while (occ) {           // randomFreePosition retry (ConcurrentAtomicDomain.cpp:46-54)
+                pos = pcg_uniform64(rng, 1ull, S.domainLenU);
+                bin = gen_bin_of(S, pos); r1 = gen_div_k(S, bin); c1 = bin - r1 * K;
+                gen_find_gap(S, pos, bin, &hl, &hr, &occ, &nh);
+            }
+            flags &= ~(GEN_F_BINEMPTY | GEN_F_WORDZERO | GEN_F_NEWHEAD);
+            if (nh) flags |= GEN_F_NEWHEAD;
+            if (S.binHead[bin] == CG_NONE) { flags |= GEN_F_BINEMPTY; if (S.bits0[bin >> 6] == 0ull) flags |= GEN_F_WORDZERO; }
+            old1 = S.sparse ? S.rows[(size_t)r1 * S.Kpad + c1] : S.mat[(size_t)c1 * S.Mpad + r1]; gib1 = S.otherColPos[c1];      // the retry may have moved the birth to another bin
+            lposB = (hl != CG_NONE) ? S.atoms[hl].pos : 0ull;
+            if (hr != CG_NONE) { rposB = S.atoms[hr].pos; rmassB = S.atoms[hr].mass; } else { rposB = 0ull; rmassB = 0.f; }
+        }
+    } else if (pick && type == 'E') {
+        if (frontE) {
+            rbpos = b3.pos; m2x = b3.mass;
+            const uint32_t bin2 = gen_bin_of(S, rbpos);
+            r2 = gen_div_k(S, bin2); c2 = bin2 - r2 * K;
+            old2 = S.sparse ? S.rows[(size_t)r2 * S.Kpad + c2] : S.mat[(size_t)c2 * S.Mpad + r2]; gib2 = S.otherColPos[c2];
+        }
+        if (r1 == r2 && c1 == c2) {
+            flags |= GEN_F_INLINE;
+            const float m1 = a.mass, m2 = m2x;
+            const float newMass = pcg_trunc_gamma_upper(rng, S.luts, m1 + m2, 1.f / S.lambda, S.mathMode);
+            const float delta = (m1 > m2) ? newMass - m1 : m2 - newMass;
+            if (m1 + delta > GAPS_EPSILON && m2 - delta > GAPS_EPSILON) { flags |= GEN_F_APPLY; nm1 = m1 + delta; nm2 = m2 - delta; }
+        }
+    }
+    GEN_PIN(pos); GEN_PIN(flags); GEN_PIN(r2); GEN_PIN(c2); GEN_PIN(rbpos); GEN_PIN(nm1);
+    GEN_TS(14);
+
+    // ------------------------------------------------------------------ B1: register rows / atoms / gaps
+    // Round 1 of a batch (95 % of all rounds) keeps the conflict sets in an LDS hash table; later rounds,
+    // which must also see what earlier rounds of the batch committed, use the stamp tables in HBM.
+    const bool live = go && !(flags & GEN_F_FAIL);
+    const bool queuedM = live && type == 'M' && !(flags & GEN_F_INLINE);
+    const bool ldsRound = roundNo == 1u;
+    if (go) { sh.cpos[ct] = cpos; sh.pos[ct] = pos; sh.type[ct] = queuedM ? (uint8_t)'M' : (uint8_t)0; }
+    if (live && ldsRound) {
+        // up to three (key, field) registrations; an unused one repeats the first.  Predicates are 0/1 words
+        // combined with bit operations: every short-circuit would be a branch, and a branch costs more
+        // than the arithmetic it skips when one wave owns the SIMD
+        const uint32_t inl = flags & GEN_F_INLINE, tB = type == 'B', tD = type == 'D', tM = type == 'M';
+        const uint32_t k0 = inl ? h1 : (GEN_TAB_ROW | r1), f0 = inl << 1;
+        const uint32_t use1 = 1u ^ (inl & tM), use2 = tM & (inl ^ 1u);
+        const uint32_t hlKey = (hl == CG_NONE) ? GEN_TAB_FRONT : hl;
+        uint32_t k1 = GEN_TAB_ROW | r2;              // queued move / exchange: the second row
+        k1 = tD ? h1 : k1;                           // death: the atom
+        k1 = tB ? hlKey : k1;                        // birth: the gap right of the left neighbour
+        k1 = inl ? h2 : k1;                          // same-bin exchange: the partner
+        k1 = use1 ? k1 : k0;
+        uint32_t f1 = inl ? 2u : tB; f1 = use1 ? f1 : f0;
+        const uint32_t k2 = use2 ? h1 : k0, f2 = use2 ? 0u : f0;
+        // claim the three slots together: one compare-and-swap each per probe step (a placed key
+        // repeats the swap on its own slot, which changes nothing)
+        const uint32_t hh0 = gen_tab_hash(k0), hh1 = gen_tab_hash(k1), hh2 = gen_tab_hash(k2);
+        uint32_t b0 = gen_tab_bucket(hh0), b1_ = gen_tab_bucket(hh1), b2_ = gen_tab_bucket(hh2);
+        const uint32_t j0 = gen_tab_start(hh0), j1 = gen_tab_start(hh1), j2 = gen_tab_start(hh2);
+        uint32_t s0 = 0, s1 = 0, s2 = 0, d0 = 0, d1 = 0, d2 = 0;
+        for (uint32_t i = 0; ; ++i) {
+            const uint32_t p0 = d0 ? s0 : 4u * b0 + ((j0 + i) & 3u), p1 = d1 ? s1 : 4u * b1_ + ((j1 + i) & 3u), p2 = d2 ? s2 : 4u * b2_ + ((j2 + i) & 3u);
+            const uint32_t o0 = cg_atomic_cas_u32(&sh.bkey[p0], GEN_TAB_EMPTY, k0);
+            const uint32_t o1 = cg_atomic_cas_u32(&sh.bkey[p1], GEN_TAB_EMPTY, k1);
+            const uint32_t o2 = cg_atomic_cas_u32(&sh.bkey[p2], GEN_TAB_EMPTY, k2);
+            s0 = p0; s1 = p1; s2 = p2;
+            d0 |= (uint32_t)(o0 == GEN_TAB_EMPTY) | (uint32_t)(o0 == k0);
+            d1 |= (uint32_t)(o1 == GEN_TAB_EMPTY) | (uint32_t)(o1 == k1);
+            d2 |= (uint32_t)(o2 == GEN_TAB_EMPTY) | (uint32_t)(o2 == k2);
+            if (d0 & d1 & d2) break;
+            const uint32_t wrap = (i & 3u) == 3u;      // bucket exhausted: the next one
+            b0 = (b0 + wrap) & (uint32_t)(GEN_TAB_NB - 1); b1_ = (b1_ + wrap) & (uint32_t)(GEN_TAB_NB - 1); b2_ = (b2_ + wrap) & (uint32_t)(GEN_TAB_NB - 1);
+        }
+        // every value word was set to "nobody" (all ones) at kernel entry by the helper wave, so the slot can be written at once:
+        // the smallest registering ordinal wins, whoever opened the slot
+        uint32_t *words = &sh.bval[0].used;       // word 0 = used, 1 = gap, 2 = inl
+        cg_atomic_min_u32(&words[4u * s0 + f0], ct);
+        cg_atomic_min_u32(&words[4u * s1 + f1], ct);
+        cg_atomic_min_u32(&words[4u * s2 + f2], ct);
+    } else if (live) {
+        // up to three keys: (kind, id)
+        uint32_t rk[3], rid[3]; int nk = 0;
+        const bool inl = (flags & GEN_F_INLINE) != 0;
+        if (type == 'B') { rk[0] = GEN_K_ROW; rid[0] = r1; rk[1] = GEN_K_GAP; rid[1] = (hl == CG_NONE) ? 0u : hl + 1u; nk = 2; }
+        else if (type == 'D') { rk[0] = GEN_K_ROW; rid[0] = r1; rk[1] = GEN_K_ATOM; rid[1] = h1; nk = 2; }
+        else if (type == 'M') {
+            if (inl) { rk[0] = GEN_K_INL; rid[0] = h1; nk = 1; }
+            else { rk[0] = GEN_K_ROW; rid[0] = r1; rk[1] = GEN_K_ROW; rid[1] = r2; rk[2] = GEN_K_ATOM; rid[2] = h1; nk = 3; }
+        } else {
+            if (inl) { rk[0] = GEN_K_INL; rid[0] = h1; rk[1] = GEN_K_INL; rid[1] = h2; nk = 2; }
+            else { rk[0] = GEN_K_ROW; rid[0] = r1; rk[1] = GEN_K_ROW; rid[1] = r2; nk = 2; }
+        }
+        const unsigned long long st = gen_stamp(batchEpoch, roundNo, ct);
+        for (int k = 0; k < nk; ++k) cg_atomic_max_u64(gen_stamp_ptr(S, rk[k], rid[k]), st);
+    }
+    GEN_TS(15);
+    if (ldsRound) cg_sync_lds(); else cg_sync();
+    GEN_TS(16);
+
+    // ------------------------------------------------------------------ B2: probe the sets (all probes of a lane
+    // are independent: issued together, then the per-type logic runs on registers)
+    if (live && ldsRound) {
+        // six bucket reads, then the six value reads of the matching slots; a key that is not in the table
+        // reads "nobody".  0/1 words and bit operations again (see B1).
+        const uint32_t tB = type == 'B', tM = type == 'M', tE = type == 'E', inl = flags & GEN_F_INLINE;
+        const uint32_t hasL = hl != CG_NONE, hasR = hr != CG_NONE, noRight = (flags & GEN_F_HASRIGHT) == 0u;
+        uint32_t key[6], use[6];
+        key[0] = GEN_TAB_ROW | r1; use[0] = 1u;
+        key[1] = GEN_TAB_ROW | r2; use[1] = tM | tE;
+        key[2] = ((tM | tB) & hasL) ? hl : GEN_TAB_FRONT; use[2] = tM | tB | (tE & noRight);
+        // (same-bin exchange: the gap LEFT of the centre -- a birth there earlier in this window is the holder of the centre's cached mass)
+        const uint32_t eInl = tE & (uint32_t)(inl != 0u);
+        key[3] = eInl ? (hasL ? hl : GEN_TAB_FRONT) : hr; use[3] = ((tM | tB) & hasR) | eInl;
+        const uint32_t tD = type == 'D';
+        key[4] = h1; use[4] = tM | tE | tD;
+        key[5] = h2; use[5] = tE;
+        uint32_t bk[6]; GenTabKeys kq[6];
+        for (int k = 0; k < 6; ++k) { bk[k] = gen_tab_bucket(gen_tab_hash(key[k])); kq[k] = *(const GenTabKeys *)&sh.bkey[4u * bk[k]]; }
+        uint32_t sl[6], hit[6], over = 0;
+        for (int k = 0; k < 6; ++k) {
+            const uint32_t *q4 = kq[k].k;
+            const uint32_t e1 = q4[1] == key[k], e2 = q4[2] == key[k], e3 = q4[3] == key[k];
+            const uint32_t found = (uint32_t)(q4[0] == key[k]) | e1 | e2 | e3;
+            const uint32_t hole = (uint32_t)(q4[0] == GEN_TAB_EMPTY) | (uint32_t)(q4[1] == GEN_TAB_EMPTY) | (uint32_t)(q4[2] == GEN_TAB_EMPTY) | (uint32_t)(q4[3] == GEN_TAB_EMPTY);
+            sl[k] = 4u * bk[k] + e1 + 2u * e2 + 3u * e3;
+            hit[k] = use[k] & found;
+            over |= use[k] & (found ^ 1u) & (hole ^ 1u);             // the key may have spilled into the next bucket
+        }
+        if (over) {                                                   // rare
+            for (int k = 0; k < 6; ++k) if (use[k]) { const uint32_t f = gen_tab_find<WIN>(sh, key[k]); hit[k] = f != GEN_TAB_EMPTY; sl[k] = hit[k] ? f : 0u; }
+        }
+        GenTabVal e[6];
+        for (int k = 0; k < 6; ++k) e[k] = sh.bval[hit[k] ? sl[k] : 0u];
+        // E(v) = 1 when an earlier attempt of this window registered under the word
+        #define GEN_E(k, w) (hit[k] & (uint32_t)(e[k].w < ct))
+        uint32_t fail = GEN_E(0, used) | GEN_E(1, used);                              // a row in use
+        // move: a neighbour in use (mUsedAtoms), or a birth earlier in this window inside (left, right)
+        fail |= tM & (GEN_E(2, used) | GEN_E(3, used) | GEN_E(2, gap) | GEN_E(4, gap));
+        // exchange: an earlier birth right of the centre is the true partner (or, for the last atom, a new front())
+        fail |= tE & (GEN_E(4, gap) | GEN_E(2, gap));
+        // birth: an earlier birth in the same gap; move / birth / same-bin exchange: an earlier same-bin
+        // move or exchange of this window touched an atom whose position this attempt relied on
+        uint32_t haz = tB & (GEN_E(2, gap) | GEN_E(2, inl) | GEN_E(3, inl));
+        haz |= tM & (GEN_E(4, inl) | GEN_E(2, inl) | GEN_E(3, inl));
+        // death / exchange: the masses in the queue record were read before an earlier same-bin exchange of
+        // this window rewrote them
+        haz |= (tE | tD) & (GEN_E(4, inl) | GEN_E(5, inl));
+        // same-bin exchange: it rewrites the copy of the centre's mass that the centre's left neighbour caches, and an earlier birth
+        // of this window between the two has become that neighbour
+        haz |= eInl & GEN_E(3, gap);
+        if (tB) {
+            // mProposedMoves.overlap(pos): a neighbour has a queued move whose interval covers pos
+            const uint32_t uL = GEN_E(2, used), uR = GEN_E(3, used);
+            const uint32_t iL = uL ? e[2].used : 0u, iR = uR ? e[3].used : 0u;
+            const uint64_t aL = sh.cpos[iL], bL = sh.pos[iL], aR = sh.cpos[iR], bR = sh.pos[iR];
+            const uint32_t mL = uL & (uint32_t)(sh.type[iL] == 'M'), mR = uR & (uint32_t)(sh.type[iR] == 'M');
+            const uint64_t loL = aL < bL ? aL : bL, hiL = aL < bL ? bL : aL, loR = aR < bR ? aR : bR, hiR = aR < bR ? bR : aR;
+            fail |= mL & (uint32_t)(loL < pos) & (uint32_t)(pos < hiL);
+            fail |= mR & (uint32_t)(loR < pos) & (uint32_t)(pos < hiR);
+        }
+        #undef GEN_E
+        GEN_PIN(flags);
+        GEN_TS(17);
+        flags |= haz ? GEN_F_HAZARD : (fail ? GEN_F_FAIL : 0u);
+    } else if (live) {
+        const bool tB = type == 'B', tM = type == 'M', tE = type == 'E', inl = (flags & GEN_F_INLINE) != 0;
+        const uint32_t keyL = (hl == CG_NONE) ? 0u : hl + 1u;
+        uint32_t pk[10], pid[10]; bool pu[10];
+        pk[0] = GEN_K_ROW; pid[0] = r1; pu[0] = true;
+        pk[1] = GEN_K_ROW; pid[1] = r2; pu[1] = tM || tE;
+        pk[2] = GEN_K_ATOM; pid[2] = hl; pu[2] = (tM || tB) && hl != CG_NONE;
+        pk[3] = GEN_K_ATOM; pid[3] = hr; pu[3] = (tM || tB) && hr != CG_NONE;
+        pk[4] = GEN_K_GAP; pid[4] = (tB || tM) ? keyL : h1 + 1u; pu[4] = tB || tM || tE;
+        pk[5] = GEN_K_GAP; pid[5] = tM ? h1 + 1u : 0u; pu[5] = tM || (tE && !(flags & GEN_F_HASRIGHT));
+        const bool tD = type == 'D';
+        pk[6] = GEN_K_INL; pid[6] = tB ? hl : h1; pu[6] = tM || (tB && hl != CG_NONE) || tE || tD;
+        pk[7] = GEN_K_INL; pid[7] = tM ? hl : (tB ? hr : h2); pu[7] = (tM && hl != CG_NONE) || (tB && hr != CG_NONE) || tE;
+        pk[8] = GEN_K_INL; pid[8] = hr; pu[8] = tM && hr != CG_NONE;
+        pk[9] = GEN_K_GAP; pid[9] = keyL; pu[9] = tE && inl;       // same-bin exchange: a birth of this window left of the centre (see the LDS round)
+        int res[10]; uint32_t rix[10]; uint64_t d9 = 0, d10 = 0;
+        {
+            unsigned long long v[10];
+            for (int k = 0; k < 10; ++k) v[k] = cg_load_l2_u64(pu[k] ? gen_stamp_ptr(S, pk[k], pid[k]) : &S.gapStamp[0]);
+            d9 = (tB && hl != CG_NONE) ? S.atomDest[hl] : 0ull; d10 = (tB && hr != CG_NONE) ? S.atomDest[hr] : 0ull;
+            for (int k = 0; k < 10; ++k) { rix[k] = 0; res[k] = pu[k] ? gen_probe(v[k], batchEpoch, roundNo, ct, &rix[k]) : 0; }
+        }
+        bool fail = res[0] != 0, haz = false;                                        // row r1 in use
+        if (res[1] != 0) fail = true;                                                // row r2 in use
+        if (tB) {
+            if (res[4] == 2) haz = true;                                             // an earlier birth of this window in the same gap
+            const uint32_t nb[2] = {hl, hr}; const uint64_t dest[2] = {d9, d10};
+            for (int k = 0; k < 2; ++k) {
+                if (nb[k] == CG_NONE) continue;
+                // mProposedMoves.overlap(pos): the neighbour has a queued move whose interval covers pos
+                const int u = res[2 + k]; const uint32_t ix = rix[2 + k];
+                uint64_t ma = 0, mb = 0; bool mv = false;
+                if (u == 1 && dest[k] != 0ull) { ma = S.atoms[nb[k]].pos; mb = dest[k]; mv = true; }
+                else if (u == 2 && sh.type[ix] == 'M') { ma = sh.cpos[ix]; mb = sh.pos[ix]; mv = true; }
+                if (mv) { const uint64_t lo = ma < mb ? ma : mb, hi = ma < mb ? mb : ma; if (lo < pos && pos < hi) fail = true; }
+                // an earlier same-bin move of this window shifted the neighbour this gap search compared against
+                if (res[6 + k] == 2) haz = true;
+            }
+        } else if (tM) {
+            if (res[2] != 0 || res[3] != 0) fail = true;                             // mUsedAtoms: a neighbour is in use
+            // a birth earlier in this window inside (left, right) is the true neighbour, and it is "used"
+            if (res[4] == 2 || res[5] == 2) fail = true;
+            // an earlier same-bin move/exchange of this window touched the centre or a neighbour: positions stale
+            if (res[6] == 2 || res[7] == 2 || res[8] == 2) haz = true;
+        } else if (tE) {
+            // an earlier birth right of the centre is the true partner (or, for the last atom, a new front())
+            if (res[4] == 2 || res[5] == 2) fail = true;
+            // the masses in the queue record were read before an earlier same-bin exchange of this window rewrote them
+            if (res[6] == 2 || res[7] == 2) haz = true;
+            if (res[9] == 2) haz = true;
+        } else if (tD) {
+            if (res[6] == 2) haz = true;
+        }
+        if (haz) flags |= GEN_F_HAZARD; else if (fail) flags |= GEN_F_FAIL;
+    }
+    GEN_TS(18);
+    if (go && (flags & (GEN_F_HAZARD | GEN_F_FAIL))) cg_atomic_min_u32(&sh.stopKey, 2u * ct + ((flags & GEN_F_HAZARD) ? 0u : 1u));
+    if (ldsRound) cg_sync_lds(); else cg_sync();
+    GEN_TS(19);
+
+    // ------------------------------------------------------------------ C: commit attempts [0, stopT)
+    const uint32_t stopKey = sh.stopKey;
+    const uint32_t stopT = (stopKey == 0xFFFFFFFFu) ? winN : (stopKey >> 1);
+    const bool stopFail = (stopKey != 0xFFFFFFFFu) && (stopKey & 1u);
+    const bool commit = go && ct < stopT;            // every such attempt is live
+    const bool queued = commit && (type == 'B' || type == 'D' || !(flags & GEN_F_INLINE));
+    // what the commit reads of the round's scalars, taken BEFORE the barrier: behind it the helper wave's bookkeeping rewrites them
+    // while the attempt lanes commit
+    const uint32_t c_fc = sh.g.freeCount, c_handleHi = sh.g.handleHi, c_flushBase = sh.flushBase, c_flushM = sh.flushM, c_qlen = sh.qlen;
+    const uint32_t c_traceOn = sh.g.traceOn, c_traceCount = sh.g.traceCount, c_traceCap = sh.g.traceCap, c_nBatches = sh.g.nBatches;
+    const bool endB = stopFail || (processed + stopT >= remaining);      // the batch ends with this round (every lane knows)
+    if (commit) {
+        const unsigned long long bit = 1ull << (ct & 63u);
+        if (queued) cg_atomic_or_u64(&sh.mq[ct >> 6], bit);
+        if (type == 'B') { cg_atomic_or_u64(&sh.mb[ct >> 6], bit); if (hl == CG_NONE) sh.frontPending = 1u; }      // (at most one birth of a round lands before the front atom: two would share the gap)
+        if (type == 'D') cg_atomic_or_u64(&sh.md[ct >> 6], bit);
+    }
+    cg_sync_lds();
+    GEN_TS(20);
+    if (commit) {
+        uint32_t qBefore = 0, bRank = 0;
+        {
+            const uint32_t wq = ct >> 6; const unsigned long long lt = (1ull << (ct & 63u)) - 1ull;
+            for (uint32_t w = 0; w < wq; ++w) { qBefore += (uint32_t)cg_popc64(sh.mq[w]); bRank += (uint32_t)cg_popc64(sh.mb[w]); }
+            qBefore += (uint32_t)cg_popc64(sh.mq[wq] & lt); bRank += (uint32_t)cg_popc64(sh.mb[wq] & lt);
+        }
+        const unsigned long long done = (batchEpoch << 24) | GEN_STAMP_COMMITTED;
+        const bool more = !endB;   // another round of this batch follows: it reads these
+        if (type == 'B') {
+            // handle allocation: free stack first (deterministic by rank), then bump
+            const uint32_t fc = c_fc;
+            // the top of the stack is what this launch's flush pushed, still in LDS
+            uint32_t hb;
+            if (bRank < fc) { const uint32_t fi = fc - 1u - bRank; hb = (fi >= c_flushBase && fi - c_flushBase < c_flushM) ? sh.fh[fi - c_flushBase] : S.freeHandles[fi]; }
+            else hb = c_handleHi + (bRank - fc);
+            const uint32_t idx = nR + bRank;
+            if (hb >= S.atomCap || idx >= S.atomCap) { gs->error = GAPS_ERR_ATOM_CAP; hb = 0; }
+            S.vec[idx] = hb;
+            AtomRec n; n.pos = pos; n.lpos = lposB; n.rpos = rposB; n.left = hl; n.right = hr; n.mass = 0.f; n.rmass = rmassB; n.idx = idx; n.pad0 = 0;
+            S.atoms[hb] = n;
+            h1 = hb;
+            // splice: the neighbours' links and the copies they cache of the new atom (its mass is 0 until the evaluation sets it)
+            if (hl != CG_NONE) { S.atoms[hl].right = hb; S.atoms[hl].rpos = pos; S.atoms[hl].rmass = 0.f; } else { sh.g.front = hb; if (endB) gs->front = hb; }      // (the helper's write-back leaves this word alone: frontPending)
+            if (hr != CG_NONE) { S.atoms[hr].left = hb; S.atoms[hr].lpos = pos; }
+            if (flags & GEN_F_NEWHEAD) S.binHead[bin] = hb;
+            if (flags & GEN_F_BINEMPTY) {
+                cg_atomic_or_u64(&S.bits0[bin >> 6], 1ull << (bin & 63u));
+                if (flags & GEN_F_WORDZERO) { const uint32_t wa = bin >> 6, wb = wa >> 6, wc = wb >> 6; cg_atomic_or_u64(&S.bits1[wb], 1ull << (wa & 63u)); cg_atomic_or_u64(&S.bits2[wc], 1ull << (wb & 63u)); }
+            }
+            if (more) { S.rowStamp[r1] = done; S.atomStamp[hb] = done; S.atomDest[hb] = 0ull; }
+        } else if (type == 'D') {
+            if (more) { S.rowStamp[r1] = done; S.atomStamp[h1] = done; S.atomDest[h1] = 0ull; }
+        } else if (type == 'M') {
+            if (flags & GEN_F_INLINE) atom_set_pos(S, h1, hl, hr, pos);       // domain.move, same bin
+            else if (more) { S.rowStamp[r1] = done; S.rowStamp[r2] = done; S.atomStamp[h1] = done; S.atomDest[h1] = pos; }
+        } else {
+            if (flags & GEN_F_INLINE) { if (flags & GEN_F_APPLY) { atom_set_mass(S, h1, hl, nm1); atom_set_mass(S, h2, (hr != CG_NONE) ? h1 : CG_NONE, nm2); } }
+            else if (more) { S.rowStamp[r1] = done; S.rowStamp[r2] = done; }
+        }
+        if (queued) {
+            const uint32_t slot = c_qlen + qBefore;
+            if (slot >= S.queueCap) gs->error = GAPS_ERR_QUEUE_CAP;
+            else {
+                if (c_traceOn && type == 'E') i2 = S.atoms[h2].idx;         // the partner's index: traces only
+                PropRec p; p.pos = (type == 'M') ? pos : 0ull; p.rng = rng; p.h1 = h1; p.h2 = h2; p.i1 = i1; p.i2 = i2;
+                p.r1 = r1; p.c1 = c1; p.r2 = r2; p.c2 = c2; p.type = type; p.batch = 0; p.pad[0] = p.pad[1] = p.pad[2] = 0;
+                const bool two = type == 'M' || type == 'E';
+                p.gibbs = (gib1 > 0u ? 1u : 0u) | ((two && gib2 > 0u) ? 2u : 0u);
+                p.m1 = (type == 'B') ? 0.f : a.mass; p.m2 = (type == 'E') ? m2x : 0.f;
+                p.old1 = old1; p.old2 = two ? old2 : 0.f; p.curPos = (type == 'M') ? cpos : 0ull;
+                S.queue[slot] = p;
+                if (c_traceOn) { const uint32_t ti = c_traceCount + slot; if (ti < c_traceCap) { p.batch = c_nBatches; S.trace[ti] = p; } }
+            }
+        }
+    }
+    GEN_TS(21);
+    if (endB) { GEN_TS(22); { const uint32_t e_prevQ = c.e_prevQ; (void)e_prevQ; GEN_TS_DUMP_WAVE(); } }
+    return endB;
+}
+
+// sp: the sampler's record in device memory (constant address space: scalar loads).  ASYNC: the launch's hot pointers arrived as
+// preloaded kernel arguments, the record's lines are requested behind the first trip and waited for after the conflict table has been
+// emptied (one-chain launch); otherwise the caller has read the record already (batched launch: the hot pointers come from it).
+template <int WIN, bool ASYNC>
+CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
+{
+    CG_SHARED GenShared<WIN> sh;
+    constexpr unsigned TPB = (unsigned)WIN + 64u;       // attempt lanes + the helper wave
+    const unsigned t = cg_tid();
+    const bool helper = t >= (unsigned)WIN;             // wave-uniform
+    const unsigned ht = t - (unsigned)WIN, ta = helper ? 0u : t;
+    GenScalars *gs = hot.gs;
+
+    GEN_TS_INIT(); GEN_TS(0); GEN_TS(0);
+    // k-step PCG jumps for this lane's (u1,u2): k = 2t, or 2(t-1) when attempt 0 replays cached values
+    const uint64_t jm0 = hot.lcgMul[2u * ta], ji0 = hot.lcgInc[2u * ta];
+    const uint64_t jm1 = hot.lcgMul[ta ? 2u * (ta - 1u) : 0u], ji1 = hot.lcgInc[ta ? 2u * (ta - 1u) : 0u];
+    // first memory trip of the launch, everything independent: the scalars every lane needs (one lane per word into LDS, where they
+    // live for the whole launch), the erase cache (helper lanes) and the traffic-unit slots (attempt lanes) read speculatively
+    const unsigned long long specE = (helper && ht < (unsigned)FLUSH_MAX && ht < hot.eraseCap) ? hot.eraseList[ht] : 0ull;
+    uint32_t units = (!helper && t < hot.queueCap) ? hot.queueUnits[t] : 0u;
+    const uint64_t jmW = hot.lcgMul[2 * WIN], jiW = hot.lcgInc[2 * WIN];
+    constexpr uint32_t GSW = (uint32_t)(sizeof(GenScalars) / 4u);
+    static_assert(GSW <= 2u * TPB, "at most two words of GenScalars per lane");
+    const uint32_t gword = (t < GSW) ? reinterpret_cast<const uint32_t *>(gs)[t] : 0u;
+    const uint32_t gword2 = (t + TPB < GSW) ? reinterpret_cast<const uint32_t *>(gs)[t + TPB] : 0u;
+    cg_sched_fence();
+    GEN_TS(26);
+    // the record's lines are requested, the conflict table is emptied while they and the first trip are on their way
+    cg_const_lines lines;
+    if (ASYNC) cg_const_warm_begin<sizeof(SamplerDev)>(sp, lines);
+    {   // empty conflict table: keys, and the value words ("nobody" = all ones: whoever registers first under a key needs no
+        // opener) -- by ALL lanes: one wave alone stores to LDS at a fraction of the workgroup's rate (the helper wave presetting
+        // the 64 KB of value words by itself took 5 k cycles, longer than the trip)
+        GenTabKeys none; none.k[0] = none.k[1] = none.k[2] = none.k[3] = GEN_TAB_EMPTY;
+        for (uint32_t i = t; i < (uint32_t)GEN_TAB_NB; i += TPB) *(GenTabKeys *)&sh.bkey[4u * i] = none;
+        for (uint32_t i = t; i < 4u * (uint32_t)GEN_TAB_NB; i += TPB) *(GenTabKeys *)&sh.bval[i] = none;
+    }
+    GEN_TS(27);
+    if (ASYNC) sp = cg_const_warm_end(sp, lines);
+    const SamplerDev &S = *(const SamplerDev *)sp;
+    GEN_TS(28);
+    if (t < GSW) reinterpret_cast<uint32_t *>(&sh.g)[t] = gword;
+    if (t + TPB < GSW) reinterpret_cast<uint32_t *>(&sh.g)[t + TPB] = gword2;
+    if (t == 0) { sh.newFront = CG_KEEP; sh.unitSum = 0; sh.jmul[WIN] = jmW; sh.jinc[WIN] = jiW; }
+    if (!helper) { sh.jmul[t] = jm0; sh.jinc[t] = ji0; }        // even-step PCG jumps, for the round bookkeeping
+    GEN_TS(29);
+    cg_sync_lds();
+    // the scalars every lane needs, from the LDS copy (wave-uniform: kept in scalar registers)
+    const uint32_t e_m = cg_uniform_u32(sh.g.eraseCount), e_n = cg_uniform_u32(sh.g.nAtoms), e_fc = cg_uniform_u32(sh.g.freeCount), e_prevQ = cg_uniform_u32(sh.g.qlen),
+                   e_nDone = cg_uniform_u32(sh.g.nDone), e_nSteps = cg_uniform_u32(sh.g.nSteps);
+    GEN_TS(1);
+    const bool updateDone = e_nDone >= e_nSteps;
+    if (!helper) {   // roofline bookkeeping: add up the traffic units the evaluation kernel left per queue slot (the helper wave adds
+        // the sum to evalBytes at the end of the batch)
+        if (t >= e_prevQ) units = 0;
+        for (uint32_t q = t + WIN; q < e_prevQ; q += WIN) units += S.queueUnits[q];
+        const uint32_t waveUnits = cg_wave_sum_u32(units);
+        if ((t & 63u) == 0u && waveUnits) cg_atomic_add_u32(&sh.unitSum, waveUnits);
+    }
+    if (updateDone) {
+        // a launch past the end of the update: the last erase cache is flushed (by the helper wave alone) and the progress words reported
+        cg_sync_lds();                          // (the unit sum is complete)
+        if (!helper) return;
+        GenFlushRegs fr;
+        gen_flush_fetch<WIN>(S, fr, ht, e_m, e_n, specE);
+        if (ht == 0) { sh.flushM = 0; sh.flushBase = e_fc; sh.nLow = 0; }
+        cg_wave_sync();
+        for (int part = 0; part < 3; ++part) { gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, part); cg_wave_sync(); }
+        if (ht == 0) { gs->nAtoms = sh.g.nAtoms; gs->front = sh.g.front; gs->freeCount = sh.g.freeCount; gs->eraseCount = 0; gs->qlen = 0; gs->batchNproc = 0; gs->updateFlushed = 1;
+                       gs->evalBytes = sh.g.evalBytes + (unsigned long long)sh.unitSum * S.unitBytes; gs->evalProps = sh.g.evalProps + e_prevQ; }
+        return;
+    }
+    if (helper) { gen_helper<WIN>(S, sh, gs, ht, specE, e_m, e_n, e_fc, e_prevQ, e_nDone, e_nSteps); return; }
+
+    // ================================================================================ attempt lanes
+    // second trip (addresses from the first): this round's seeds
+    const uint64_t seed1 = (e_nDone + t < e_nSteps) ? S.seeds[e_nDone + t] : 0ull;
+    const uint32_t n0 = e_n - e_m;                  // after the flush (which the helper wave runs meanwhile) the domain holds this many atoms
+    {
+        // death probability (ProposalQueue::deathProb) for every atom count an attempt of this window can see:
+        // lane t fills the entries for t births / t deaths ahead of it
+        sh.dpHi[t] = gm_death_prob((double)((uint64_t)n0 + t), S.domainLenD, S.alphaD, S.numBins);
+        sh.dpLo[t] = (n0 >= t) ? gm_death_prob((double)(uint64_t)(n0 - t), S.domainLenD, S.alphaD, S.numBins) : 0.f;
+    }
+    const uint64_t batchEpoch = sh.g.batchEpoch + 1;
+    const uint32_t updBase = e_nDone;           // attempts consumed by earlier batches of this update
+    const uint32_t remaining = e_nSteps - e_nDone;
+    const uint32_t K = S.K;
+    // round 1 takes its scalars from the LDS copy of GenScalars (complete since the first barrier); the helper wave writes the round
+    // variables' LDS copies, which later phases and rounds read
+    const float dp0 = gm_death_prob((double)(uint64_t)n0, S.domainLenD, S.alphaD, S.numBins);
+    const uint64_t g_qrng = sh.g.qrng; const uint32_t g_skip = sh.g.useCached ? 1u : 0u; const float g_u1 = sh.g.u1, g_u2 = sh.g.u2;
+
+    GenRoundCtx rc; rc.t = t; rc.jm0 = jm0; rc.ji0 = ji0; rc.jm1 = jm1; rc.ji1 = ji1; rc.seed1 = seed1; rc.batchEpoch = batchEpoch; rc.g_qrng = g_qrng; rc.n0 = n0; rc.updBase = updBase;
+    rc.remaining = remaining; rc.K = K; rc.g_skip = g_skip; rc.e_prevQ = e_prevQ; rc.dp0 = dp0; rc.g_u1 = g_u1; rc.g_u2 = g_u2; rc.gs = gs;
+    if (gen_round<WIN, true>(S, sh, rc, 1u)) return;
+    for (uint32_t roundNo = 2; ; ++roundNo) {
+        // ------------------------------------------------------------------ set-up of the next round of this batch (the helper wave has published
+        // sh.nR / sh.minAtoms and resets the masks and the stop key between the two barriers)
+        cg_sync_lds();
+        {
+            const uint32_t nn = sh.nR, m0 = sh.minAtoms;
+            sh.dpHi[t] = gm_death_prob((double)((uint64_t)nn + t), S.domainLenD, S.alphaD, S.numBins);
+            sh.dpLo[t] = (m0 >= t) ? gm_death_prob((double)(uint64_t)(m0 - t), S.domainLenD, S.alphaD, S.numBins) : 0.f;
+        }
+        cg_sync();
+        if (gen_round<WIN, false>(S, sh, rc, roundNo)) return;
+    }
+}
+
+// WIN attempt lanes + the helper wave.  The launch's first loads need only the leading scalar arguments (preloaded into SGPRs); the
+// sampler's record is read from device memory through `sp`
 template <int WIN>
-CG_KERNEL void CG_LAUNCH_BOUNDS(WIN) gen_kernel(const uint64_t *lcgMul, const uint64_t *lcgInc, GenScalars *gs, const unsigned long long *eraseList, const uint32_t *queueUnits,
-                                               uint32_t eraseCap, uint32_t queueCap, SamplerDev S)
+CG_KERNEL void CG_LAUNCH_BOUNDS(WIN + 64) gen_kernel(const uint64_t *lcgMul, const uint64_t *lcgInc, GenScalars *gs, const unsigned long long *eraseList, const uint32_t *queueUnits,
+                                                    uint32_t eraseCap, uint32_t queueCap, const SamplerDev CG_CONSTANT *sp)
 {
     GenHot hot; hot.lcgMul = lcgMul; hot.lcgInc = lcgInc; hot.gs = gs; hot.eraseList = eraseList; hot.queueUnits = queueUnits; hot.eraseCap = eraseCap; hot.queueCap = queueCap;
-    gen_body<WIN, (int)sizeof(SamplerDev) + 48>(S, hot);
+    gen_body<WIN, true>(sp, hot);
 }
 // batched multi-chain launch (eval_kernel.h): one workgroup per chain
 template <int WIN>
-CG_KERNEL void CG_LAUNCH_BOUNDS(WIN) gen_kernel_multi(const SamplerDev CG_CONSTANT *arr)
+CG_KERNEL void CG_LAUNCH_BOUNDS(WIN + 64) gen_kernel_multi(const SamplerDev CG_CONSTANT *arr)
 {
     const SamplerDev CG_CONSTANT *sp = arr + cg_bid();
     cg_const_warm<sizeof(SamplerDev)>(sp);
     const SamplerDev &S = *(const SamplerDev *)sp;
     GenHot hot; hot.lcgMul = S.lcgMul; hot.lcgInc = S.lcgInc; hot.gs = S.gs; hot.eraseList = S.eraseList; hot.queueUnits = S.queueUnits; hot.eraseCap = S.eraseCap; hot.queueCap = S.queueCap;
-    gen_body<WIN, 0>(S, hot);
+    gen_body<WIN, false>(sp, hot);
 }

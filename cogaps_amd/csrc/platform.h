@@ -29,6 +29,9 @@ CG_DEVICE void cg_sync() { __syncthreads(); }
 // workgroup barrier that orders LDS traffic only: outstanding global loads / stores stay in flight across it
 // (__syncthreads waits for vmcnt(0) as well).  Only where the lanes exchange nothing through global memory.
 CG_DEVICE void cg_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// ordering point inside ONE wave (all its lanes call it): LDS traffic issued before it has completed before anything after it is
+// issued -- what a lane needs to read another lane's LDS write when both belong to the same wave (no workgroup barrier involved)
+CG_DEVICE void cg_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
 
 // Pull the whole kernel-argument segment into the scalar cache with one memory trip.  The scalar cache is
 // cold at kernel entry and the compiler loads the fields of a by-value argument struct where they are first
@@ -65,6 +68,36 @@ CG_DEVICE void cg_const_warm(const T CG_CONSTANT *p)
 #pragma unroll
     for (int i = 0; i < (BYTES + 63) / 64; ++i) acc |= w[(i * 64 < BYTES - 4 ? i * 64 : BYTES - 4) / 4];
     asm volatile("" :: "s"(acc));
+}
+
+// The same in two halves, for a kernel that has other work to do while the record's lines are on their way: _begin issues one load per
+// 64-byte line, _end waits for them and returns the pointer THROUGH the wait: every load the compiler derives from the returned
+// pointer is ordered behind it and finds the lines in the scalar cache.  (A by-value kernel argument cannot be fenced like this: the
+// compiler is free to load its fields at the kernel's entry, before any statement of the source -- with the 540-byte SamplerDev it
+// did, group after group, each waiting for its own cold miss because the scalar registers had to be spilled in between: seven
+// serial misses in front of the generator's first instruction.)  The destination registers hold nothing anyone reads; they are
+// outputs of the first statement and inputs of the second only so that the compiler keeps them allocated in between.
+struct cg_const_lines { uint32_t d[10]; };
+template <int BYTES, class T>
+CG_DEVICE void cg_const_warm_begin(const T CG_CONSTANT *p, cg_const_lines &k)
+{
+    static_assert(BYTES <= 640, "extend the line list");
+    constexpr int L = BYTES - 4;
+#define CG_KA_OFF(i) ((i) * 64 < L ? (i) * 64 : L)
+    asm volatile("s_load_dword %0, %10, %11\n\ts_load_dword %1, %10, %12\n\ts_load_dword %2, %10, %13\n\ts_load_dword %3, %10, %14\n\t"
+                 "s_load_dword %4, %10, %15\n\ts_load_dword %5, %10, %16\n\ts_load_dword %6, %10, %17\n\ts_load_dword %7, %10, %18\n\t"
+                 "s_load_dword %8, %10, %19\n\ts_load_dword %9, %10, %20"
+                 : "=&s"(k.d[0]), "=&s"(k.d[1]), "=&s"(k.d[2]), "=&s"(k.d[3]), "=&s"(k.d[4]), "=&s"(k.d[5]), "=&s"(k.d[6]), "=&s"(k.d[7]), "=&s"(k.d[8]), "=&s"(k.d[9])
+                 : "s"(p), "n"(CG_KA_OFF(0)), "n"(CG_KA_OFF(1)), "n"(CG_KA_OFF(2)), "n"(CG_KA_OFF(3)), "n"(CG_KA_OFF(4)), "n"(CG_KA_OFF(5)),
+                   "n"(CG_KA_OFF(6)), "n"(CG_KA_OFF(7)), "n"(CG_KA_OFF(8)), "n"(CG_KA_OFF(9))
+                 : "memory");
+#undef CG_KA_OFF
+}
+template <class T>
+CG_DEVICE const T CG_CONSTANT *cg_const_warm_end(const T CG_CONSTANT *p, cg_const_lines &k)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(p) : "s"(k.d[0]), "s"(k.d[1]), "s"(k.d[2]), "s"(k.d[3]), "s"(k.d[4]), "s"(k.d[5]), "s"(k.d[6]), "s"(k.d[7]), "s"(k.d[8]), "s"(k.d[9]) : "memory");
+    return p;
 }
 
 // four packed floats; a read of four that bypasses the caches' retention (non-temporal: rows used once per batch)
@@ -121,6 +154,16 @@ CG_DEVICE float cg_wave_allsum_f32(float x)
     const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 16));
     const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 48));
     return (r0 + r1) + (r2 + r3);
+}
+// the sum of x over the wave's 64 lanes (inactive lanes of a divergent caller must not call: all lanes call it), in every lane: DPP
+// row operations + four lane reads.  (An LDS atomicAdd at one address from every lane is turned by the compiler into a serial loop
+// over the active lanes -- s_ff1 / v_readlane / s_add, 64 iterations, 2-3 k cycles per wave.)
+CG_DEVICE uint32_t cg_wave_sum_u32(uint32_t x)
+{
+#define CG_DPP_ADDU(ctrl) x = x + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, (ctrl), 0xF, 0xF, false)
+    CG_DPP_ADDU(0xB1); CG_DPP_ADDU(0x4E); CG_DPP_ADDU(0x141); CG_DPP_ADDU(0x140);
+#undef CG_DPP_ADDU
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 0) + (uint32_t)__builtin_amdgcn_readlane((int)x, 16) + (uint32_t)__builtin_amdgcn_readlane((int)x, 32) + (uint32_t)__builtin_amdgcn_readlane((int)x, 48);
 }
 CG_DEVICE unsigned long long cg_clock() { return __builtin_readcyclecounter(); }
 CG_DEVICE int cg_clz64(unsigned long long x) { return __clzll((long long)x); }

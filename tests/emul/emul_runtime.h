@@ -18,6 +18,7 @@ namespace cgemu {
 struct LaneCtx { unsigned tid, bid, bdim, gdim; };
 extern LaneCtx g_lane;
 void block_barrier();                       // __syncthreads()
+void wave_barrier();                        // all lanes of one wave (they run in lockstep on the device)
 float wave_exchange_f32(float v, int src_lane_xor); // shfl_xor across the 64-lane wave
 float wave_read_f32(float v, int src_lane);         // shfl: read lane src_lane of the wave
 unsigned long long wave_ballot(bool p);
@@ -30,7 +31,11 @@ inline unsigned cg_bdim() { return cgemu::g_lane.bdim; }
 inline unsigned cg_gdim() { return cgemu::g_lane.gdim; }
 inline void cg_sync() { cgemu::block_barrier(); }
 inline void cg_sync_lds() { cg_sync(); }
+inline void cg_wave_sync() { cgemu::wave_barrier(); }
 template <int BYTES> inline void cg_kernarg_warm() {}
+struct cg_const_lines { };
+template <int BYTES, class T> inline void cg_const_warm_begin(const T *, cg_const_lines &) {}
+template <class T> inline const T *cg_const_warm_end(const T *p, cg_const_lines &) { return p; }
 #define CG_CONSTANT
 template <int BYTES, class T> inline void cg_const_warm(const T *) {}
 inline void cg_keep_f32(float) {}
@@ -59,6 +64,11 @@ inline float cg_shfl_xor_f32(float v, int mask) { return cgemu::wave_exchange_f3
 inline float cg_wave_allsum_f32(float x) { for (int off = 1; off < 64; off <<= 1) x = x + cgemu::wave_exchange_f32(x, off); return x; }
 inline float cg_shfl_f32(float v, int lane) { return cgemu::wave_read_f32(v, lane); }
 inline float cg_lane_read_f32(float v, int lane) { return cgemu::wave_read_f32(v, lane); }
+inline uint32_t cg_wave_sum_u32(uint32_t x)
+{
+    for (int off = 1; off < 64; off <<= 1) { float f; memcpy(&f, &x, 4); const float g = cgemu::wave_exchange_f32(f, off); uint32_t y; memcpy(&y, &g, 4); x += y; }
+    return x;
+}
 inline unsigned long long cg_clock() { return 0; }
 inline int cg_clz64(unsigned long long x) { return x ? __builtin_clzll(x) : 64; }
 inline int cg_ctz64(unsigned long long x) { return x ? __builtin_ctzll(x) : -1; }

@@ -10,28 +10,31 @@ data = synthetic_dense(20000, 2000)
 if SPARSE: data *= (np.random.Generator(np.random.MT19937(777)).random(data.shape) >= 0.95)
 S = _capi.Session(data, lib=PL, nPatterns=50, nIterations=100, seed=42, sparseOptimization=SPARSE)
 S.run_iterations(1, 0, int(sys.argv[1]) if len(sys.argv) > 1 else 40)
-names = {0: 'entry', 1: 'entry loads+sync', 2: 'flush', 4: 'round set-up sync', 5: 'A1 pcg+guess', 6: 'A1 count3 #1', 7: 'A1 exact decide', 8: 'A1 count3 #2+perm',
-         9: 'A1 sync', 10: 'A2 stage1 rng/addr', 11: 'A2 stage2 (vec/bits0 used)', 12: 'A2 stage3 (atoms/binHead used)', 13: 'A2 neighbour loads issued', 14: 'A2 finish',
-         15: 'B1 inserts', 16: 'B1 sync', 17: 'B2 lookups', 18: 'B2 logic', 19: 'B2 sync', 20: 'C scan sync', 21: 'C commit', 22: 'C commit sync', 23: 'bookkeeping sync', 24: 'write-back'}
-buf = (ctypes.c_uint64 * 256)()
+names = {0: 'entry', 1: 'entry loads+sync (B0)', 2: 'helper: round vars set, flush loads issued', 3: 'helper: flush written back (before join)', 4: 'round top', 5: 'A1 pcg+guess', 6: 'A1 count3 #1 (C1)',
+         7: 'A1 exact decide', 8: 'A1 count3 #2+perm (C2)', 9: 'A1 sync (C3)', 10: 'A2 stage1 rng/addr', 25: 'A2 join with the flush', 11: 'A2 stage2 (vec/bits0 used)', 12: 'A2 stage3 (atoms/binHead used)',
+         13: 'A2 neighbour loads issued', 14: 'A2 finish', 15: 'B1 registrations', 16: 'B1 sync', 17: 'B2 lookups', 18: 'B2 logic', 19: 'B2 sync (Bp)', 20: 'C masks sync (Bc1)', 21: 'C commit issued',
+         22: 'attempt wave ends', 26: 'entry: loads issued', 27: 'entry: conflict table preset', 28: 'entry: kernel arguments in', 29: 'entry: first trip landed, scalars in LDS', 23: 'helper: bookkeeping done', 24: 'helper: write-back issued'}
+WAVES = 5
+buf = (ctypes.c_uint64 * (WAVES * 64))()
 PL.cogaps_debug_timeline.argtypes = [ctypes.c_void_p, ctypes.c_int]
-assert PL.cogaps_debug_timeline(buf, 256) == 0
-a = np.array(buf).reshape(4, 64)
-t0 = min(int(a[w, 0]) >> 8 for w in range(4) if a[w, 0])
-print('%-34s' % 'mark' + ''.join('   wave%d (+delta)' % w for w in range(4)))
-seq = {w: [(int(x) & 0xFF, (int(x) >> 8) - t0) for x in a[w] if x] for w in range(4)}
+assert PL.cogaps_debug_timeline(buf, WAVES * 64) == 0
+a = np.array(buf).reshape(WAVES, 64)
+seq = {w: [(int(x) & 0xFF, int(x) >> 8) for x in a[w] if x] for w in range(WAVES)}
+print('cycles since the wave\'s own first mark (+ since its previous mark); waves 0-3: attempt lanes, wave 4: the helper wave')
+print('%-46s' % 'mark' + ''.join('      wave%d        ' % w for w in range(WAVES)))
 order = []
-for w in range(4):
+for w in range(WAVES):
     for ident, _ in seq[w]:
         if ident not in order: order.append(ident)
-order.sort()
+pos = {ident: min(i for w in range(WAVES) for i, (d, _) in enumerate(seq[w]) if d == ident) for ident in order}
+order.sort(key=lambda d: (pos[d], d))
 for ident in order:
-    row = '%-34s' % names.get(ident, str(ident))
-    for w in range(4):
+    row = '%-46s' % names.get(ident, str(ident))
+    for w in range(WAVES):
         hit = [i for i, (d, _) in enumerate(seq[w]) if d == ident]
-        if not hit: row += ' ' * 17; continue
-        i = hit[-1]; c = seq[w][i][1]; d = c - seq[w][i - 1][1] if i else 0
-        row += ' %7d (%5d) ' % (c, d)
+        if not hit: row += ' ' * 19; continue
+        i = hit[-1]; c = seq[w][i][1] - seq[w][0][1]; d = seq[w][i][1] - seq[w][i - 1][1] if i else 0
+        row += ' %7d (%6d)  ' % (c, d)
     print(row)
 
 # ---- evaluation kernel: first 16 workgroups of the last big launch of each sampler (A: 64 lanes, P: 1024 lanes)
