@@ -28,7 +28,7 @@
 __device__ unsigned long long g_timeline[(GEN_WIN / 64 + 1) * 64];
 #define GEN_TS(id) do { if ((t & 63u) == 0u && ts_n < 64u) { sh.ts[(t & ~63u) + ts_n] = ((unsigned long long)cg_clock() << 8) | (unsigned long long)(id); ++ts_n; } } while (0)
 // every wave leaves its own marks when it ends (a launch that found a well filled queue: the populated chain)
-#define GEN_TS_DUMP_WAVE() do { if ((t & 63u) == 0u && e_prevQ >= 140u && (t >> 6) <= (unsigned)(GEN_WIN / 64)) { for (uint32_t i_ = 0; i_ < 64u; ++i_) g_timeline[(t & ~63u) + i_] = i_ < ts_n ? sh.ts[(t & ~63u) + i_] : 0ull; } } while (0)
+#define GEN_TS_DUMP_WAVE() do { if ((t & 63u) == 0u && ts_ok && (t >> 6) <= (unsigned)(GEN_WIN / 64)) { for (uint32_t i_ = 0; i_ < 64u; ++i_) g_timeline[(t & ~63u) + i_] = i_ < ts_n ? sh.ts[(t & ~63u) + i_] : 0ull; } } while (0)
 #define GEN_TS_INIT() uint32_t ts_n = 0
 #define GEN_TS_RESUME(k) ts_n = (k)
 #define GEN_PIN(x) asm volatile("" : "+v"(x) :: "memory")      // the value is computed before the next timestamp
@@ -52,10 +52,11 @@ __device__ unsigned long long g_timeline[(GEN_WIN / 64 + 1) * 64];
 #define GEN_F_WORDZERO 256u // ... and its whole level-0 bitmap word was empty (hints must be set)
 
 #define GEN_STAMP_COMMITTED 0xFFFFFFull
-#ifndef GEN_TAB_BBITS
-#define GEN_TAB_BBITS 10
-#endif
-#define GEN_TAB_NB (1 << GEN_TAB_BBITS)   // buckets of the LDS conflict table (round 1 of a batch); 4 slots each
+// buckets of the LDS conflict table (round 1 of a batch), 4 slots each: 1024 for a window of 256 attempts (at most 768 registrations:
+// 19 % of the slots), half of that for the 128-lane window -- the table is emptied at every launch (80 KB / 40 KB of LDS stores).
+// (Both macros read the enclosing template's WIN.)
+#define GEN_TAB_BBITS (WIN <= 128 ? 9 : 10)
+#define GEN_TAB_NB (1 << GEN_TAB_BBITS)
 #define GEN_K_ROW 0u
 #define GEN_K_ATOM 1u
 #define GEN_K_GAP 2u
@@ -334,13 +335,13 @@ CG_DEVICE int gen_probe(unsigned long long v, uint64_t batchEpoch, uint32_t roun
 #define GEN_TAB_FRONT 0x7FFFFFFFu
 #define GEN_TAB_EMPTY 0xFFFFFFFFu
 CG_DEVICE uint32_t gen_tab_hash(uint32_t key) { return key * 2654435761u; }
-CG_DEVICE uint32_t gen_tab_bucket(uint32_t h) { return h >> (32 - GEN_TAB_BBITS); }
-CG_DEVICE uint32_t gen_tab_start(uint32_t h) { return (h >> (30 - GEN_TAB_BBITS)) & 3u; }
+template <int WIN> CG_DEVICE uint32_t gen_tab_bucket(uint32_t h) { return h >> (32 - GEN_TAB_BBITS); }
+template <int WIN> CG_DEVICE uint32_t gen_tab_start(uint32_t h) { return (h >> (30 - GEN_TAB_BBITS)) & 3u; }
 template <int WIN>
 CG_DEVICE uint32_t gen_tab_claim(GenShared<WIN> &sh, uint32_t key)
 {
-    const uint32_t h = gen_tab_hash(key), j = gen_tab_start(h);
-    uint32_t b = gen_tab_bucket(h);
+    const uint32_t h = gen_tab_hash(key), j = gen_tab_start<WIN>(h);
+    uint32_t b = gen_tab_bucket<WIN>(h);
     for (;;) {
         for (uint32_t i = 0; i < 4u; ++i) {
             const uint32_t s = 4u * b + ((j + i) & 3u);
@@ -354,8 +355,8 @@ CG_DEVICE uint32_t gen_tab_claim(GenShared<WIN> &sh, uint32_t key)
 template <int WIN>
 CG_DEVICE uint32_t gen_tab_find(const GenShared<WIN> &sh, uint32_t key)
 {
-    const uint32_t h = gen_tab_hash(key), j = gen_tab_start(h);
-    uint32_t b = gen_tab_bucket(h);
+    const uint32_t h = gen_tab_hash(key), j = gen_tab_start<WIN>(h);
+    uint32_t b = gen_tab_bucket<WIN>(h);
     for (;;) {
         for (uint32_t i = 0; i < 4u; ++i) {
             const uint32_t s = 4u * b + ((j + i) & 3u);

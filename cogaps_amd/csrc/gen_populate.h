@@ -36,14 +36,14 @@ CG_DEVICE void gen_flush_fetch(const SamplerDev &S, GenFlushRegs &f, const unsig
     // (the bin travels with the handle in the erase cache: the bin's head is asked for in the same trip as the record)
     if (m <= (uint32_t)FLUSH_MAX && ht < m) { f.myH = (uint32_t)specE; f.myBin = (uint32_t)(specE >> 32); f.rec = S.atoms[f.myH]; f.myHead = S.binHead[f.myBin]; f.vtail = S.vec[n - m + ht]; }
 }
-// steps 2-4: sort, surgery, replay, write-back.  part 0: sort; part 1: list surgery + bin heads + index replay; part 2: write-back
+// steps 2-5.  part 0: sort (waits for the records); part 1: list surgery + bin heads; part 2: index replay; part 3: write-back
 template <int WIN>
 CG_DEVICE void gen_flush_part(const SamplerDev &S, GenShared<WIN> &sh, const GenFlushRegs &f, const unsigned ht, const uint32_t m, const uint32_t n, const uint32_t fc0, const int part)
 {
     GenScalars &g = sh.g;
     if (m == 0) return;                      // uniform across the wave
     if (m > (uint32_t)FLUSH_MAX) {           // rare: serial fallback, exactly the reference's procedure (one lane, in the last part)
-        if (part == 2 && ht == 0) {
+        if (part == 3 && ht == 0) {
             for (uint32_t i = 1; i < m; ++i) {
                 const unsigned long long e = S.eraseList[i]; uint64_t p = S.atoms[(uint32_t)e].pos; uint32_t j = i;
                 while (j > 0 && S.atoms[(uint32_t)S.eraseList[j - 1]].pos > p) { S.eraseList[j] = S.eraseList[j - 1]; --j; }
@@ -91,6 +91,9 @@ CG_DEVICE void gen_flush_part(const SamplerDev &S, GenShared<WIN> &sh, const Gen
             }
             S.freeHandles[fc0 + k] = h;           // pushed in erase order
         }
+        return;
+    }
+    if (part == 2) {
         // swap-with-last replay on indices (mAtoms[idx] = mAtoms.back(); pop_back), one lane, LDS only
         if (ht == 0) {
             uint32_t curN = n, nl = 0;
@@ -146,12 +149,16 @@ CG_DEVICE void gen_helper(const SamplerDev &S, GenShared<WIN> &sh, GenScalars *g
         const bool first = roundNo == 1u;
         const bool ldsRound = first;
         // ---- A1's three barriers (gen_count3 twice, then the sorted slots); round 1: the flush goes on between them
-        cg_sync_lds();
+        // (the flush's steps are placed so that each takes about as long as what the attempt waves do meanwhile: the sort -- it waits
+        // for the records -- while they draw and guess, the list surgery during the exact decision, the index replay during the type
+        // sort, the write-back during the first stage of A2)
         if (first) gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 0);
         cg_sync_lds();
         if (first) gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 1);
         cg_sync_lds();
-        if (first) { gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 2); GEN_TS(3); cg_sync(); }      // the join: the flush's stores are acknowledged (vmcnt(0)) before any lane reads the domain
+        if (first) gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 2);
+        cg_sync_lds();
+        if (first) { gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 3); GEN_TS(3); cg_sync(); }      // the join: the flush's stores are acknowledged (vmcnt(0)) before any lane reads the domain
         // ---- B1 / B2 barriers
         if (ldsRound) cg_sync_lds(); else cg_sync();
         if (ldsRound) cg_sync_lds(); else cg_sync();
@@ -215,7 +222,7 @@ CG_DEVICE void gen_helper(const SamplerDev &S, GenShared<WIN> &sh, GenScalars *g
             for (uint32_t w = ht; w < GEN_GS_WORDS; w += 64u)
                 if (w != GEN_GS_ERROR_WORD && !(frontPending && w == frontWord)) reinterpret_cast<uint32_t *>(gs)[w] = reinterpret_cast<const uint32_t *>(&sh.g)[w];
             GEN_TS(24);
-            GEN_TS_DUMP_WAVE();
+            { const bool ts_ok = e_prevQ >= 140u && remaining >= 512u; (void)ts_ok; GEN_TS_DUMP_WAVE(); }
             return;
         }
         // ---- another round of this batch: its set-up once every lane is done with this round's masks
@@ -481,8 +488,8 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
         // claim the three slots together: one compare-and-swap each per probe step (a placed key
         // repeats the swap on its own slot, which changes nothing)
         const uint32_t hh0 = gen_tab_hash(k0), hh1 = gen_tab_hash(k1), hh2 = gen_tab_hash(k2);
-        uint32_t b0 = gen_tab_bucket(hh0), b1_ = gen_tab_bucket(hh1), b2_ = gen_tab_bucket(hh2);
-        const uint32_t j0 = gen_tab_start(hh0), j1 = gen_tab_start(hh1), j2 = gen_tab_start(hh2);
+        uint32_t b0 = gen_tab_bucket<WIN>(hh0), b1_ = gen_tab_bucket<WIN>(hh1), b2_ = gen_tab_bucket<WIN>(hh2);
+        const uint32_t j0 = gen_tab_start<WIN>(hh0), j1 = gen_tab_start<WIN>(hh1), j2 = gen_tab_start<WIN>(hh2);
         uint32_t s0 = 0, s1 = 0, s2 = 0, d0 = 0, d1 = 0, d2 = 0;
         for (uint32_t i = 0; ; ++i) {
             const uint32_t p0 = d0 ? s0 : 4u * b0 + ((j0 + i) & 3u), p1 = d1 ? s1 : 4u * b1_ + ((j1 + i) & 3u), p2 = d2 ? s2 : 4u * b2_ + ((j2 + i) & 3u);
@@ -541,7 +548,7 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
         key[4] = h1; use[4] = tM | tE | tD;
         key[5] = h2; use[5] = tE;
         uint32_t bk[6]; GenTabKeys kq[6];
-        for (int k = 0; k < 6; ++k) { bk[k] = gen_tab_bucket(gen_tab_hash(key[k])); kq[k] = *(const GenTabKeys *)&sh.bkey[4u * bk[k]]; }
+        for (int k = 0; k < 6; ++k) { bk[k] = gen_tab_bucket<WIN>(gen_tab_hash(key[k])); kq[k] = *(const GenTabKeys *)&sh.bkey[4u * bk[k]]; }
         uint32_t sl[6], hit[6], over = 0;
         for (int k = 0; k < 6; ++k) {
             const uint32_t *q4 = kq[k].k;
@@ -724,7 +731,7 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
         }
     }
     GEN_TS(21);
-    if (endB) { GEN_TS(22); { const uint32_t e_prevQ = c.e_prevQ; (void)e_prevQ; GEN_TS_DUMP_WAVE(); } }
+    if (endB) { GEN_TS(22); { const bool ts_ok = c.e_prevQ >= 140u && c.remaining >= 512u; (void)ts_ok; GEN_TS_DUMP_WAVE(); } }
     return endB;
 }
 
@@ -796,7 +803,7 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
         gen_flush_fetch<WIN>(S, fr, ht, e_m, e_n, specE);
         if (ht == 0) { sh.flushM = 0; sh.flushBase = e_fc; sh.nLow = 0; }
         cg_wave_sync();
-        for (int part = 0; part < 3; ++part) { gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, part); cg_wave_sync(); }
+        for (int part = 0; part < 4; ++part) { gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, part); cg_wave_sync(); }
         if (ht == 0) { gs->nAtoms = sh.g.nAtoms; gs->front = sh.g.front; gs->freeCount = sh.g.freeCount; gs->eraseCount = 0; gs->qlen = 0; gs->batchNproc = 0; gs->updateFlushed = 1;
                        gs->evalBytes = sh.g.evalBytes + (unsigned long long)sh.unitSum * S.unitBytes; gs->evalProps = sh.g.evalProps + e_prevQ; }
         return;

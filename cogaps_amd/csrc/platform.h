@@ -165,6 +165,21 @@ CG_DEVICE uint32_t cg_wave_sum_u32(uint32_t x)
 #undef CG_DPP_ADDU
     return (uint32_t)__builtin_amdgcn_readlane((int)x, 0) + (uint32_t)__builtin_amdgcn_readlane((int)x, 16) + (uint32_t)__builtin_amdgcn_readlane((int)x, 32) + (uint32_t)__builtin_amdgcn_readlane((int)x, 48);
 }
+// exclusive prefix sum of x over the wave's lanes, and the wave's total (all 64 lanes call it with exec full; a lane that has nothing
+// passes 0): Hillis-Steele inside the rows of 16 by DPP row shifts, then the rows' totals by the two row broadcasts.  What an LDS
+// atomicAdd-with-return at one address from every lane computes, without the compiler's serial scan over the active lanes.
+CG_DEVICE uint32_t cg_wave_excl_scan_u32(uint32_t x, uint32_t &total)
+{
+    uint32_t v = x;
+#define CG_DPP_SCAN(ctrl, rows) v = v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, (ctrl), (rows), 0xF, false)
+    CG_DPP_SCAN(0x111, 0xF); CG_DPP_SCAN(0x112, 0xF); CG_DPP_SCAN(0x114, 0xF); CG_DPP_SCAN(0x118, 0xF);      // row_shr:1,2,4,8
+    CG_DPP_SCAN(0x142, 0xA);      // row_bcast:15 -> rows 1 and 3
+    CG_DPP_SCAN(0x143, 0xC);      // row_bcast:31 -> rows 2 and 3
+#undef CG_DPP_SCAN
+    total = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    return v - x;
+}
+CG_DEVICE uint32_t cg_wave_bcast_u32(uint32_t x, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)x, lane); }
 CG_DEVICE unsigned long long cg_clock() { return __builtin_readcyclecounter(); }
 CG_DEVICE int cg_clz64(unsigned long long x) { return __clzll((long long)x); }
 CG_DEVICE int cg_ctz64(unsigned long long x) { return __ffsll((long long)x) - 1; }

@@ -198,8 +198,18 @@ CG_DEVICE void sp_partial_balanced(const SamplerDev &S, uint32_t row, uint32_t c
             }
             cnt = (uint32_t)cg_popc64(common);
             visited += cnt;
+        }
+        {   // list slots: a wave's words take one block of the list (one LDS atomic per wave), a word's offset inside it from a DPP
+            // prefix sum over the wave's counts.  (An atomicAdd-with-return per lane at the one address is what the compiler turns
+            // into a serial scan over the active lanes: 64 iterations, 2-3 k cycles per wave and call.)
+            uint32_t waveTot;
+            const uint32_t ex = cg_wave_excl_scan_u32(cnt, waveTot);
+            uint32_t wbase = 0;
+            if ((t & 63u) == 0u && waveTot) wbase = cg_atomic_add_u32(&bal.n, waveTot);
+            base = cg_wave_bcast_u32(wbase, 0) + ex;
+        }
+        if (w < S.Wn) {
             if (cnt) {
-                base = cg_atomic_add_u32(&bal.n, cnt);
                 if (base + cnt <= (uint32_t)SP_BAL_CAP) {
                     unsigned long long c = common; uint32_t j = 0;
                     while (c != 0ull) {
@@ -425,7 +435,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
             else if (two) sp_partial_balanced<SP_MODE_SAME>(S, p.r1, p.c1, p.c2, 0.f, arowA, bal, preA, x[0], x[1], nz);
             else sp_partial_balanced<SP_MODE_ONE>(S, p.r1, p.c1, 0u, 0.f, arowA, bal, preA, x[0], x[1], nz);
             EVAL_TS(3);
-            if (nz) cg_atomic_add_u32(&nzShared, nz);
+            { const uint32_t waveNz = cg_wave_sum_u32(nz); if ((t & 63u) == 0u && waveNz) cg_atomic_add_u32(&nzShared, waveNz); }
 #pragma unroll
             for (int c = 0; c < 4; ++c) x[c] = cg_wave_allsum_f32(x[c]);
             float tot[4] = {x[0], x[1], x[2], x[3]};

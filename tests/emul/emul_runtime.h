@@ -69,6 +69,17 @@ inline uint32_t cg_wave_sum_u32(uint32_t x)
     for (int off = 1; off < 64; off <<= 1) { float f; memcpy(&f, &x, 4); const float g = cgemu::wave_exchange_f32(f, off); uint32_t y; memcpy(&y, &g, 4); x += y; }
     return x;
 }
+inline uint32_t cg_wave_bcast_u32_from(uint32_t x, int srcLane) { float f; memcpy(&f, &x, 4); const float g = cgemu::wave_read_f32(f, srcLane < 0 ? 0 : srcLane); uint32_t y; memcpy(&y, &g, 4); return y; }
+inline uint32_t cg_wave_bcast_u32(uint32_t x, int lane) { float f; memcpy(&f, &x, 4); const float g = cgemu::wave_read_f32(f, lane); uint32_t y; memcpy(&y, &g, 4); return y; }
+inline uint32_t cg_wave_excl_scan_u32(uint32_t x, uint32_t &total)
+{
+    // inclusive Hillis-Steele by lane reads (a lane below the wave's first reads nothing)
+    const unsigned lane = cgemu::g_lane.tid & 63u;
+    uint32_t v = x;
+    for (unsigned off = 1; off < 64u; off <<= 1) { const uint32_t o = cg_wave_bcast_u32_from(v, (int)lane - (int)off); v += lane >= off ? o : 0u; }
+    total = cg_wave_bcast_u32(v, 63);
+    return v - x;
+}
 inline unsigned long long cg_clock() { return 0; }
 inline int cg_clz64(unsigned long long x) { return x ? __builtin_clzll(x) : 64; }
 inline int cg_ctz64(unsigned long long x) { return x ? __builtin_ctzll(x) : -1; }
