@@ -353,7 +353,7 @@ def main():
         # of an update (empty queue) are kept out of the averages; every sync (AP transpose) launch is timed.
         def window(w):
             d = {k: perf1[w][k] - perf0[w][k] for k in ("evalBytes", "batches", "evalLaunches", "genLaunches")}
-            for k in ("evalMs", "genMs", "timedBatches", "evalTimed", "genTimed", "evalNoopMs", "evalNoopTimed"):
+            for k in ("evalMs", "genMs", "timedBatches", "evalTimed", "genTimed", "evalNoopMs", "evalNoopTimed", "genNoopMs", "genNoopTimed"):
                 d[k] = perf1[w][k]           # counted from set_timing(1)
             return d
         kt = {w: window(w) for w in "AP"}
@@ -416,7 +416,10 @@ def main():
                        "avg_queue_A": S.avg_queue("A"), "avg_queue_P": S.avg_queue("P"),
                        "atoms_A": S.natoms("A"), "atoms_P": S.natoms("P"),
                        "timed_region_ms_rank0": 1e3 * dt, "gen_kernel_ms_rank0": gen_ms, "eval_kernel_ms_rank0": ev_ms, "sync_kernel_ms_rank0": tot["syncMs"],
-                       "launches_per_batch": sum(kt[w]["evalLaunches"] + kt[w]["genLaunches"] for w in "AP") / max(1, batches)},
+                       "launches_per_batch": sum(kt[w]["evalLaunches"] + kt[w]["genLaunches"] for w in "AP") / max(1, batches),
+                       # launches enqueued past the end of an update find nothing to do: what a launch costs before it does any work
+                       "empty_launch_us": {w: {"gen": (1e3 * kt[w]["genNoopMs"] / kt[w]["genNoopTimed"]) if kt[w]["genNoopTimed"] else None,
+                                               "eval": (1e3 * kt[w]["evalNoopMs"] / kt[w]["evalNoopTimed"]) if kt[w]["evalNoopTimed"] else None} for w in "AP"}},
             # roofline.achieved = B_alg / (sum of kernel time) over the whole path -- generator, evaluation and sync
             # kernels of the timed region -- with each kernel's own figure alongside.  One "launch" of the path = one batch.
             "roofline": {"bound": "hbm", "kernel": "path: gen_kernel + evaluation kernels + sync, per batch (dominant by time: %s, sampler %s)" % (dominant["kernel"], dominant["sampler"]),
