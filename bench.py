@@ -185,8 +185,21 @@ def chains_main(args):
         # 1.4x the sampled ones (profiles/r02_chains8_*), so bytes / summed samples would flatter the path; with several groups
         # the groups' launches overlap and only the wall clock adds up anyway.  The per-launch samples stay listed as what they are.
         ach = (tot_bytes / 1e9) / dt
+        # HBM bytes from the PMC counters (two separate rocprofv3 --pmc passes over this mode with 8 chains in one batch,
+        # tools/r3_pmc_pass.sh, committed under profiles/): per step of the batch, weighted by this run's A and P step counts
+        traffic, traffic_src = None, None
+        if C == 8 and G == 1 and not args.sparse and (args.genes, args.samples, args.patterns) == (20000, 2000, 50):
+            import glob
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_chains8_pmc_traffic.json")))
+            if files:
+                per = json.load(open(files[-1]))["hbm_bytes_per_step"]
+                st = {w: sum(k["steps"] for k in kern if k["kernel"].startswith("batched evaluation launch, sampler %s" % w)) for w in "AP"}
+                if st["A"] + st["P"]:
+                    traffic = (per["A (generator + fused evaluation)"] * st["A"] + per["P (generator + split evaluation)"] * st["P"]) / (st["A"] + st["P"])
+                    traffic_src = "%s: HBM bytes per step of the 8-chain batch (FETCH_SIZE x2 + WRITE_SIZE), A and P steps weighted by this run's counts" % os.path.relpath(files[-1], ROOT)
         roof = {"bound": "hbm", "kernel": "path: batched generator + evaluation launches, algorithmic bytes over the wall time of the timed region", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": None, "sampled_kernel_time_over_wall": tot_ms / (1e3 * dt), "kernels": kern,
+                "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_step": tot_bytes / max(1, sum(k["steps"] for k in kern if k["kernel"].startswith("batched evaluation"))),
+                "sampled_kernel_time_over_wall": tot_ms / (1e3 * dt), "kernels": kern,
                 "note": "`kernels` lists HIP-event samples of plain (not graph-replayed) launches: they exclude the boundary write-back a replayed launch waits for, so their per-launch `frac` is an upper bound on what the launch reaches inside the graph"}
     print(json.dumps({"metric": METRIC + " [informational: %d chains on one GPU, %s]" % (C, "batched multi-chain launches" if batched else "one thread and stream per chain"),
                       "value": sum(upd) / dt, "unit": "proposals/s",
