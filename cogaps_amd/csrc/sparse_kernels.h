@@ -64,37 +64,6 @@ CG_DEVICE float sp_row_dot(const float *a, const SpRow &R, uint32_t n)
     }
     return d;
 }
-// gaps::dot(a, b) for two zero-padded LDS vectors, n <= 64: b is read into registers as whole float4 chunks (sixteen reads in flight),
-// then sp_row_dot -- the table terms' K-length dots took 2.2 k cycles as an element-by-element LDS loop
-CG_DEVICE float sp_dot_lds(const float *a, const float *b, uint32_t n)
-{
-    if (n > 64u) return sp_dot(a, b, n);
-    SpRow R; const uint32_t nq = (n + 3u) >> 2;
-#pragma unroll
-    for (uint32_t c = 0; c < 16u; ++c) R.r[c] = c < nq ? *reinterpret_cast<const cg_f4 *>(b + 4u * c) : f4_zero();
-    return sp_row_dot(a, R, n);
-}
-// gaps::dot_diff(a, b, c) = sum a[k] * (b[k] - c[k]), k ascending (VectorMath.h:137-155), three zero-padded LDS vectors
-CG_DEVICE float sp_dot_diff_lds(const float *a, const float *b, const float *c, uint32_t n)
-{
-    float d = 0.f;
-    if (n > 64u) { for (uint32_t k = 0; k < n; ++k) d += a[k] * (b[k] - c[k]); return d; }
-    const uint32_t nq = (n + 3u) >> 2;
-    cg_f4 A[16], B[16], C[16];
-#pragma unroll
-    for (uint32_t q = 0; q < 16u; ++q) {
-        A[q] = q < nq ? *reinterpret_cast<const cg_f4 *>(a + 4u * q) : f4_zero();
-        B[q] = q < nq ? *reinterpret_cast<const cg_f4 *>(b + 4u * q) : f4_zero();
-        C[q] = q < nq ? *reinterpret_cast<const cg_f4 *>(c + 4u * q) : f4_zero();
-    }
-#pragma unroll
-    for (uint32_t q = 0; q < 16u; ++q) {
-        if (q < nq) {      // (a padding element adds 0 * (0 - 0) = +0)
-            d = d + A[q].x * (B[q].x - C[q].x); d = d + A[q].y * (B[q].y - C[q].y); d = d + A[q].z * (B[q].z - C[q].z); d = d + A[q].w * (B[q].w - C[q].w);
-        }
-    }
-    return d;
-}
 // any length: straight from memory, 8 float4 at a time
 CG_DEVICE float sp_dot_row(const float *a, const float *row, uint32_t n)
 {
@@ -387,8 +356,8 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
     cg_sched_fence();
     if (WARM > 0) cg_kernarg_warm<(WARM > 0 ? WARM : 4)>();
     CG_SHARED float lds[16 * 4];
-    CG_SHARED alignas(16) float arowA[SP_KMAX]; CG_SHARED alignas(16) float arowB[SP_KMAX];
-    CG_SHARED alignas(16) float z2A[SP_KMAX]; CG_SHARED alignas(16) float z2B[SP_KMAX];        // the Z2 columns of c1 / c2 (table terms)
+    CG_SHARED float arowA[SP_KMAX], arowB[SP_KMAX];
+    CG_SHARED float z2A[SP_KMAX], z2B[SP_KMAX];        // the Z2 columns of c1 / c2 (table terms)
     CG_SHARED float decf; CG_SHARED uint32_t deci;
     CG_SHARED uint32_t nzShared;           // common non-zeros visited by this workgroup (roofline bookkeeping)
     CG_SHARED uint32_t seqCnt[SEQ ? SP_SEQ_WORDS + 1 : 1]; CG_SHARED float seqBc[2];     // verification mode (sp_alpha_seq)
@@ -429,8 +398,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
             for (uint32_t k = t; k < S.Kpad; k += BS) {
                 arowA[k] = S.rows[(size_t)p.r1 * S.Kpad + k];
                 if (diff) arowB[k] = S.rows[(size_t)p.r2 * S.Kpad + k];
-                // (zero-padded like the rows: sp_dot_lds reads whole chunks)
-                z2A[k] = k < K ? S.Z2[(size_t)p.c1 * K + k] : 0.f; if (two) z2B[k] = k < K ? S.Z2[(size_t)p.c2 * K + k] : 0.f;
+                if (k < K) { z2A[k] = S.Z2[(size_t)p.c1 * K + k]; if (two) z2B[k] = S.Z2[(size_t)p.c2 * K + k]; }
             }
             cg_sync();
             EVAL_TS(2);
@@ -480,16 +448,17 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
             if (scalarLane) {
                 // table terms (SparseNormalModel.cpp:160-161, 205-207, 256-258), then beta
                 if (diff) {
-                    const float sa = (z1a + tot[0]) * beta, ma = (-1.f * sp_dot_lds(arowA, z2A, K) + tot[1]) * beta;
-                    const float sb = (z1b + tot[2]) * beta, mb = (-1.f * sp_dot_lds(arowB, z2B, K) + tot[3]) * beta;
+                    const float sa = (z1a + tot[0]) * beta, ma = (-1.f * sp_dot(arowA, z2A, K) + tot[1]) * beta;
+                    const float sb = (z1b + tot[2]) * beta, mb = (-1.f * sp_dot(arowB, z2B, K) + tot[3]) * beta;
                     s = sa + sb; smu = ma - mb;                                    // AlphaParameters.cpp:11-14
                 } else if (two) {
                     float s0 = z1a - 2.f * z2B[p.c1] + z1b;
-                    const float d0 = sp_dot_diff_lds(arowA, z2A, z2B, K);      // dot_diff, VectorMath.h:137-155
+                    float d0 = 0.f;
+                    for (uint32_t k = 0; k < K; ++k) d0 += arowA[k] * (z2A[k] - z2B[k]);   // dot_diff, VectorMath.h:137-155
                     float m0 = -1.f * d0;
                     s = (s0 + tot[0]) * beta; smu = (m0 + tot[1]) * beta;
                 } else {
-                    float m0 = -1.f * sp_dot_lds(arowA, z2A, K);
+                    float m0 = -1.f * sp_dot(arowA, z2A, K);
                     if (p.type == 'D') m0 -= (-1.f * m1) * z2A[p.c1];
                     s = (z1a + tot[0]) * beta; smu = (m0 + tot[1]) * beta;
                 }
