@@ -66,6 +66,14 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(256) init_ap_kernel(SamplerDev S, uint32_t tiles
 }
 
 // number of entries > 0 per column of mat (canUseGibbs counters), one workgroup per column
+// ProposalQueue::deathProb (ProposalQueue.cpp:123-127) for every atom count the domain's arrays can hold (+ a window's worth): the
+// generator's lanes read the entries of the counts their window can see (gen_populate.h) -- the same gm_death_prob, evaluated once
+// per session instead of twice per lane and launch
+CG_KERNEL void death_prob_table_kernel(float *tab, uint32_t n, double domainLen, double alpha, double numBins)
+{
+    const uint32_t i = cg_bid() * cg_bdim() + cg_tid();
+    if (i < n) tab[i] = gm_death_prob((double)(uint64_t)i, domainLen, alpha, numBins);
+}
 CG_KERNEL void count_pos_kernel(SamplerDev S)
 {
     CG_SHARED uint32_t cnt;

@@ -206,10 +206,20 @@ static double now_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
 
 template <class T> static T *dalloc(size_t n) { return (T *)rt_malloc(n * sizeof(T)); }
 
+// SamplerDev::deathProb for the atom arrays' current capacity (the sampler's creation, grow_atoms)
+static void build_death_prob_table(cogaps_session *s, SamplerDev &d)
+{
+    const uint32_t n = d.atomCap + GAPS_DEATH_PROB_PAD;
+    float *tab = dalloc<float>(n);
+    RT_LAUNCH(death_prob_table_kernel, (n + 255u) / 256u, 256, s->stream, tab, n, d.domainLenD, d.alphaD, d.numBins);
+    rt_sync(s->stream);
+    d.deathProb = tab;
+}
+
 static void free_sampler(HostSampler &h)
 {
     SamplerDev &d = h.d;
-    rt_free(d.seqScratch);
+    rt_free(d.seqScratch); rt_free((void *)d.deathProb);
     rt_free((void *)d.D); rt_free((void *)d.S2); rt_free(d.AP); rt_free(d.mat); rt_free(d.colPos);
     rt_free(d.atoms); rt_free(d.vec); rt_free(d.freeHandles); rt_free(d.binHead);
     rt_free(d.bits0); rt_free(d.bits1); rt_free(d.bits2); rt_free(d.eraseList); rt_free(d.queue); rt_free(d.queueUnits); rt_free(d.partials);
@@ -332,6 +342,7 @@ static void build_sampler(cogaps_session *s, HostSampler &h, char name, const fl
     if (nBins >= 0xFFFFFFF0ull) throw std::runtime_error("rows x nPatterns must stay below 2^32");
     d.rboundNone = gm_u64_from_double_x86(d.domainLenD);
     d.iPartL = 0xFFFFFFFFFFFFFFFFull / d.domainLenU; d.limitL = d.domainLenU * d.iPartL;   // uniform64(1, L)
+    build_death_prob_table(s, d);
     d.gs = dalloc<GenScalars>(1);
     GenScalars g; memset(&g, 0, sizeof(g));
     g.front = CG_NONE;
@@ -380,6 +391,8 @@ static void grow_atoms(cogaps_session *s, HostSampler &h, uint32_t need)
     regrow(d.atomStamp, 8); regrow(d.inlineStamp, 8); regrow(d.atomDest, 8);
     { void *n = rt_malloc(((size_t)cap + 1) * 8); rt_d2d(n, d.gapStamp, ((size_t)d.atomCap + 1) * 8, s->stream); rt_sync(s->stream); rt_free(d.gapStamp); d.gapStamp = (unsigned long long *)n; }
     d.atomCap = cap;
+    rt_free((void *)d.deathProb); d.deathProb = nullptr;
+    build_death_prob_table(s, d);
 }
 
 // HIP-event timing of a sample of the launches (every 8th): the start / stop events are attached to the kernel's

@@ -76,6 +76,7 @@ struct GenScalars {
 
 enum GapsError { GAPS_OK = 0, GAPS_ERR_ATOM_CAP = 1, GAPS_ERR_QUEUE_CAP = 2, GAPS_ERR_ERASE_CAP = 3, GAPS_ERR_SPIN = 4 };
 
+#define GAPS_DEATH_PROB_PAD 1024u
 struct SamplerDev {
     // ---- dimensions -------------------------------------------------------------------------
     uint32_t M;        // rows of this sampler's factor matrix (genes for A, samples for P)
@@ -124,6 +125,8 @@ struct SamplerDev {
     uint64_t domainLenU;   // ConcurrentAtomicDomain::mDomainLength (exact)
     double domainLenD;     // ProposalQueue::mDomainLength
     double numBins, alphaD;
+    const float *deathProb; // [atomCap + GAPS_DEATH_PROB_PAD] ProposalQueue::deathProb(n) for every atom count n (death_prob_table_kernel): a window's
+                            // attempts see counts within +-GEN_WIN of the domain's, the generator reads its two rows of the table instead of dividing
     double invBinLen;      // 1.0 / binLength (quotient estimate of gen_bin_of)
     double invK;           // 1.0 / nPatterns (gen_div_k)
     uint64_t rboundNone;   // static_cast<uint64_t>(mDomainLength), ProposalQueue.cpp:216

@@ -241,6 +241,7 @@ CG_DEVICE void gen_helper(const SamplerDev &S, GenShared<WIN> &sh, GenScalars *g
 // first attempt was looked at, and the wait for the seeds at the loop's head -- and a dozen scalar registers spilled to carry them.
 struct GenRoundCtx {
     unsigned t; uint64_t jm0, ji0, jm1, ji1, seed1, batchEpoch, g_qrng; uint32_t n0, updBase, remaining, K, g_skip, e_prevQ; float dp0, g_u1, g_u2; GenScalars *gs;
+    float tabHi, tabLo;      // round 1: this lane's entries of the window's death-probability rows, on their way from SamplerDev::deathProb
 };
 template <int WIN, bool FIRST>
 CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRoundCtx &c, const uint32_t roundNo)
@@ -275,6 +276,7 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
         GEN_PIN(guess); GEN_PIN(u1); GEN_PIN(u2);
         GEN_TS(5);
         sh.u1[t] = u1; sh.u2[t] = u2;
+        if (first) { sh.dpHi[t] = c.tabHi; sh.dpLo[t] = c.tabLo; }      // read after the barrier inside the count (later rounds: gen_body)
         uint32_t bBefore, dBefore, e3, tB, tD, t3;
         gen_count3<WIN>(sh.wtotA, t, guess == 'B', guess == 'D', false, bBefore, dBefore, e3, tB, tD, t3);
         GEN_TS(6);
@@ -769,9 +771,14 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
     {   // empty conflict table: keys, and the value words ("nobody" = all ones: whoever registers first under a key needs no
         // opener) -- by ALL lanes: one wave alone stores to LDS at a fraction of the workgroup's rate (the helper wave presetting
         // the 64 KB of value words by itself took 5 k cycles, longer than the trip)
+        // keys and value words are one contiguous region of 5 * GEN_TAB_NB 16-byte units: a fixed number of stores per lane at constant
+        // offsets from one address (a run-time loop bound made every store a loop iteration with its own branch)
         GenTabKeys none; none.k[0] = none.k[1] = none.k[2] = none.k[3] = GEN_TAB_EMPTY;
-        for (uint32_t i = t; i < (uint32_t)GEN_TAB_NB; i += TPB) *(GenTabKeys *)&sh.bkey[4u * i] = none;
-        for (uint32_t i = t; i < 4u * (uint32_t)GEN_TAB_NB; i += TPB) *(GenTabKeys *)&sh.bval[i] = none;
+        static_assert(offsetof(GenShared<WIN>, bval) == offsetof(GenShared<WIN>, bkey) + 16u * (size_t)GEN_TAB_NB, "keys and value words are contiguous");
+        constexpr uint32_t UNITS = 5u * (uint32_t)GEN_TAB_NB, ROUNDS = (UNITS + TPB - 1u) / TPB;
+        GenTabKeys *tab = reinterpret_cast<GenTabKeys *>(&sh.bkey[0]) + t;
+#pragma unroll
+        for (uint32_t k = 0; k < ROUNDS; ++k) { if ((k + 1u) * TPB <= UNITS || t + k * TPB < UNITS) tab[k * TPB] = none; }
     }
     GEN_TS(27);
     if (ASYNC) sp = cg_const_warm_end(sp, lines);
@@ -814,12 +821,11 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
     // second trip (addresses from the first): this round's seeds
     const uint64_t seed1 = (e_nDone + t < e_nSteps) ? S.seeds[e_nDone + t] : 0ull;
     const uint32_t n0 = e_n - e_m;                  // after the flush (which the helper wave runs meanwhile) the domain holds this many atoms
-    {
-        // death probability (ProposalQueue::deathProb) for every atom count an attempt of this window can see:
-        // lane t fills the entries for t births / t deaths ahead of it
-        sh.dpHi[t] = gm_death_prob((double)((uint64_t)n0 + t), S.domainLenD, S.alphaD, S.numBins);
-        sh.dpLo[t] = (n0 >= t) ? gm_death_prob((double)(uint64_t)(n0 - t), S.domainLenD, S.alphaD, S.numBins) : 0.f;
-    }
+    // death probability (ProposalQueue::deathProb) for every atom count an attempt of this window can see: lane t takes the entries for
+    // t births / t deaths ahead of it from the session's table (the same gm_death_prob, evaluated once per session).  They are needed
+    // after the first count of the classification, and are parked in LDS just before it: the trip runs under the draws and the
+    // first guess, which needs only the entry of the count itself (computed here: the load would be on the critical path).
+    const float tabHi = S.deathProb[n0 + t], tabLo = (n0 >= t) ? S.deathProb[n0 - t] : 0.f;
     const uint64_t batchEpoch = sh.g.batchEpoch + 1;
     const uint32_t updBase = e_nDone;           // attempts consumed by earlier batches of this update
     const uint32_t remaining = e_nSteps - e_nDone;
@@ -830,7 +836,7 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
     const uint64_t g_qrng = sh.g.qrng; const uint32_t g_skip = sh.g.useCached ? 1u : 0u; const float g_u1 = sh.g.u1, g_u2 = sh.g.u2;
 
     GenRoundCtx rc; rc.t = t; rc.jm0 = jm0; rc.ji0 = ji0; rc.jm1 = jm1; rc.ji1 = ji1; rc.seed1 = seed1; rc.batchEpoch = batchEpoch; rc.g_qrng = g_qrng; rc.n0 = n0; rc.updBase = updBase;
-    rc.remaining = remaining; rc.K = K; rc.g_skip = g_skip; rc.e_prevQ = e_prevQ; rc.dp0 = dp0; rc.g_u1 = g_u1; rc.g_u2 = g_u2; rc.gs = gs;
+    rc.remaining = remaining; rc.K = K; rc.g_skip = g_skip; rc.e_prevQ = e_prevQ; rc.dp0 = dp0; rc.g_u1 = g_u1; rc.g_u2 = g_u2; rc.gs = gs; rc.tabHi = tabHi; rc.tabLo = tabLo;
     if (gen_round<WIN, true>(S, sh, rc, 1u)) return;
     for (uint32_t roundNo = 2; ; ++roundNo) {
         // ------------------------------------------------------------------ set-up of the next round of this batch (the helper wave has published
