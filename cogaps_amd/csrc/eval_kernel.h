@@ -66,7 +66,7 @@ template <int NC, int V>
 CG_DEVICE void eval_vfinish(const float *lds, float (&tot)[NC])
 {
     constexpr int NV = NC * V;
-    const uint32_t t = cg_tid(), nw = cg_bdim() >> 6;
+    const uint32_t t = cg_tid(), nw = cg_fresh_u32(cg_bdim() >> 6);
     if (t < 64u) {
         const uint32_t i = t < (uint32_t)NV ? t : 0u;
         // all sixteen slots are read at once (one wait instead of one per wave) and the ones past the last wave masked afterwards:

@@ -112,6 +112,10 @@ CG_HD float cg_sqrtf(float x) { return sqrtf(x); }        // correctly rounded (
 #define CG_PLATFORM_NAME "HIP gfx950 (MI355X)"
 // a value every lane of the wave holds alike, moved to a scalar register
 CG_DEVICE uint32_t cg_uniform_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+// A wave-uniform value the compiler must treat as new from here on (it stays in a scalar register).  Tests on a kernel-wide invariant --
+// "chunk c of the row exists", "wave w exists" -- are otherwise evaluated once at kernel entry, sixteen at a time, as 64-bit lane masks
+// that stay live for the whole kernel: the sparse evaluation spilled 280 scalar registers into vector lanes before looking at its record.
+CG_DEVICE uint32_t cg_fresh_u32(uint32_t x) { asm volatile("" : "+s"(x)); return x; }
 // nothing is scheduled across this point: what was issued before it stays before
 CG_DEVICE void cg_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // keeps a loaded value (and so the load) alive without using it

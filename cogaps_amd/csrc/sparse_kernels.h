@@ -33,7 +33,7 @@ CG_DEVICE float sp_dot(const float *a, const float *b, uint32_t n)
 struct SpRow { cg_f4 r[16]; };
 CG_DEVICE void sp_row_load(SpRow &R, const float *row, uint32_t n)
 {
-    const uint32_t nq = (n + 3u) >> 2;
+    const uint32_t nq = cg_fresh_u32((n + 3u) >> 2);
 #pragma unroll
     for (uint32_t c = 0; c < 16u; ++c) R.r[c] = c < nq ? ld4(row, c) : f4_zero();
 }
@@ -44,6 +44,7 @@ CG_DEVICE void sp_row_load(SpRow &R, const float *row, uint32_t n)
 CG_DEVICE float sp_row_dot(const float *a, const SpRow &R, uint32_t n)
 {
     float d = 0.f;
+    n = cg_fresh_u32(n);
     const uint32_t nq = (n + 3u) >> 2;
     if (n <= 25u) {
 #pragma unroll

@@ -41,6 +41,7 @@ template <int BYTES, class T> inline void cg_const_warm(const T *) {}
 inline void cg_keep_f32(float) {}
 inline void cg_sched_fence() {}
 inline uint32_t cg_uniform_u32(uint32_t x) { return x; }
+inline uint32_t cg_fresh_u32(uint32_t x) { return x; }
 struct cg_f4 { float x, y, z, w; };
 inline cg_f4 cg_ld4_stream(const float *base, uint32_t j) { return reinterpret_cast<const cg_f4 *>(base)[j]; }
 inline float cg_sqrtf(float x) { return __builtin_sqrtf(x); }
