@@ -443,18 +443,19 @@ static void launch_gen(cogaps_session *s, HostSampler &h)
 static void launch_eval(cogaps_session *s, HostSampler &h)
 {
     const int slot = timing_slot(s, h, 1, h.evalLaunches);
+    const SamplerDev CG_CONSTANT *rec = (const SamplerDev CG_CONSTANT *)h.dRecord;      // (kept current by sync_record, as for the generator)
     if (h.d.seq) {
         // verification mode: one workgroup per proposal whatever the vector length, sums in the reference's order
         if (h.d.sparse) LAUNCH_MAYBE_TIMED(slot, eval_sparse_seq_kernel, std::min<uint32_t>(h.d.queueCap, SEQ_SPARSE_GRID), cogaps_sparse_width(h.d.N), h.d);
-        else LAUNCH_MAYBE_TIMED(slot, eval_kernel<EVAL_SEQ>, std::min<uint32_t>(h.d.queueCap, 512u), EVAL_SEQ_BS, (const PropRec *)h.d.queue, (const GenScalars *)h.d.gs, h.d.queueCap, 1u, h.d);
+        else LAUNCH_MAYBE_TIMED(slot, eval_kernel<EVAL_SEQ>, std::min<uint32_t>(h.d.queueCap, 512u), EVAL_SEQ_BS, (const PropRec *)h.d.queue, (const GenScalars *)h.d.gs, h.d.queueCap, 1u, rec);
     } else if (h.d.sparse) {
         const uint32_t grid = std::min<uint32_t>(h.d.queueCap, 1024u);
-        LAUNCH_MAYBE_TIMED(slot, eval_sparse_kernel, grid, cogaps_sparse_width(h.d.N), (const PropRec *)h.d.queue, (const GenScalars *)h.d.gs, h.d.queueCap, h.d);
+        LAUNCH_MAYBE_TIMED(slot, eval_sparse_kernel, grid, cogaps_sparse_width(h.d.N), (const PropRec *)h.d.queue, (const GenScalars *)h.d.gs, h.d.queueCap, rec);
     } else if (h.d.redW <= 1024u) {
         // one workgroup of W threads per proposal
         static const uint32_t fusedGrid = getenv("COGAPS_FUSED_GRID") ? (uint32_t)atoi(getenv("COGAPS_FUSED_GRID")) : 512u;      // dev: A/B of the launch size
         const uint32_t grid = std::min<uint32_t>(h.d.queueCap, fusedGrid);
-        LAUNCH_MAYBE_TIMED(slot, eval_kernel<EVAL_FUSED>, grid, h.d.redW, (const PropRec *)h.d.queue, (const GenScalars *)h.d.gs, h.d.queueCap, 1u, h.d);
+        LAUNCH_MAYBE_TIMED(slot, eval_kernel<EVAL_FUSED>, grid, h.d.redW, (const PropRec *)h.d.queue, (const GenScalars *)h.d.gs, h.d.queueCap, 1u, rec);
     } else {
         // long data vectors: `slices` workgroups of `bs` threads per proposal, alpha kernel then apply kernel
         // (512 threads fill the machine a little better than 1024; at most 16 slices fit the partials record)
@@ -464,8 +465,8 @@ static void launch_eval(cogaps_session *s, HostSampler &h)
         const uint32_t grid = std::min<uint32_t>(h.d.queueCap, perWave) * slices;
         int slot2 = -1;
         if (slot >= 0 && s->evUsed < s->evPool.size()) { slot2 = (int)s->evUsed++; s->evKind[slot2] = 3; s->evOwner[slot2] = &h; s->evOrd[slot2] = h.updLaunches; }
-        LAUNCH_MAYBE_TIMED(slot, eval_kernel<EVAL_ALPHA>, grid, bs, (const PropRec *)h.d.queue, (const GenScalars *)h.d.gs, h.d.queueCap, slices, h.d);
-        LAUNCH_MAYBE_TIMED(slot2, eval_kernel<EVAL_APPLY>, grid, bs, (const PropRec *)h.d.queue, (const GenScalars *)h.d.gs, h.d.queueCap, slices, h.d);
+        LAUNCH_MAYBE_TIMED(slot, eval_kernel<EVAL_ALPHA>, grid, bs, (const PropRec *)h.d.queue, (const GenScalars *)h.d.gs, h.d.queueCap, slices, rec);
+        LAUNCH_MAYBE_TIMED(slot2, eval_kernel<EVAL_APPLY>, grid, bs, (const PropRec *)h.d.queue, (const GenScalars *)h.d.gs, h.d.queueCap, slices, rec);
     }
     h.evalLaunches++;
 }

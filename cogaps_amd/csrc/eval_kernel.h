@@ -381,23 +381,43 @@ CG_DEVICE EvalAtoms eval_atoms_load(const SamplerDev &S, const PropRec &p, bool 
 // vbid / vgdim: this workgroup's index and the number of workgroups that serve THIS sampler's queue (the grid itself, or
 // one chain's share of a batched multi-chain launch)
 // hot: the three values a workgroup's first memory trip needs, passed as leading scalar kernel arguments so that the dispatcher preloads
-// them into SGPRs (-amdgpu-kernarg-preload-count): the queue record is requested at once, the by-value SamplerDev's
-// kernel-argument lines (WARM bytes, 0 = the caller warmed them) come in under the same trip.
+// them into SGPRs (-amdgpu-kernarg-preload-count): the queue record is requested at once, the lines of the sampler's record come in
+// under the same trip (eval_first / eval_record).
 struct EvalHot { const PropRec *queue; const GenScalars *gs; uint32_t queueCap; };
-template <int PHASE, int WARM>
-CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vbid, const uint32_t vgdim, const EvalHot hot)
+// The first memory trip of an evaluation workgroup: its first queue record, the queue length, the annealing temperature.  The
+// addresses need only `hot` and the workgroup index, so the one-chain kernels issue it before they have seen the sampler's record.
+struct EvalFirst { PropRec p; uint32_t qlen; float T; };
+template <int PHASE>
+CG_DEVICE EvalFirst eval_first(const EvalHot hot, uint32_t slices, uint32_t vbid)
+{
+    const uint32_t qFirst = (PHASE == EVAL_FUSED || PHASE == EVAL_SEQ) ? vbid : vbid / slices;
+    EvalFirst f; f.p = hot.queue[qFirst < hot.queueCap ? qFirst : 0u]; f.qlen = hot.gs->qlen; f.T = hot.gs->annealTemp;
+    return f;
+}
+// The one-chain kernels read the sampler's record through a pointer in the constant address space (scalar loads), requested behind
+// the first trip and fenced (platform.h, cg_const_warm_begin / _end) -- as the generator does.  Taken by value the 550-byte record was
+// loaded at kernel entry, group by group, and with everything the compiler derives from it kept 40-280 scalar registers spilled in
+// vector lanes for the whole kernel (the batched kernels, which always went through a pointer, spill 0-18).
+template <int PHASE>
+CG_DEVICE const SamplerDev &eval_record(const SamplerDev CG_CONSTANT *sp)
+{
+    cg_sched_fence();
+    cg_const_lines lines;
+    cg_const_warm_begin<sizeof(SamplerDev)>(sp, lines);
+    sp = cg_const_warm_end(sp, lines);
+    return *(const SamplerDev *)sp;
+}
+// SINGLE: a one-chain launch (the fused form then asks for the chunk it will rewrite before the scalar step, see EvalPre)
+template <int PHASE, bool SINGLE>
+CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vbid, const uint32_t vgdim, const EvalHot hot, const EvalFirst &first)
 {
 #if defined(GEN_TIMELINE)
     unsigned long long ets[11]; uint32_t ets_n = 0;
 #endif
-    // the first record's trip starts before anything else is computed: its address needs only preloaded kernel arguments and the
-    // workgroup index; the by-value SamplerDev's kernel-argument lines come in under it
     const uint32_t qFirst = (PHASE == EVAL_FUSED || PHASE == EVAL_SEQ) ? vbid : vbid / slices;
-    PropRec pNext = hot.queue[qFirst < hot.queueCap ? qFirst : 0u];
-    const uint32_t qlen = hot.gs->qlen;
-    const float T = hot.gs->annealTemp;
-    cg_sched_fence();
-    if (WARM > 0) cg_kernarg_warm<(WARM > 0 ? WARM : 4)>();
+    PropRec pNext = first.p;
+    const uint32_t qlen = first.qlen;
+    const float T = first.T;
     CG_SHARED float lds[16 * 4];
     CG_SHARED float decf; CG_SHARED uint32_t deci;     // decision of wave 0, broadcast to the other waves
     CG_SHARED float seqTerm[PHASE == EVAL_SEQ ? 4 * 4 * EVAL_SEQ_BS : 1];
@@ -442,7 +462,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
         float s = 0.f, smu = 0.f;          // un-annealed sums, valid in wave 0
         // the one-chain fused launch only: the batched one is throughput bound and at its register budget, and the split form's APPLY
         // launch got slower with it (10.3 -> 12 us: 80 KB rows fetched for every rejected proposal, registers at the launch bound)
-        constexpr bool PRE = PHASE == EVAL_FUSED && WARM > 0;
+        constexpr bool PRE = PHASE == EVAL_FUSED && SINGLE;
         EvalPre pre; pre.v1 = f4_zero(); pre.p1 = f4_zero(); pre.v2 = f4_zero(); pre.p2 = f4_zero();
         const uint32_t jPre = chunk0 + t;
 #define EVAL_PREFETCH() do { if (PRE && jPre < (S.Npad >> 2)) { \
@@ -597,10 +617,12 @@ template <int PHASE>
 #ifndef EVAL_APPLY_WAVES
 #define EVAL_APPLY_WAVES 6       // 70 VGPRs, nothing spilled (8 waves: 64 VGPRs and 12-20 bytes of scratch per lane; split evaluation 10.85 -> 10.40 us)
 #endif
-CG_KERNEL void CG_LAUNCH_BOUNDS2((PHASE == EVAL_SEQ ? EVAL_SEQ_BS : 1024), (PHASE == EVAL_FUSED || PHASE == EVAL_SEQ ? 4 : (PHASE == EVAL_APPLY ? EVAL_APPLY_WAVES : 8))) eval_kernel(const PropRec *hotQueue, const GenScalars *hotGs, uint32_t hotCap, uint32_t slices, SamplerDev S)
+CG_KERNEL void CG_LAUNCH_BOUNDS2((PHASE == EVAL_SEQ ? EVAL_SEQ_BS : 1024), (PHASE == EVAL_FUSED || PHASE == EVAL_SEQ ? 4 : (PHASE == EVAL_APPLY ? EVAL_APPLY_WAVES : 8))) eval_kernel(const PropRec *hotQueue, const GenScalars *hotGs, uint32_t hotCap, uint32_t slices, const SamplerDev CG_CONSTANT *sp)
 {
     EvalHot hot; hot.queue = hotQueue; hot.gs = hotGs; hot.queueCap = hotCap;
-    eval_body<PHASE, (int)sizeof(SamplerDev) + 24>(S, slices, cg_bid(), cg_gdim(), hot);
+    const EvalFirst first = eval_first<PHASE>(hot, slices, cg_bid());
+    const SamplerDev &S = eval_record<PHASE>(sp);
+    eval_body<PHASE, true>(S, slices, cg_bid(), cg_gdim(), hot, first);
 }
 
 // Batched multi-chain launch: the samplers of C independent chains (GWCoGAPS / scCoGAPS shards on one GPU) stepped in lock-step by
@@ -617,5 +639,6 @@ CG_KERNEL void CG_LAUNCH_BOUNDS2(1024, (PHASE == EVAL_FUSED ? EVAL_MULTI_FUSED_W
     cg_const_warm<sizeof(SamplerDev)>(sp);
     const SamplerDev &S = *(const SamplerDev *)sp;
     EvalHot hot; hot.queue = S.queue; hot.gs = S.gs; hot.queueCap = S.queueCap;
-    eval_body<PHASE, 0>(S, slices, cg_bid() - chain * wgPerChain, wgPerChain, hot);
+    const uint32_t vbid = cg_bid() - chain * wgPerChain;
+    eval_body<PHASE, false>(S, slices, vbid, wgPerChain, hot, eval_first<PHASE>(hot, slices, vbid));
 }

@@ -347,15 +347,13 @@ CG_DEVICE void sp_safely_change_matrix(const SamplerDev &S, uint32_t row, uint32
 
 // One workgroup of W = cogaps_sparse_width(N) threads per queued proposal (AsynchronousGibbsSampler.h:127-219 over the
 // sparse model).
-template <bool SEQ, int WARM>
-CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const uint32_t vgdim, const EvalHot hot)
+template <bool SEQ>
+CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const uint32_t vgdim, const EvalHot hot, const EvalFirst &first)
 {
-    // (eval_kernel.h: the first record's trip starts from preloaded kernel arguments, the SamplerDev lines come in under it)
-    PropRec pNext = hot.queue[vbid < hot.queueCap ? vbid : 0u];
-    const uint32_t qlen = hot.gs->qlen;
-    const float T = hot.gs->annealTemp;
-    cg_sched_fence();
-    if (WARM > 0) cg_kernarg_warm<(WARM > 0 ? WARM : 4)>();
+    // (eval_kernel.h: the first record's trip starts from preloaded kernel arguments, the sampler's record comes in under it)
+    PropRec pNext = first.p;
+    const uint32_t qlen = first.qlen;
+    const float T = first.T;
     CG_SHARED float lds[16 * 4];
     CG_SHARED float arowA[SP_KMAX], arowB[SP_KMAX];
     CG_SHARED float z2A[SP_KMAX], z2B[SP_KMAX];        // the Z2 columns of c1 / c2 (table terms)
@@ -533,10 +531,12 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
         cg_sync();
     }
 }
-CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_kernel(const PropRec *hotQueue, const GenScalars *hotGs, uint32_t hotCap, SamplerDev S)
+CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_kernel(const PropRec *hotQueue, const GenScalars *hotGs, uint32_t hotCap, const SamplerDev CG_CONSTANT *sp)
 {
     EvalHot hot; hot.queue = hotQueue; hot.gs = hotGs; hot.queueCap = hotCap;
-    eval_sparse_body<false, (int)sizeof(SamplerDev) + 24>(S, cg_bid(), cg_gdim(), hot);
+    const EvalFirst first = eval_first<EVAL_FUSED>(hot, 1u, cg_bid());
+    const SamplerDev &S = eval_record<EVAL_FUSED>(sp);
+    eval_sparse_body<false>(S, cg_bid(), cg_gdim(), hot, first);
 }
 CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_kernel_multi(const SamplerDev CG_CONSTANT *arr, uint32_t wgPerChain)
 {
@@ -545,13 +545,14 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_kernel_multi(const SamplerDev C
     cg_const_warm<sizeof(SamplerDev)>(sp);
     const SamplerDev &S = *(const SamplerDev *)sp;
     EvalHot hot; hot.queue = S.queue; hot.gs = S.gs; hot.queueCap = S.queueCap;
-    eval_sparse_body<false, 0>(S, cg_bid() - chain * wgPerChain, wgPerChain, hot);
+    const uint32_t vbid = cg_bid() - chain * wgPerChain;
+    eval_sparse_body<false>(S, vbid, wgPerChain, hot, eval_first<EVAL_FUSED>(hot, 1u, vbid));
 }
 CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_seq_kernel(SamplerDev S)
 {
     cg_kernarg_warm<sizeof(SamplerDev)>();
     EvalHot hot; hot.queue = S.queue; hot.gs = S.gs; hot.queueCap = S.queueCap;
-    eval_sparse_body<true, 0>(S, cg_bid(), cg_gdim(), hot);
+    eval_sparse_body<true>(S, cg_bid(), cg_gdim(), hot, eval_first<EVAL_FUSED>(hot, 1u, cg_bid()));
 }
 
 // SparseNormalModel::generateLookupTables (SparseNormalModel.cpp:294-311): Z1[i] = sum_k other(k,i)^2 through the
