@@ -424,7 +424,9 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
     constexpr bool WHOLE = PHASE == EVAL_FUSED || PHASE == EVAL_SEQ;      // one workgroup owns the whole proposal
     const uint32_t mm = (PHASE == EVAL_SEQ) ? S.mathMode : GM_MATH_PORTABLE;
     const uint32_t t = cg_tid(), BS = cg_bdim();
-    unsigned long long eprof_last = cg_clock(); (void)eprof_last;
+#if defined(GEN_PROFILE) && !defined(GEN_SUBMARKS) && !defined(GEN_ROUNDMARKS)
+    unsigned long long eprof_last = cg_clock();      // (only the profile build reads the clock: the read is not free and cannot be dropped by the compiler)
+#endif
     const float lambda = S.lambda;
     EVAL_TS(0);
     // (every slice workgroup of the split form repeats the scalar step and its two dependent table lookups; touching the tables' lines at
