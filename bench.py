@@ -402,7 +402,7 @@ def main():
         traffic, traffic_src, traffic_kernels = None, None, None
         if not args.sparse and (args.genes, args.samples, args.patterns) == (20000, 2000, 50):
             import glob
-            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+            files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")) if "chains" not in os.path.basename(f))
             if files:
                 pk = json.load(open(files[-1]))["kernels"]
                 traffic_kernels = {k: v["hbm_bytes_per_launch"] for k, v in pk.items()}
