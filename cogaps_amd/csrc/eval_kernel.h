@@ -415,11 +415,6 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
     unsigned long long ets[11]; uint32_t ets_n = 0;
 #endif
     const uint32_t qFirst = (PHASE == EVAL_FUSED || PHASE == EVAL_SEQ) ? vbid : vbid / slices;
-#if !defined(COGAPS_EMUL)
-    // the fields between the record's arrival and the rows' request, read in one scalar trip here (while the first trip is still out)
-    // instead of three, one after the other, on the way to the rows
-    if (SINGLE) asm volatile("" :: "s"(S.Npad), "s"(S.defaultS), "s"(S.D), "s"(S.S2), "s"(S.AP), "s"(S.other), "s"(S.atoms));
-#endif
     PropRec pNext = first.p;
     const uint32_t qlen = first.qlen;
     const float T = first.T;
