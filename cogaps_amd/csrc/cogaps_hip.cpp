@@ -27,7 +27,9 @@
 // A sampler whose batches are short takes half the window: every wave with live lanes costs a generator launch 0.4-0.9 us, a second
 // round of a batch that outgrows the window ~3.5 us (profiles/r02_ab_generator_window.txt: the headline shape's P sampler, ~94 attempts
 // per batch, is 0.75 us per launch faster with 128 lanes; its A sampler, ~157, needs the 256).  Any window gives the same batches.
-#define GEN_WIN_HALF (GEN_WIN / 2 >= 64 ? GEN_WIN / 2 : GEN_WIN)
+#ifndef GEN_WIN_HALF
+#define GEN_WIN_HALF (GEN_WIN / 2 >= 64 ? GEN_WIN / 2 : GEN_WIN)      // the narrower instantiation, for a sampler with short batches
+#endif
 static uint32_t gen_window_for(uint32_t current, float stepsPerBatch)
 {
     if (GEN_WIN_HALF == GEN_WIN || stepsPerBatch <= 1.f) return current;
