@@ -106,8 +106,20 @@ CG_DEVICE void eval_vpark(float x, int j, float *lds, float (&tot)[1])
 // tot = {s, s_mu} per row, valid in wave 0 (in every lane of a one-wave workgroup).  A chunk index past the
 // row reads nothing and contributes (v=0, S2=1, D=AP=0) -> +0 to both sums, which leaves them bit-unchanged.
 // lds: [16][2*NR].
+// The accept test's logarithm, ahead of time (one-chain fused form).  log(uniform) is the last thing a death or a move computes, it is a
+// chain of ~50 dependent fp64 operations, and its argument does not depend on the reduction: it is the proposal's first draw, or its
+// second when the truncated normal of a death's rebirth consumed one (Random.cpp:178-191 draws only if it returns a value).  Wave 0
+// computes the candidates right behind the request for its row chunks, while they travel, and the scalar step picks one.
+struct EvalSpec { uint64_t rng; uint32_t n, mm; float l1, l2; };
+CG_DEVICE void eval_spec_run(EvalSpec &sp)
+{
+    uint64_t r = sp.rng;
+    sp.l1 = gm_logf_m(pcg_uniform(r), sp.mm);
+    if (sp.n > 1u) sp.l2 = gm_logf_m(pcg_uniform(r), sp.mm);
+    sp.n = 0u;
+}
 template <int NR, int MODE>
-CG_DEVICE void eval_alpha(const SamplerDev &S, const uint32_t (&row)[NR], const uint32_t (&col)[NR], uint32_t col2, float ch, uint32_t chunk0, uint32_t stride, float *lds, float (&tot)[2 * NR] EVAL_TS_PARAMS)
+CG_DEVICE void eval_alpha(const SamplerDev &S, const uint32_t (&row)[NR], const uint32_t (&col)[NR], uint32_t col2, float ch, uint32_t chunk0, uint32_t stride, float *lds, float (&tot)[2 * NR], EvalSpec &spec EVAL_TS_PARAMS)
 {
     constexpr int NC = 2 * NR;
     const uint32_t nq = S.Npad >> 2, BS = cg_bdim(), t = cg_tid(), nw = BS >> 6;
@@ -124,6 +136,7 @@ CG_DEVICE void eval_alpha(const SamplerDev &S, const uint32_t (&row)[NR], const 
             const float *Vr = S.other + (size_t)col[r] * S.Npad, *V2 = S.other + (size_t)col2 * S.Npad;
             v[r] = ld4(Vr, j); d[r] = ld4_stream(Dr, j); if (!S.defaultS) s[r] = ld4_stream(Sr, j); p[r] = ld4(Ar, j); if (MODE == EVAL_MODE_SAME) w2 = ld4(V2, j);
         }
+        if (spec.n) { cg_sched_fence(); eval_spec_run(spec); cg_sched_fence(); }      // (wave-uniform; the loads above are out)
         if (S.defaultS) {
             // default uncertainty S = max(0.1 D, 0.1) (MatrixMath.cpp:74-84), S*S: the same three fp32 operations the host
             // made when it filled S2, on the value just loaded -- one row less to bring in from HBM per proposal
@@ -470,6 +483,9 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
 #define EVAL_PREFETCH() do { if (PRE && jPre < (S.Npad >> 2)) { \
             pre.v1 = ld4(S.other + (size_t)p.c1 * S.Npad, jPre); pre.p1 = ld4(S.AP + (size_t)p.r1 * S.Npad, jPre); \
             if (two) { pre.v2 = ld4(S.other + (size_t)p.c2 * S.Npad, jPre); if (p.r1 != p.r2) pre.p2 = ld4(S.AP + (size_t)p.r2 * S.Npad, jPre); } } } while (0)
+        constexpr bool AHEAD = PHASE == EVAL_FUSED && SINGLE;       // (the batched fused kernel is at its register budget)
+        EvalSpec spec; spec.rng = rng; spec.mm = mm; spec.l1 = 0.f; spec.l2 = 0.f;
+        spec.n = (AHEAD && scalarLane && need && (p.type == 'D' || p.type == 'M')) ? ((p.type == 'D' && gibbs1) ? 2u : 1u) : 0u;
         if (need) {
             float tot[4] = {0.f, 0.f, 0.f, 0.f};
             if (PHASE == EVAL_SEQ) {
@@ -488,12 +504,12 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
                 const uint32_t rowA[1] = {p.r1}, colA[1] = {p.c1};
                 if (diff) {
                     const uint32_t rowAB[2] = {p.r1, p.r2}, colAB[2] = {p.c1, p.c2};
-                    eval_alpha<2, EVAL_MODE_ONE>(S, rowAB, colAB, 0u, 0.f, chunk0, stride, lds, tot EVAL_TS_ARGS);
+                    eval_alpha<2, EVAL_MODE_ONE>(S, rowAB, colAB, 0u, 0.f, chunk0, stride, lds, tot, spec EVAL_TS_ARGS);
                 } else {
                     float t2[2] = {0.f, 0.f};
-                    if (p.type == 'D') eval_alpha<1, EVAL_MODE_CH>(S, rowA, colA, 0u, -1.f * m1, chunk0, stride, lds, t2 EVAL_TS_ARGS);
-                    else if (two) eval_alpha<1, EVAL_MODE_SAME>(S, rowA, colA, p.c2, 0.f, chunk0, stride, lds, t2 EVAL_TS_ARGS);
-                    else eval_alpha<1, EVAL_MODE_ONE>(S, rowA, colA, 0u, 0.f, chunk0, stride, lds, t2 EVAL_TS_ARGS);
+                    if (p.type == 'D') eval_alpha<1, EVAL_MODE_CH>(S, rowA, colA, 0u, -1.f * m1, chunk0, stride, lds, t2, spec EVAL_TS_ARGS);
+                    else if (two) eval_alpha<1, EVAL_MODE_SAME>(S, rowA, colA, p.c2, 0.f, chunk0, stride, lds, t2, spec EVAL_TS_ARGS);
+                    else eval_alpha<1, EVAL_MODE_ONE>(S, rowA, colA, 0u, 0.f, chunk0, stride, lds, t2, spec EVAL_TS_ARGS);
                     tot[0] = t2[0]; tot[1] = t2[1];
                 }
                 if (PHASE == EVAL_ALPHA) { if (t == 0) { float *o = S.partials + (size_t)q * 64u + slice; o[0] = tot[0]; o[16] = tot[1]; o[32] = tot[2]; o[48] = tot[3]; } }
@@ -508,6 +524,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
                 }
             }
             s = diff ? tot[0] + tot[2] : tot[0]; smu = diff ? tot[1] - tot[3] : tot[1];        // AlphaParameters.cpp:11-14
+            if (AHEAD && spec.n) eval_spec_run(spec);      // (a lane of wave 0 without a chunk: vectors shorter than 256 elements)
         }
         EVAL_PIN(s); EVAL_TS(3);
         if (PHASE == EVAL_FUSED) EVAL_PREFETCH();                    // (after the reduction: the registers are free again)
@@ -538,12 +555,14 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
             EVAL_PROF(1);
             uint32_t acc = 0;
             if (scalarLane) {
+                bool drew = false;
                 if (gibbs1) {
                     OptF g = gm_gibbs_mass(s, smu, 0.f, S.maxGibbsMass, rng, S.luts, true, lambda);
-                    if (g.has) rebirth = g.v;
+                    if (g.has) { rebirth = g.v; drew = true; }
                 }
                 const float deltaLL = rebirth * (smu - s * rebirth / 2.f);
-                acc = (gm_logf_m(pcg_uniform(rng), mm) < deltaLL) ? 1u : 0u;
+                const float logU = AHEAD ? (drew ? spec.l2 : spec.l1) : gm_logf_m(pcg_uniform(rng), mm);
+                acc = (logU < deltaLL) ? 1u : 0u;
             }
             EVAL_PIN(acc); EVAL_TS(4);
             EVAL_BCAST(rebirth, acc);
@@ -566,7 +585,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
         } else if (p.type == 'M') {
             // ---------------------------------------------------------------- move (:184-196)
             uint32_t acc = 0; float unused = 0.f;
-            if (scalarLane) { const float deltaLL = -1.f * m1 * (smu + s * m1 / 2.f); acc = (gm_logf_m(pcg_uniform(rng), mm) < deltaLL) ? 1u : 0u; }
+            if (scalarLane) { const float deltaLL = -1.f * m1 * (smu + s * m1 / 2.f); const float logU = AHEAD ? spec.l1 : gm_logf_m(pcg_uniform(rng), mm); acc = (logU < deltaLL) ? 1u : 0u; }
             EVAL_PIN(acc); EVAL_TS(4);
             EVAL_BCAST(unused, acc);
             EVAL_TS(5);
