@@ -452,7 +452,9 @@ static void launch_eval(cogaps_session *s, HostSampler &h)
         else LAUNCH_MAYBE_TIMED(slot, eval_kernel<EVAL_SEQ>, std::min<uint32_t>(h.d.queueCap, 512u), EVAL_SEQ_BS, (const PropRec *)h.d.queue, (const GenScalars *)h.d.gs, h.d.queueCap, 1u, rec);
     } else if (h.d.sparse) {
         const uint32_t grid = std::min<uint32_t>(h.d.queueCap, 1024u);
-        LAUNCH_MAYBE_TIMED(slot, eval_sparse_kernel, grid, cogaps_sparse_width(h.d.N), (const PropRec *)h.d.queue, (const GenScalars *)h.d.gs, h.d.queueCap, rec);
+        const uint32_t W = cogaps_sparse_width(h.d.N);
+        if (h.d.Wn > W) LAUNCH_MAYBE_TIMED(slot, eval_sparse_kernel_wide, grid, W, (const PropRec *)h.d.queue, (const GenScalars *)h.d.gs, h.d.queueCap, rec);      // several rounds of flag words per vector
+        else LAUNCH_MAYBE_TIMED(slot, eval_sparse_kernel, grid, W, (const PropRec *)h.d.queue, (const GenScalars *)h.d.gs, h.d.queueCap, rec);
     } else if (h.d.redW <= 1024u) {
         // one workgroup of W threads per proposal
         static const uint32_t fusedGrid = getenv("COGAPS_FUSED_GRID") ? (uint32_t)atoi(getenv("COGAPS_FUSED_GRID")) : 512u;      // dev: A/B of the launch size

@@ -143,8 +143,9 @@ CG_DEVICE void sp_term(float d_val, float v_val, float v2_val, float ex, float a
 // computes the entry's complete term (the loads, the dot, sp_term_vals), and the owner folds its own word's terms back in bit
 // order: the same additions in the same order as if every owner had worked through its words alone.  A round (one word per thread)
 // that lists more than SP_BAL_CAP entries is done that way.
-#define SP_BAL_CAP 2048
-struct SpBal { uint32_t n; uint32_t idx[SP_BAL_CAP], dpos[SP_BAL_CAP]; float ts[SP_BAL_CAP], tm[SP_BAL_CAP], tm2[SP_BAL_CAP]; };
+#define SP_BAL_CAP 2048            // ... of the one-round form; the merged form (sp_partial_merged) lists up to SP_BAL_CAP_WIDE entries
+#define SP_BAL_CAP_WIDE 4096
+template <int CAP> struct SpBal { uint32_t n; uint32_t idx[CAP], dpos[CAP]; float ts[CAP], tm[CAP], tm2[CAP]; };
 
 template <int MODE>
 CG_DEVICE void sp_bal_term(const SamplerDev &S, uint32_t col, float ch, const float *arow, const float *data, const float *V, const float *V2,
@@ -175,8 +176,9 @@ CG_DEVICE SpPre sp_preload(const SamplerDev &S, uint32_t row, uint32_t col, uint
     return o;
 }
 
-template <int MODE>
-CG_DEVICE void sp_partial_balanced(const SamplerDev &S, uint32_t row, uint32_t col, uint32_t col2, float ch, const float *arow, SpBal &bal, const SpPre &pre0, float &ps, float &pm, uint32_t &visited)
+// round by round (one word per thread and round): any vector length, any number of common non-zeros
+template <int MODE, int CAP>
+CG_DEVICE void sp_partial_rounds(const SamplerDev &S, uint32_t row, uint32_t col, uint32_t col2, float ch, const float *arow, SpBal<CAP> &bal, const SpPre &pre0, float &ps, float &pm, uint32_t &visited)
 {
     const uint32_t BS = cg_bdim(), t = cg_tid();
     const unsigned long long *fD = S.dflags + (size_t)row * S.Wn;
@@ -211,7 +213,7 @@ CG_DEVICE void sp_partial_balanced(const SamplerDev &S, uint32_t row, uint32_t c
         }
         if (w < S.Wn) {
             if (cnt) {
-                if (base + cnt <= (uint32_t)SP_BAL_CAP) {
+                if (base + cnt <= (uint32_t)CAP) {
                     unsigned long long c = common; uint32_t j = 0;
                     while (c != 0ull) {
                         const uint32_t bit = (uint32_t)cg_ctz64(c); c &= c - 1ull;
@@ -224,7 +226,7 @@ CG_DEVICE void sp_partial_balanced(const SamplerDev &S, uint32_t row, uint32_t c
         }
         cg_sync();
         const uint32_t total = bal.n;
-        if (total <= (uint32_t)SP_BAL_CAP) {
+        if (total <= (uint32_t)CAP) {
             // every lane: listed entries round-robin, two in flight
             for (uint32_t e = t; e < total; e += 2u * BS) {
                 const uint32_t e1 = e + BS; const bool second = e1 < total;
@@ -252,6 +254,98 @@ CG_DEVICE void sp_partial_balanced(const SamplerDev &S, uint32_t row, uint32_t c
         }
         cg_sync();      // the list is reused by the next round / the next call
     }
+}
+
+// Up to SP_MERGE_ROUNDS rounds of words listed TOGETHER, then one pass over all listed entries, then the owners fold their words' terms
+// in round order (= increasing word order, as the lane order prescribes).  A round by itself lists about one and a half entries per
+// lane: its gather trip, three barriers and the fold were paid per round -- four times per alpha evaluation on BASELINE configs[4]'s
+// 50000-element vectors -- for work that fits one trip.  Falls back to the round-by-round form when the vector has more rounds or the
+// list would overflow.
+#define SP_MERGE_ROUNDS 4
+template <int MODE, int CAP>
+CG_DEVICE void sp_partial_merged(const SamplerDev &S, uint32_t row, uint32_t col, uint32_t col2, float ch, const float *arow, SpBal<CAP> &bal, const SpPre &pre0, float &ps, float &pm, uint32_t &visited)
+{
+    const uint32_t BS = cg_bdim(), t = cg_tid();
+    if (S.Wn <= BS || S.Wn > (uint32_t)SP_MERGE_ROUNDS * BS) { sp_partial_rounds<MODE, CAP>(S, row, col, col2, ch, arow, bal, pre0, ps, pm, visited); return; }      // (one round: nothing to merge)
+    const unsigned long long *fD = S.dflags + (size_t)row * S.Wn;
+    const unsigned long long *fV = S.oflags + (size_t)col * S.oMw, *fV2 = S.oflags + (size_t)col2 * S.oMw;
+    const uint32_t *pre = S.dprefix + (size_t)row * S.Wn;
+    const float *data = S.dvals + S.dptr[row];
+    const float *V = S.other + (size_t)col * S.Npad, *V2 = S.other + (size_t)col2 * S.Npad;
+    if (t == 0) bal.n = 0u;
+    cg_sync();
+    // all the rounds' words in one trip
+    unsigned long long dfl[SP_MERGE_ROUNDS], common[SP_MERGE_ROUNDS]; uint32_t dbase[SP_MERGE_ROUNDS], cnt[SP_MERGE_ROUNDS], base[SP_MERGE_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < SP_MERGE_ROUNDS; ++r) {
+        const uint32_t w = (uint32_t)r * BS + t;
+        dfl[r] = 0ull; common[r] = 0ull; dbase[r] = 0u; cnt[r] = 0u; base[r] = 0u;
+        if (w < S.Wn) {
+            if (r == 0) { dfl[0] = pre0.dfl; common[0] = pre0.dfl & pre0.fv; dbase[0] = pre0.dbase; }
+            else { dfl[r] = fD[w]; common[r] = dfl[r] & (MODE == SP_MODE_SAME ? (fV[w] | fV2[w]) : fV[w]); dbase[r] = pre[w]; }
+        }
+    }
+    uint32_t mine = 0;
+#pragma unroll
+    for (int r = 0; r < SP_MERGE_ROUNDS; ++r) { cnt[r] = (uint32_t)cg_popc64(common[r]); mine += cnt[r]; }
+    {   // list slots: one block per wave (one LDS atomic), a thread's rounds contiguous inside it
+        uint32_t waveTot;
+        const uint32_t ex = cg_wave_excl_scan_u32(mine, waveTot);
+        uint32_t wbase = 0;
+        if ((t & 63u) == 0u && waveTot) wbase = cg_atomic_add_u32(&bal.n, waveTot);
+        uint32_t b = cg_wave_bcast_u32(wbase, 0) + ex;
+#pragma unroll
+        for (int r = 0; r < SP_MERGE_ROUNDS; ++r) { base[r] = b; b += cnt[r]; }
+    }
+    cg_sync();
+    const uint32_t total = bal.n;
+    if (total > (uint32_t)CAP) {      // (uniform) more common non-zeros than the list holds: round by round
+        cg_sync();
+        sp_partial_rounds<MODE, CAP>(S, row, col, col2, ch, arow, bal, pre0, ps, pm, visited);
+        return;
+    }
+    visited += mine;
+#pragma unroll
+    for (int r = 0; r < SP_MERGE_ROUNDS; ++r) {
+        unsigned long long c = common[r]; uint32_t j = 0;
+        const uint32_t w = (uint32_t)r * BS + t;
+        while (c != 0ull) {
+            const uint32_t bit = (uint32_t)cg_ctz64(c); c &= c - 1ull;
+            bal.idx[base[r] + j] = 64u * w + bit;
+            bal.dpos[base[r] + j] = dbase[r] + (uint32_t)cg_popc64(dfl[r] & ((1ull << bit) - 1ull));
+            ++j;
+        }
+    }
+    cg_sync();
+    for (uint32_t e = t; e < total; e += 2u * BS) {      // every lane: listed entries round-robin, two in flight
+        const uint32_t e1 = e + BS; const bool second = e1 < total;
+        float a0, b0, c0, a1 = 0.f, b1 = 0.f, c1 = 0.f;
+        const uint32_t i0 = bal.idx[e], p0 = bal.dpos[e], i1 = second ? bal.idx[e1] : i0, p1 = second ? bal.dpos[e1] : p0;
+        sp_bal_term<MODE>(S, col, ch, arow, data, V, V2, i0, p0, a0, b0, c0);
+        if (second) sp_bal_term<MODE>(S, col, ch, arow, data, V, V2, i1, p1, a1, b1, c1);
+        bal.ts[e] = a0; bal.tm[e] = b0; if (MODE == SP_MODE_CH) bal.tm2[e] = c0;
+        if (second) { bal.ts[e1] = a1; bal.tm[e1] = b1; if (MODE == SP_MODE_CH) bal.tm2[e1] = c1; }
+    }
+    cg_sync();
+    ps = 0.f; pm = 0.f;
+#pragma unroll
+    for (int r = 0; r < SP_MERGE_ROUNDS; ++r) {          // the owner: its words in increasing order, a word's terms in bit order
+        for (uint32_t j = 0; j < cnt[r]; ++j) {
+            ps = ps + bal.ts[base[r] + j];
+            pm = pm + bal.tm[base[r] + j];
+            if (MODE == SP_MODE_CH) pm = pm + bal.tm2[base[r] + j];
+        }
+    }
+    cg_sync();      // the list is reused by the next call
+}
+
+// WIDE: the kernel instantiation for data vectors whose flag words take several rounds (launch_eval); the one-round kernel does not
+// carry the merged form's registers (205 against 145 VGPRs) and its 90 KB list
+template <int MODE, bool WIDE, int CAP>
+CG_DEVICE void sp_partial_balanced(const SamplerDev &S, uint32_t row, uint32_t col, uint32_t col2, float ch, const float *arow, SpBal<CAP> &bal, const SpPre &pre0, float &ps, float &pm, uint32_t &visited)
+{
+    if (WIDE) sp_partial_merged<MODE, CAP>(S, row, col, col2, ch, arow, bal, pre0, ps, pm, visited);
+    else sp_partial_rounds<MODE, CAP>(S, row, col, col2, ch, arow, bal, pre0, ps, pm, visited);
 }
 
 // ---- verification mode: SparseNormalModel.cpp:153-292 in the reference's own order -------------------------------------
@@ -347,7 +441,7 @@ CG_DEVICE void sp_safely_change_matrix(const SamplerDev &S, uint32_t row, uint32
 
 // One workgroup of W = cogaps_sparse_width(N) threads per queued proposal (AsynchronousGibbsSampler.h:127-219 over the
 // sparse model).
-template <bool SEQ>
+template <bool SEQ, bool WIDE>
 CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const uint32_t vgdim, const EvalHot hot, const EvalFirst &first)
 {
     // (eval_kernel.h: the first record's trip starts from preloaded kernel arguments, the sampler's record comes in under it)
@@ -360,7 +454,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
     CG_SHARED float decf; CG_SHARED uint32_t deci;
     CG_SHARED uint32_t nzShared;           // common non-zeros visited by this workgroup (roofline bookkeeping)
     CG_SHARED uint32_t seqCnt[SEQ ? SP_SEQ_WORDS + 1 : 1]; CG_SHARED float seqBc[2];     // verification mode (sp_alpha_seq)
-    CG_SHARED SpBal bal;                   // lane-balanced term list (sp_partial_balanced); unused in verification mode
+    CG_SHARED SpBal<(WIDE ? SP_BAL_CAP_WIDE : SP_BAL_CAP)> bal;                   // lane-balanced term list (sp_partial_balanced); unused in verification mode
     const uint32_t mm = SEQ ? S.mathMode : GM_MATH_PORTABLE;
     const uint32_t t = cg_tid(), BS = cg_bdim(), K = S.K;
     const float lambda = S.lambda, beta = S.beta;
@@ -429,10 +523,10 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
                 if (t == 0) nzShared = vis;
             } else {
             float x[4] = {0.f, 0.f, 0.f, 0.f};
-            if (diff) { sp_partial_balanced<SP_MODE_ONE>(S, p.r1, p.c1, 0u, 0.f, arowA, bal, preA, x[0], x[1], nz); sp_partial_balanced<SP_MODE_ONE>(S, p.r2, p.c2, 0u, 0.f, arowB, bal, preB, x[2], x[3], nz); }
-            else if (p.type == 'D') sp_partial_balanced<SP_MODE_CH>(S, p.r1, p.c1, 0u, -1.f * m1, arowA, bal, preA, x[0], x[1], nz);
-            else if (two) sp_partial_balanced<SP_MODE_SAME>(S, p.r1, p.c1, p.c2, 0.f, arowA, bal, preA, x[0], x[1], nz);
-            else sp_partial_balanced<SP_MODE_ONE>(S, p.r1, p.c1, 0u, 0.f, arowA, bal, preA, x[0], x[1], nz);
+            if (diff) { sp_partial_balanced<SP_MODE_ONE, WIDE>(S, p.r1, p.c1, 0u, 0.f, arowA, bal, preA, x[0], x[1], nz); sp_partial_balanced<SP_MODE_ONE, WIDE>(S, p.r2, p.c2, 0u, 0.f, arowB, bal, preB, x[2], x[3], nz); }
+            else if (p.type == 'D') sp_partial_balanced<SP_MODE_CH, WIDE>(S, p.r1, p.c1, 0u, -1.f * m1, arowA, bal, preA, x[0], x[1], nz);
+            else if (two) sp_partial_balanced<SP_MODE_SAME, WIDE>(S, p.r1, p.c1, p.c2, 0.f, arowA, bal, preA, x[0], x[1], nz);
+            else sp_partial_balanced<SP_MODE_ONE, WIDE>(S, p.r1, p.c1, 0u, 0.f, arowA, bal, preA, x[0], x[1], nz);
             EVAL_TS(3);
             { const uint32_t waveNz = cg_wave_sum_u32(nz); if ((t & 63u) == 0u && waveNz) cg_atomic_add_u32(&nzShared, waveNz); }
 #pragma unroll
@@ -536,7 +630,15 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_kernel(const PropRec *hotQueue,
     EvalHot hot; hot.queue = hotQueue; hot.gs = hotGs; hot.queueCap = hotCap;
     const EvalFirst first = eval_first<EVAL_FUSED>(hot, 1u, cg_bid());
     const SamplerDev &S = eval_record<EVAL_FUSED>(sp);
-    eval_sparse_body<false>(S, cg_bid(), cg_gdim(), hot, first);
+    eval_sparse_body<false, false>(S, cg_bid(), cg_gdim(), hot, first);
+}
+// data vectors of more than one round of flag words (more than 16384 elements): the rounds' common non-zeros listed together (sp_partial_merged)
+CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_kernel_wide(const PropRec *hotQueue, const GenScalars *hotGs, uint32_t hotCap, const SamplerDev CG_CONSTANT *sp)
+{
+    EvalHot hot; hot.queue = hotQueue; hot.gs = hotGs; hot.queueCap = hotCap;
+    const EvalFirst first = eval_first<EVAL_FUSED>(hot, 1u, cg_bid());
+    const SamplerDev &S = eval_record<EVAL_FUSED>(sp);
+    eval_sparse_body<false, true>(S, cg_bid(), cg_gdim(), hot, first);
 }
 CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_kernel_multi(const SamplerDev CG_CONSTANT *arr, uint32_t wgPerChain)
 {
@@ -546,13 +648,13 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_kernel_multi(const SamplerDev C
     const SamplerDev &S = *(const SamplerDev *)sp;
     EvalHot hot; hot.queue = S.queue; hot.gs = S.gs; hot.queueCap = S.queueCap;
     const uint32_t vbid = cg_bid() - chain * wgPerChain;
-    eval_sparse_body<false>(S, vbid, wgPerChain, hot, eval_first<EVAL_FUSED>(hot, 1u, vbid));
+    eval_sparse_body<false, false>(S, vbid, wgPerChain, hot, eval_first<EVAL_FUSED>(hot, 1u, vbid));
 }
 CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_seq_kernel(SamplerDev S)
 {
     cg_kernarg_warm<sizeof(SamplerDev)>();
     EvalHot hot; hot.queue = S.queue; hot.gs = S.gs; hot.queueCap = S.queueCap;
-    eval_sparse_body<true>(S, cg_bid(), cg_gdim(), hot, eval_first<EVAL_FUSED>(hot, 1u, cg_bid()));
+    eval_sparse_body<true, false>(S, cg_bid(), cg_gdim(), hot, eval_first<EVAL_FUSED>(hot, 1u, cg_bid()));
 }
 
 // SparseNormalModel::generateLookupTables (SparseNormalModel.cpp:294-311): Z1[i] = sum_k other(k,i)^2 through the

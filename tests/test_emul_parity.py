@@ -207,6 +207,16 @@ def test_sparse_balanced_list_overflow(emul_lib):
     pu.run_stepwise(emul_lib(256), pu.synthetic_counts(20000, 6, zeros=0.85, seed=3), 3, trace=False, nPatterns=3, seed=6, total_iter=10, check_every=3, sparseOptimization=True)
 
 
+def test_sparse_wide_vectors_merged_rounds(emul_lib):
+    """data vectors of more than one round of flag words (more than 16384 elements: the kernel instantiation eval_sparse_kernel_wide):
+    three rounds listed together (sp_partial_merged); four rounds whose common non-zeros overflow the merged list (falls back to the
+    round-by-round form, which overflows its own list in turn); five rounds (beyond SP_MERGE_ROUNDS: round by round)"""
+    lib = emul_lib(256)
+    pu.run_stepwise(lib, pu.synthetic_counts(40000, 5, zeros=0.9, seed=9), 3, trace=False, nPatterns=3, seed=6, total_iter=10, check_every=3, sparseOptimization=True)
+    pu.run_stepwise(lib, pu.synthetic_counts(60000, 4, zeros=0.5, seed=11), 2, trace=False, nPatterns=3, seed=7, total_iter=10, check_every=2, sparseOptimization=True)
+    pu.run_stepwise(lib, pu.synthetic_counts(70000, 4, zeros=0.95, seed=12), 2, trace=False, nPatterns=3, seed=8, total_iter=10, check_every=2, sparseOptimization=True)
+
+
 def test_update_of_zero_steps(emul_lib, gist, monkeypatch):
     """update(0) -- a Poisson draw of 0 has probability e^-10 per draw while a chain holds at most ten atoms -- is a no-op
     (AsynchronousGibbsSampler.h:94) for a single session (against the oracle) and inside a lock-stepped batch, which must not wait
