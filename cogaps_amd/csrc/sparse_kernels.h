@@ -339,6 +339,63 @@ CG_DEVICE void sp_partial_merged(const SamplerDev &S, uint32_t row, uint32_t col
     cg_sync();      // the list is reused by the next call
 }
 
+// The two alpha evaluations of a move / exchange across rows (SparseNormalModel.cpp:242-292: alphaParameters(r1, c1) + alphaParameters(r2, c2)),
+// one-round vectors: both evaluations' common non-zeros in ONE list, one pass over the entries, each owner folds its word's terms per
+// evaluation.  One after the other they paid the list, the gather trip and the barriers twice -- and an evaluation launch lasts as long
+// as its slowest workgroup, which nearly always is one of the few two-row proposals of the batch.  (x: {s, s_mu} of the first
+// evaluation, then of the second; bit 31 of a listed index marks the second.)
+template <int CAP>
+CG_DEVICE void sp_partial_pair(const SamplerDev &S, uint32_t rowA, uint32_t colA, const float *arowA, const SpPre &preA, uint32_t rowB, uint32_t colB, const float *arowB, const SpPre &preB,
+                               SpBal<CAP> &bal, float (&x)[4], uint32_t &visited)
+{
+    const uint32_t BS = cg_bdim(), t = cg_tid();
+    const float *dataA = S.dvals + S.dptr[rowA], *dataB = S.dvals + S.dptr[rowB];
+    const float *VA = S.other + (size_t)colA * S.Npad, *VB = S.other + (size_t)colB * S.Npad;
+    if (t == 0) bal.n = 0u;
+    cg_sync();
+    const unsigned long long comA = preA.dfl & preA.fv, comB = preB.dfl & preB.fv;      // (words past the vector's last read as 0: sp_preload)
+    const uint32_t cntA = (uint32_t)cg_popc64(comA), cntB = (uint32_t)cg_popc64(comB);
+    uint32_t baseA, baseB;
+    {
+        uint32_t waveTot;
+        const uint32_t ex = cg_wave_excl_scan_u32(cntA + cntB, waveTot);
+        uint32_t wbase = 0;
+        if ((t & 63u) == 0u && waveTot) wbase = cg_atomic_add_u32(&bal.n, waveTot);
+        baseA = cg_wave_bcast_u32(wbase, 0) + ex; baseB = baseA + cntA;
+    }
+    cg_sync();
+    const uint32_t total = bal.n;
+    if (total > (uint32_t)CAP) {      // (uniform) rare: one after the other
+        cg_sync();
+        sp_partial_rounds<SP_MODE_ONE, CAP>(S, rowA, colA, 0u, 0.f, arowA, bal, preA, x[0], x[1], visited);
+        sp_partial_rounds<SP_MODE_ONE, CAP>(S, rowB, colB, 0u, 0.f, arowB, bal, preB, x[2], x[3], visited);
+        return;
+    }
+    visited += cntA + cntB;
+    {
+        unsigned long long c = comA; uint32_t j = 0;
+        while (c != 0ull) { const uint32_t bit = (uint32_t)cg_ctz64(c); c &= c - 1ull; bal.idx[baseA + j] = 64u * t + bit; bal.dpos[baseA + j] = preA.dbase + (uint32_t)cg_popc64(preA.dfl & ((1ull << bit) - 1ull)); ++j; }
+        c = comB; j = 0;
+        while (c != 0ull) { const uint32_t bit = (uint32_t)cg_ctz64(c); c &= c - 1ull; bal.idx[baseB + j] = (64u * t + bit) | 0x80000000u; bal.dpos[baseB + j] = preB.dbase + (uint32_t)cg_popc64(preB.dfl & ((1ull << bit) - 1ull)); ++j; }
+    }
+    cg_sync();
+    for (uint32_t e = t; e < total; e += 2u * BS) {      // every lane: listed entries round-robin, two in flight
+        const uint32_t e1 = e + BS; const bool second = e1 < total;
+        float a0, b0, c0, a1 = 0.f, b1 = 0.f, c1 = 0.f;
+        const uint32_t i0 = bal.idx[e], p0 = bal.dpos[e], i1 = second ? bal.idx[e1] : i0, p1 = second ? bal.dpos[e1] : p0;
+        const bool B0 = (i0 >> 31) != 0u, B1 = (i1 >> 31) != 0u;
+        sp_bal_term<SP_MODE_ONE>(S, B0 ? colB : colA, 0.f, B0 ? arowB : arowA, B0 ? dataB : dataA, B0 ? VB : VA, VA, i0 & 0x7FFFFFFFu, p0, a0, b0, c0);
+        if (second) sp_bal_term<SP_MODE_ONE>(S, B1 ? colB : colA, 0.f, B1 ? arowB : arowA, B1 ? dataB : dataA, B1 ? VB : VA, VA, i1 & 0x7FFFFFFFu, p1, a1, b1, c1);
+        bal.ts[e] = a0; bal.tm[e] = b0;
+        if (second) { bal.ts[e1] = a1; bal.tm[e1] = b1; }
+    }
+    cg_sync();
+    x[0] = 0.f; x[1] = 0.f; x[2] = 0.f; x[3] = 0.f;
+    for (uint32_t j = 0; j < cntA; ++j) { x[0] = x[0] + bal.ts[baseA + j]; x[1] = x[1] + bal.tm[baseA + j]; }
+    for (uint32_t j = 0; j < cntB; ++j) { x[2] = x[2] + bal.ts[baseB + j]; x[3] = x[3] + bal.tm[baseB + j]; }
+    cg_sync();      // the list is reused by the next call
+}
+
 // WIDE: the kernel instantiation for data vectors whose flag words take several rounds (launch_eval); the one-round kernel does not
 // carry the merged form's registers (205 against 145 VGPRs) and its 90 KB list
 template <int MODE, bool WIDE, int CAP>
@@ -523,7 +580,10 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
                 if (t == 0) nzShared = vis;
             } else {
             float x[4] = {0.f, 0.f, 0.f, 0.f};
-            if (diff) { sp_partial_balanced<SP_MODE_ONE, WIDE>(S, p.r1, p.c1, 0u, 0.f, arowA, bal, preA, x[0], x[1], nz); sp_partial_balanced<SP_MODE_ONE, WIDE>(S, p.r2, p.c2, 0u, 0.f, arowB, bal, preB, x[2], x[3], nz); }
+            if (diff) {
+                if (!WIDE && S.Wn <= BS) sp_partial_pair(S, p.r1, p.c1, arowA, preA, p.r2, p.c2, arowB, preB, bal, x, nz);      // (one-round vectors: both evaluations in one pass)
+                else { sp_partial_balanced<SP_MODE_ONE, WIDE>(S, p.r1, p.c1, 0u, 0.f, arowA, bal, preA, x[0], x[1], nz); sp_partial_balanced<SP_MODE_ONE, WIDE>(S, p.r2, p.c2, 0u, 0.f, arowB, bal, preB, x[2], x[3], nz); }
+            }
             else if (p.type == 'D') sp_partial_balanced<SP_MODE_CH, WIDE>(S, p.r1, p.c1, 0u, -1.f * m1, arowA, bal, preA, x[0], x[1], nz);
             else if (two) sp_partial_balanced<SP_MODE_SAME, WIDE>(S, p.r1, p.c1, p.c2, 0.f, arowA, bal, preA, x[0], x[1], nz);
             else sp_partial_balanced<SP_MODE_ONE, WIDE>(S, p.r1, p.c1, 0u, 0.f, arowA, bal, preA, x[0], x[1], nz);
