@@ -396,6 +396,96 @@ CG_DEVICE void sp_partial_pair(const SamplerDev &S, uint32_t rowA, uint32_t colA
     cg_sync();      // the list is reused by the next call
 }
 
+// sp_partial_pair for the wide kernel: the words of both evaluations' rounds listed into the one list (first evaluation, then second, bit 31
+// marking the second), one pass over the entries, the owners' folds per evaluation in round order.
+template <int CAP>
+CG_DEVICE void sp_list_rounds(const SamplerDev &S, uint32_t row, uint32_t col, const SpPre &pre0, SpBal<CAP> &bal, uint32_t tag,
+                              uint32_t (&cnt)[SP_MERGE_ROUNDS], uint32_t (&base)[SP_MERGE_ROUNDS], uint32_t &mine)
+{
+    const uint32_t BS = cg_bdim(), t = cg_tid();
+    const unsigned long long *fD = S.dflags + (size_t)row * S.Wn, *fV = S.oflags + (size_t)col * S.oMw;
+    const uint32_t *pre = S.dprefix + (size_t)row * S.Wn;
+    unsigned long long dfl[SP_MERGE_ROUNDS], common[SP_MERGE_ROUNDS]; uint32_t dbase[SP_MERGE_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < SP_MERGE_ROUNDS; ++r) {
+        const uint32_t w = (uint32_t)r * BS + t;
+        dfl[r] = 0ull; common[r] = 0ull; dbase[r] = 0u;
+        if (w < S.Wn) {
+            if (r == 0) { dfl[0] = pre0.dfl; common[0] = pre0.dfl & pre0.fv; dbase[0] = pre0.dbase; }
+            else { dfl[r] = fD[w]; common[r] = dfl[r] & fV[w]; dbase[r] = pre[w]; }
+        }
+    }
+    mine = 0;
+#pragma unroll
+    for (int r = 0; r < SP_MERGE_ROUNDS; ++r) { cnt[r] = (uint32_t)cg_popc64(common[r]); mine += cnt[r]; }
+    {
+        uint32_t waveTot;
+        const uint32_t ex = cg_wave_excl_scan_u32(mine, waveTot);
+        uint32_t wbase = 0;
+        if ((t & 63u) == 0u && waveTot) wbase = cg_atomic_add_u32(&bal.n, waveTot);
+        uint32_t b = cg_wave_bcast_u32(wbase, 0) + ex;
+#pragma unroll
+        for (int r = 0; r < SP_MERGE_ROUNDS; ++r) { base[r] = b; b += cnt[r]; }
+    }
+#pragma unroll
+    for (int r = 0; r < SP_MERGE_ROUNDS; ++r) {
+        if (base[r] + cnt[r] <= (uint32_t)CAP) {      // (a list that overflows is not used: the caller falls back)
+            unsigned long long c = common[r]; uint32_t j = 0;
+            const uint32_t w = (uint32_t)r * BS + t;
+            while (c != 0ull) {
+                const uint32_t bit = (uint32_t)cg_ctz64(c); c &= c - 1ull;
+                bal.idx[base[r] + j] = (64u * w + bit) | tag;
+                bal.dpos[base[r] + j] = dbase[r] + (uint32_t)cg_popc64(dfl[r] & ((1ull << bit) - 1ull));
+                ++j;
+            }
+        }
+    }
+}
+template <int CAP>
+CG_DEVICE void sp_partial_merged_pair(const SamplerDev &S, uint32_t rowA, uint32_t colA, const float *arowA, const SpPre &preA, uint32_t rowB, uint32_t colB, const float *arowB, const SpPre &preB,
+                                      SpBal<CAP> &bal, float (&x)[4], uint32_t &visited)
+{
+    const uint32_t BS = cg_bdim(), t = cg_tid();
+    if (S.Wn <= BS || S.Wn > (uint32_t)SP_MERGE_ROUNDS * BS || S.N >= 0x80000000u) {
+        sp_partial_merged<SP_MODE_ONE, CAP>(S, rowA, colA, 0u, 0.f, arowA, bal, preA, x[0], x[1], visited);
+        sp_partial_merged<SP_MODE_ONE, CAP>(S, rowB, colB, 0u, 0.f, arowB, bal, preB, x[2], x[3], visited);
+        return;
+    }
+    const float *dataA = S.dvals + S.dptr[rowA], *dataB = S.dvals + S.dptr[rowB];
+    const float *VA = S.other + (size_t)colA * S.Npad, *VB = S.other + (size_t)colB * S.Npad;
+    if (t == 0) bal.n = 0u;
+    cg_sync();
+    uint32_t cntA[SP_MERGE_ROUNDS], baseA[SP_MERGE_ROUNDS], cntB[SP_MERGE_ROUNDS], baseB[SP_MERGE_ROUNDS], mineA, mineB;
+    sp_list_rounds<CAP>(S, rowA, colA, preA, bal, 0u, cntA, baseA, mineA);
+    sp_list_rounds<CAP>(S, rowB, colB, preB, bal, 0x80000000u, cntB, baseB, mineB);
+    cg_sync();
+    const uint32_t total = bal.n;
+    if (total > (uint32_t)CAP) {      // (uniform) one evaluation after the other, each with the list to itself
+        cg_sync();
+        sp_partial_merged<SP_MODE_ONE, CAP>(S, rowA, colA, 0u, 0.f, arowA, bal, preA, x[0], x[1], visited);
+        sp_partial_merged<SP_MODE_ONE, CAP>(S, rowB, colB, 0u, 0.f, arowB, bal, preB, x[2], x[3], visited);
+        return;
+    }
+    visited += mineA + mineB;
+    for (uint32_t e = t; e < total; e += 2u * BS) {      // every lane: listed entries round-robin, two in flight
+        const uint32_t e1 = e + BS; const bool second = e1 < total;
+        float a0, b0, c0, a1 = 0.f, b1 = 0.f, c1 = 0.f;
+        const uint32_t i0 = bal.idx[e], p0 = bal.dpos[e], i1 = second ? bal.idx[e1] : i0, p1 = second ? bal.dpos[e1] : p0;
+        const bool B0 = (i0 >> 31) != 0u, B1 = (i1 >> 31) != 0u;
+        sp_bal_term<SP_MODE_ONE>(S, B0 ? colB : colA, 0.f, B0 ? arowB : arowA, B0 ? dataB : dataA, B0 ? VB : VA, VA, i0 & 0x7FFFFFFFu, p0, a0, b0, c0);
+        if (second) sp_bal_term<SP_MODE_ONE>(S, B1 ? colB : colA, 0.f, B1 ? arowB : arowA, B1 ? dataB : dataA, B1 ? VB : VA, VA, i1 & 0x7FFFFFFFu, p1, a1, b1, c1);
+        bal.ts[e] = a0; bal.tm[e] = b0;
+        if (second) { bal.ts[e1] = a1; bal.tm[e1] = b1; }
+    }
+    cg_sync();
+    x[0] = 0.f; x[1] = 0.f; x[2] = 0.f; x[3] = 0.f;
+#pragma unroll
+    for (int r = 0; r < SP_MERGE_ROUNDS; ++r) for (uint32_t j = 0; j < cntA[r]; ++j) { x[0] = x[0] + bal.ts[baseA[r] + j]; x[1] = x[1] + bal.tm[baseA[r] + j]; }
+#pragma unroll
+    for (int r = 0; r < SP_MERGE_ROUNDS; ++r) for (uint32_t j = 0; j < cntB[r]; ++j) { x[2] = x[2] + bal.ts[baseB[r] + j]; x[3] = x[3] + bal.tm[baseB[r] + j]; }
+    cg_sync();      // the list is reused by the next call
+}
+
 // WIDE: the kernel instantiation for data vectors whose flag words take several rounds (launch_eval); the one-round kernel does not
 // carry the merged form's registers (205 against 145 VGPRs) and its 90 KB list
 template <int MODE, bool WIDE, int CAP>
@@ -582,6 +672,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
             float x[4] = {0.f, 0.f, 0.f, 0.f};
             if (diff) {
                 if (!WIDE && S.Wn <= BS) sp_partial_pair(S, p.r1, p.c1, arowA, preA, p.r2, p.c2, arowB, preB, bal, x, nz);      // (one-round vectors: both evaluations in one pass)
+                else if (WIDE) sp_partial_merged_pair(S, p.r1, p.c1, arowA, preA, p.r2, p.c2, arowB, preB, bal, x, nz);
                 else { sp_partial_balanced<SP_MODE_ONE, WIDE>(S, p.r1, p.c1, 0u, 0.f, arowA, bal, preA, x[0], x[1], nz); sp_partial_balanced<SP_MODE_ONE, WIDE>(S, p.r2, p.c2, 0u, 0.f, arowB, bal, preB, x[2], x[3], nz); }
             }
             else if (p.type == 'D') sp_partial_balanced<SP_MODE_CH, WIDE>(S, p.r1, p.c1, 0u, -1.f * m1, arowA, bal, preA, x[0], x[1], nz);
