@@ -243,7 +243,8 @@ def self_launch(n):
            os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL across processes needs dmabuf IPC on this driver
-    rc = subprocess.call(cmd, env=env)
+    sys.stdout.flush()
+    rc = subprocess.call(cmd, env=env, stdout=sys.stdout)      # the ranks' stdout = this process's real stdout (see __main__)
     if rc:
         raise SystemExit("bench.py --gpus %d: the %d-rank launch failed (exit code %d); no line was printed for fewer ranks" % (n, n, rc))
     return 0
@@ -472,4 +473,11 @@ def main():
 
 
 if __name__ == "__main__":
+    # stdout carries the JSON line and nothing else: libraries that write to file descriptor 1 (RCCL prints its version block there
+    # when the communicator is created) are sent to stderr, Python's own sys.stdout keeps the real descriptor
+    sys.stdout.flush()
+    _real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    sys.stdout = os.fdopen(_real_stdout, "w", buffering=1)
     main()
+    sys.stdout.flush()
