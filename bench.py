@@ -462,7 +462,11 @@ def main():
         }
         if not args.no_cpu and world == 1:
             cb = cpu_baseline(data, params, args.cpu_seconds, cpu_state, burn + W, K)
-            cb["gpu_over_cpu_same_window"] = out["value"] / cb["value"]
+            # like for like only when the port ran the WHOLE timed window (the driver's --steps 20 does; the 190-step default lets
+            # the port cover the window's first part, where the chain is still growing and the port is slower per proposal)
+            covered = max(b["iterations"] for b in cb["by_threads"] if b["threads"] == cb["cores"]) / float(K)
+            cb["window_covered"] = covered
+            cb["gpu_over_cpu_same_window" if covered >= 1.0 else "gpu_over_cpu_partial_window"] = out["value"] / cb["value"]
             out["cpu_baseline"] = cb
         else:
             out["cpu_baseline"] = None
