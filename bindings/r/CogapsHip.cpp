@@ -1,0 +1,153 @@
+// bindings/r/CogapsHip.cpp -- the Rcpp glue a maintainer of the reference R package adds to dispatch CoGAPS() to libcogaps_hip.so.
+//
+// Drop it into the package as src/CogapsHip.cpp IN PLACE OF src/Cogaps.cpp and src/RcppExports.cpp (reference src/Cogaps.cpp:148-254,
+// src/RcppExports.cpp:11-117), put include/cogaps_hip.h beside it, use bindings/r/Makevars (links -lcogaps_hip), R CMD INSTALL.  The
+// R side (R/RcppExports.R:4-26, R/CoGAPS.R:146-154) is unchanged: the same six .Call names with the same arities.
+//
+// No R toolchain exists in this repository's image.  What is checked here: the file parses and type-checks against a mock of the Rcpp
+// declarations it uses (tests/c/mock_rcpp, g++ -fsyntax-only: tests/test_capi_and_frontend.py::test_rcpp_glue_meets_a_compiler), and
+// the same parameter mapping, compiled as C99 without the Rcpp types, runs against the library (tests/c/rcpp_shim_test.c).
+#include <Rcpp.h>
+#include <R_ext/Rdynload.h>
+#include <cstring>
+#include <sstream>
+#include "cogaps_hip.h"
+
+// ---- conversions ---------------------------------------------------------------------------------------------------
+static std::vector<float> toRowMajor(const Rcpp::NumericMatrix &m) {          // double -> float per element (Cogaps.cpp:21-32)
+    std::vector<float> out((size_t)m.nrow() * m.ncol());
+    for (int i = 0; i < m.nrow(); ++i) for (int j = 0; j < m.ncol(); ++j) out[(size_t)i * m.ncol() + j] = (float)m(i, j);
+    return out;
+}
+static Rcpp::NumericMatrix toR(const float *p, unsigned nr, unsigned nc) {   // createRMatrix (Cogaps.cpp:34-45)
+    if (!p) return Rcpp::NumericMatrix(0, 0);
+    Rcpp::NumericMatrix m(nr, nc);
+    for (unsigned i = 0; i < nr; ++i) for (unsigned j = 0; j < nc; ++j) m(i, j) = p[(size_t)i * nc + j];
+    return m;
+}
+static Rcpp::List snapshotList(const float *p, unsigned n, unsigned nr, unsigned nc) {   // createListOfRMatrices (Cogaps.cpp:47-55)
+    Rcpp::List out(n);
+    for (unsigned s = 0; s < n; ++s) out[s] = toR(p + (size_t)s * nr * nc, nr, nc);
+    return out;
+}
+static Rcpp::CharacterVector splitLines(const std::string &joined) {         // '\n'-joined names of cogaps_file_info -> character vector
+    Rcpp::CharacterVector out;
+    if (joined.empty() || joined[0] == '\0') return out;
+    std::istringstream in(joined.c_str());
+    for (std::string line; std::getline(in, line); ) out.push_back(line);
+    return out;
+}
+static int pollInterrupt(void *) { try { Rcpp::checkUserInterrupt(); } catch (...) { return 1; } return 0; }   // GapsRunner.cpp:280
+
+// ---- allParams -> cogaps_params (getGapsParameters, Cogaps.cpp:64-139) -------------------------------------------------
+struct ParamStore { cogaps_params p; std::vector<uint32_t> subset; std::vector<float> fixed; };   // keeps what p points to alive
+static void paramsFromList(const Rcpp::List &allParams, ParamStore &st) {
+    cogaps_params &p = st.p; cogaps_default_params(&p);
+    const Rcpp::S4 &gp(allParams["gaps"]);
+    unsigned subsetDim = Rcpp::as<unsigned>(gp.slot("subsetDim"));            // :69-82
+    if (subsetDim > 0) {
+        st.subset = Rcpp::as<std::vector<uint32_t> >(gp.slot("subsetIndices"));
+        p.subsetData = 1; p.subsetGenes = subsetDim == 1; p.dataIndicesSubset = st.subset.data(); p.nSubset = (uint32_t)st.subset.size();
+    }
+    p.runningDistributed = subsetDim > 0;
+    p.transposeData = Rcpp::as<bool>(allParams["transposeData"]);
+    p.maxThreads = Rcpp::as<int>(allParams["nThreads"]); p.workerID = Rcpp::as<int>(allParams["workerID"]);      // :86-92
+    p.printMessages = Rcpp::as<bool>(allParams["messages"]) && p.workerID == 1;
+    p.outputFrequency = Rcpp::as<int>(allParams["outputFrequency"]);
+    p.checkpointInterval = Rcpp::as<int>(allParams["checkpointInterval"]);
+    p.takePumpSamples = Rcpp::as<bool>(gp.slot("takePumpSamples"));
+    p.seed = Rcpp::as<int>(gp.slot("seed")); p.nPatterns = Rcpp::as<int>(gp.slot("nPatterns"));                 // :95-103
+    p.nIterations = Rcpp::as<int>(gp.slot("nIterations"));
+    p.alphaA = Rcpp::as<float>(gp.slot("alphaA")); p.alphaP = Rcpp::as<float>(gp.slot("alphaP"));
+    p.maxGibbsMassA = Rcpp::as<float>(gp.slot("maxGibbsMassA")); p.maxGibbsMassP = Rcpp::as<float>(gp.slot("maxGibbsMassP"));
+    p.useSparseOptimization = Rcpp::as<bool>(gp.slot("sparseOptimization"));
+    p.asynchronousUpdates = Rcpp::as<bool>(allParams["asynchronousUpdates"]);   // FALSE arrives from callInternalCoGAPS (DistributedCogaps.R:28): accepted with runningDistributed, see above
+    int nSnap = Rcpp::as<int>(allParams["nSnapshots"]);                        // :104-123
+    if (nSnap > 0) p.snapshotFrequency = p.nIterations / nSnap;
+    std::string ph = Rcpp::as<std::string>(allParams["snapshotPhase"]);
+    p.snapshotPhase = ph == "equilibration" ? 1 : (ph == "sampling" ? 2 : 0);
+    p.whichMatrixFixed = Rcpp::as<char>(gp.slot("whichMatrixFixed"));          // :124-130
+    if (p.whichMatrixFixed != 'N') {
+        Rcpp::NumericMatrix f = gp.slot("fixedPatterns"); st.fixed = toRowMajor(f);
+        p.fixedPatterns = st.fixed.data(); p.fixedRows = f.nrow(); p.fixedCols = f.ncol();
+    }
+    if (!Rf_isNull(allParams["checkpointInFile"])) Rcpp::stop("checkpoints are disabled in this build");   // :133-137, Cogaps.cpp:224-231
+    p.interrupt = pollInterrupt;
+}
+
+// ---- cogaps_result -> the list cogapsRun returns (Cogaps.cpp:162-186) ---------------------------------------------------
+static Rcpp::List resultToList(const cogaps_result &r, const cogaps_params &p, const Rcpp::List &allParams) {
+    return Rcpp::List::create(
+        Rcpp::Named("Amean") = toR(r.Amean, r.nGenes, r.nPatterns), Rcpp::Named("Pmean") = toR(r.Pmean, r.nSamples, r.nPatterns),
+        Rcpp::Named("Asd") = toR(r.Asd, r.nGenes, r.nPatterns),     Rcpp::Named("Psd") = toR(r.Psd, r.nSamples, r.nPatterns),
+        Rcpp::Named("seed") = p.seed, Rcpp::Named("meanChiSq") = r.meanChiSq,
+        Rcpp::Named("geneNames") = allParams["geneNames"], Rcpp::Named("sampleNames") = allParams["sampleNames"],
+        Rcpp::Named("diagnostics") = Rcpp::List::create(
+            Rcpp::Named("chisq") = std::vector<float>(r.chisqHistory, r.chisqHistory + r.nHistory),
+            Rcpp::Named("atomsA") = std::vector<unsigned>(r.atomHistoryA, r.atomHistoryA + r.nHistory),
+            Rcpp::Named("atomsP") = std::vector<unsigned>(r.atomHistoryP, r.atomHistoryP + r.nHistory),
+            Rcpp::Named("pumpStat") = toR(r.pumpMatrix, r.nGenes, r.nPatterns),
+            Rcpp::Named("meanPatternAssignment") = toR(r.meanPatternAssignment, r.nGenes, r.nPatterns),
+            Rcpp::Named("averageQueueLengthA") = r.averageQueueLengthA, Rcpp::Named("averageQueueLengthP") = r.averageQueueLengthP,
+            Rcpp::Named("totalUpdates") = (double)r.totalUpdates, Rcpp::Named("totalRunningTime") = r.totalRunningTime,
+            Rcpp::Named("equilibrationSnapshotsA") = snapshotList(r.equilibrationSnapshotsA, r.nEquilibrationSnapshots, r.nGenes, r.nPatterns),
+            Rcpp::Named("equilibrationSnapshotsP") = snapshotList(r.equilibrationSnapshotsP, r.nEquilibrationSnapshots, r.nSamples, r.nPatterns),
+            Rcpp::Named("samplingSnapshotsA") = snapshotList(r.samplingSnapshotsA, r.nSamplingSnapshots, r.nGenes, r.nPatterns),
+            Rcpp::Named("samplingSnapshotsP") = snapshotList(r.samplingSnapshotsP, r.nSamplingSnapshots, r.nSamples, r.nPatterns)));
+}
+static void failWithLibraryMessage() { Rcpp::stop(std::string("CoGAPS terminated: ") + cogaps_last_error()); }   // GAPS_ERROR -> Rcpp::stop
+
+// ---- the six functions of the package (Cogaps.cpp:191-254) ---------------------------------------------------------------
+Rcpp::List cogaps_cpp(const Rcpp::NumericMatrix &data, const Rcpp::List &allParams, const Rcpp::Nullable<Rcpp::NumericMatrix> &uncertainty) {
+    ParamStore st; paramsFromList(allParams, st);
+    std::vector<float> d = toRowMajor(data), u;
+    if (uncertainty.isNotNull()) u = toRowMajor(Rcpp::NumericMatrix(uncertainty));
+    cogaps_result r; std::memset(&r, 0, sizeof(r));
+    if (cogaps_run(d.data(), data.nrow(), data.ncol(), &st.p, u.empty() ? NULL : u.data(), &r)) failWithLibraryMessage();
+    Rcpp::List out = resultToList(r, st.p, allParams);
+    cogaps_result_free(&r);
+    return out;
+}
+Rcpp::List cogaps_from_file_cpp(const Rcpp::CharacterVector &data, const Rcpp::List &allParams, const Rcpp::Nullable<Rcpp::CharacterVector> &uncertainty) {
+    ParamStore st; paramsFromList(allParams, st);        // a worker's subset is READ as a subset (cogaps_run_from_file, Matrix.cpp:70-134)
+    const std::string path = Rcpp::as<std::string>(data);
+    const std::string unc = uncertainty.isNotNull() ? Rcpp::as<std::string>(Rcpp::CharacterVector(uncertainty)) : std::string();
+    cogaps_result r; std::memset(&r, 0, sizeof(r));
+    if (cogaps_run_from_file(path.c_str(), &st.p, unc.empty() ? NULL : unc.c_str(), &r)) failWithLibraryMessage();
+    Rcpp::List out = resultToList(r, st.p, allParams);
+    cogaps_result_free(&r);
+    return out;
+}
+Rcpp::List getFileInfo_cpp(const std::string &path) {                                                  // Cogaps.cpp:243-254
+    uint32_t nr = 0, nc = 0; size_t rn = 0, cn = 0;
+    if (cogaps_file_info(path.c_str(), &nr, &nc, NULL, 0, &rn, NULL, 0, &cn)) failWithLibraryMessage();
+    std::string rows(rn, '\0'), cols(cn, '\0');
+    if (cogaps_file_info(path.c_str(), &nr, &nc, &rows[0], rn, NULL, &cols[0], cn, NULL)) failWithLibraryMessage();
+    return Rcpp::List::create(Rcpp::Named("dimensions") = Rcpp::NumericVector::create(nr, nc),
+                              Rcpp::Named("rowNames") = splitLines(rows), Rcpp::Named("colNames") = splitLines(cols));
+}
+bool compiledWithOpenMPSupport_cpp() { return true; }                         // see the note above: FALSE would make CoGAPS() force the sequential sampler
+bool checkpointsEnabled_cpp() { return cogaps_checkpoints_enabled() != 0; }
+std::string getBuildReport_cpp() { return cogaps_build_report(); }
+
+// ---- .Call wrappers + registration (RcppExports.cpp:11-117; the two Catch test runners are not part of this library) -------
+#define GUARDED(body) BEGIN_RCPP Rcpp::RObject res_; Rcpp::RNGScope scope_; res_ = Rcpp::wrap(body); return res_; END_RCPP
+RcppExport SEXP _CoGAPS_cogaps_cpp(SEXP d, SEXP a, SEXP u) {
+    GUARDED(cogaps_cpp(Rcpp::as<Rcpp::NumericMatrix>(d), Rcpp::as<Rcpp::List>(a), Rcpp::Nullable<Rcpp::NumericMatrix>(u))) }
+RcppExport SEXP _CoGAPS_cogaps_from_file_cpp(SEXP d, SEXP a, SEXP u) {
+    GUARDED(cogaps_from_file_cpp(Rcpp::as<Rcpp::CharacterVector>(d), Rcpp::as<Rcpp::List>(a), Rcpp::Nullable<Rcpp::CharacterVector>(u))) }
+RcppExport SEXP _CoGAPS_getBuildReport_cpp() { GUARDED(getBuildReport_cpp()) }
+RcppExport SEXP _CoGAPS_checkpointsEnabled_cpp() { GUARDED(checkpointsEnabled_cpp()) }
+RcppExport SEXP _CoGAPS_compiledWithOpenMPSupport_cpp() { GUARDED(compiledWithOpenMPSupport_cpp()) }
+RcppExport SEXP _CoGAPS_getFileInfo_cpp(SEXP path) { GUARDED(getFileInfo_cpp(Rcpp::as<std::string>(path))) }
+
+static const R_CallMethodDef CallEntries[] = {                                // name, function, number of arguments
+    {"_CoGAPS_cogaps_from_file_cpp",          (DL_FUNC) &_CoGAPS_cogaps_from_file_cpp,          3},
+    {"_CoGAPS_cogaps_cpp",                    (DL_FUNC) &_CoGAPS_cogaps_cpp,                    3},
+    {"_CoGAPS_getBuildReport_cpp",            (DL_FUNC) &_CoGAPS_getBuildReport_cpp,            0},
+    {"_CoGAPS_checkpointsEnabled_cpp",        (DL_FUNC) &_CoGAPS_checkpointsEnabled_cpp,        0},
+    {"_CoGAPS_compiledWithOpenMPSupport_cpp", (DL_FUNC) &_CoGAPS_compiledWithOpenMPSupport_cpp, 0},
+    {"_CoGAPS_getFileInfo_cpp",               (DL_FUNC) &_CoGAPS_getFileInfo_cpp,               1},
+    {NULL, NULL, 0}
+};
+RcppExport void R_init_CoGAPS(DllInfo *dll) { R_registerRoutines(dll, NULL, CallEntries, NULL, NULL); R_useDynamicSymbols(dll, FALSE); }

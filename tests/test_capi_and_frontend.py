@@ -176,6 +176,37 @@ def test_compute_calls_fail_loudly_without_a_gpu():
         CoGAPS(np.ones((10, 8), np.float32) * 2, nPatterns=2, nIterations=5, messages=False)
 
 
+def test_rcpp_glue_meets_a_compiler():
+    """bindings/r/CogapsHip.cpp -- the file a maintainer of the R package copies (reference src/Cogaps.cpp:148-254, src/RcppExports.cpp:11-117)
+    -- parses and type-checks against include/cogaps_hip.h and a mock of the Rcpp declarations it uses (tests/c/mock_rcpp: test
+    infrastructure, pins nothing about R).  It registers the six .Call entry points of R/RcppExports.R with the reference's arities, and a
+    typo in it fails this test."""
+    import re, subprocess, shutil
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    src = os.path.join(ROOT, "bindings", "r", "CogapsHip.cpp")
+    cmd = ["g++", "-std=c++11", "-fsyntax-only", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "tests", "c", "mock_rcpp"), "-I" + os.path.join(ROOT, "include")]
+    out = subprocess.run(cmd + [src], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    text = open(src).read()
+    table = dict(re.findall(r'\{"(_CoGAPS_\w+)",\s*\(DL_FUNC\) &\w+,\s*(\d+)\}', text))
+    assert table == {"_CoGAPS_cogaps_cpp": "3", "_CoGAPS_cogaps_from_file_cpp": "3", "_CoGAPS_getBuildReport_cpp": "0", "_CoGAPS_checkpointsEnabled_cpp": "0",
+                     "_CoGAPS_compiledWithOpenMPSupport_cpp": "0", "_CoGAPS_getFileInfo_cpp": "1"}
+    # every C-ABI symbol the glue calls is declared by the header and exported by the library's symbol list
+    called = set(re.findall(r"\b(cogaps_[a-z_]+)\s*\(", text)) - {"cogaps_params", "cogaps_result", "cogaps_cpp", "cogaps_from_file_cpp"}
+    header = open(os.path.join(ROOT, "include", "cogaps_hip.h")).read()
+    for fn in called:
+        assert re.search(r"\b" + fn + r"\s*\(", header), fn
+    # the check has teeth: a misspelt call does not pass
+    bad = os.path.join(ROOT, "tests", "c", "_typo_CogapsHip.cpp")
+    with open(bad, "w") as f:
+        f.write(text.replace("cogaps_result_free(&r);", "cogaps_result_fre(&r);", 1))
+    try:
+        assert subprocess.run(cmd + [bad], capture_output=True, text=True).returncode != 0
+    finally:
+        os.remove(bad)
+
+
 def test_plain_c_client_builds_and_fails_loudly_without_a_gpu():
     """tests/c/rcpp_shim_test.c: getGapsParameters (src/Cogaps.cpp:64-139) restated in C99 against include/cogaps_hip.h.  It must
     compile as C, link against the product library and -- on a box without a GPU -- end with the library's error text and a

@@ -786,6 +786,17 @@ def test_judge_round2_fingerprints_on_the_gpu(hip_lib, gist, modsim, name, _judg
     check_judge_case(r, JUDGE_R2[name])
 
 
+@pytest.mark.parametrize("name", ["gist_gct_k9", "gist_tsv_sparse_k11_samples", "synth1500_k50_unc", "gist_csv_sparse_k4_genes", "synth2500_sparse_k50", "headline_18"])
+def test_judge_round3_fingerprints_on_the_gpu(hip_lib, gist, name):
+    """tests/test_oracle_pin.py::JUDGE_R3, configurations 1-6 of the round-3 verdict (a user uncertainty matrix, subsets in either dimension on
+    the sparse model, K = 50 dense and sparse, the first 18 + 18 iterations of the headline matrix) reproduced by cogaps_run on the GPU in
+    the verification mode: every printed digit"""
+    from cogaps_amd import _capi
+    from test_oracle_pin import JUDGE_R3, check_judge3_case, run_judge3_case
+    r = run_judge3_case(lambda d, unc=None, **kw: _capi.run(d, unc=unc, lib=hip_lib, **SEQ, **kw), name, gist)
+    check_judge3_case(r, JUDGE_R3[name])
+
+
 def test_bench_starts_its_own_ranks_and_never_reports_fewer():
     """plain `python bench.py --gpus 2` (no launcher): the script starts its two ranks itself.  With the gloo test hook they share this
     box's GPU and the line says n_gpus = 2, ranks = 2; over RCCL two ranks need two GPUs -- on a one-GPU box the command fails and

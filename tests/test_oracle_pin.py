@@ -298,3 +298,222 @@ def run_judge_case(run, name, gist, modsim, cache):
 def test_judge_round2_fingerprints(oracle, gist, modsim, name, _judge_cache={}):
     r = run_judge_case(oracle.run, name, gist, modsim, _judge_cache)
     check_judge_case(r, JUDGE_R2[name])
+
+
+# ---- the oracle against the reference BUILD on random configurations (round 4) ----------------------------------------------------
+# tools/refprobe compiles the reference's core where it lies (/root/reference/src) with this repository's stand-ins for the Boost
+# headers the image lacks, into /tmp -- a probe, not oracle/_ref (parity stays "partial" by rule).  Every number
+# the probe prints (%.9g: atom / chi2 histories, totalUpdates, meanChiSq, queue lengths, three rows of each statistic) and an FNV hash of
+# each full statistics matrix are compared with pyoracle.run in the reference's arithmetic (sequential sums, libm) bit for bit.
+# Skipped where the reference sources or g++ are absent (the GPU box).
+N_RANDOM_REFERENCE_CONFIGS = 40
+
+
+def _refprobe():
+    sys_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "refprobe")
+    import sys
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    import refprobe
+    return refprobe
+
+
+@pytest.fixture(scope="session")
+def refprobe_bin():
+    rp = _refprobe()
+    if not rp.available():
+        pytest.skip("no /root/reference sources or no g++ here: the reference-build probe runs in the build container only")
+    return rp.build()
+
+
+def random_reference_config(i):
+    """configuration number i (seeded): data, file format, and both parameter sets (probe arguments / pyoracle keywords)"""
+    g = np.random.Generator(np.random.MT19937(20240 + i))
+    fmt = (".mtx", ".csv", ".tsv", ".gct")[i % 4]
+    sparse = bool(i % 3 == 1)
+    nG, nS = int(g.integers(24, 150)), int(g.integers(6, 40))
+    rank = int(g.integers(2, 5))
+    d = (g.gamma(2.0, 0.5, (nG, rank)) * (g.random((nG, rank)) > 0.4)) @ (g.gamma(2.0, 0.5, (rank, nS)) * (g.random((rank, nS)) > 0.3))
+    d = d * (0.8 + 0.4 * g.random((nG, nS))) + 0.01
+    if sparse:
+        d = d * (g.random((nG, nS)) >= g.uniform(0.6, 0.95))
+    d = np.ascontiguousarray(d, dtype=np.float32)
+    KS = [1, 2, 3, 4, 5, 7, 11, 13, 24, 25, 26, 33, 50, 60]          # (25 / 26: both directions of gaps::dot, VectorMath.h:41-134)
+    K = KS[i % len(KS)] if i < 2 * len(KS) else int(g.choice(KS))
+    nIter = int(g.integers(20, 110))
+    outFreq = max(1, nIter // int(g.integers(2, 11)))
+    cfg = dict(fmt=fmt, sparse=sparse, K=K, nIter=nIter, outFreq=outFreq, seed=int(g.integers(1, 2 ** 31 - 1)), threads=int(g.integers(1, 5)),
+               transpose=bool(g.random() < 0.3), subsetDim=0, subset=None, unc=None, fixed="N", fixedPatterns=None,
+               pump=bool(g.random() < 0.2), snaps=0, snapPhase=3, alphaA=0.01, alphaP=0.01, maxA=100.0, maxP=100.0)
+    genes, samples = nG, nS
+    if g.random() < 0.4:
+        cfg["subsetDim"] = int(g.integers(1, 3))
+        n = genes if cfg["subsetDim"] == 1 else samples
+        keep = max(4, int(n * g.uniform(0.4, 0.9)))
+        cfg["subset"] = np.sort(g.choice(n, size=keep, replace=False)).astype(np.uint32) + 1       # 1-based, sorted (Matrix.cpp:112 sorts them for file inputs)
+        if cfg["subsetDim"] == 1:
+            genes = keep
+        else:
+            samples = keep
+    if not sparse and g.random() < 0.3:
+        cfg["unc"] = np.maximum(0.2 * d, 0.3).astype(np.float32)
+    if g.random() < 0.25:
+        cfg["fixed"] = "A" if g.random() < 0.5 else "P"
+        rows = genes if cfg["fixed"] == "A" else samples
+        cfg["fixedPatterns"] = (g.gamma(2.0, 0.5, (rows, K)) * (g.random((rows, K)) > 0.2)).astype(np.float32)
+    if g.random() < 0.2:
+        cfg["snaps"] = int(g.integers(2, 5)); cfg["snapPhase"] = int(g.integers(1, 4))
+    if g.random() < 0.25:
+        cfg["alphaA"], cfg["alphaP"] = float(np.float32(g.uniform(0.005, 0.5))), float(np.float32(g.uniform(0.005, 0.5)))
+        cfg["maxA"], cfg["maxP"] = float(np.float32(g.uniform(5, 200))), float(np.float32(g.uniform(5, 200)))
+    cfg["data"] = d
+    return cfg
+
+
+def run_reference_config(rp, binary, cfg, tmp):
+    stored = np.ascontiguousarray(cfg["data"].T) if cfg["transpose"] else cfg["data"]
+    path = os.path.join(tmp, "d" + cfg["fmt"])
+    rp.write_matrix(path, stored)
+    kw = dict(nPatterns=cfg["K"], nIterations=cfg["nIter"], seed=cfg["seed"], threads=cfg["threads"], outFreq=cfg["outFreq"], sparse=cfg["sparse"],
+              transpose=cfg["transpose"], pump=cfg["pump"], alphaA=repr(cfg["alphaA"]), alphaP=repr(cfg["alphaP"]), maxGibbsA=repr(cfg["maxA"]), maxGibbsP=repr(cfg["maxP"]))
+    extra = {}
+    if cfg["subsetDim"]:
+        sp = os.path.join(tmp, "subset.txt")
+        np.savetxt(sp, cfg["subset"], fmt="%d")
+        extra.update(subsetDim=cfg["subsetDim"], subset=sp)
+    if cfg["unc"] is not None:
+        up = os.path.join(tmp, "u" + cfg["fmt"])
+        rp.write_matrix(up, np.ascontiguousarray(cfg["unc"].T) if cfg["transpose"] else cfg["unc"])
+        extra["unc"] = up
+    if cfg["fixed"] != "N":
+        fpth = os.path.join(tmp, "fixed.csv")
+        rp.write_matrix(fpth, cfg["fixedPatterns"])
+        extra.update(fixed=cfg["fixed"], fixedFile=fpth)
+    if cfg["snaps"]:
+        kw.update(snapshots=cfg["snaps"], snapshotPhase=cfg["snapPhase"])
+    return rp.run(binary, path, timeout=600, **extra, **kw), stored
+
+
+def oracle_for_config(oracle, cfg, stored):
+    unc = None
+    if cfg["unc"] is not None:
+        unc = np.ascontiguousarray(cfg["unc"].T) if cfg["transpose"] else cfg["unc"]
+    return oracle.run(stored, unc=unc, omp=cfg["threads"] > 1, nPatterns=cfg["K"], nIterations=cfg["nIter"], seed=cfg["seed"], outputFrequency=cfg["outFreq"],
+                      maxThreads=cfg["threads"], alphaA=cfg["alphaA"], alphaP=cfg["alphaP"], maxGibbsMassA=cfg["maxA"], maxGibbsMassP=cfg["maxP"],
+                      transposeData=cfg["transpose"], subsetIndices=cfg["subset"], subsetDim=cfg["subsetDim"], whichMatrixFixed=cfg["fixed"],
+                      fixedPatterns=cfg["fixedPatterns"], sparseOptimization=cfg["sparse"], takePumpSamples=cfg["pump"],
+                      snapshotFrequency=(cfg["nIter"] // cfg["snaps"]) if cfg["snaps"] else 0, snapshotPhase=(cfg["snapPhase"] % 3) if cfg["snaps"] else 0)      # (the oracle numbers "all phases" 0, the reference GAPS_ALL_PHASES = 3)
+
+
+def compare_with_reference_build(rp, ref, o):
+    """every printed value, bit for bit (the probe prints %.9g, which identifies an fp32 value)"""
+    assert ref["atomsA"].tolist() == o["atomsA"].tolist() and ref["atomsP"].tolist() == o["atomsP"].tolist()
+    assert ref["totalUpdates"] == o["totalUpdates"]
+    assert np.array_equal(ref["chisq"], o["chisq"].astype(np.float32))
+    for key, okey in (("meanChiSq", "meanChiSq"), ("qA", "averageQueueLengthA"), ("qP", "averageQueueLengthP")):
+        assert ref[key] == np.float32(o[okey]), (key, ref[key], o[okey])
+    for name in ("Amean", "Asd", "Pmean", "Psd"):
+        for (n, r), vals in ref["rows"].items():
+            if n == name:
+                assert np.array_equal(vals, o[name][r]), (name, r)
+        h, cnt = ref["hashes"][name]
+        assert cnt == o[name].size and h == rp.fnv_matrix(o[name]), name
+    if "pump" in ref["hashes"]:
+        assert ref["hashes"]["pump"][0] == rp.fnv_matrix(o["pumpMatrix"]) and ref["hashes"]["meanPattern"][0] == rp.fnv_matrix(o["meanPatternAssignment"])
+    assert len(ref["snapE"]) == o["equilibrationSnapshotsA"].shape[0] and len(ref["snapS"]) == o["samplingSnapshotsA"].shape[0]
+    for k, (ha, hp) in enumerate(ref["snapE"]):
+        assert ha == rp.fnv_matrix(o["equilibrationSnapshotsA"][k]) and hp == rp.fnv_matrix(o["equilibrationSnapshotsP"][k])
+    for k, (ha, hp) in enumerate(ref["snapS"]):
+        assert ha == rp.fnv_matrix(o["samplingSnapshotsA"][k]) and hp == rp.fnv_matrix(o["samplingSnapshotsP"][k])
+
+
+@pytest.mark.parametrize("i", range(N_RANDOM_REFERENCE_CONFIGS))
+def test_oracle_equals_reference_build_on_random_configs(oracle, refprobe_bin, tmp_path, i):
+    rp = _refprobe()
+    cfg = random_reference_config(i)
+    ref, stored = run_reference_config(rp, refprobe_bin, cfg, str(tmp_path))
+    compare_with_reference_build(rp, ref, oracle_for_config(oracle, cfg, stored))
+
+
+# ---- VERDICT.md round 3, "Judge's own checks": seven more configurations of the reference build (the judge's own stand-in headers and
+# driver), every printed float given to nine digits.  1-6 run here and on the GPU in the verification mode; 7 -- BASELINE configs[2]
+# whole, 100 + 100 iterations, 53 M proposals, four minutes of eight cores -- only with COGAPS_LONG_TESTS=1 (tools/ref_vs_port_c3.py makes the
+# same comparison against the probe and keeps its record under profiles/).  Regenerate / extend: tools/refprobe/regen_fingerprints.py.
+def _judge3_data(name, gist):
+    import bench
+    if name in ("gist_gct_k9", "gist_tsv_sparse_k11_samples", "gist_csv_sparse_k4_genes"):
+        return gist, None
+    if name == "synth1500_k50_unc":
+        d = bench.synthetic_dense(1500, 350)
+        return d, np.maximum(np.float32(0.2) * d, np.float32(0.3)).astype(np.float32)
+    if name == "synth2500_sparse_k50":
+        d = bench.synthetic_dense(2500, 600)
+        return np.ascontiguousarray(d * (np.random.Generator(np.random.MT19937(99)).random(d.shape) >= 0.95), dtype=np.float32), None
+    return bench.synthetic_dense(20000, 2000), None
+
+
+JUDGE_R3 = {
+    "gist_gct_k9": dict(kw=dict(nPatterns=9, nIterations=180, seed=777, outputFrequency=18),
+                        atomsA=[392, 1272, 2109, 2892, 3635, 4013, 4330, 4625, 4901, 5051, 5116, 5068, 5045, 4948, 4866, 4723, 4625, 4511, 4465, 4429],
+                        atomsP=[12, 17, 26, 33, 36, 43, 46, 53, 55, 58, 57, 60, 61, 64, 66, 64, 67, 70, 70, 68],
+                        totalUpdates=1433511, meanChiSq=5047.65088, qA=36.055397, qP=2.97920275),
+    "gist_tsv_sparse_k11_samples": dict(kw=dict(nPatterns=11, nIterations=120, seed=5, outputFrequency=12, sparseOptimization=True, subsetIndices=np.arange(2, 9, dtype=np.uint32), subsetDim=2),
+                                        atomsA=[250, 881, 1629, 2313, 2914, 3304, 3440, 3488, 3556, 3639, 3670, 3710, 3729, 3805, 3820, 3846, 3844, 3850, 3935, 3902],
+                                        atomsP=[7, 12, 17, 20, 24, 27, 31, 33, 34, 36, 38, 38, 40, 40, 40, 41, 44, 49, 53, 50],
+                                        totalUpdates=745027, meanChiSq=3149.55542, qA=34.574707, qP=2.4916687),
+    "synth1500_k50_unc": dict(kw=dict(nPatterns=50, nIterations=20, seed=7, outputFrequency=2),
+                              atomsA=[13, 21, 50, 107, 210, 415, 692, 1064, 1477, 1978, 2509, 3054, 3622, 4229, 4796, 5354, 5996, 6589, 7200, 7818],
+                              atomsP=[9, 22, 40, 73, 135, 198, 287, 392, 512, 620, 735, 873, 1016, 1150, 1276, 1443, 1579, 1735, 1887, 2040],
+                              totalUpdates=131487, meanChiSq=5212348.0, qA=35.5075798, qP=17.6584644),
+    "gist_csv_sparse_k4_genes": dict(kw=dict(nPatterns=4, nIterations=150, seed=1234, outputFrequency=15, sparseOptimization=True, subsetIndices=np.arange(200, 901, dtype=np.uint32), subsetDim=1),
+                                     atomsA=[122, 293, 472, 647, 826, 1008, 1193, 1356, 1458, 1564, 1643, 1740, 1785, 1801, 1875, 1898, 1941, 1967, 1976, 2025],
+                                     atomsP=[6, 9, 11, 12, 15, 17, 17, 19, 19, 21, 21, 21, 21, 22, 23, 25, 27, 26, 28, 32],
+                                     totalUpdates=401805, meanChiSq=16062.7295, qA=23.7872849, qP=2.56697607),
+    "synth2500_sparse_k50": dict(kw=dict(nPatterns=50, nIterations=15, seed=3, outputFrequency=3, sparseOptimization=True),
+                                 atomsA=[18, 54, 149, 371, 747, 1328, 2057, 2928, 3909, 4890], atomsP=[12, 27, 75, 162, 300, 480, 702, 963, 1227, 1514],
+                                 totalUpdates=52553, meanChiSq=4371113.5, qA=36.8032532, qP=18.0268326),
+    "headline_18": dict(kw=dict(nPatterns=50, nIterations=18, seed=42, outputFrequency=3),
+                        atomsA=[22, 69, 246, 802, 2384, 5938, 12012, 20386, 30052, 40759, 51989, 63811], atomsP=[24, 65, 197, 586, 1168, 2020, 3047, 4212, 5406, 6596, 7868, 9130],
+                        totalUpdates=658260, meanChiSq=2147591936.0, qA=None, qP=None),      # (the fp32 chi2 accumulator saturating at 2^31 is the reference's own behaviour)
+    "headline_100": dict(kw=dict(nPatterns=50, nIterations=100, seed=42, outputFrequency=10),
+                         atomsA=[376, 9731, 40869, 80358, 121928, 163065, 201598, 235212, 264287, 289635, 312314, 331845, 347230, 358467, 365076, 368751, 370696, 371881, 371160, 370151],
+                         atomsP=None, totalUpdates=53070346, meanChiSq=64217980.0, qA=157.304565, qP=50.5546989),
+}
+
+
+def check_judge3_case(r, fp):
+    """nine printed digits identify an fp32 value: equality of the floats"""
+    assert r["atomsA"].tolist() == fp["atomsA"]
+    if fp["atomsP"] is not None:
+        assert r["atomsP"].tolist() == fp["atomsP"]
+    assert r["totalUpdates"] == fp["totalUpdates"]
+    assert np.float32(r["meanChiSq"]) == np.float32(fp["meanChiSq"]), r["meanChiSq"]
+    if fp["qA"] is not None:
+        assert np.float32(r["averageQueueLengthA"]) == np.float32(fp["qA"]) and np.float32(r["averageQueueLengthP"]) == np.float32(fp["qP"])
+
+
+def run_judge3_case(run, name, gist):
+    d, unc = _judge3_data(name, gist)
+    return run(d, unc=unc, **JUDGE_R3[name]["kw"])
+
+
+@pytest.mark.parametrize("name", list(JUDGE_R3))
+def test_judge_round3_fingerprints(oracle, gist, name):
+    if name == "headline_100" and os.environ.get("COGAPS_LONG_TESTS") != "1":
+        pytest.skip("four minutes of eight cores: COGAPS_LONG_TESTS=1 (tools/ref_vs_port_c3.py keeps the record of the same comparison)")
+    big = name.startswith("headline")
+    r = run_judge3_case(lambda d, unc=None, **kw: oracle.run(d, unc=unc, omp=big, maxThreads=8 if big else 1, **kw), name, gist)
+    check_judge3_case(r, JUDGE_R3[name])
+
+
+def test_typed_fingerprints_regenerate_from_the_reference_build(refprobe_bin, tmp_path):
+    """the reference-printed tables above (judge rounds 1-3) are not just typed in: tools/refprobe/regen_fingerprints.py
+    re-runs the reference build on each configuration (the K = 50 and headline-sized ones only with --all) and finds the same numbers"""
+    rp = _refprobe()
+    import regen_fingerprints as rg
+    cs = rg.cases(str(tmp_path), skip=rg.BIG)
+    n = 0
+    for name, (data, kw, fp) in cs.items():
+        assert rg.check(rp.run(refprobe_bin, data, **kw), fp), name
+        n += 1
+    assert n >= 13
