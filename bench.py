@@ -98,9 +98,30 @@ def cpu_baseline(data, params, budget_s, state, first_step, n_steps):
                     "sample": "schedule steps %d-%d of the SAME chain, started from the GPU chain's state at the start of its timed window (%d + %d atoms): "
                               "%d proposals in %.1f s; the GPU's timed window is steps %d-%d; best of OMP threads %s"
                               % (first_step + 1, first_step + it, len(state["atomsA"]["pos"]), len(state["atomsP"]["pos"]), props, dt, first_step + 1, first_step + n_steps, [t for t, _ in plan])}
+    if best is None:      # no whole-iteration leg finished an iteration inside its share (a tiny --cpu-seconds, or --steps 0)
+        best = {"value": None, "unit": "proposals/s", "cores": None, "kind": "port", "host_cpus": ncpu,
+                "sample": "no whole iteration of the window fitted the time budget (%.0f s): see by_threads" % budget_s}
     best["by_threads"] = by_threads
     best["nproc_threads_value"] = next((b["value"] for b in by_threads if b["threads"] == ncpu), None)
     return best
+
+
+def reference_translation():
+    """How the port compares with the REFERENCE BUILD where both can run (the build container, tools/ref_vs_port_c3.py: configs[2] whole,
+    sampler time only, same chain bit for bit).  Only this repository reaches the GPU box, so the bench's CPU figure is the port's; this
+    record -- with its host named -- is what translates a GPU / port ratio into a GPU / reference-build ratio."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_reference_vs_port_container.json")))
+    if not files:
+        return None
+    rec = json.load(open(files[-1]))
+    legs = {l["threads"]: l for l in rec["legs"]}
+    best = max(rec["legs"], key=lambda l: l["reference_build_proposals_per_s"])
+    return {"source": os.path.relpath(files[-1], ROOT), "host": rec["host"], "workload": rec["workload"],
+            "port_over_reference_build": {str(t): l["port_over_reference_build"] for t, l in sorted(legs.items())},
+            "reference_build_best_proposals_per_s_on_that_host": best["reference_build_proposals_per_s"], "reference_build_best_threads": best["threads"],
+            "note": "port_over_reference_build[t] = reference build's sampler seconds / port's, at t OpenMP threads, in the build container; "
+                    "> 1 means the port is the faster of the two there (the harder baseline)"}
 
 
 def chains_main(args):
@@ -269,6 +290,9 @@ def main():
     ap.add_argument("--chains-mode", choices=("batched", "threads"), default="batched")
     ap.add_argument("--chain-groups", type=int, default=1, help="with --chains: split the chains into this many batches, each driven by its own host thread and stream")
     args = ap.parse_args()
+    # RCCL across processes needs dmabuf IPC on this driver (hipIpcGetMemHandle fails without it): set before torch / HIP initialise,
+    # whoever launched the ranks (the driver's torch.distributed.run line never passes through self_launch)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.chains > 1:
         return chains_main(args)
 
@@ -345,7 +369,7 @@ def main():
     run_steps(burn, W)
     # the chain state at the start of the timed window, for the CPU baseline's like-for-like sample (copied out before the timed region)
     cpu_state = None
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and not args.no_cpu:
         cpu_state = {"atomsA": S.atoms("A"), "A": S.rows("A"), "atomsP": S.atoms("P"), "P": S.rows("P")}
     perf0 = {w: S.perf(w) for w in "AP"}
     S.set_timing(True)
@@ -368,7 +392,7 @@ def main():
     S.set_timing(False)
     perf1 = {w: S.perf(w) for w in "AP"}
 
-    tot_updates, max_dt = float(updates), dt
+    tot_updates, max_dt, rank_seconds = float(updates), dt, [dt]
     if dist is not None:
         t = torch.tensor([float(updates), dt], dtype=torch.float64, device=comm_dev)
         u = t.clone()
@@ -376,6 +400,9 @@ def main():
         m = t.clone()
         dist.all_reduce(m, op=dist.ReduceOp.MAX)
         tot_updates, max_dt = float(u[0].item()), float(m[1].item())
+        per_rank = [torch.zeros(1, dtype=torch.float64, device=comm_dev) for _ in range(world)]
+        dist.all_gather(per_rank, torch.tensor([dt], dtype=torch.float64, device=comm_dev))
+        rank_seconds = sorted(float(x.item()) for x in per_rank)
 
     if rank == 0:
         # HIP start/stop events ride on the dispatch packets of a sample of the launches (hipExtLaunchKernelGGL on the kernels'
@@ -392,7 +419,7 @@ def main():
         batches = kt["A"]["batches"] + kt["P"]["batches"]
         fusedA = args.sparse or S.dims("A")[1] <= 4096
         fusedP = args.sparse or S.dims("P")[1] <= 4096
-        ev_name = lambda fused: "eval_sparse_kernel" if args.sparse else ("eval_kernel<EVAL_FUSED>" if fused else "eval_kernel<EVAL_ALPHA> + eval_kernel<EVAL_APPLY> (two launches per batch)")
+        ev_name = lambda fused: "eval_sparse_kernel" if args.sparse else ("eval_kernel<EVAL_FUSED>" if fused else "eval_kernel<EVAL_DECIDE> (split evaluation, one launch; its A*P updates run beside the next generator launch)")
 
         def kernel_line(name, sampler, ms, launches, nbytes, sampled):
             us = 1e3 * ms / launches if launches else 0.0
@@ -402,8 +429,8 @@ def main():
         kernels = [
             kernel_line(ev_name(fusedA), "A", kt["A"]["evalMs"], kt["A"]["timedBatches"], kt["A"]["evalBytes"], kt["A"]["evalTimed"]),
             kernel_line(ev_name(fusedP), "P", kt["P"]["evalMs"], kt["P"]["timedBatches"], kt["P"]["evalBytes"], kt["P"]["evalTimed"]),
-            kernel_line("gen_kernel", "A", kt["A"]["genMs"], kt["A"]["timedBatches"], 0, kt["A"]["genTimed"]),
-            kernel_line("gen_kernel", "P", kt["P"]["genMs"], kt["P"]["timedBatches"], 0, kt["P"]["genTimed"]),
+            kernel_line("gen_kernel" if fusedA else "gen_apply_kernel (workgroup 0: generator; the others: the previous batch's A*P updates)", "A", kt["A"]["genMs"], kt["A"]["timedBatches"], 0, kt["A"]["genTimed"]),
+            kernel_line("gen_kernel" if fusedP else "gen_apply_kernel (workgroup 0: generator; the others: the previous batch's A*P updates)", "P", kt["P"]["genMs"], kt["P"]["timedBatches"], 0, kt["P"]["genTimed"]),
             kernel_line("sparse_tables_kernel (not timed)" if args.sparse else "transpose_kernel (sync)", "A+P", tot["syncMs"], tot["syncTimed"], tot["syncBytes"], tot["syncTimed"]),
         ]
         gen_ms = kt["A"]["genMs"] + kt["P"]["genMs"]
@@ -417,17 +444,27 @@ def main():
         # HBM bytes from the PMC counters: two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; tools/pmc_pass.sh) over this
         # same workload, committed under profiles/ -- a bench run cannot collect them itself.  Quoted whenever the workload shape
         # is the one they were measured on (any --steps / --warmup: per-launch means of the populated chain).
-        traffic, traffic_src, traffic_kernels = None, None, None
+        traffic, traffic_src, traffic_kernels, traffic_stale, traffic_measured_on = None, None, None, None, None
+        lib_hash = _capi.load().cogaps_source_hash().decode()
+        import glob
+        files = []
         if not args.sparse and (args.genes, args.samples, args.patterns) == (20000, 2000, 50):
-            import glob
-            files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")) if "chains" not in os.path.basename(f))
-            if files:
-                pk = json.load(open(files[-1]))["kernels"]
+            files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")) if "chains" not in os.path.basename(f) and "sparse" not in os.path.basename(f))
+        elif args.sparse and (args.genes, args.samples, args.patterns) == (50000, 12500, 50):      # BASELINE configs[4]'s per-GPU shard
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sparse_c4shape_pmc_traffic.json")))
+        if files:
+            if True:
+                rec_ = json.load(open(files[-1]))
+                pk = rec_["kernels"]
+                # the counters were collected on ONE build of the library: quoted only while the running library is that build
+                traffic_measured_on = rec_.get("lib_source_hash")
+                traffic_stale = traffic_measured_on != lib_hash
                 traffic_kernels = {k: v["hbm_bytes_per_launch"] for k, v in pk.items()}
                 tb = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in pk.values())
                 nb = sum(v["launches"] for k, v in pk.items() if k.startswith("gen_kernel"))
-                if nb:
+                if nb and not traffic_stale:
                     traffic = tb / nb
+                if nb:
                     traffic_src = ("%s: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + --pmc WRITE_SIZE, separate passes over this workload; sum over "
                                    "the generator and evaluation kernels of (bytes per launch x launches) / batches" % os.path.relpath(files[-1], ROOT))
         out = {
@@ -442,6 +479,7 @@ def main():
                                         else "the SparseNormalModel on a configs[2]-sized product; BASELINE configs[4]'s shard is --genes 50000 --samples 12500") if args.sparse
                                        else ("BASELINE configs[2]" if (args.genes, args.samples, args.patterns) == (20000, 2000, 50) else "not a BASELINE shape")),
                                       ("; scCoGAPS nSets=%d cell-wise shards, one per GPU" % world if args.sparse else "; GWCoGAPS nSets=%d gene-wise shards, configs[3]" % world) if world > 1 else ""),
+                       "rank_seconds": {"min": rank_seconds[0], "median": rank_seconds[len(rank_seconds) // 2], "max": rank_seconds[-1]},
                        "ranks": world, "collective_backend": (backend if dist is not None else None), "shared_factor_gathered": (shared_factor if dist is not None else None),
                        "nIterations": n_iter, "untimed_schedule_steps_before_warmup": burn, "proposals_timed": int(tot_updates), "batches_rank0": int(batches),
                        "avg_queue_A": S.avg_queue("A"), "avg_queue_P": S.avg_queue("P"),
@@ -455,18 +493,34 @@ def main():
             # kernels of the timed region -- with each kernel's own figure alongside.  One "launch" of the path = one batch.
             "roofline": {"bound": "hbm", "kernel": "path: gen_kernel + evaluation kernels + sync, per batch (dominant by time: %s, sampler %s)" % (dominant["kernel"], dominant["sampler"]),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved is not None else None,
-                         "traffic": traffic, "traffic_source": traffic_src, "traffic_bytes_per_launch_by_kernel": traffic_kernels,
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_bytes_per_launch_by_kernel": (traffic_kernels if not traffic_stale else None),
+                         # the committed counter pass names the library build it measured; another build -> no figure, no ratio, re-run tools/r4_pmc_pass.sh
+                         "traffic_stale": traffic_stale, "traffic_measured_on_lib": traffic_measured_on, "lib_source_hash": lib_hash,
                          "bytes_per_launch": b_alg / max(1, batches), "avg_launch_us": 1e3 * kernel_ms / max(1, batches), "launches": int(batches),
                          "kernel_time_over_wall": kernel_ms / (1e3 * dt), "timing_consistent": bool(consistent),
                          "kernels": kernels},
         }
-        if not args.no_cpu and world == 1:
+        if not args.no_cpu:
             cb = cpu_baseline(data, params, args.cpu_seconds, cpu_state, burn + W, K)
-            # like for like only when the port ran the WHOLE timed window (the driver's --steps 20 does; the 190-step default lets
-            # the port cover the window's first part, where the chain is still growing and the port is slower per proposal)
-            covered = max(b["iterations"] for b in cb["by_threads"] if b["threads"] == cb["cores"]) / float(K)
-            cb["window_covered"] = covered
-            cb["gpu_over_cpu_same_window" if covered >= 1.0 else "gpu_over_cpu_partial_window"] = out["value"] / cb["value"]
+            if cb["value"] is not None:
+                if world > 1:
+                    # the CPU comparator of a GWCoGAPS / scCoGAPS job is nSets port runs, one per subset.  Rank 0's
+                    # shard was timed (same window, same start state); the job's figure is that rate x nSets -- the subsets are of one
+                    # shape, the host runs them side by side (`cores` threads each of its `host_cpus`) -- labelled as the extrapolation it is
+                    cb["value_one_shard"] = cb["value"]
+                    cb["value"] = cb["value"] * world
+                    cb["sample"] = ("rank 0's shard x nSets = %d (BASELINE.md 3.5: one port run per subset with its dataIndicesSubset, side by side on the host; "
+                                    "one shard measured, the others are of the same shape): " % world) + cb["sample"]
+                # like for like only when the port ran the WHOLE timed window (the driver's --steps 20 does; the 190-step default lets
+                # the port cover the window's first part, where the chain is still growing and the port is slower per proposal)
+                covered = max(b["iterations"] for b in cb["by_threads"] if b["threads"] == cb["cores"]) / float(K)
+                cb["window_covered"] = covered
+                cb["gpu_over_cpu_same_window" if covered >= 1.0 else "gpu_over_cpu_partial_window"] = out["value"] / cb["value"]
+                # north_star's target is 10x the CPU path: where that line lies on this host and how far the GPU figure is from it
+                cb["ten_x_line"] = 10.0 * cb["value"]
+                cb["gpu_over_ten_x_line"] = out["value"] / (10.0 * cb["value"])
+            # the port timed here against the REFERENCE BUILD where both can run (build container, committed record)
+            cb["port_over_reference_build"] = reference_translation()
             out["cpu_baseline"] = cb
         else:
             out["cpu_baseline"] = None

@@ -68,8 +68,8 @@ TRACE_DTYPE = np.dtype([
 
 # every symbol include/cogaps_hip.h declares
 EXPORTS = [
-    "cogaps_default_params", "cogaps_run", "cogaps_result_free", "cogaps_last_error",
-    "cogaps_build_report", "cogaps_checkpoints_enabled", "cogaps_compiled_with_openmp",
+    "cogaps_default_params", "cogaps_run", "cogaps_result_free", "cogaps_last_error", "cogaps_last_error_code",
+    "cogaps_build_report", "cogaps_source_hash", "cogaps_checkpoints_enabled", "cogaps_compiled_with_openmp",
     "cogaps_session_create", "cogaps_session_destroy", "cogaps_session_set_annealing",
     "cogaps_session_draw_steps", "cogaps_session_update", "cogaps_session_sync",
     "cogaps_session_iterate", "cogaps_session_run_iterations", "cogaps_session_natoms",
@@ -87,6 +87,27 @@ _REDUCE = {"lanes": REDUCE_LANES, "seq": REDUCE_SEQ}
 _MATH = {"portable": MATH_PORTABLE, "glibc-fma": MATH_GLIBC_FMA, "glibc-sse2": MATH_GLIBC_SSE2}
 _PUMP = {"unique": 0, "cut": 1}
 
+ERR_GENERIC, ERR_OUT_OF_DEVICE_MEMORY, ERR_OUT_OF_HOST_MEMORY = 1, 2, 3      # cogaps_last_error_code()
+
+
+class CogapsError(RuntimeError):
+    """a failing call of the C ABI: the library's message, and its kind as a code (include/cogaps_hip.h, cogaps_last_error_code)"""
+
+    def __init__(self, message, code=ERR_GENERIC):
+        super().__init__(message)
+        self.code = code
+
+
+class OutOfDeviceMemory(CogapsError):
+    """hipErrorOutOfMemory inside the library (COGAPS_ERR_OUT_OF_DEVICE_MEMORY)"""
+
+
+def _error(L, prefix=""):
+    """the exception for the calling thread's last failing call"""
+    code = int(L.cogaps_last_error_code())
+    msg = prefix + L.cogaps_last_error().decode()
+    return OutOfDeviceMemory(msg, code) if code == ERR_OUT_OF_DEVICE_MEMORY else CogapsError(msg, code)
+
 
 def bind(L):
     """Attach prototypes to an opened library implementing include/cogaps_hip.h."""
@@ -97,7 +118,9 @@ def bind(L):
     L.cogaps_result_free.argtypes = [C.POINTER(CogapsResultC)]
     L.cogaps_result_free.restype = None
     L.cogaps_last_error.restype = C.c_char_p
+    L.cogaps_last_error_code.restype = C.c_int
     L.cogaps_build_report.restype = C.c_char_p
+    L.cogaps_source_hash.restype = C.c_char_p
     L.cogaps_session_create.restype = vp
     L.cogaps_session_create.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(CogapsParamsC), vp, C.c_int]
     L.cogaps_session_destroy.argtypes = [vp]
@@ -269,11 +292,11 @@ class Session:
         self.h = self.L.cogaps_session_create(self.d.ctypes.data, self.d.shape[0], self.d.shape[1], C.byref(self.p),
                                               None if self.u is None else self.u.ctypes.data, 0)
         if not self.h:
-            raise RuntimeError("cogaps_session_create: " + self.L.cogaps_last_error().decode())
+            raise _error(self.L, "cogaps_session_create: ")
 
     def _ck(self, rc):
         if rc:
-            raise RuntimeError(self.L.cogaps_last_error().decode())
+            raise _error(self.L)
 
     def close(self):
         if getattr(self, "h", None):
@@ -418,7 +441,7 @@ def read_matrix_file(path, lib=None, rows=None, cols=None):
         idx = np.ascontiguousarray(rows if rows is not None else cols, dtype=np.uint32)
         rc = L.cogaps_read_matrix_file_subset(os.fsencode(path), int(rows is not None), idx.ctypes.data_as(C.POINTER(C.c_uint32)), idx.size, C.byref(nr), C.byref(nc), C.byref(ptr))
     if rc:
-        raise RuntimeError(L.cogaps_last_error().decode())
+        raise _error(L)
     try:
         return np.ctypeslib.as_array(ptr, shape=(nr.value, nc.value)).copy() if nr.value * nc.value else np.zeros((nr.value, nc.value), np.float32)
     finally:
@@ -430,10 +453,10 @@ def file_info(path, lib=None):
     L = lib or load()
     nr, nc, rn, cn = C.c_uint32(), C.c_uint32(), C.c_size_t(), C.c_size_t()
     if L.cogaps_file_info(os.fsencode(path), C.byref(nr), C.byref(nc), None, 0, C.byref(rn), None, 0, C.byref(cn)):
-        raise RuntimeError(L.cogaps_last_error().decode())
+        raise _error(L)
     rb, cb = C.create_string_buffer(rn.value), C.create_string_buffer(cn.value)
     if L.cogaps_file_info(os.fsencode(path), C.byref(nr), C.byref(nc), rb, rn.value, None, cb, cn.value, None):
-        raise RuntimeError(L.cogaps_last_error().decode())
+        raise _error(L)
     names = lambda b: b.value.decode().split("\n") if b.value else []
     return nr.value, nc.value, names(rb), names(cb)
 
@@ -444,7 +467,7 @@ def run_from_file(path, unc_path=None, lib=None, **kw):
     params = make_params(L, **kw)
     res = CogapsResultC()
     if L.cogaps_run_from_file(os.fsencode(path), C.byref(params), os.fsencode(unc_path) if unc_path else None, C.byref(res)):
-        raise RuntimeError("cogaps_run_from_file: " + L.cogaps_last_error().decode())
+        raise _error(L, "cogaps_run_from_file: ")
     return result_to_dict(L, res)
 
 
@@ -457,7 +480,7 @@ def run(data, unc=None, lib=None, **kw):
     r = CogapsResultC()
     rc = L.cogaps_run(_fp(d), d.shape[0], d.shape[1], C.byref(p), None if u is None else _fp(u), C.byref(r))
     if rc:
-        raise RuntimeError("cogaps_run: " + L.cogaps_last_error().decode())
+        raise _error(L, "cogaps_run: ")
     return result_to_dict(L, r)
 
 
@@ -467,7 +490,7 @@ def debug_math(fn, x, mathMode="portable", on_device=False, lib=None):
     xs = np.ascontiguousarray(x, dtype=np.float32)
     ys = np.zeros_like(xs)
     if L.cogaps_debug_math({"log": 0, "exp": 1}[fn], _MATH[mathMode] if isinstance(mathMode, str) else int(mathMode), _fp(xs), _fp(ys), xs.size, int(on_device)):
-        raise RuntimeError(L.cogaps_last_error().decode())
+        raise _error(L)
     return ys
 
 
@@ -476,7 +499,7 @@ def device_memory(device=-1, lib=None):
     L = lib if lib is not None else load()
     f, t = C.c_uint64(0), C.c_uint64(0)
     if L.cogaps_device_memory(int(device), C.byref(f), C.byref(t)):
-        raise RuntimeError(L.cogaps_last_error().decode())
+        raise _error(L)
     return int(f.value), int(t.value)
 
 
@@ -485,7 +508,7 @@ def current_device(lib=None):
     L = lib if lib is not None else load()
     d = C.c_int(0)
     if L.cogaps_current_device(C.byref(d)):
-        raise RuntimeError(L.cogaps_last_error().decode())
+        raise _error(L)
     return d.value
 
 
@@ -499,11 +522,11 @@ class Batch:
         arr = (C.c_void_p * len(self.sessions))(*[s.h for s in self.sessions])
         self.h = self.L.cogaps_batch_create(arr, len(self.sessions))
         if not self.h:
-            raise RuntimeError("cogaps_batch_create: " + self.L.cogaps_last_error().decode())
+            raise _error(self.L, "cogaps_batch_create: ")
 
     def _ck(self, rc):
         if rc:
-            raise RuntimeError(self.L.cogaps_last_error().decode())
+            raise _error(self.L)
 
     def run_iterations(self, phase, first, n):
         upd = (C.c_uint64 * len(self.sessions))()

@@ -40,7 +40,15 @@ static uint32_t gen_window_for(uint32_t current, float stepsPerBatch)
 
 
 static thread_local std::string g_last_error;
-static int fail(const std::string &m) { g_last_error = m; return 1; }
+static thread_local int g_last_code = COGAPS_OK;
+static int fail(const std::string &m, int code = COGAPS_ERR_GENERIC) { g_last_error = m; g_last_code = code; return 1; }
+// a caught exception: device memory exhausted and host memory exhausted keep their own codes (cogaps_last_error_code)
+static int fail_exc(const std::exception &e)
+{
+    if (dynamic_cast<const rt_out_of_memory *>(&e)) return fail(e.what(), COGAPS_ERR_OUT_OF_DEVICE_MEMORY);
+    if (dynamic_cast<const std::bad_alloc *>(&e)) return fail(e.what(), COGAPS_ERR_OUT_OF_HOST_MEMORY);
+    return fail(e.what());
+}
 
 // ------------------------------------------------------------------------------------------------
 // host RNG pieces: Xoroshiro128+ seeder (Random.cpp:221-248) and the runner's PCG (GapsRunner.cpp:437)
@@ -224,7 +232,7 @@ static void free_sampler(HostSampler &h)
     rt_free(d.seqScratch); rt_free((void *)d.deathProb);
     rt_free((void *)d.D); rt_free((void *)d.S2); rt_free(d.AP); rt_free(d.mat); rt_free(d.colPos);
     rt_free(d.atoms); rt_free(d.vec); rt_free(d.freeHandles); rt_free(d.binHead);
-    rt_free(d.bits0); rt_free(d.bits1); rt_free(d.bits2); rt_free(d.eraseList); rt_free(d.queue); rt_free(d.queueUnits); rt_free(d.partials);
+    rt_free(d.bits0); rt_free(d.bits1); rt_free(d.bits2); rt_free(d.eraseList); rt_free(d.queue); rt_free(d.queueUnits); rt_free(d.partials); rt_free(d.grans); rt_free(d.dec);
     rt_free(d.rowStamp); rt_free(d.atomStamp); rt_free(d.gapStamp); rt_free(d.inlineStamp); rt_free(d.atomDest);
     rt_free(d.gs); rt_free(d.trace); rt_free(d.traceBatchNproc); rt_free(d.traceBatchQlen);
     rt_free(h.Sraw); rt_free(h.seeds); rt_free_host(h.hSeeds); rt_free(h.partial); rt_free(h.dRecord);
@@ -330,7 +338,7 @@ static void build_sampler(cogaps_session *s, HostSampler &h, char name, const fl
     d.nWords0 = (uint32_t)((nBins + 63) / 64); d.nWords1 = (d.nWords0 + 63) / 64; d.nWords2 = (d.nWords1 + 63) / 64;
     d.bits0 = dalloc<unsigned long long>(d.nWords0); d.bits1 = dalloc<unsigned long long>(d.nWords1); d.bits2 = dalloc<unsigned long long>(d.nWords2);
     d.queueCap = d.M + 8; d.eraseCap = d.queueCap;
-    d.eraseList = dalloc<unsigned long long>(d.eraseCap); d.queue = dalloc<PropRec>(d.queueCap); d.queueUnits = dalloc<uint32_t>(d.queueCap); d.partials = dalloc<float>((size_t)d.queueCap * 64);
+    d.eraseList = dalloc<unsigned long long>(d.eraseCap); d.queue = dalloc<PropRec>(d.queueCap); d.queueUnits = dalloc<uint32_t>(d.queueCap); d.partials = dalloc<float>((size_t)d.queueCap * 64); d.grans = dalloc<unsigned long long>((size_t)d.queueCap * 64); d.dec = dalloc<DecRec>(d.queueCap);
     d.rowStamp = dalloc<unsigned long long>(d.M);
     d.atomStamp = dalloc<unsigned long long>(d.atomCap); d.gapStamp = dalloc<unsigned long long>((size_t)d.atomCap + 1);
     d.inlineStamp = dalloc<unsigned long long>(d.atomCap); d.atomDest = dalloc<uint64_t>(d.atomCap);
@@ -434,10 +442,34 @@ static void sync_record(cogaps_session *s, HostSampler &h)
     rt_sync(s->stream);
     h.recordValid = true;
 }
+// The one-chain split evaluation (data vectors of more than 4096 elements, dense model, product arithmetic) is ONE launch that decides
+// (eval_kernel<EVAL_DECIDE>); the A*P updates it owes are carried out by the further workgroups of the NEXT generator launch
+// (gen_apply_kernel) -- see eval_kernel.h.  The batched multi-chain launches keep the two-launch form (alpha, apply).
+static bool split_one_launch(const HostSampler &h)
+{
+    static const bool twoLaunches = getenv("COGAPS_SPLIT_TWO_LAUNCHES") != nullptr;      // dev: A/B against the two-launch form (alpha kernel, apply kernel)
+    return !twoLaunches && !h.d.seq && !h.d.sparse && h.d.redW > 1024u;
+}
+static uint32_t apply_grid()
+{
+#if defined(COGAPS_EMUL)
+    static const uint32_t g = 5u;        // (test-only emulator: a workgroup is a set of fibers, few of them keep the tests quick; 5 does not divide the items evenly)
+#else
+    static const uint32_t g = getenv("COGAPS_APPLY_GRID") ? (uint32_t)atoi(getenv("COGAPS_APPLY_GRID")) : 255u;      // dev: A/B of the update workgroups' number
+#endif
+    return g < 1u ? 1u : g;
+}
 static void launch_gen(cogaps_session *s, HostSampler &h)
 {
     const int slot = timing_slot(s, h, 0, h.genLaunches);
     const SamplerDev CG_CONSTANT *rec = (const SamplerDev CG_CONSTANT *)h.dRecord;
+    if (split_one_launch(h)) {
+        const uint32_t grid = 1u + apply_grid();
+        if (h.genWin == (uint32_t)GEN_WIN) LAUNCH_MAYBE_TIMED(slot, gen_apply_kernel<GEN_WIN>, grid, GEN_WIN + 64, h.d.lcgMul, h.d.lcgInc, h.d.gs, (const unsigned long long *)h.d.eraseList, (const uint32_t *)h.d.queueUnits, h.d.eraseCap, h.d.queueCap, rec);
+        else LAUNCH_MAYBE_TIMED(slot, gen_apply_kernel<GEN_WIN_HALF>, grid, GEN_WIN_HALF + 64, h.d.lcgMul, h.d.lcgInc, h.d.gs, (const unsigned long long *)h.d.eraseList, (const uint32_t *)h.d.queueUnits, h.d.eraseCap, h.d.queueCap, rec);
+        h.genLaunches++;
+        return;
+    }
     if (h.genWin == (uint32_t)GEN_WIN) LAUNCH_MAYBE_TIMED(slot, gen_kernel<GEN_WIN>, 1, GEN_WIN + 64, h.d.lcgMul, h.d.lcgInc, h.d.gs, (const unsigned long long *)h.d.eraseList, (const uint32_t *)h.d.queueUnits, h.d.eraseCap, h.d.queueCap, rec);
     else LAUNCH_MAYBE_TIMED(slot, gen_kernel<GEN_WIN_HALF>, 1, GEN_WIN_HALF + 64, h.d.lcgMul, h.d.lcgInc, h.d.gs, (const unsigned long long *)h.d.eraseList, (const uint32_t *)h.d.queueUnits, h.d.eraseCap, h.d.queueCap, rec);
     h.genLaunches++;
@@ -467,10 +499,16 @@ static void launch_eval(cogaps_session *s, HostSampler &h)
         const uint32_t slices = std::min<uint32_t>(h.d.redW / bs, ((h.d.Npad >> 2) + bs - 1u) / bs);
         const uint32_t perWave = std::max<uint32_t>(1u, (512u * (1024u / bs)) / slices);   // two resident 1024-thread workgroups per compute unit
         const uint32_t grid = std::min<uint32_t>(h.d.queueCap, perWave) * slices;
-        int slot2 = -1;
-        if (slot >= 0 && s->evUsed < s->evPool.size()) { slot2 = (int)s->evUsed++; s->evKind[slot2] = 3; s->evOwner[slot2] = &h; s->evOrd[slot2] = h.updLaunches; }
-        LAUNCH_MAYBE_TIMED(slot, eval_kernel<EVAL_ALPHA>, grid, bs, (const PropRec *)h.d.queue, (const GenScalars *)h.d.gs, h.d.queueCap, slices, rec);
-        LAUNCH_MAYBE_TIMED(slot2, eval_kernel<EVAL_APPLY>, grid, bs, (const PropRec *)h.d.queue, (const GenScalars *)h.d.gs, h.d.queueCap, slices, rec);
+        if (split_one_launch(h)) {
+            // one launch: the slices' totals reach the proposal's last slice workgroup inside it (eval_kernel.h, EVAL_DECIDE); the A*P updates
+            // follow beside the next generator launch (launch_gen)
+            LAUNCH_MAYBE_TIMED(slot, eval_kernel<EVAL_DECIDE>, grid, bs, (const PropRec *)h.d.queue, (const GenScalars *)h.d.gs, h.d.queueCap, slices, rec);
+        } else {
+            int slot2 = -1;
+            if (slot >= 0 && s->evUsed < s->evPool.size()) { slot2 = (int)s->evUsed++; s->evKind[slot2] = 3; s->evOwner[slot2] = &h; s->evOrd[slot2] = h.updLaunches; }
+            LAUNCH_MAYBE_TIMED(slot, eval_kernel<EVAL_ALPHA>, grid, bs, (const PropRec *)h.d.queue, (const GenScalars *)h.d.gs, h.d.queueCap, slices, rec);
+            LAUNCH_MAYBE_TIMED(slot2, eval_kernel<EVAL_APPLY>, grid, bs, (const PropRec *)h.d.queue, (const GenScalars *)h.d.gs, h.d.queueCap, slices, rec);
+        }
     }
     h.evalLaunches++;
 }
@@ -621,12 +659,12 @@ int cogaps_debug_math(int fn, int mathMode, const float *x, float *y, uint32_t n
         rt_d2h(y, dy, (size_t)n * 4, st); rt_sync(st);
         rt_free(dx); rt_free(dy); rt_stream_destroy(st);
         return 0;
-    } catch (const std::exception &e) { return fail(e.what()); }
+    } catch (const std::exception &e) { return fail_exc(e); }
 }
 
 int cogaps_current_device(int *device)
 {
-    try { if (!device) return fail("null argument"); *device = rt_get_device(); return 0; } catch (const std::exception &e) { return fail(e.what()); }
+    try { if (!device) return fail("null argument"); *device = rt_get_device(); return 0; } catch (const std::exception &e) { return fail_exc(e); }
 }
 
 int cogaps_device_memory(int device, uint64_t *freeBytes, uint64_t *totalBytes)
@@ -639,7 +677,7 @@ int cogaps_device_memory(int device, uint64_t *freeBytes, uint64_t *totalBytes)
         if (device >= 0) rt_set_device(before);
         *freeBytes = (uint64_t)f; *totalBytes = (uint64_t)t;
         return 0;
-    } catch (const std::exception &e) { return fail(e.what()); }
+    } catch (const std::exception &e) { return fail_exc(e); }
 }
 
 void cogaps_default_params(cogaps_params *p)
@@ -650,9 +688,14 @@ void cogaps_default_params(cogaps_params *p)
     p->printMessages = 0; p->asynchronousUpdates = 1; p->whichMatrixFixed = 'N'; p->workerID = 1; p->device = -1;
 }
 const char *cogaps_last_error(void) { return g_last_error.c_str(); }
+int cogaps_last_error_code(void) { return g_last_code; }
+#ifndef COGAPS_SOURCE_HASH
+#define COGAPS_SOURCE_HASH "unknown"      // (builds that do not go through csrc/Makefile: the test-only emulator)
+#endif
+const char *cogaps_source_hash(void) { return COGAPS_SOURCE_HASH; }
 const char *cogaps_build_report(void)
 {
-    static const std::string rep = std::string("cogaps-amd 0.2 | ") + CG_PLATFORM_NAME + " | asynchronous Gibbs sampler, dense and sparse normal model | checkpoints: no";
+    static const std::string rep = std::string("cogaps-amd 0.2 | ") + CG_PLATFORM_NAME + " | asynchronous Gibbs sampler, dense and sparse normal model | checkpoints: no | sources " + COGAPS_SOURCE_HASH;
     return rep.c_str();
 }
 int cogaps_checkpoints_enabled(void) { return 0; }
@@ -765,7 +808,7 @@ cogaps_session *cogaps_session_create(const float *data, uint32_t nrow, uint32_t
         fflush(stdout);
         return s;
     } catch (const std::exception &e) {
-        fail(e.what());
+        fail_exc(e);
         if (s) cogaps_session_destroy(s);
         return nullptr;
     }
@@ -786,7 +829,7 @@ void cogaps_session_destroy(cogaps_session *s)
 
 // (the HIP current device belongs to the calling host thread: a session used from another thread than its creator's selects its GPU again)
 #define SESSION_TRY try { rt_set_device(s->p.device); rt_alloc_scope allocOn_(s->stream);      // allocations made on behalf of a session fill on its stream
-#define SESSION_END } catch (const std::exception &e) { return fail(e.what()); } return 0;
+#define SESSION_END } catch (const std::exception &e) { return fail_exc(e); } return 0;
 
 static HostSampler &pick(cogaps_session *s, char w) { return w == 'A' ? s->A : s->P; }
 
@@ -866,10 +909,13 @@ static int iteration_head(cogaps_session *s, int phase, uint32_t it, uint32_t *n
         cogaps_session_set_annealing(s, gm_min(1.f, temp));
     }
     const int rc = cogaps_session_draw_steps(s, nA, nP);
-    // tests: COGAPS_TEST_ZERO_STEPS="<workerID>:<iteration>" turns that worker's A update of that equilibration iteration into
-    // update(0) -- what a Poisson draw of 0 (probability e^-10 per draw while a chain holds at most ten atoms) does -- after the
-    // draw, so the generators' sequences are unchanged
+#if defined(COGAPS_EMUL)
+    // TEST-ONLY emulator build (never in the product library: a stray environment variable must not be able to change a chain):
+    // COGAPS_TEST_ZERO_STEPS="<workerID>:<iteration>" turns that worker's A update of that equilibration iteration into update(0) -- what a
+    // Poisson draw of 0 (probability e^-10 per draw while a chain holds at most ten atoms) does -- after the draw, so the generators'
+    // sequences are unchanged
     if (phase == 1) if (const char *z = getenv("COGAPS_TEST_ZERO_STEPS")) { unsigned wk = 0, zi = 0; if (sscanf(z, "%u:%u", &wk, &zi) == 2 && wk == s->p.workerID && zi == it) *nA = 0; }
+#endif
     return rc;
 }
 // ... and its tail (:314-325): snapshots, status line / histories
@@ -1098,7 +1144,7 @@ cogaps_batch *cogaps_batch_create(cogaps_session **sessions, uint32_t n)
             if (s->p.useSparseOptimization != s0->p.useSparseOptimization || s->p.whichMatrixFixed != s0->p.whichMatrixFixed || s->p.device != s0->p.device
                 || s->A.d.redW != s0->A.d.redW || s->P.d.redW != s0->P.d.redW || ((s->A.d.Npad >> 2) + 511u) / 512u != ((s0->A.d.Npad >> 2) + 511u) / 512u
                 || ((s->P.d.Npad >> 2) + 511u) / 512u != ((s0->P.d.Npad >> 2) + 511u) / 512u
-                || cogaps_sparse_width(s->A.d.N) != cogaps_sparse_width(s0->A.d.N) || cogaps_sparse_width(s->P.d.N) != cogaps_sparse_width(s0->P.d.N))
+                || (s->p.useSparseOptimization && (cogaps_sparse_width(s->A.d.N) != cogaps_sparse_width(s0->A.d.N) || cogaps_sparse_width(s->P.d.N) != cogaps_sparse_width(s0->P.d.N))))      // (the dense kernels never see the sparse model's workgroup width: subsets of 4095 and 4096 rows share a batch)
             { fail("the sessions of a batch must share the model, the fixed matrix, the device and the evaluation launch shape (equal reduction widths)"); return nullptr; }
         }
         rt_set_device(s0->p.device);
@@ -1118,7 +1164,7 @@ cogaps_batch *cogaps_batch_create(cogaps_session **sessions, uint32_t n)
         }
         return b;
     } catch (const std::exception &e) {
-        fail(e.what());
+        fail_exc(e);
         if (b) {
             for (int w = 0; w < 2; ++w) rt_free(b->dev[w]);
             rt_free_host(b->hGs);
@@ -1169,7 +1215,7 @@ int cogaps_batch_run_iterations(cogaps_batch *b, int phase, uint32_t firstIter, 
         const double dt = now_s() - t0;
         for (cogaps_session *s : b->ss) s->samplerSeconds += dt;
         return 0;
-    } catch (const std::exception &e) { return fail(e.what()); }
+    } catch (const std::exception &e) { return fail_exc(e); }
 }
 
 int cogaps_batch_set_timing(cogaps_batch *b, int on)
@@ -1179,7 +1225,7 @@ int cogaps_batch_set_timing(cogaps_batch *b, int on)
         if (on && !b->timing) for (int w = 0; w < 2; ++w) { b->genMs[w] = b->evalMs[w] = 0; b->genTimed[w] = b->evalTimed[w] = 0; }
         b->timing = on != 0;
         return 0;
-    } catch (const std::exception &e) { return fail(e.what()); }
+    } catch (const std::exception &e) { return fail_exc(e); }
 }
 
 // mean HIP-event time of the sampled batched launches since cogaps_batch_set_timing(1), per sampler side (0 = A, 1 = P); the
@@ -1455,7 +1501,7 @@ int cogaps_read_matrix_file(const char *path, uint32_t *nrow, uint32_t *ncol, fl
     try {
         if (!path || !nrow || !ncol || !data) return fail("null argument");
         return table_out(cgio::read_matrix_file(path), nrow, ncol, data);
-    } catch (const std::exception &e) { return fail(e.what()); }
+    } catch (const std::exception &e) { return fail_exc(e); }
 }
 // the rows (byRows != 0) or columns of the file named by the 1-based `indices`, as the reference's workers read their subset of a
 // file (Matrix(path, genesInCols, subsetGenes, indices), data_structures/Matrix.cpp:70-134: sorted indices, lower_bound placement);
@@ -1466,7 +1512,7 @@ int cogaps_read_matrix_file_subset(const char *path, int byRows, const uint32_t 
         if (!path || !nrow || !ncol || !data || !indices || nIndices == 0) return fail("null argument or empty subset");
         cgio::ReadOpts o; o.sub = cgio::Subset(byRows != 0, indices, nIndices);
         return table_out(cgio::read_matrix_file(path, o), nrow, ncol, data);
-    } catch (const std::exception &e) { return fail(e.what()); }
+    } catch (const std::exception &e) { return fail_exc(e); }
 }
 
 void cogaps_matrix_free(float *data) { free(data); }
@@ -1488,7 +1534,7 @@ int cogaps_file_info(const char *path, uint32_t *nrow, uint32_t *ncol, char *row
         };
         join(t.rowNames, rowNames, rowCap, rowNeeded); join(t.colNames, colNames, colCap, colNeeded);
         return 0;
-    } catch (const std::exception &e) { return fail(e.what()); }
+    } catch (const std::exception &e) { return fail_exc(e); }
 }
 
 int cogaps_run_from_file(const char *dataPath, const cogaps_params *params, const char *uncertaintyPath, cogaps_result *out)
@@ -1510,7 +1556,7 @@ int cogaps_run_from_file(const char *dataPath, const cogaps_params *params, cons
             if (u.nrow != d.nrow || u.ncol != d.ncol || u.fileRows != d.fileRows || u.fileCols != d.fileCols) return fail("uncertainty matrix has different dimensions than the data");
         }
         return cogaps_run(d.v.data(), d.nrow, d.ncol, &p, haveUnc ? u.v.data() : nullptr, out);
-    } catch (const std::exception &e) { return fail(e.what()); }
+    } catch (const std::exception &e) { return fail_exc(e); }
 }
 
 void cogaps_result_free(cogaps_result *r)

@@ -385,6 +385,9 @@ CG_DEVICE EvalAtoms eval_atoms_load(const SamplerDev &S, const PropRec &p, bool 
 #define EVAL_ALPHA 1     // split evaluation, first kernel: `slices` workgroups per proposal, per-slice alpha partials
 #define EVAL_APPLY 2     // split evaluation, second kernel: combine the partials, decide, update the slice
 #define EVAL_SEQ 3       // verification mode: one workgroup per proposal, sums in the reference's scalar order, session math mode
+#define EVAL_DECIDE 4    // split evaluation in ONE launch (one-chain form): the slices' workgroups hand their totals to the proposal's last slice
+                         // workgroup, which decides and records what the A*P cache owes (DecRec); eval_apply_items carries that out beside the
+                         // NEXT generator launch (gen_apply_kernel), off the generate -> decide -> generate chain
 
 // The split form serves data vectors of more than 4096 elements (W > 1024 virtual lanes): one workgroup can pull a
 // row no faster than its compute unit's ~64 B/clk, so the row is cut into slices of 1024 chunks, one workgroup
@@ -399,12 +402,13 @@ CG_DEVICE EvalAtoms eval_atoms_load(const SamplerDev &S, const PropRec &p, bool 
 struct EvalHot { const PropRec *queue; const GenScalars *gs; uint32_t queueCap; };
 // The first memory trip of an evaluation workgroup: its first queue record, the queue length, the annealing temperature.  The
 // addresses need only `hot` and the workgroup index, so the one-chain kernels issue it before they have seen the sampler's record.
-struct EvalFirst { PropRec p; uint32_t qlen; float T; };
+struct EvalFirst { PropRec p; uint32_t qlen; float T; uint32_t tag; };      // tag: the batch's number (low word), what the in-launch hand-off marks its granules with
 template <int PHASE>
 CG_DEVICE EvalFirst eval_first(const EvalHot hot, uint32_t slices, uint32_t vbid)
 {
     const uint32_t qFirst = (PHASE == EVAL_FUSED || PHASE == EVAL_SEQ) ? vbid : vbid / slices;
     EvalFirst f; f.p = hot.queue[qFirst < hot.queueCap ? qFirst : 0u]; f.qlen = hot.gs->qlen; f.T = hot.gs->annealTemp;
+    f.tag = (PHASE == EVAL_DECIDE) ? (uint32_t)hot.gs->batchEpoch : 0u;
     return f;
 }
 // The one-chain kernels read the sampler's record through a pointer in the constant address space (scalar loads), requested behind
@@ -449,8 +453,12 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
     const uint32_t slice = WHOLE ? 0u : vbid % slices;
     const uint32_t qStep = WHOLE ? vgdim : vgdim / slices;
     const uint32_t chunk0 = slice * BS, stride = WHOLE ? BS : S.redW;
-    const bool writer = slice == 0u && t == 0u;          // the one thread that stores the proposal's scalar results
-#define EVAL_BCAST(F0, I0) do { if (multiWave) { if (t == 0) { decf = (F0); deci = (I0); } cg_sync(); (F0) = decf; (I0) = deci; } } while (0)
+    constexpr bool DECIDE = PHASE == EVAL_DECIDE;
+    const bool decider = DECIDE && slice + 1u == slices;      // the proposal's last slice: it is dispatched last, so its siblings are on the machine when it waits for their totals
+    const bool writer = (DECIDE ? decider : slice == 0u) && t == 0u;          // the one thread that stores the proposal's scalar results
+    // (the deciding workgroup's other waves have nothing to do with the decision: no broadcast)
+#define EVAL_BCAST(F0, I0) do { if (multiWave && !DECIDE) { if (t == 0) { decf = (F0); deci = (I0); } cg_sync(); (F0) = decf; (I0) = deci; } } while (0)
+    if (DECIDE && vbid == 0u && t == 0u) S.gs->applyCount = qlen;      // what the next generator launch's update workgroups will find in S.dec (0: this launch found no queue)
     for (uint32_t q = qFirst; ; q += qStep) {
         // one trip: the record (slot q always exists: q < queueCap), the queue length, the annealing temperature
         const PropRec p = pNext;
@@ -483,7 +491,13 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
 #define EVAL_PREFETCH() do { if (PRE && jPre < (S.Npad >> 2)) { \
             pre.v1 = ld4(S.other + (size_t)p.c1 * S.Npad, jPre); pre.p1 = ld4(S.AP + (size_t)p.r1 * S.Npad, jPre); \
             if (two) { pre.v2 = ld4(S.other + (size_t)p.c2 * S.Npad, jPre); if (p.r1 != p.r2) pre.p2 = ld4(S.AP + (size_t)p.r2 * S.Npad, jPre); } } } while (0)
-        constexpr bool AHEAD = PHASE == EVAL_FUSED && SINGLE;       // (the batched fused kernel is at its register budget)
+        // the A*P update(s) an accepted step owes: carried out here -- or, in the one-launch split form, recorded for eval_apply_items
+        DecRec owe; owe.n = 0; owe.r1 = 0; owe.c1 = 0; owe.d1 = 0.f; owe.r2 = 0; owe.c2 = 0; owe.d2 = 0.f; owe.pad = 0;
+#define EVAL_UPD1(ROW, COL, DELTA) do { if (DECIDE) { owe.n = 1u; owe.r1 = (ROW); owe.c1 = (COL); owe.d1 = (DELTA); } \
+            else if (PRE) eval_update_pre1(S, (ROW), (COL), (DELTA), chunk0, stride, pre.v1, pre.p1); else eval_update_ap(S, (ROW), (COL), (DELTA), chunk0, stride); } while (0)
+#define EVAL_UPD2(R1, C1, D1, R2, C2, D2) do { if (DECIDE) { owe.n = 2u; owe.r1 = (R1); owe.c1 = (C1); owe.d1 = (D1); owe.r2 = (R2); owe.c2 = (C2); owe.d2 = (D2); } \
+            else if (PRE) eval_update_pre2(S, (R1), (C1), (D1), (R2), (C2), (D2), chunk0, stride, pre); else eval_update_ap2(S, (R1), (C1), (D1), (R2), (C2), (D2), chunk0, stride); } while (0)
+        constexpr bool AHEAD = (PHASE == EVAL_FUSED && SINGLE) || DECIDE;       // (the batched fused kernel is at its register budget)
         EvalSpec spec; spec.rng = rng; spec.mm = mm; spec.l1 = 0.f; spec.l2 = 0.f;
         spec.n = (AHEAD && scalarLane && need && (p.type == 'D' || p.type == 'M')) ? ((p.type == 'D' && gibbs1) ? 2u : 1u) : 0u;
         if (need) {
@@ -513,6 +527,32 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
                     tot[0] = t2[0]; tot[1] = t2[1];
                 }
                 if (PHASE == EVAL_ALPHA) { if (t == 0) { float *o = S.partials + (size_t)q * 64u + slice; o[0] = tot[0]; o[16] = tot[1]; o[32] = tot[2]; o[48] = tot[3]; } }
+                if (DECIDE && t < 64u) {
+                    // The slices' totals go to the proposal's deciding workgroup inside this launch: four {value, batch tag} granules per slice,
+                    // one write-through store each; the decider (wave 0: lane i holds element (component i / 16, slice i % 16), as the two-launch
+                    // form's record does) reads them past its caches until every tag is this batch's, then folds the slices in the same
+                    // ascending order (the top bits of the butterfly; slots past the last slice hold +0).
+                    unsigned long long *gr = S.grans + (size_t)q * 64u;
+                    if (!decider) {
+                        if (t < 4u) { const float v = t == 0u ? tot[0] : (t == 1u ? tot[1] : (t == 2u ? tot[2] : tot[3])); cg_store_agent_u64(&gr[slice * 4u + t], ((unsigned long long)first.tag << 32) | (unsigned long long)gm_f2u(v)); }
+                    } else {
+                        const uint32_t comp = t >> 4, sl = t & 15u;
+                        const bool want = sl + 1u < slices;
+                        unsigned long long g = 0ull; uint32_t spins = 0;
+                        for (;;) {
+                            if (want) g = cg_load_l2_u64(&gr[sl * 4u + comp]);
+                            const bool ok = !want || (uint32_t)(g >> 32) == first.tag;
+                            if (cg_ballot(!ok) == 0ull) break;
+                            if (++spins > (1u << 20)) { if (t == 0u) S.gs->error = GAPS_ERR_SPIN; break; }      // (bounded: a launch never hangs the GPU)
+                            cg_poll_pause();
+                        }
+                        const float own = comp == 0u ? tot[0] : (comp == 1u ? tot[1] : (comp == 2u ? tot[2] : tot[3]));
+                        float z = want ? gm_u2f((uint32_t)g) : (sl + 1u == slices ? own : 0.f);
+                        const uint32_t slots = S.redW / BS;
+                        for (uint32_t st = 1; st < slots; st <<= 1) z = z + cg_shfl_xor_f32(z, (int)st);
+                        tot[0] = cg_lane_read_f32(z, 0); tot[1] = cg_lane_read_f32(z, 16); tot[2] = cg_lane_read_f32(z, 32); tot[3] = cg_lane_read_f32(z, 48);
+                    }
+                }
             } else {
                 // fold the slices: the top bits of the butterfly (slots past the last slice hold +0, as the empty lanes
                 // do).  Wave 0 only: lane i holds element (component i / 16, slice i % 16) of the 64-float record.
@@ -528,8 +568,8 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
         }
         EVAL_PIN(s); EVAL_TS(3);
         if (PHASE == EVAL_FUSED) EVAL_PREFETCH();                    // (after the reduction: the registers are free again)
-        if (PHASE == EVAL_APPLY) ea = eval_atoms_load(S, p, writer);
-        if (PHASE == EVAL_ALPHA) { if (q + qStep >= qlen) break; { const uint32_t qn_ = q + qStep; pNext = hot.queue[qn_ < hot.queueCap ? qn_ : 0u]; } cg_sync(); continue; }
+        if (PHASE == EVAL_APPLY || DECIDE) ea = eval_atoms_load(S, p, writer);
+        if (PHASE == EVAL_ALPHA || (DECIDE && !decider)) { if (q + qStep >= qlen) break; { const uint32_t qn_ = q + qStep; pNext = hot.queue[qn_ < hot.queueCap ? qn_ : 0u]; } cg_sync(); continue; }
         s = s * T; smu = smu * T;
 #if defined(GEN_PROFILE)
         if (S.dbg & 8u) { if (q + qStep >= qlen) break; { const uint32_t qn_ = q + qStep; pNext = hot.queue[qn_ < hot.queueCap ? qn_ : 0u]; } cg_sync(); continue; }    // timing experiment: stop before the scalar step
@@ -545,7 +585,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
             EVAL_BCAST(bv, bhas);
             EVAL_TS(5);
             if (bhas != 0u && bv >= GAPS_EPSILON) {
-                if (PRE) eval_update_pre1(S, p.r1, p.c1, bv, chunk0, stride, pre.v1, pre.p1); else eval_update_ap(S, p.r1, p.c1, bv, chunk0, stride);
+                EVAL_UPD1(p.r1, p.c1, bv);
                 ++nUpd;                          // changeMatrix
                 if (writer) { atom_set_mass(S, p.h1, ea.a1.left, bv); eval_store_matrix(S, p.r1, p.c1, old1, old1 + bv); }
             } else if (writer) eval_cache_erase(S, p.h1, p.r1, p.c1);
@@ -561,7 +601,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
                     if (g.has) { rebirth = g.v; drew = true; }
                 }
                 const float deltaLL = rebirth * (smu - s * rebirth / 2.f);
-                const float logU = AHEAD ? (drew ? spec.l2 : spec.l1) : gm_logf_m(pcg_uniform(rng), mm);
+                const float logU = (AHEAD && need) ? (drew ? spec.l2 : spec.l1) : gm_logf_m(pcg_uniform(rng), mm);      // (need is always true here; a dev build that switches the reduction off -- dbg & 16 -- never ran the look-ahead)
                 acc = (logU < deltaLL) ? 1u : 0u;
             }
             EVAL_PIN(acc); EVAL_TS(4);
@@ -571,13 +611,13 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
             if (acc != 0u) {
                 if (rebirth != m1) {
                     const float nv = gm_max(old1 + (rebirth - m1), 0.f);            // safelyChangeMatrix
-                    if (PRE) eval_update_pre1(S, p.r1, p.c1, nv - old1, chunk0, stride, pre.v1, pre.p1); else eval_update_ap(S, p.r1, p.c1, nv - old1, chunk0, stride);
+                    EVAL_UPD1(p.r1, p.c1, nv - old1);
                     ++nUpd;
                     if (writer) { eval_store_matrix(S, p.r1, p.c1, old1, nv); atom_set_mass(S, p.h1, ea.a1.left, rebirth); }
                 }
             } else {
                 const float nv = gm_max(old1 + (-1.f * m1), 0.f);
-                if (PRE) eval_update_pre1(S, p.r1, p.c1, nv - old1, chunk0, stride, pre.v1, pre.p1); else eval_update_ap(S, p.r1, p.c1, nv - old1, chunk0, stride);
+                EVAL_UPD1(p.r1, p.c1, nv - old1);
                 ++nUpd;
                 if (writer) { eval_store_matrix(S, p.r1, p.c1, old1, nv); eval_cache_erase(S, p.h1, p.r1, p.c1); }
             }
@@ -585,13 +625,13 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
         } else if (p.type == 'M') {
             // ---------------------------------------------------------------- move (:184-196)
             uint32_t acc = 0; float unused = 0.f;
-            if (scalarLane) { const float deltaLL = -1.f * m1 * (smu + s * m1 / 2.f); const float logU = AHEAD ? spec.l1 : gm_logf_m(pcg_uniform(rng), mm); acc = (logU < deltaLL) ? 1u : 0u; }
+            if (scalarLane) { const float deltaLL = -1.f * m1 * (smu + s * m1 / 2.f); const float logU = (AHEAD && need) ? spec.l1 : gm_logf_m(pcg_uniform(rng), mm); acc = (logU < deltaLL) ? 1u : 0u; }
             EVAL_PIN(acc); EVAL_TS(4);
             EVAL_BCAST(unused, acc);
             EVAL_TS(5);
             if (acc) {
                 const float nv1 = gm_max(old1 + (-m1), 0.f);                    // safelyChangeMatrix(r1,c1,-m)
-                if (PRE) eval_update_pre2(S, p.r1, p.c1, nv1 - old1, p.r2, p.c2, m1, chunk0, stride, pre); else eval_update_ap2(S, p.r1, p.c1, nv1 - old1, p.r2, p.c2, m1, chunk0, stride);
+                EVAL_UPD2(p.r1, p.c1, nv1 - old1, p.r2, p.c2, m1);
                 nUpd += 2;      // ... then changeMatrix(r2,c2,+m); same thread owns the same elements
                 if (writer) {
                     eval_domain_move(S, p, ea.a1);
@@ -610,7 +650,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
             if (gh != 0u && n1 > GAPS_EPSILON && n2 > GAPS_EPSILON) {
                 const float nv1 = gm_max(old1 + (n1 - m1), 0.f);
                 const float nv2 = gm_max(old2 + (n2 - m2), 0.f);
-                if (PRE) eval_update_pre2(S, p.r1, p.c1, nv1 - old1, p.r2, p.c2, nv2 - old2, chunk0, stride, pre); else eval_update_ap2(S, p.r1, p.c1, nv1 - old1, p.r2, p.c2, nv2 - old2, chunk0, stride);
+                EVAL_UPD2(p.r1, p.c1, nv1 - old1, p.r2, p.c2, nv2 - old2);
                 nUpd += 2;
                 if (writer) {
                     eval_store_matrix(S, p.r1, p.c1, old1, nv1);
@@ -621,6 +661,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
         }
         EVAL_TS(6);
         EVAL_TS_DUMP(p.type | (nUpd << 8) | ((p.r1 == p.r2 ? 1u : 0u) << 16));
+        if (DECIDE && writer) S.dec[q] = owe;
         if (writer) {   // roofline bookkeeping: algorithmic traffic of this proposal in units of 4N bytes
             // (alpha: 4 one-site, 5 two-site same row, 8 different rows; 3 per AP update); the generator sums the slots
             uint32_t units = nUpd * 3u;
@@ -638,7 +679,7 @@ template <int PHASE>
 #ifndef EVAL_APPLY_WAVES
 #define EVAL_APPLY_WAVES 6       // 70 VGPRs, nothing spilled (8 waves: 64 VGPRs and 12-20 bytes of scratch per lane; split evaluation 10.85 -> 10.40 us)
 #endif
-CG_KERNEL void CG_LAUNCH_BOUNDS2((PHASE == EVAL_SEQ ? EVAL_SEQ_BS : 1024), (PHASE == EVAL_FUSED || PHASE == EVAL_SEQ ? 4 : (PHASE == EVAL_APPLY ? EVAL_APPLY_WAVES : 8))) eval_kernel(const PropRec *hotQueue, const GenScalars *hotGs, uint32_t hotCap, uint32_t slices, const SamplerDev CG_CONSTANT *sp)
+CG_KERNEL void CG_LAUNCH_BOUNDS2((PHASE == EVAL_SEQ ? EVAL_SEQ_BS : 1024), (PHASE == EVAL_FUSED || PHASE == EVAL_SEQ ? 4 : (PHASE == EVAL_APPLY || PHASE == EVAL_DECIDE ? EVAL_APPLY_WAVES : 8))) eval_kernel(const PropRec *hotQueue, const GenScalars *hotGs, uint32_t hotCap, uint32_t slices, const SamplerDev CG_CONSTANT *sp)
 {
     EvalHot hot; hot.queue = hotQueue; hot.gs = hotGs; hot.queueCap = hotCap;
     const EvalFirst first = eval_first<PHASE>(hot, slices, cg_bid());
@@ -662,4 +703,37 @@ CG_KERNEL void CG_LAUNCH_BOUNDS2(1024, (PHASE == EVAL_FUSED ? EVAL_MULTI_FUSED_W
     EvalHot hot; hot.queue = S.queue; hot.gs = S.gs; hot.queueCap = S.queueCap;
     const uint32_t vbid = cg_bid() - chain * wgPerChain;
     eval_body<PHASE, false>(S, slices, vbid, wgPerChain, hot, eval_first<PHASE>(hot, slices, vbid));
+}
+
+// ---- the one-launch split evaluation's A*P updates, beside the NEXT generator launch ------------------------------------------------
+// What eval_kernel<EVAL_DECIDE> recorded (S.dec[0 .. applyCount)) is carried out by the workgroups 1 .. of gen_apply_kernel while
+// workgroup 0 generates the next batch: the generator needs the decisions (atoms, matrix entries, erase cache: written by the deciding
+// workgroups) but never the A*P rows, and the next evaluation launch -- which does -- starts behind this launch's end.  One item = one
+// proposal x one of `parts` interleaved shares of its row(s); AP += delta * other, element by element, the same operations in the same
+// order as the two-launch form's apply kernel (a move's / exchange's second update continues from the first: eval_update_ap2).
+CG_DEVICE void eval_apply_items(const SamplerDev &S, const uint32_t wg, const uint32_t nwg)
+{
+    const uint32_t count = S.gs->applyCount;
+    const uint32_t TPB = cg_bdim(), nq = S.Npad >> 2;
+    uint32_t parts = (nq + 4u * TPB - 1u) / (4u * TPB);
+    parts = parts < 1u ? 1u : (parts > 64u ? 64u : parts);
+    for (uint32_t item = wg; item < count * parts; item += nwg) {
+        const uint32_t q = item / parts, part = item - q * parts;
+        const DecRec d = S.dec[q];
+        if (d.n == 1u) eval_update_ap(S, d.r1, d.c1, d.d1, part * TPB, TPB * parts);
+        else if (d.n == 2u) eval_update_ap2(S, d.r1, d.c1, d.d1, d.r2, d.c2, d.d2, part * TPB, TPB * parts);
+    }
+}
+// workgroup 0: the generator (gen_body, as gen_kernel); workgroups 1 .. : the previous batch's A*P updates
+template <int WIN>
+CG_KERNEL void CG_LAUNCH_BOUNDS(WIN + 64) gen_apply_kernel(const uint64_t *lcgMul, const uint64_t *lcgInc, GenScalars *gs, const unsigned long long *eraseList, const uint32_t *queueUnits,
+                                                          uint32_t eraseCap, uint32_t queueCap, const SamplerDev CG_CONSTANT *sp)
+{
+    if (cg_bid() != 0u) {
+        cg_const_warm<sizeof(SamplerDev)>(sp);
+        eval_apply_items(*(const SamplerDev *)sp, cg_bid() - 1u, cg_gdim() - 1u);
+        return;
+    }
+    GenHot hot; hot.lcgMul = lcgMul; hot.lcgInc = lcgInc; hot.gs = gs; hot.eraseList = eraseList; hot.queueUnits = queueUnits; hot.eraseCap = eraseCap; hot.queueCap = queueCap;
+    gen_body<WIN, true>(sp, hot);
 }

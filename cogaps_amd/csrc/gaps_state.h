@@ -47,6 +47,11 @@ struct alignas(16) PropRec {
     uint32_t pad[3];
 };
 
+// What the evaluation of one queued proposal decided about the A*P cache, for the launch that carries the updates out (split
+// evaluation, eval_kernel.h): n = 0 nothing (rejected, or accepted without a matrix change), 1: AP[:,r1] += d1 * other[:,c1],
+// 2: ... then AP[:,r2] += d2 * other[:,c2] (an accepted move / exchange; r1 == r2 allowed: the second continues from the first).
+struct alignas(16) DecRec { uint32_t n, r1, c1; float d1; uint32_t r2, c2; float d2; uint32_t pad; };
+
 // Mutable scalars of the proposal generator, one cache line region in HBM.
 struct GenScalars {
     uint64_t qrng;            // ProposalQueue::mRng state
@@ -70,7 +75,8 @@ struct GenScalars {
     float annealTemp;         // DenseNormalModel::mAnnealingTemp for this update (kernel parameters stay constant so that launches can be replayed from a graph)
     unsigned long long evalBytes;   // algorithmic HBM bytes of the evaluation kernel (roofline numerator)
     unsigned long long evalProps;   // proposals evaluated
-    uint32_t pad[2];
+    uint32_t applyCount;      // split evaluation: decision records (DecRec) the next generator launch's update workgroups have to carry out; written by every evaluation launch (0 when its queue was empty)
+    uint32_t pad;
     unsigned long long prof[16];    // GEN_PROFILE builds: cycles per generator phase
 };
 
@@ -108,7 +114,9 @@ struct SamplerDev {
     uint32_t eraseCap;
     // ---- ProposalQueue -------------------------------------------------------------------------
     PropRec *queue;    // [queueCap]
-    float *partials;      // [queueCap][4][16] per-slice alpha totals of the split evaluation (eval_kernel.h)
+    float *partials;      // [queueCap][4][16] per-slice alpha totals of the split evaluation (eval_kernel.h), batched two-launch form
+    unsigned long long *grans;   // [queueCap][16][4] the same totals as {value, batch tag} granules handed from the slices' workgroups to the proposal's deciding one inside ONE launch (one-chain form)
+    DecRec *dec;          // [queueCap] what each evaluated proposal does to the A*P cache (one-chain split form: carried out beside the next generator launch)
     uint32_t *queueUnits; // [queueCap] algorithmic traffic of each evaluated proposal, in units of 4N bytes
     uint32_t queueCap;
     const uint64_t *seeds;  // seeder outputs for this update(): candidate k of the update uses seeds[k]

@@ -40,6 +40,12 @@ __device__ unsigned long long g_timeline[(GEN_WIN / 64 + 1) * 64];
 #define GEN_TS_DUMP_WAVE() do { } while (0)
 #endif
 
+// dev: which launch the timeline keeps -- any well filled one, or (GEN_TIMELINE_ROUND2) one whose batch needed exactly two rounds
+#if defined(GEN_TIMELINE_ROUND2)
+#define GEN_TS_ROUND_OK(r) ((r) == 2u)
+#else
+#define GEN_TS_ROUND_OK(r) true
+#endif
 #define GEN_T_NONE 0
 #define GEN_F_INLINE 1u     // same-bin move / exchange: applied at populate time, not queued
 #define GEN_F_FAIL 2u       // genuine conflict or indeterminate B/D: the batch ends here
@@ -57,6 +63,13 @@ __device__ unsigned long long g_timeline[(GEN_WIN / 64 + 1) * 64];
 // (Both macros read the enclosing template's WIN.)
 #define GEN_TAB_BBITS (WIN <= 128 ? 9 : 10)
 #define GEN_TAB_NB (1 << GEN_TAB_BBITS)
+// Rounds of a batch that keep their conflict sets in the LDS table (the first always does; gen_populate.h).  Nothing is ever removed
+// from the table's keys, so a later round is admitted only while the keys of all admitted rounds (three registrations per lane and
+// round, a committed birth's atom) stay below ~70 % of the slots; the stamp tables in HBM serve the rounds after them.
+#ifndef GEN_LDS_ROUNDS_MAX
+#define GEN_LDS_ROUNDS_MAX 3       // (test variants of the emulator build lower it: 1 = every later round through the stamp tables, 2 = the hand-over after two LDS rounds)
+#endif
+#define GEN_LDS_ROUNDS ((10 * WIN) * 10 <= (4 * GEN_TAB_NB) * 7 ? GEN_LDS_ROUNDS_MAX : 1)
 #define GEN_K_ROW 0u
 #define GEN_K_ATOM 1u
 #define GEN_K_GAP 2u

@@ -147,7 +147,7 @@ CG_DEVICE void gen_helper(const SamplerDev &S, GenShared<WIN> &sh, GenScalars *g
     GEN_TS(2);
     for (uint32_t roundNo = 1; ; ++roundNo) {
         const bool first = roundNo == 1u;
-        const bool ldsRound = first;
+        const bool ldsRound = roundNo <= (uint32_t)GEN_LDS_ROUNDS;      // (as the attempt lanes decide it, gen_round)
         // ---- A1's three barriers (gen_count3 twice, then the sorted slots); round 1: the flush goes on between them
         // (the flush's steps are placed so that each takes about as long as what the attempt waves do meanwhile: the sort -- it waits
         // for the records -- while they draw and guess, the list surgery during the exact decision, the index replay during the type
@@ -222,7 +222,7 @@ CG_DEVICE void gen_helper(const SamplerDev &S, GenShared<WIN> &sh, GenScalars *g
             for (uint32_t w = ht; w < GEN_GS_WORDS; w += 64u)
                 if (w != GEN_GS_ERROR_WORD && !(frontPending && w == frontWord)) reinterpret_cast<uint32_t *>(gs)[w] = reinterpret_cast<const uint32_t *>(&sh.g)[w];
             GEN_TS(24);
-            { const bool ts_ok = e_prevQ >= 140u && remaining >= 512u; (void)ts_ok; GEN_TS_DUMP_WAVE(); }
+            { const bool ts_ok = e_prevQ >= 140u && remaining >= 512u && GEN_TS_ROUND_OK(roundNo); (void)ts_ok; GEN_TS_DUMP_WAVE(); }
             return;
         }
         // ---- another round of this batch: its set-up once every lane is done with this round's masks
@@ -470,7 +470,18 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
     // which must also see what earlier rounds of the batch committed, use the stamp tables in HBM.
     const bool live = go && !(flags & GEN_F_FAIL);
     const bool queuedM = live && type == 'M' && !(flags & GEN_F_INLINE);
-    const bool ldsRound = roundNo == 1u;
+    const bool ldsRound = FIRST || roundNo <= (uint32_t)GEN_LDS_ROUNDS;
+#if defined(COGAPS_EMUL)
+    // test-only build: how many later rounds went through the LDS table / the stamp tables (tests check that both paths were taken)
+    if (!FIRST && t == 0) cg_atomic_add_u64(&gs->prof[ldsRound ? 14 : 15], 1ull);
+#endif
+    // what an attempt registers under and compares with: its ordinal in the BATCH (window ordinal + attempts committed by earlier
+    // rounds).  Round 1: the window ordinal itself.  Entries earlier rounds left behind belong to committed attempts and are smaller
+    // than every ordinal of this window (the round's clean-up below removes everything else).
+    const uint32_t gord = processed + ct;
+    uint32_t rs0 = 0, rs1 = 0, rs2 = 0, rf0 = 0, rf1 = 0, rf2 = 0;      // the three (slot, field) registrations, for the clean-up
+    uint64_t d9 = 0, d10 = 0;       // later rounds, birth: the destinations of the neighbours' committed queued moves (mProposedMoves)
+    if (!FIRST && ldsRound && live && type == 'B') { d9 = (hl != CG_NONE) ? S.atomDest[hl] : 0ull; d10 = (hr != CG_NONE) ? S.atomDest[hr] : 0ull; }
     if (go) { sh.cpos[ct] = cpos; sh.pos[ct] = pos; sh.type[ct] = queuedM ? (uint8_t)'M' : (uint8_t)0; }
     if (live && ldsRound) {
         // up to three (key, field) registrations; an unused one repeats the first.  Predicates are 0/1 words
@@ -509,9 +520,10 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
         // every value word was set to "nobody" (all ones) at kernel entry by the helper wave, so the slot can be written at once:
         // the smallest registering ordinal wins, whoever opened the slot
         uint32_t *words = &sh.bval[0].used;       // word 0 = used, 1 = gap, 2 = inl
-        cg_atomic_min_u32(&words[4u * s0 + f0], ct);
-        cg_atomic_min_u32(&words[4u * s1 + f1], ct);
-        cg_atomic_min_u32(&words[4u * s2 + f2], ct);
+        cg_atomic_min_u32(&words[4u * s0 + f0], gord);
+        cg_atomic_min_u32(&words[4u * s1 + f1], gord);
+        cg_atomic_min_u32(&words[4u * s2 + f2], gord);
+        rs0 = s0; rs1 = s1; rs2 = s2; rf0 = f0; rf1 = f1; rf2 = f2;
     } else if (live) {
         // up to three keys: (kind, id)
         uint32_t rk[3], rid[3]; int nk = 0;
@@ -567,7 +579,7 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
         GenTabVal e[6];
         for (int k = 0; k < 6; ++k) e[k] = sh.bval[hit[k] ? sl[k] : 0u];
         // E(v) = 1 when an earlier attempt of this window registered under the word
-        #define GEN_E(k, w) (hit[k] & (uint32_t)(e[k].w < ct))
+        #define GEN_E(k, w) (hit[k] & (uint32_t)(e[k].w < gord))
         uint32_t fail = GEN_E(0, used) | GEN_E(1, used);                              // a row in use
         // move: a neighbour in use (mUsedAtoms), or a birth earlier in this window inside (left, right)
         fail |= tM & (GEN_E(2, used) | GEN_E(3, used) | GEN_E(2, gap) | GEN_E(4, gap));
@@ -586,12 +598,21 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
         if (tB) {
             // mProposedMoves.overlap(pos): a neighbour has a queued move whose interval covers pos
             const uint32_t uL = GEN_E(2, used), uR = GEN_E(3, used);
-            const uint32_t iL = uL ? e[2].used : 0u, iR = uR ? e[3].used : 0u;
+            // the registrant is an attempt of this window (its move, if it is one, sits in the window's arrays) or, in a later round,
+            // one an earlier round committed (a queued move left its destination in atomDest; the atom itself has not moved yet)
+            const uint32_t wL = uL & (uint32_t)(e[2].used >= processed), wR = uR & (uint32_t)(e[3].used >= processed);
+            const uint32_t iL = wL ? e[2].used - processed : 0u, iR = wR ? e[3].used - processed : 0u;
             const uint64_t aL = sh.cpos[iL], bL = sh.pos[iL], aR = sh.cpos[iR], bR = sh.pos[iR];
-            const uint32_t mL = uL & (uint32_t)(sh.type[iL] == 'M'), mR = uR & (uint32_t)(sh.type[iR] == 'M');
+            const uint32_t mL = wL & (uint32_t)(sh.type[iL] == 'M'), mR = wR & (uint32_t)(sh.type[iR] == 'M');
             const uint64_t loL = aL < bL ? aL : bL, hiL = aL < bL ? bL : aL, loR = aR < bR ? aR : bR, hiR = aR < bR ? bR : aR;
             fail |= mL & (uint32_t)(loL < pos) & (uint32_t)(pos < hiL);
             fail |= mR & (uint32_t)(loR < pos) & (uint32_t)(pos < hiR);
+            if (!FIRST) {
+                const uint32_t cL = uL & (wL ^ 1u) & (uint32_t)(d9 != 0ull), cR = uR & (wR ^ 1u) & (uint32_t)(d10 != 0ull);
+                const uint64_t loCL = lposB < d9 ? lposB : d9, hiCL = lposB < d9 ? d9 : lposB, loCR = rposB < d10 ? rposB : d10, hiCR = rposB < d10 ? d10 : rposB;
+                fail |= cL & (uint32_t)(loCL < pos) & (uint32_t)(pos < hiCL);
+                fail |= cR & (uint32_t)(loCR < pos) & (uint32_t)(pos < hiCR);
+            }
         }
         #undef GEN_E
         GEN_PIN(flags);
@@ -612,7 +633,7 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
         pk[7] = GEN_K_INL; pid[7] = tM ? hl : (tB ? hr : h2); pu[7] = (tM && hl != CG_NONE) || (tB && hr != CG_NONE) || tE;
         pk[8] = GEN_K_INL; pid[8] = hr; pu[8] = tM && hr != CG_NONE;
         pk[9] = GEN_K_GAP; pid[9] = keyL; pu[9] = tE && inl;       // same-bin exchange: a birth of this window left of the centre (see the LDS round)
-        int res[10]; uint32_t rix[10]; uint64_t d9 = 0, d10 = 0;
+        int res[10]; uint32_t rix[10];
         {
             unsigned long long v[10];
             for (int k = 0; k < 10; ++k) v[k] = cg_load_l2_u64(pu[k] ? gen_stamp_ptr(S, pk[k], pid[k]) : &S.gapStamp[0]);
@@ -732,8 +753,29 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
             }
         }
     }
+    if (!endB && ldsRound) {
+        // Another round of this batch follows and this one kept its conflict sets in the LDS table.  What the next round may find there
+        // is what the stamp tables would show it: rows and atoms in use by COMMITTED attempts (their ordinals are smaller than every
+        // ordinal of the next window) -- nothing of the attempts behind the cut, which are drawn again, and no gap / same-bin marks at
+        // all (the domain the next round reads already holds the committed births and same-bin moves).  A value word holds the smallest
+        // registrant, so whoever finds its own ordinal there empties the word; a committed attempt is smaller than every attempt behind
+        // the cut, so its "in use" word survives whoever else registered under it.
+        if (live) {
+            uint32_t *words = &sh.bval[0].used;
+            const bool behind = !(ct < stopT);
+            if (rf0 != 0u || behind) cg_atomic_cas_u32(&words[4u * rs0 + rf0], gord, GEN_TAB_EMPTY);
+            if (rf1 != 0u || behind) cg_atomic_cas_u32(&words[4u * rs1 + rf1], gord, GEN_TAB_EMPTY);
+            if (rf2 != 0u || behind) cg_atomic_cas_u32(&words[4u * rs2 + rf2], gord, GEN_TAB_EMPTY);
+        }
+        // a committed birth's atom is in use (mUsedAtoms.insert, ProposalQueue.cpp:183): inside its own window the gap mark says so,
+        // from the next round on the atom is an ordinary neighbour
+        if (commit && type == 'B' && roundNo + 1u <= (uint32_t)GEN_LDS_ROUNDS) {
+            const uint32_t sb = gen_tab_claim<WIN>(sh, h1);
+            cg_atomic_min_u32(&sh.bval[sb].used, gord);
+        }
+    }
     GEN_TS(21);
-    if (endB) { GEN_TS(22); { const bool ts_ok = c.e_prevQ >= 140u && c.remaining >= 512u; (void)ts_ok; GEN_TS_DUMP_WAVE(); } }
+    if (endB) { GEN_TS(22); { const bool ts_ok = c.e_prevQ >= 140u && c.remaining >= 512u && GEN_TS_ROUND_OK(roundNo); (void)ts_ok; GEN_TS_DUMP_WAVE(); } }
     return endB;
 }
 

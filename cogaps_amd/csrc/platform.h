@@ -137,6 +137,12 @@ CG_DEVICE unsigned long long cg_ballot(bool p) { return __ballot(p); }
 CG_DEVICE int cg_popc64(unsigned long long x) { return __popcll(x); }
 // loads of words that other waves of the workgroup update with L2 atomics: bypass the CU's L1
 CG_DEVICE unsigned long long cg_load_l2_u64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// A hand-off between workgroups INSIDE a launch (eval_kernel.h, split evaluation): one naturally aligned 8-byte {data, tag} granule,
+// written through to the device-coherent level by one store (agent scope: `sc1`), read with cg_load_l2_u64 past the reader's
+// non-coherent caches.  The tag says the data is this batch's, so no flag, counter, fence or ordering between two stores is needed
+// (MI355X_MICROARCH.md, persistent-kernel price list, handoff-1to1: ~0.8 us on an idle chip).
+CG_DEVICE void cg_store_agent_u64(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+CG_DEVICE void cg_poll_pause() { __builtin_amdgcn_s_sleep(1); }
 CG_DEVICE float cg_shfl_xor_f32(float v, int mask) { return __shfl_xor(v, mask, 64); }
 CG_DEVICE float cg_shfl_f32(float v, int lane) { return __shfl(v, lane, 64); }
 // the value lane `lane` holds (lane: the same in every lane of the wave) -- a lane read instead of an LDS-crossbar permute

@@ -10,10 +10,14 @@
 #include <string>
 #include <stdexcept>
 
+// device memory exhausted (hipErrorOutOfMemory): its own type, so that the C ABI can report it as a code (cogaps_last_error_code) and a
+// caller can retry with fewer sessions in flight without reading message texts
+struct rt_out_of_memory : std::runtime_error { explicit rt_out_of_memory(const std::string &m) : std::runtime_error(m) {} };
+
 #if defined(COGAPS_EMUL)
 
 typedef int rt_stream_t;
-inline void *rt_malloc(size_t n) { void *p = calloc(n ? n : 1, 1); if (!p) throw std::runtime_error("out of memory"); return p; }
+inline void *rt_malloc(size_t n) { void *p = calloc(n ? n : 1, 1); if (!p) throw rt_out_of_memory("out of memory"); return p; }
 struct rt_alloc_scope { explicit rt_alloc_scope(rt_stream_t) {} };
 inline void rt_free(void *p) { free(p); }
 inline void *rt_malloc_host(size_t n) { return rt_malloc(n); }
@@ -46,7 +50,8 @@ inline const char *rt_platform_name() { return "emulator (test only)"; }
 
 #else
 
-#define RT_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+#define RT_CHECK(expr) do { hipError_t e_ = (expr); if (e_ == hipErrorOutOfMemory) { (void)hipGetLastError(); throw rt_out_of_memory(std::string(#expr) + ": " + hipGetErrorString(e_)); } \
+    if (e_ != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 typedef hipStream_t rt_stream_t;
 // zero-filled device memory.  The fill runs on the stream the calling thread has announced (rt_alloc_scope: the session's
 // own stream) or, outside such a scope, on a temporary non-blocking stream, and is waited for: the legacy null stream is

@@ -18,9 +18,13 @@ random partition is not.  The reference's quirk that the shared factor comes bac
 (:236-237, src/GapsRunner.cpp:301-306) is reproduced in Pmean/Amean; the consensus actually used is
 returned under diagnostics["consensus"].
 """
+import os
+
 import numpy as np
 
 from . import _capi
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # see distributedCogaps
 
 
 # ------------------------------------------------------------------------------------------------
@@ -285,21 +289,33 @@ def _run_shards(spec, ids, in_flight, run_fn, shape_of=None):
                 # workgroup per chain, the latency-bound step) then runs under the other's evaluation launches.  Measured with the C3
                 # shape: 8 chains 21.2 -> 23.3 M proposals/s, 16 chains 29.0 -> 34.4 M, 32 chains 35.7 -> 44.0 M.
                 halves = [grp[0::2], grp[1::2]] if len(grp) >= 4 else [grp]
-                try:
-                    if len(halves) == 1:
-                        res = [batch(grp)]
-                    else:
-                        from concurrent.futures import ThreadPoolExecutor
-                        with ThreadPoolExecutor(max_workers=2) as pool:
-                            res = list(pool.map(batch, halves))
-                except RuntimeError as e:
-                    if "out of memory" in str(e).lower() and in_flight > 1:      # hipErrorOutOfMemory: the footprint estimate was too low
-                        in_flight = max(1, in_flight // 2)
-                        continue
-                    raise
+
+                def attempt(h):
+                    """a half's results, or the typed error that ended it (device memory: the footprint estimate was too low)"""
+                    try:
+                        return batch(h)
+                    except _capi.OutOfDeviceMemory as e:      # COGAPS_ERR_OUT_OF_DEVICE_MEMORY from the C ABI, not a message text
+                        return e
+                if len(halves) == 1:
+                    res = [attempt(grp)]
+                else:
+                    from concurrent.futures import ThreadPoolExecutor
+                    with ThreadPoolExecutor(max_workers=2) as pool:
+                        res = list(pool.map(attempt, halves))
+                failed = []
                 for h, rr in zip(halves, res):
-                    for i, r in zip(h, rr):
+                    if isinstance(rr, _capi.OutOfDeviceMemory):
+                        failed += h
+                        continue
+                    for i, r in zip(h, rr):       # a half that finished is kept whatever happened to the other
                         out[i] = r
+                if failed:
+                    if in_flight <= 1:
+                        raise next(rr for rr in res if isinstance(rr, _capi.OutOfDeviceMemory))
+                    in_flight = max(1, in_flight // 2)
+                    # only the shards of the half that failed are run again, with half as many in flight
+                    members = members[:g0] + failed + [i for i in members[g0 + len(grp):]]
+                    continue
                 g0 += len(grp)
         return out
     from concurrent.futures import ThreadPoolExecutor
@@ -357,6 +373,9 @@ class _Source:
 
 def distributedCogaps(data, params, uncertainty=None, messages=False, outputFrequency=1000, transposeData=False,
                       device=-1, run_fn=None, comm_device=None, shardsInFlight=16, nSnapshots=0, snapshotPhase="sampling", shape=None):
+    # RCCL between the ranks' processes needs dmabuf IPC on this driver; the variable is read when HIP initialises, so it is set here (and at
+    # import, below the imports) for callers whose launcher did not export it -- a process that initialised HIP earlier keeps what it had
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     run_fn = run_fn or _capi.run
     shardsInFlight = max(1, int(shardsInFlight))
     genome_wide = params.distributed == "genome-wide"

@@ -129,6 +129,10 @@ int cogaps_file_info(const char *path, uint32_t *nrow, uint32_t *ncol, char *row
                      char *colNames, size_t colCap, size_t *colNeeded);
 void cogaps_result_free(cogaps_result *r);
 const char *cogaps_last_error(void);
+/* What kind of failure the calling thread's last failing call was -- so that a caller can react to device memory running out (fewer
+ * sessions in flight) without reading message texts.  The reference has one failure path (GAPS_ERROR, utils/GapsAssert.h:19-25). */
+enum { COGAPS_OK = 0, COGAPS_ERR_GENERIC = 1, COGAPS_ERR_OUT_OF_DEVICE_MEMORY = 2, COGAPS_ERR_OUT_OF_HOST_MEMORY = 3 };
+int cogaps_last_error_code(void);
 
 /* the HIP device ordinal that is current for the calling host thread (what cogaps_params.device = -1 resolves to) */
 int cogaps_current_device(int *device);
@@ -138,6 +142,9 @@ int cogaps_device_memory(int device, uint64_t *freeBytes, uint64_t *totalBytes);
 
 /* the three trivial exports next to cogaps_cpp (src/Cogaps.cpp:217-246) */
 const char *cogaps_build_report(void);
+/* sha256 (first 16 hex digits) over the sources the library was built from, "unknown" for a build outside csrc/Makefile.  bench.py compares it
+ * with the hash recorded beside a committed counter measurement (profiles/r*_pmc_traffic.json) and marks the measurement stale when they differ. */
+const char *cogaps_source_hash(void);
 int cogaps_checkpoints_enabled(void);
 int cogaps_compiled_with_openmp(void);
 

@@ -61,6 +61,8 @@ inline unsigned long long cg_atomic_and_u64(unsigned long long *p, unsigned long
 inline unsigned long long cg_ballot(bool p) { return cgemu::wave_ballot(p); }
 inline int cg_popc64(unsigned long long x) { return __builtin_popcountll(x); }
 inline unsigned long long cg_load_l2_u64(const unsigned long long *p) { return *p; }
+inline void cg_store_agent_u64(unsigned long long *p, unsigned long long v) { *p = v; }
+inline void cg_poll_pause() {}
 inline float cg_shfl_xor_f32(float v, int mask) { return cgemu::wave_exchange_f32(v, mask); }
 inline float cg_wave_allsum_f32(float x) { for (int off = 1; off < 64; off <<= 1) x = x + cgemu::wave_exchange_f32(x, off); return x; }
 inline float cg_shfl_f32(float v, int lane) { return cgemu::wave_read_f32(v, lane); }

@@ -157,6 +157,58 @@ def test_world2_gloo_matches_single_process(tmp_path, emul_lib, gist):
     assert np.array_equal(o["Pmean"], a["u0"])
 
 
+WORKER_N = r'''
+import os, sys, ctypes, numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "oracle"))
+import torch.distributed as dist
+from cogaps_amd import _capi, CogapsParams
+from cogaps_amd.distributed import distributedCogaps
+import pyoracle as po
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=%(world)d)
+lib = _capi.bind(ctypes.CDLL(os.path.join(%(root)r, "tests", "emul", "libcogaps_emul_TESTONLY_w256.so")))
+data = po.read_mtx(os.path.join(%(root)r, "tests", "golden", "GIST.mtx"))[:%(rows)d]
+p = CogapsParams(nPatterns=2, seed=11, nIterations=40)
+p.distributed = "genome-wide"; p.setDistributedParams(nSets=%(nsets)d, minNS=2)
+p.explicitSets = [list(range(1 + k * %(per)d, 1 + (k + 1) * %(per)d)) for k in range(%(nsets)d)]
+run = lambda d, unc=None, **kw: _capi.run(d, unc=unc, lib=lib, **{k: v for k, v in kw.items() if k != "device"})
+out = distributedCogaps(data, p, run_fn=run, outputFrequency=20)
+np.savez(sys.argv[2], Amean=out["Amean"], Asd=out["Asd"], Pmean=out["Pmean"], consensus=out["consensus"], meanChiSq=out["meanChiSq"],
+         **{"u%%d" %% k: u for k, u in enumerate(out["unmatchedPatterns"])})
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world,nsets", [(8, 8), (3, 8)])
+def test_many_ranks_gloo_match_single_process(tmp_path, emul_lib, gist, world, nsets):
+    """the N > 1 path as the 8-GPU scaling run will drive it -- one subset per rank (world 8 / nSets 8) -- and with uneven ownership
+    (world 3 / nSets 8: ranks own 3, 3 and 2 subsets, the gather buffers carry padded slots): every rank's stitched result, consensus
+    and per-subset first-pass factors equal the single-process run bit for bit (reference flow: R/DistributedCogaps.R:57-97)"""
+    emul_lib(256)
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    per = 40
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER_N % {"root": ROOT, "port": port, "world": world, "nsets": nsets, "per": per, "rows": per * nsets})
+    outs = [str(tmp_path / ("r%d.npz" % r)) for r in range(world)]
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), outs[r]], env=env) for r in range(world)]
+    assert all(p.wait(timeout=900) == 0 for p in procs)
+    from cogaps_amd import _capi, CogapsParams
+    from cogaps_amd.distributed import distributedCogaps
+    lib = emul_lib(256)
+    p = CogapsParams(nPatterns=2, seed=11, nIterations=40)
+    p.distributed = "genome-wide"; p.setDistributedParams(nSets=nsets, minNS=2)
+    p.explicitSets = [list(range(1 + k * per, 1 + (k + 1) * per)) for k in range(nsets)]
+    run = lambda d, unc=None, **kw: _capi.run(d, unc=unc, lib=lib, **{k: v for k, v in kw.items() if k != "device"})
+    ref = distributedCogaps(gist[:per * nsets], p, run_fn=run, outputFrequency=20)
+    for r in range(world):
+        a = np.load(outs[r])
+        for k in ("Amean", "Asd", "Pmean", "consensus", "meanChiSq"):
+            assert np.array_equal(ref[k], a[k]), "rank %d: %s" % (r, k)
+        for k in range(nsets):
+            assert np.array_equal(ref["unmatchedPatterns"][k], a["u%d" % k]), "rank %d: first-pass factor of subset %d" % (r, k)
+
+
 def test_clustering_agrees_with_scipy_on_random_matrices():
     """the restated cluster::agnes(method = "complete") + stats::cutree against an independent implementation (scipy's
     linkage('complete') + cut_tree) on 240 random 1 - cor matrices: the same partition for every cut, labels numbered by first

@@ -19,6 +19,35 @@ def test_gist_stepwise(emul_lib, gist, win, n):
     pu.run_stepwise(emul_lib(win), gist, n, nPatterns=7, seed=42, total_iter=40)
 
 
+@pytest.mark.parametrize("lds_rounds", [3, 2, 1])
+def test_batches_of_several_rounds_use_the_lds_table_then_the_stamp_tables(emul_lib, lds_rounds):
+    """a batch that outlives its window goes on in further rounds: the first GEN_LDS_ROUNDS keep the conflict sets in the LDS table (carried
+    over; the marks of the attempts behind a cut and all gap / same-bin marks removed, committed births' atoms added), later ones use the stamp
+    tables in HBM.  The product build admits three LDS rounds, after which further rounds are rare; the variants with two and one keep the
+    hand-over to the stamp tables and the stamp-table rounds themselves under test (round counts from the test-only build's counters).
+    2000 rows at a 64-attempt window (batches of ~56 attempts with a long tail) and a 5 x 2 domain full of hazards, against the oracle."""
+    from cogaps_amd import _capi
+    lib = emul_lib(64) if lds_rounds == 3 else emul_lib(64, extra="-DGEN_LDS_ROUNDS_MAX=%d" % lds_rounds, tag="_lds%d" % lds_rounds)
+    data = pu.synthetic(2000, 10, seed=7)
+    tiny = pu.synthetic(5, 6, rank=2, seed=3)
+    pu.run_stepwise(lib, data, 24, nPatterns=3, seed=123, total_iter=40, check_every=4)
+    pu.run_stepwise(lib, tiny, 100, nPatterns=2, seed=9, total_iter=100)
+    n_lds = n_hbm = 0
+    for d, kw, n in ((data, dict(nPatterns=3, seed=123, nIterations=40), 24), (tiny, dict(nPatterns=2, seed=9, nIterations=100), 100)):
+        S = _capi.Session(d, lib=lib, **kw)
+        S.run_iterations(1, 0, n)
+        for w in "AP":
+            prof = S.debug_prof(w)
+            n_lds += prof[14]; n_hbm += prof[15]
+        S.close()
+    if lds_rounds == 1:
+        assert n_lds == 0 and n_hbm > 100, (n_lds, n_hbm)
+    elif lds_rounds == 2:
+        assert n_lds > 100 and n_hbm > 10, (n_lds, n_hbm)
+    else:
+        assert n_lds > 100, (n_lds, n_hbm)
+
+
 def test_tiny_domain_hazards(emul_lib):
     """5 rows x 2 patterns: every window is full of row conflicts, same-bin moves and neighbour hazards"""
     data = pu.synthetic(5, 6, rank=2, seed=3)
@@ -198,6 +227,20 @@ def test_batched_chains_equal_single_sessions(emul_lib, gist):
     check([gist[:150], gist[150:300]], [dict(seed=1), dict(seed=2)], nPatterns=3, nIterations=10, outputFrequency=5, whichMatrixFixed="P", fixedPatterns=fp)
     with pytest.raises(RuntimeError, match="launch shape"):
         _capi.run_batch([pu.synthetic(6000, 8), pu.synthetic(300, 8)], lib=lib, nPatterns=3, nIterations=4)
+    # dense subsets of 4095 and 4096 rows: one reduction width, one slice count -- and, for the dense kernels, nothing else to agree on (the
+    # sparse model's workgroup width differs, 64 vs 128, and used to be compared for every model: distributed.py groups such shards into one
+    # batch by the key _launch_shape computes, so the library must take them)
+    from cogaps_amd.distributed import _launch_shape
+    import cogaps_amd._capi as cc
+    orig = cc.load
+    cc.load = lambda: lib
+    try:
+        assert _launch_shape(4095, 6, False) == _launch_shape(4096, 6, False) and _launch_shape(4095, 6, True) != _launch_shape(4096, 6, True)
+    finally:
+        cc.load = orig
+    check([pu.synthetic(4095, 6, seed=3), pu.synthetic(4096, 6, seed=4)], [dict(seed=8), dict(seed=9)], nPatterns=2, nIterations=3, outputFrequency=3)
+    with pytest.raises(RuntimeError, match="launch shape"):
+        _capi.run_batch([pu.synthetic_counts(4095, 6, seed=3), pu.synthetic_counts(4096, 6, seed=4)], lib=lib, nPatterns=2, nIterations=3, sparseOptimization=True)
 
 
 def test_sparse_balanced_list_overflow(emul_lib):

@@ -455,14 +455,21 @@ def test_bench_multi_rank_path_on_one_gpu():
     env = dict(os.environ, COGAPS_BENCH_BACKEND="gloo")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "4",
-                          "--genes", "4000", "--samples", "400", "--patterns", "10"],
+                          "--genes", "4000", "--samples", "400", "--patterns", "10", "--cpu-seconds", "8"],
                          env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 12 and d["warmup"] == 4 and d["scaling"] == "weak" and d["unit"] == "proposals/s"
-    assert d["value"] > 0 and d["cpu_baseline"] is None and d["roofline"]["traffic"] is None
+    assert d["value"] > 0 and d["roofline"]["traffic"] is None          # (not the shape the counters were collected on)
+    # the N > 1 line carries the CPU comparator of BASELINE.md 3.5 (rank 0's shard through the port on the same window, x nSets, labelled), the
+    # spread of the ranks' timed regions and the library build the line was measured with
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] == 2 * cb["value_one_shard"] and "x nSets = 2" in cb["sample"] and cb["ten_x_line"] == 10 * cb["value"]
+    rs = d["config"]["rank_seconds"]
+    assert 0 < rs["min"] <= rs["median"] <= rs["max"] and abs(rs["max"] * 1e3 / 12 - d["ms_per_step"]) < 1e-6 * d["ms_per_step"] + 1e-9
+    assert len(d["roofline"]["lib_source_hash"]) == 16
     assert d["config"]["proposals_timed"] > 0
 
 

@@ -13,7 +13,7 @@ def per_kernel(d, counter):
         for r in csv.DictReader(open(f)):
             if r['Counter_Name'] == counter:
                 name = r['Kernel_Name'].split('(')[0]
-                if 'gen_kernel<' in name: name = 'gen_kernel'          # (both window instantiations: one generator)
+                if 'gen_kernel<' in name or 'gen_apply_kernel<' in name: name = 'gen_kernel'          # (both window instantiations, with or without the update workgroups: one generator launch per batch)
                 rows[name].append((int(r['Dispatch_Id']), float(r['Counter_Value'])))
     for v in rows.values():
         v.sort()
@@ -23,11 +23,16 @@ def per_kernel(d, counter):
 fetch, write = per_kernel(sys.argv[1], 'FETCH_SIZE'), per_kernel(sys.argv[2], 'WRITE_SIZE')
 bench = json.load(open(sys.argv[3]))
 ks = bench['roofline']['kernels']        # [evaluation A, evaluation P, generator A, generator P, sync]
-want = {'eval_kernel<0>': ks[0]['launches'], 'eval_kernel<1>': ks[1]['launches'], 'eval_kernel<2>': ks[1]['launches'],
-        'gen_kernel': ks[2]['launches'] + ks[3]['launches']}
+want = {'eval_kernel<0>': ks[0]['launches'], 'eval_kernel<1>': ks[1]['launches'], 'eval_kernel<2>': ks[1]['launches'], 'eval_kernel<4>': ks[1]['launches'],
+        'gen_kernel': ks[2]['launches'] + ks[3]['launches']}      # (<1> + <2>: the two-launch split form of rounds 1-3; <4>: the one-launch form, whose updates are counted with the generator launch)
+if 'sparse' in ks[0]['kernel']:      # the sparse model: one evaluation kernel per sampler (the wide form where a vector has more flag words than word owners)
+    names = sorted({k for k in fetch if 'eval_sparse_kernel' in k})
+    want = {'gen_kernel': ks[2]['launches'] + ks[3]['launches']}
+    for k in names:
+        want[k] = 0       # all its launches that moved data
 out = {}
 for name, n in want.items():
-    fk = [k for k in fetch if name in k]; wk = [k for k in write if name in k]
+    fk = [k for k in fetch if (name == k or (name in k and 'sparse' not in name))]; wk = [k for k in write if (name == k or (name in k and 'sparse' not in name))]
     if not fk or not wk:
         continue
     f, w = fetch[fk[0]], write[wk[0]]
@@ -40,5 +45,7 @@ for name, n in want.items():
                  'all_launches_in_run': len(f)}
     print(name, out[name])
 json.dump({'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) -- COGAPS_NO_GRAPH=1 python bench.py --no-cpu', 'kernels': out,
+           # the build the counters were collected on (cogaps_source_hash) and the workload: bench.py quotes the figures only for this build and shape
+           'lib_source_hash': bench['roofline'].get('lib_source_hash'), 'workload': bench['config']['workload'],
            'bench_algorithmic_bytes_per_launch': {'eval_kernel<0>': ks[0]['bytes_per_launch'], 'eval_kernel<1>+<2>': ks[1]['bytes_per_launch'], 'path (per batch)': bench['roofline']['bytes_per_launch']}},
           open(sys.argv[4], 'w'), indent=1)
