@@ -455,7 +455,7 @@ static uint32_t apply_grid()
 #if defined(COGAPS_EMUL)
     static const uint32_t g = 5u;        // (test-only emulator: a workgroup is a set of fibers, few of them keep the tests quick; 5 does not divide the items evenly)
 #else
-    static const uint32_t g = getenv("COGAPS_APPLY_GRID") ? (uint32_t)atoi(getenv("COGAPS_APPLY_GRID")) : 255u;      // dev: A/B of the update workgroups' number
+    static const uint32_t g = getenv("COGAPS_APPLY_GRID") ? (uint32_t)atoi(getenv("COGAPS_APPLY_GRID")) : 127u;      // dev: A/B of the update workgroups' number
 #endif
     return g < 1u ? 1u : g;
 }

@@ -93,7 +93,7 @@ struct GenShared {
     uint32_t info[WIN];                  // per attempt: type | bBefore << 8
     uint16_t perm[WIN];                  // lane -> attempt after sorting attempts by type
     unsigned long long mq[WIN / 64], mb[WIN / 64], md[WIN / 64];   // committed attempts: queued / birth / death bit masks
-    uint32_t wtotA[3][WIN / 64], wtotB[3][WIN / 64];
+    uint32_t wtotA[3][WIN / 64], wtotB[3][WIN / 64], wtot4[4][WIN / 64];
     // flush: erase cache sorted by position (handles, links, vector indices, bins), the tail of the unsorted
     // vector and the net writes of the swap-with-last replay
     uint64_t fpos[FLUSH_MAX], flpos[FLUSH_MAX], frpos[FLUSH_MAX]; float frmass[FLUSH_MAX]; uint32_t fh[FLUSH_MAX], fl[FLUSH_MAX], fr[FLUSH_MAX], fidx[FLUSH_MAX], fbin[FLUSH_MAX], fhead[FLUSH_MAX], vt[FLUSH_MAX], lowSlot[FLUSH_MAX], lowH[FLUSH_MAX];
@@ -302,6 +302,24 @@ CG_DEVICE void gen_count3(uint32_t (*w)[WIN / 64], unsigned t, bool a, bool b, b
         const uint32_t before = k < wave ? 0xFFFFFFFFu : 0u;
         ea += xa & before; eb += xb & before; ec += xc & before;
         ta += xa; tb += xb; tc += xc;
+    }
+}
+
+// the same for four flags (the classification's one exchange: births, deaths, moves, exchanges of the window by their first guess)
+template <int WIN>
+CG_DEVICE void gen_count4(uint32_t (*w)[WIN / 64], unsigned t, bool a, bool b, bool c, bool d, uint32_t (&e)[4], uint32_t (&tot)[4])
+{
+    const unsigned lane = t & 63u, wave = t >> 6;
+    const unsigned long long m0 = cg_ballot(a), m1 = cg_ballot(b), m2 = cg_ballot(c), m3 = cg_ballot(d);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    if (lane == 0) { w[0][wave] = (uint32_t)cg_popc64(m0); w[1][wave] = (uint32_t)cg_popc64(m1); w[2][wave] = (uint32_t)cg_popc64(m2); w[3][wave] = (uint32_t)cg_popc64(m3); }
+    cg_sync_lds();
+    e[0] = (uint32_t)cg_popc64(m0 & lt); e[1] = (uint32_t)cg_popc64(m1 & lt); e[2] = (uint32_t)cg_popc64(m2 & lt); e[3] = (uint32_t)cg_popc64(m3 & lt);
+    tot[0] = tot[1] = tot[2] = tot[3] = 0;
+    for (unsigned k = 0; k < (unsigned)(WIN / 64); ++k) {
+        const uint32_t before = k < wave ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) { const uint32_t x = w[f][k]; e[f] += x & before; tot[f] += x; }
     }
 }
 

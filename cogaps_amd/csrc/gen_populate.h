@@ -148,15 +148,12 @@ CG_DEVICE void gen_helper(const SamplerDev &S, GenShared<WIN> &sh, GenScalars *g
     for (uint32_t roundNo = 1; ; ++roundNo) {
         const bool first = roundNo == 1u;
         const bool ldsRound = roundNo <= (uint32_t)GEN_LDS_ROUNDS;      // (as the attempt lanes decide it, gen_round)
-        // ---- A1's three barriers (gen_count3 twice, then the sorted slots); round 1: the flush goes on between them
-        // (the flush's steps are placed so that each takes about as long as what the attempt waves do meanwhile: the sort -- it waits
-        // for the records -- while they draw and guess, the list surgery during the exact decision, the index replay during the type
-        // sort, the write-back during the first stage of A2)
+        // ---- A1's two barriers (the classification's one count exchange, then the sorted slots); round 1: the flush goes on between them
+        // (the sort -- it waits for the records -- while the attempt waves draw and guess; the list surgery and the index replay during
+        // the type sort; the write-back during the first stage of A2)
         if (first) gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 0);
         cg_sync_lds();
-        if (first) gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 1);
-        cg_sync_lds();
-        if (first) gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 2);
+        if (first) { gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 1); gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 2); }
         cg_sync_lds();
         if (first) { gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 3); GEN_TS(3); cg_sync(); }      // the join: the flush's stores are acknowledged (vmcnt(0)) before any lane reads the domain
         // ---- B1 / B2 barriers
@@ -261,6 +258,7 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
     const uint32_t winN = left_ < (uint32_t)WIN ? left_ : (uint32_t)WIN;
 
     // ------------------------------------------------------------------ A1 (lane = attempt): (u1,u2), B/D/M/E
+    uint32_t bBeforeA1 = 0, dBeforeA1 = 0, guessA1 = 0, activeA1 = 0; float u1A1 = 0.f, u2A1 = 0.f;      // the lane's OWN attempt, for its exact decision below
     {
         // (0/1 words and selects instead of short-circuit logic: with one wave per SIMD a branch costs more
         // than the arithmetic it would skip)
@@ -277,28 +275,25 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
         GEN_TS(5);
         sh.u1[t] = u1; sh.u2[t] = u2;
         if (first) { sh.dpHi[t] = c.tabHi; sh.dpLo[t] = c.tabLo; }      // read after the barrier inside the count (later rounds: gen_body)
-        uint32_t bBefore, dBefore, e3, tB, tD, t3;
-        gen_count3<WIN>(sh.wtotA, t, guess == 'B', guess == 'D', false, bBefore, dBefore, e3, tB, tD, t3);
+        // ONE exchange for the whole classification (round 4; two until then): how many births / deaths / moves / exchanges -- by the first
+        // guess -- precede this attempt.  The counts give the attempt's sorted slot (births+deaths | moves | exchanges: a wave runs one
+        // code path) at once; the EXACT birth / death decision, which needs the birth / death counts, no longer stands between the two
+        // counts: it is made by the attempt's own lane further down, under the draws' first memory trip (gen_a1_exact), and only feeds the
+        // stop key.  An attempt whose exact decision will differ from its guess (a hazard: the window is cut there) is sorted and drawn like
+        // the others -- it and everything behind it is never committed, and what it registers is only ever compared by later attempts.
+        uint32_t eX[4], tX[4];
+        gen_count4<WIN>(sh.wtot4, t, guess == 'B', guess == 'D', guess == 'M', guess == 'E', eX, tX);
         GEN_TS(6);
-        // the exact B/D/indeterminate decision depends on how many births / deaths precede this attempt
-        const uint32_t exact = gen_decide(u1, u2, (uint64_t)minR - dBefore, (uint64_t)nR + bBefore, sh.dpLo[dBefore], sh.dpHi[bBefore]);
-        const uint32_t hazA = active & (uint32_t)(exact != guess);
-        const uint32_t failA = active & (hazA ^ 1u) & (uint32_t)(guess == GEN_T_NONE);   // indeterminate: batch ends, no seed used
-        uint32_t aflags = hazA ? GEN_F_HAZARD : (failA ? GEN_F_FAIL : 0u);
-        if (aflags) cg_atomic_min_u32(&sh.stopKey, 2u * t + (hazA ^ 1u));
-        GEN_PIN(aflags);
-        GEN_TS(7);
-        // sort the attempts that go on by code path: births+deaths | moves | exchanges
-        const uint32_t go = active & (uint32_t)(aflags == 0u);
-        const uint32_t k0 = go & ((uint32_t)(guess == 'B') | (uint32_t)(guess == 'D')), k1 = go & (uint32_t)(guess == 'M'), k2 = go & (uint32_t)(guess == 'E');
-        uint32_t e0, e1, e2, T0, T1, T2;
-        gen_count3<WIN>(sh.wtotB, t, k0 != 0u, k1 != 0u, k2 != 0u, e0, e1, e2, T0, T1, T2);
+        bBeforeA1 = eX[0]; dBeforeA1 = eX[1]; u1A1 = u1; u2A1 = u2; guessA1 = guess; activeA1 = active;
+        const uint32_t go = (uint32_t)(guess != GEN_T_NONE);
+        const uint32_t k0 = (uint32_t)(guess == 'B') | (uint32_t)(guess == 'D'), k1 = (uint32_t)(guess == 'M');
+        const uint32_t T0 = tX[0] + tX[1], T1 = tX[2], T2 = tX[3];
         if (go) {
-            uint32_t slot = T0 + T1 + e2;
-            slot = k1 ? T0 + e1 : slot;
-            slot = k0 ? e0 : slot;
+            uint32_t slot = T0 + T1 + eX[3];
+            slot = k1 ? T0 + eX[2] : slot;
+            slot = k0 ? eX[0] + eX[1] : slot;
             sh.perm[slot] = (uint16_t)t;
-            sh.info[t] = guess | (bBefore << 8);
+            sh.info[t] = guess | (eX[0] << 8);
             sh.seed[t] = mySeed;                                     // consumed after the type sort
         }
         GEN_TS(8);
@@ -347,6 +342,15 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
 #if defined(GEN_SUBMARKS)
     if (v1 == 12345678u || w0 == 0x123456789ull) flags |= 0x80000000u;
 #endif
+    {   // the exact B/D/indeterminate decision of this lane's own attempt (ProposalQueue.cpp:129-160 with the atom bounds as the births /
+        // deaths before it leave them), while the trip above is on its way: a guess that does not hold is a hazard (the window is cut
+        // there and redrawn with exact bounds), an indeterminate attempt ends the batch -- the smallest such attempt is the stop key
+        const uint32_t exact = gen_decide(u1A1, u2A1, (uint64_t)minR - dBeforeA1, (uint64_t)nR + bBeforeA1, sh.dpLo[dBeforeA1], sh.dpHi[bBeforeA1]);
+        const uint32_t hazA = activeA1 & (uint32_t)(exact != guessA1);
+        const uint32_t failA = activeA1 & (hazA ^ 1u) & (uint32_t)(guessA1 == GEN_T_NONE);   // indeterminate: batch ends, no seed used
+        if (hazA | failA) cg_atomic_min_u32(&sh.stopKey, 2u * t + (hazA ^ 1u));
+        GEN_TS(7);
+    }
     GEN_PIN(v1); GEN_PIN(w0);
     GEN_TS(11);
     // stage 2 ---------------------------------------------------------------------------------
