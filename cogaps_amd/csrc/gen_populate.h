@@ -337,7 +337,11 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
     if (FIRST) cg_sync();
     GEN_TS(25);
     uint32_t v1 = CG_NONE;
-    if (isB) w0 = S.bits0[bin >> 6];
+    // (the word after the bin's own travels in the same trip: when the rest of the bin's word is empty -- one birth in twenty-five at the
+    // headline shape's occupancy -- the successor bin is nearly always in the next 64, and the full search through the bitmap's upper
+    // levels, half a dozen dependent trips that the whole wave waits for, stays for the domain's sparse stretches)
+    unsigned long long w0n = 0ull;
+    if (isB) { w0 = S.bits0[bin >> 6]; w0n = ((bin >> 6) + 1u < S.nWords0) ? S.bits0[(bin >> 6) + 1u] : 0ull; }
     if (pick) v1 = S.vec[i1];
 #if defined(GEN_SUBMARKS)
     if (v1 == 12345678u || w0 == 0x123456789ull) flags |= 0x80000000u;
@@ -361,7 +365,7 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
         else {
             flags |= GEN_F_BINEMPTY; if (w0 == 0ull) flags |= GEN_F_WORDZERO;
             const unsigned long long m = (bit == 63u) ? 0ull : (w0 & ~((2ull << bit) - 1ull));
-            if (m) headBin = (bin & ~63u) + (uint32_t)cg_ctz64(m); else slowB = true;
+            if (m) headBin = (bin & ~63u) + (uint32_t)cg_ctz64(m); else if (w0n) headBin = (bin & ~63u) + 64u + (uint32_t)cg_ctz64(w0n); else slowB = true;
         }
     }
     uint32_t v2 = CG_NONE; AtomRec a; a.pos = 0; a.lpos = 0; a.rpos = 0; a.left = CG_NONE; a.right = CG_NONE; a.mass = 0.f; a.rmass = 0.f; a.idx = 0;
@@ -577,8 +581,32 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
             hit[k] = use[k] & found;
             over |= use[k] & (found ^ 1u) & (hole ^ 1u);             // the key may have spilled into the next bucket
         }
-        if (over) {                                                   // rare
-            for (int k = 0; k < 6; ++k) if (use[k]) { const uint32_t f = gen_tab_find<WIN>(sh, key[k]); hit[k] = f != GEN_TAB_EMPTY; sl[k] = hit[k] ? f : 0u; }
+        if (over) {
+            // Rare per key (a full bucket that does not hold it: 0.3 % of the lookups) but not per launch: with ~200 lookups per wave half
+            // of the waves meet one, and the barrier behind this phase waits for the slowest wave.  So the spill is followed ONE bucket
+            // on for exactly the keys that need it, all of them at once (the probe order of gen_tab_claim: the same start slot, next
+            // bucket); only a key that finds a second full bucket without itself takes the serial search.
+            uint32_t need[6], over2 = 0; GenTabKeys kq2[6];
+            for (int k = 0; k < 6; ++k) {
+                const uint32_t *q4 = kq[k].k;
+                const uint32_t found = (uint32_t)(q4[0] == key[k]) | (uint32_t)(q4[1] == key[k]) | (uint32_t)(q4[2] == key[k]) | (uint32_t)(q4[3] == key[k]);
+                const uint32_t hole = (uint32_t)(q4[0] == GEN_TAB_EMPTY) | (uint32_t)(q4[1] == GEN_TAB_EMPTY) | (uint32_t)(q4[2] == GEN_TAB_EMPTY) | (uint32_t)(q4[3] == GEN_TAB_EMPTY);
+                need[k] = use[k] & (found ^ 1u) & (hole ^ 1u);
+                kq2[k] = *(const GenTabKeys *)&sh.bkey[4u * ((bk[k] + 1u) & (uint32_t)(GEN_TAB_NB - 1))];
+            }
+            for (int k = 0; k < 6; ++k) {
+                const uint32_t *q4 = kq2[k].k;
+                const uint32_t e1 = q4[1] == key[k], e2 = q4[2] == key[k], e3 = q4[3] == key[k];
+                const uint32_t found = (uint32_t)(q4[0] == key[k]) | e1 | e2 | e3;
+                const uint32_t hole = (uint32_t)(q4[0] == GEN_TAB_EMPTY) | (uint32_t)(q4[1] == GEN_TAB_EMPTY) | (uint32_t)(q4[2] == GEN_TAB_EMPTY) | (uint32_t)(q4[3] == GEN_TAB_EMPTY);
+                const uint32_t s2 = 4u * ((bk[k] + 1u) & (uint32_t)(GEN_TAB_NB - 1)) + e1 + 2u * e2 + 3u * e3;
+                sl[k] = need[k] ? s2 : sl[k];
+                hit[k] = need[k] ? found : hit[k];
+                over2 |= need[k] & (found ^ 1u) & (hole ^ 1u);
+            }
+            if (over2) {                                              // two full buckets in a row: the serial search
+                for (int k = 0; k < 6; ++k) if (use[k]) { const uint32_t f = gen_tab_find<WIN>(sh, key[k]); hit[k] = f != GEN_TAB_EMPTY; sl[k] = hit[k] ? f : 0u; }
+            }
         }
         GenTabVal e[6];
         for (int k = 0; k < 6; ++k) e[k] = sh.bval[hit[k] ? sl[k] : 0u];

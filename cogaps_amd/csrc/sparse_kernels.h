@@ -883,6 +883,61 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(1024) chisq_sparse_kernel(SamplerDev S, float *p
     if (t == 0) partial[row] = tot[0];
 }
 
+// The same for SP_CHI_ROWS vectors per workgroup (nPatterns <= 64): a row of the other matrix, once in registers, serves all of them.  The
+// one-vector kernel re-reads the whole other matrix (N x K floats) for every vector -- 125 GB at BASELINE configs[4]'s shard shape
+// (12500 vectors of 50000 elements, K = 50), 13.4 ms per call; eight vectors per workgroup read an eighth of that.  Every vector's sum is
+// the one the kernel above computes: the same virtual lane takes the same elements in the same order, the same dot products, the same
+// butterfly -- the vectors of a workgroup only share the loads.
+#define SP_CHI_ROWS 8
+template <int V>
+CG_KERNEL void CG_LAUNCH_BOUNDS(1024) chisq_sparse_tiled_kernel(SamplerDev S, float *partial)
+{
+    constexpr int R = SP_CHI_ROWS;
+    CG_SHARED float lds[R][16 * V];
+    CG_SHARED float arow[R][64];
+    const uint32_t row0 = cg_bid() * (uint32_t)R, t = cg_tid(), BS = cg_bdim(), W = (uint32_t)V * BS, nq = S.Npad >> 2, K = S.K;
+    const uint32_t nr = (S.M - row0) < (uint32_t)R ? (S.M - row0) : (uint32_t)R;
+    for (uint32_t k = t; k < (uint32_t)R * 64u; k += BS) { const uint32_t r = k >> 6, c = k & 63u; arow[r][c] = (r < nr && c < K) ? S.rows[(size_t)(row0 + r) * S.Kpad + c] : 0.f; }
+    cg_sync();
+    float tot[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) tot[r] = 0.f;
+    for (int j = 0; j < V; ++j) {
+        float acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = 0.f;
+        for (uint32_t c = (uint32_t)j * BS + t; c < nq; c += W) {
+            for (uint32_t e = 0; e < 4u; ++e) {
+                const uint32_t i = 4u * c + e;
+                if (i < S.N) {
+                    SpRow O; sp_row_load(O, S.orows + (size_t)i * S.oKpad, K);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        if ((uint32_t)r < nr) {
+                            const float dot = sp_row_dot(arow[r], O, K);
+                            acc[r] = acc[r] + dot * dot;
+                            const unsigned long long fl = S.dflags[(size_t)(row0 + r) * S.Wn + (i >> 6)];
+                            if ((fl >> (i & 63u)) & 1ull) {
+                                const float d = S.dvals[S.dptr[row0 + r] + S.dprefix[(size_t)(row0 + r) * S.Wn + (i >> 6)] + (uint32_t)cg_popc64(fl & ((1ull << (i & 63u)) - 1ull))];
+                                const float dsq = d * d;
+                                acc[r] = acc[r] + (1 + dot * (dot - 2 * d - dsq * dot) / dsq);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) { float t1[1] = {tot[r]}; eval_vpark<V>(acc[r], j, lds[r], t1); tot[r] = t1[0]; }
+    }
+    if (BS > 64u) {
+        cg_sync();
+#pragma unroll
+        for (int r = 0; r < R; ++r) { float t1[1] = {0.f}; eval_vfinish<1, V>(lds[r], t1); tot[r] = t1[0]; }
+    }
+    if (t == 0) { for (uint32_t r = 0; r < nr; ++r) partial[row0 + r] = tot[r]; }
+}
+
 // ---- verification mode: the same three in the reference's order (aux_kernels.h: seq_sum) ---------------------------------
 // generateLookupTables: Z1 front to back; Z2 through gaps::dot, i.e. back to front for vectors of at most 25 elements
 CG_KERNEL void CG_LAUNCH_BOUNDS(256) sparse_tables_seq_kernel(SamplerDev S)

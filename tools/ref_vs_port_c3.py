@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--iterations", type=int, default=100)
     ap.add_argument("--threads", default="8,1")
     ap.add_argument("--one-thread-iterations", type=int, default=30, help="iterations (per phase) of the one-thread leg: the whole run takes an hour on one core")
+    ap.add_argument("--port-first", action="store_true", help="run the port before the reference build (the host is shared: a second pass in the other order shows how much of a difference is drift)")
     ap.add_argument("--genes", type=int, default=20000)
     ap.add_argument("--samples", type=int, default=2000)
     a = ap.parse_args()
@@ -54,14 +55,23 @@ def main():
         for thr in [int(x) for x in a.threads.split(",")]:
             it = a.iterations if thr > 1 else min(a.iterations, a.one_thread_iterations)
             out_freq = max(1, it // 10)
-            ref = rp.run(binary, path, nPatterns=50, nIterations=it, seed=42, outFreq=out_freq, threads=thr)
-            sys.stderr.write("reference build, %d threads, %d + %d iterations: %.1f s\n" % (thr, it, it, ref["samplerSeconds"]))
-            o = po.run(data, omp=thr > 1, nPatterns=50, nIterations=it, seed=42, outputFrequency=out_freq, maxThreads=thr)
-            sys.stderr.write("port, %d threads: %.1f s\n" % (thr, o["samplerSeconds"]))
+            def run_ref():
+                r = rp.run(binary, path, nPatterns=50, nIterations=it, seed=42, outFreq=out_freq, threads=thr)
+                sys.stderr.write("reference build, %d threads, %d + %d iterations: %.1f s\n" % (thr, it, it, r["samplerSeconds"]))
+                return r
+
+            def run_port():
+                r = po.run(data, omp=thr > 1, nPatterns=50, nIterations=it, seed=42, outputFrequency=out_freq, maxThreads=thr)
+                sys.stderr.write("port, %d threads: %.1f s\n" % (thr, r["samplerSeconds"]))
+                return r
+            if a.port_first:
+                o = run_port(); ref = run_ref()
+            else:
+                ref = run_ref(); o = run_port()
             same = (ref["atomsA"].tolist() == o["atomsA"].tolist() and ref["atomsP"].tolist() == o["atomsP"].tolist() and ref["totalUpdates"] == o["totalUpdates"]
                     and ref["meanChiSq"] == np.float32(o["meanChiSq"]) and ref["qA"] == np.float32(o["averageQueueLengthA"]) and ref["qP"] == np.float32(o["averageQueueLengthP"])
                     and all(ref["hashes"][n][0] == rp.fnv_matrix(o[n]) for n in ("Amean", "Asd", "Pmean", "Psd")))
-            legs.append(dict(threads=thr, iterations_per_phase=it, totalUpdates=ref["totalUpdates"], same_chain_bit_for_bit=bool(same),
+            legs.append(dict(threads=thr, order=("port, reference build" if a.port_first else "reference build, port"), iterations_per_phase=it, totalUpdates=ref["totalUpdates"], same_chain_bit_for_bit=bool(same),
                              reference_build_seconds=round(ref["samplerSeconds"], 2), port_seconds=round(o["samplerSeconds"], 2),
                              reference_build_proposals_per_s=round(ref["totalUpdates"] / ref["samplerSeconds"], 1), port_proposals_per_s=round(o["totalUpdates"] / o["samplerSeconds"], 1),
                              port_over_reference_build=round(ref["samplerSeconds"] / o["samplerSeconds"], 4),
