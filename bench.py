@@ -47,8 +47,9 @@ def cpu_baseline(data, params, budget_s, state, first_step, n_steps):
     port's session takes over the chain state the GPU had at the start of its timed window (atoms and factor matrices, copied out
     before the timed region; go_import_state rebuilds the A*P caches) and runs the window's iterations -- as many as fit the time
     budget -- with its own generators: the same populated chain, the same batch lengths, like for like in phase.  `"kind": "port"`:
-    only this repository reaches the GPU box, so the comparator is the port, not the reference binary; BASELINE.md records how the
-    two compare where both can run (the port is the faster one, i.e. the harder baseline).  A batch holds only ~50-160 proposals, so
+    only this repository reaches the GPU box, so the comparator is the port, not the reference binary; BASELINE.md section 4 records how the
+    two compare where both can run (configs[2] whole, build container: the same speed within +-25 % at 8 threads, the port 1.4x faster on one;
+    printed with the line as cpu_baseline.port_over_reference_build).  A batch holds only ~50-160 proposals, so
     threads beyond a handful only add fork/join cost: 8 and 16 threads share most of the budget, the nproc-thread run SURVEY.md
     section 8d asks for gets the rest and is cut into slices of an iteration so that it ends with its share (it never sets
     `value`); `value` is the best whole-iteration rate, every thread count's rate is listed in `by_threads`."""
@@ -115,13 +116,17 @@ def reference_translation():
     if not files:
         return None
     rec = json.load(open(files[-1]))
-    legs = {l["threads"]: l for l in rec["legs"]}
+    by_thr = {}
+    for l in rec["legs"]:
+        by_thr.setdefault(l["threads"], []).append(l["port_over_reference_build"])
     best = max(rec["legs"], key=lambda l: l["reference_build_proposals_per_s"])
     return {"source": os.path.relpath(files[-1], ROOT), "host": rec["host"], "workload": rec["workload"],
-            "port_over_reference_build": {str(t): l["port_over_reference_build"] for t, l in sorted(legs.items())},
+            # every pass that was made (the host is shared: passes in both orders), and their geometric mean
+            "port_over_reference_build": {str(t): {"passes": v, "geometric_mean": float(np.exp(np.mean(np.log(v))))} for t, v in sorted(by_thr.items())},
+            "judge_round3_same_container_8_threads": rec.get("judge_round3"),
             "reference_build_best_proposals_per_s_on_that_host": best["reference_build_proposals_per_s"], "reference_build_best_threads": best["threads"],
-            "note": "port_over_reference_build[t] = reference build's sampler seconds / port's, at t OpenMP threads, in the build container; "
-                    "> 1 means the port is the faster of the two there (the harder baseline)"}
+            "note": "port_over_reference_build = reference build's sampler seconds / port's at that many OpenMP threads, in the build container; "
+                    "> 1: the port is the faster of the two there.  The passes differ by more than the two programs do (shared host): read it as 'the same speed within +-25 %'"}
 
 
 def chains_main(args):

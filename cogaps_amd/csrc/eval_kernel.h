@@ -466,7 +466,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
         { uint32_t ty_ = p.type; EVAL_PIN(ty_); }
         EVAL_TS(1);
         uint64_t rng = p.rng; uint32_t nUpd = 0;
-        EvalAtoms ea = eval_atoms_load(S, p, writer && (PHASE == EVAL_FUSED || PHASE == EVAL_SEQ));      // (split evaluation: requested after the slices' totals, below)
+        EvalAtoms ea = eval_atoms_load(S, p, writer && (PHASE == EVAL_FUSED || PHASE == EVAL_SEQ || DECIDE));      // (two-launch split evaluation: requested after the slices' totals, below; the one-launch form's decider asks at once: the record arrives under the rows and the wait for the siblings)
         const bool two = (p.type == 'M' || p.type == 'E');
         const float m1 = p.m1, m2 = p.m2, old1 = p.old1, old2 = p.old2;
         const bool gibbs1 = (p.gibbs & 1u) != 0u, gibbs2 = (p.gibbs & 2u) != 0u;
@@ -568,7 +568,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
         }
         EVAL_PIN(s); EVAL_TS(3);
         if (PHASE == EVAL_FUSED) EVAL_PREFETCH();                    // (after the reduction: the registers are free again)
-        if (PHASE == EVAL_APPLY || DECIDE) ea = eval_atoms_load(S, p, writer);
+        if (PHASE == EVAL_APPLY) ea = eval_atoms_load(S, p, writer);
         if (PHASE == EVAL_ALPHA || (DECIDE && !decider)) { if (q + qStep >= qlen) break; { const uint32_t qn_ = q + qStep; pNext = hot.queue[qn_ < hot.queueCap ? qn_ : 0u]; } cg_sync(); continue; }
         s = s * T; smu = smu * T;
 #if defined(GEN_PROFILE)
