@@ -438,6 +438,12 @@ def main():
             kernel_line("gen_kernel" if fusedP else "gen_apply_kernel (workgroup 0: generator; the others: the previous batch's A*P updates)", "P", kt["P"]["genMs"], kt["P"]["timedBatches"], 0, kt["P"]["genTimed"]),
             kernel_line("sparse_tables_kernel (not timed)" if args.sparse else "transpose_kernel (sync)", "A+P", tot["syncMs"], tot["syncTimed"], tot["syncBytes"], tot["syncTimed"]),
         ]
+        for i_, fused_ in ((0, fusedA), (1, fusedP)):
+            if not fused_ and not args.sparse:
+                # one-launch split evaluation: the A*P updates this kernel's proposals owe (12N bytes each, counted in bytes_per_launch by
+                # SURVEY 8d's formula) are carried out by the update workgroups of the NEXT generator launch, whose time is in that line:
+                # this line's achieved / frac are an upper bound for the evaluation launch alone; the path figure is unaffected
+                kernels[i_]["note"] = "bytes_per_launch includes the A*P updates carried out inside the next gen_apply_kernel launch: achieved / frac overstate this launch alone"
         gen_ms = kt["A"]["genMs"] + kt["P"]["genMs"]
         ev_ms = kt["A"]["evalMs"] + kt["P"]["evalMs"]
         kernel_ms = gen_ms + ev_ms + tot["syncMs"]
