@@ -629,7 +629,7 @@ static float chisq_of(cogaps_session *s, HostSampler &h)
         rt_d2h(&c, h.partial, 4, s->stream); rt_sync(s->stream);
         return h.d.sparse ? c * h.d.beta : c;
     }
-    if (h.d.sparse && h.d.K <= 64u) LAUNCH_V(chisq_sparse_tiled_kernel, h.d.redW, (h.d.M + (uint32_t)SP_CHI_ROWS - 1u) / (uint32_t)SP_CHI_ROWS, s->stream, h.d, h.partial);      // eight vectors per workgroup share the other matrix's rows
+    if (h.d.sparse && h.d.K <= 64u) LAUNCH_V(chisq_sparse_tiled_kernel, h.d.redW, (h.d.M + (uint32_t)SP_CHI_ROWS - 1u) / (uint32_t)SP_CHI_ROWS, s->stream, h.d, h.partial);      // SP_CHI_ROWS vectors per workgroup share the other matrix's rows
     else if (h.d.sparse) LAUNCH_V(chisq_sparse_kernel, h.d.redW, h.d.M, s->stream, h.d, h.partial);
     else LAUNCH_V(chisq_rows_kernel_s, h.d.redW, h.d.M, s->stream, h.d, (const float *)h.Sraw, h.partial);
     std::vector<float> part(h.d.M);

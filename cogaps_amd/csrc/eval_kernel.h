@@ -466,7 +466,11 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
         { uint32_t ty_ = p.type; EVAL_PIN(ty_); }
         EVAL_TS(1);
         uint64_t rng = p.rng; uint32_t nUpd = 0;
-        EvalAtoms ea = eval_atoms_load(S, p, writer && (PHASE == EVAL_FUSED || PHASE == EVAL_SEQ));      // (split evaluation: requested after the slices' totals, below -- asked for at once by the one-launch form's decider it cost 0.6 us: 7.2 -> 7.8 us per launch, the rows' wait then includes it)
+#if defined(EVAL_ATOMS_LATE)
+        EvalAtoms ea = eval_atoms_load(S, p, writer && PHASE == EVAL_SEQ);      // dev A/B: the fused form asks for the writer's atom record behind the reduction (below), with the update's chunks
+#else
+        EvalAtoms ea = eval_atoms_load(S, p, writer && (PHASE == EVAL_FUSED || PHASE == EVAL_SEQ));
+#endif      // (split evaluation: requested after the slices' totals, below -- asked for at once by the one-launch form's decider it cost 0.6 us: 7.2 -> 7.8 us per launch, the rows' wait then includes it)
         bool eaLoaded = false;
         const bool two = (p.type == 'M' || p.type == 'E');
         const float m1 = p.m1, m2 = p.m2, old1 = p.old1, old2 = p.old2;
@@ -572,6 +576,9 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
         }
         EVAL_PIN(s); EVAL_TS(3);
         if (PHASE == EVAL_FUSED) EVAL_PREFETCH();                    // (after the reduction: the registers are free again)
+#if defined(EVAL_ATOMS_LATE)
+        if (PHASE == EVAL_FUSED) ea = eval_atoms_load(S, p, writer);
+#endif
         if (PHASE == EVAL_APPLY || (DECIDE && !eaLoaded)) ea = eval_atoms_load(S, p, writer);
         if (PHASE == EVAL_ALPHA || (DECIDE && !decider)) { if (q + qStep >= qlen) break; { const uint32_t qn_ = q + qStep; pNext = hot.queue[qn_ < hot.queueCap ? qn_ : 0u]; } cg_sync(); continue; }
         s = s * T; smu = smu * T;

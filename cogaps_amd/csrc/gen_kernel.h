@@ -98,6 +98,7 @@ struct GenShared {
     // vector and the net writes of the swap-with-last replay
     uint64_t fpos[FLUSH_MAX], flpos[FLUSH_MAX], frpos[FLUSH_MAX]; float frmass[FLUSH_MAX]; uint32_t fh[FLUSH_MAX], fl[FLUSH_MAX], fr[FLUSH_MAX], fidx[FLUSH_MAX], fbin[FLUSH_MAX], fhead[FLUSH_MAX], vt[FLUSH_MAX], lowSlot[FLUSH_MAX], lowH[FLUSH_MAX];
     uint32_t nLow, newFront, flushM, flushBase, unitSum, frontPending;
+    uint32_t freeTop[16];                // the free-handle stack's top entries as the launch found them (below what its own flush pushes): a committing birth's handle without a memory trip
 #if defined(GEN_TIMELINE)
     unsigned long long ts[(WIN / 64 + 1) * 64];
 #endif

@@ -26,11 +26,14 @@
 // indices held in LDS (no memory traffic), and only its net effect (<= m slots) is written back.
 // ht: helper lane 0..63.  The steps are separate functions because the caller interleaves them with the barriers it owes the
 // attempt waves; inside the one wave a step sees the previous step's LDS writes after cg_wave_sync().
-struct GenFlushRegs { uint32_t myH, myBin, myHead; AtomRec rec; uint32_t vtail; };
+struct GenFlushRegs { uint32_t myH, myBin, myHead; AtomRec rec; uint32_t vtail, freeTop; };
 // step 1: request the erased atoms' records, their bins' heads and the tail of the unsorted vector (no wait)
 template <int WIN>
-CG_DEVICE void gen_flush_fetch(const SamplerDev &S, GenFlushRegs &f, const unsigned ht, const uint32_t m, const uint32_t n, const unsigned long long specE)
+CG_DEVICE void gen_flush_fetch(const SamplerDev &S, GenFlushRegs &f, const unsigned ht, const uint32_t m, const uint32_t n, const unsigned long long specE, const uint32_t fc)
 {
+    // (the stack's top sixteen entries ride along: half of the launches commit a birth that pops below what the flush pushed, and its
+    // wave -- the launch's last phase -- waited a memory trip for the handle)
+    f.freeTop = (ht < 16u && ht < fc) ? S.freeHandles[fc - 1u - ht] : CG_NONE;
     f.myH = 0; f.myBin = 0; f.myHead = CG_NONE; f.vtail = CG_NONE;
     f.rec.pos = 0; f.rec.lpos = 0; f.rec.rpos = 0; f.rec.left = CG_NONE; f.rec.right = CG_NONE; f.rec.mass = 0.f; f.rec.rmass = 0.f; f.rec.idx = 0; f.rec.pad0 = 0;
     // (the bin travels with the handle in the erase cache: the bin's head is asked for in the same trip as the record)
@@ -132,7 +135,7 @@ CG_DEVICE void gen_helper(const SamplerDev &S, GenShared<WIN> &sh, GenScalars *g
     const unsigned t = (unsigned)WIN + ht;
     GEN_TS_INIT(); GEN_TS_RESUME(7);      // (marks 0, 0, 26-29, 1 were left by gen_body)
     GenFlushRegs fr;
-    gen_flush_fetch<WIN>(S, fr, ht, e_m, e_n, specE);          // the flush's one memory trip: under the attempt waves' A1
+    gen_flush_fetch<WIN>(S, fr, ht, e_m, e_n, specE, e_fc);          // the flush's one memory trip: under the attempt waves' A1
     const uint32_t n0 = e_n - e_m;                              // the domain holds this many atoms after the flush
     const uint64_t batchEpoch = sh.g.batchEpoch + 1;
     const uint32_t remaining = e_nSteps - e_nDone;
@@ -151,7 +154,7 @@ CG_DEVICE void gen_helper(const SamplerDev &S, GenShared<WIN> &sh, GenScalars *g
         // ---- A1's two barriers (the classification's one count exchange, then the sorted slots); round 1: the flush goes on between them
         // (the sort -- it waits for the records -- while the attempt waves draw and guess; the list surgery and the index replay during
         // the type sort; the write-back during the first stage of A2)
-        if (first) gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 0);
+        if (first) { gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 0); if (ht < 16u) sh.freeTop[ht] = fr.freeTop; }
         cg_sync_lds();
         if (first) { gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 1); gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 2); }
         cg_sync_lds();
@@ -743,7 +746,7 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
             const uint32_t fc = c_fc;
             // the top of the stack is what this launch's flush pushed, still in LDS
             uint32_t hb;
-            if (bRank < fc) { const uint32_t fi = fc - 1u - bRank; hb = (fi >= c_flushBase && fi - c_flushBase < c_flushM) ? sh.fh[fi - c_flushBase] : S.freeHandles[fi]; }
+            if (bRank < fc) { const uint32_t fi = fc - 1u - bRank; hb = (fi >= c_flushBase && fi - c_flushBase < c_flushM) ? sh.fh[fi - c_flushBase] : ((fi < c_flushBase && c_flushBase - 1u - fi < 16u) ? sh.freeTop[c_flushBase - 1u - fi] : S.freeHandles[fi]); }
             else hb = c_handleHi + (bRank - fc);
             const uint32_t idx = nR + bRank;
             if (hb >= S.atomCap || idx >= S.atomCap) { gs->error = GAPS_ERR_ATOM_CAP; hb = 0; }
@@ -881,7 +884,7 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
         cg_sync_lds();                          // (the unit sum is complete)
         if (!helper) return;
         GenFlushRegs fr;
-        gen_flush_fetch<WIN>(S, fr, ht, e_m, e_n, specE);
+        gen_flush_fetch<WIN>(S, fr, ht, e_m, e_n, specE, e_fc);
         if (ht == 0) { sh.flushM = 0; sh.flushBase = e_fc; sh.nLow = 0; }
         cg_wave_sync();
         for (int part = 0; part < 4; ++part) { gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, part); cg_wave_sync(); }

@@ -883,12 +883,12 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(1024) chisq_sparse_kernel(SamplerDev S, float *p
     if (t == 0) partial[row] = tot[0];
 }
 
-// The same for SP_CHI_ROWS vectors per workgroup (nPatterns <= 64): a row of the other matrix, once in registers, serves all of them.  The
+// The same for SP_CHI_ROWS vectors per workgroup (nPatterns <= 64: sixteen): a row of the other matrix, once in registers, serves all of them.  The
 // one-vector kernel re-reads the whole other matrix (N x K floats) for every vector -- 125 GB at BASELINE configs[4]'s shard shape
-// (12500 vectors of 50000 elements, K = 50), 13.4 ms per call; eight vectors per workgroup read an eighth of that.  Every vector's sum is
+// (12500 vectors of 50000 elements, K = 50), 13.4 ms per call; sixteen vectors per workgroup read a sixteenth of that.  Every vector's sum is
 // the one the kernel above computes: the same virtual lane takes the same elements in the same order, the same dot products, the same
 // butterfly -- the vectors of a workgroup only share the loads.
-#define SP_CHI_ROWS 8
+#define SP_CHI_ROWS 16
 template <int V>
 CG_KERNEL void CG_LAUNCH_BOUNDS(1024) chisq_sparse_tiled_kernel(SamplerDev S, float *partial)
 {

@@ -71,6 +71,17 @@ def test_split_evaluation(emul_lib, genes, iters):
     pu.run_stepwise(emul_lib(256), data, iters, trace=False, nPatterns=3, seed=7, total_iter=10)
 
 
+def test_two_launch_split_evaluation_still_matches(emul_lib):
+    """COGAPS_SPLIT_TWO_LAUNCHES=1 (the A/B switch of round 4) brings back the alpha + apply launches for one chain: the same bits as the
+    one-launch form, i.e. as the oracle (the variable is read once per process: a child process runs the comparison)"""
+    import os, subprocess, sys
+    emul_lib(256)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "dev_parity_synth.py"), "256", "6000", "8", "3", "6"],
+                         env=dict(os.environ, COGAPS_SPLIT_TWO_LAUNCHES="1"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().splitlines()[-1].startswith("OK 6000 8 3 6"), out.stdout[-500:] + out.stderr[-500:]
+
+
 @pytest.mark.parametrize("sparse,transpose,fixed,subset,k,with_unc", pu.option_cases()[1::3])
 def test_option_combinations_stepwise(emul_lib, sparse, transpose, fixed, subset, k, with_unc):
     """a third of the 36 option combinations the GPU suite runs (parity_util.option_cases), on the emulator"""
