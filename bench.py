@@ -424,6 +424,8 @@ def main():
         batches = kt["A"]["batches"] + kt["P"]["batches"]
         fusedA = args.sparse or S.dims("A")[1] <= 4096
         fusedP = args.sparse or S.dims("P")[1] <= 4096
+        chained = {w: S.chained(w) for w in "AP"}      # one launch per batch (csrc/chain_kernel.h): its time is the "evaluation" time, there is no generator launch
+        CHAIN_NAME = "chain_kernel (one launch: workgroups 0..n-2 evaluate batch n as eval_kernel<EVAL_FUSED> does, the last workgroup generates batch n+1)"
         ev_name = lambda fused: "eval_sparse_kernel" if args.sparse else ("eval_kernel<EVAL_FUSED>" if fused else "eval_kernel<EVAL_DECIDE> (split evaluation, one launch; its A*P updates run beside the next generator launch)")
 
         def kernel_line(name, sampler, ms, launches, nbytes, sampled):
@@ -432,12 +434,14 @@ def main():
             return {"kernel": name, "sampler": sampler, "launches": int(launches), "sampled_launches": int(sampled), "avg_launch_us": us, "total_ms": ms,
                     "bytes_per_launch": nbytes / launches if launches else 0.0, "achieved": ach, "frac": ach / HBM_PEAK_GBS}
         kernels = [
-            kernel_line(ev_name(fusedA), "A", kt["A"]["evalMs"], kt["A"]["timedBatches"], kt["A"]["evalBytes"], kt["A"]["evalTimed"]),
-            kernel_line(ev_name(fusedP), "P", kt["P"]["evalMs"], kt["P"]["timedBatches"], kt["P"]["evalBytes"], kt["P"]["evalTimed"]),
-            kernel_line("gen_kernel" if fusedA else "gen_apply_kernel (workgroup 0: generator; the others: the previous batch's A*P updates)", "A", kt["A"]["genMs"], kt["A"]["timedBatches"], 0, kt["A"]["genTimed"]),
-            kernel_line("gen_kernel" if fusedP else "gen_apply_kernel (workgroup 0: generator; the others: the previous batch's A*P updates)", "P", kt["P"]["genMs"], kt["P"]["timedBatches"], 0, kt["P"]["genTimed"]),
+            kernel_line(CHAIN_NAME if chained["A"] else ev_name(fusedA), "A", kt["A"]["evalMs"], kt["A"]["timedBatches"], kt["A"]["evalBytes"], kt["A"]["evalTimed"]),
+            kernel_line(CHAIN_NAME if chained["P"] else ev_name(fusedP), "P", kt["P"]["evalMs"], kt["P"]["timedBatches"], kt["P"]["evalBytes"], kt["P"]["evalTimed"]),
+            kernel_line("gen_kernel" if fusedA else "gen_apply_kernel (workgroup 0: generator; the others: the previous batch's A*P updates)", "A", kt["A"]["genMs"], 0 if chained["A"] else kt["A"]["timedBatches"], 0, kt["A"]["genTimed"]),
+            kernel_line("gen_kernel" if fusedP else "gen_apply_kernel (workgroup 0: generator; the others: the previous batch's A*P updates)", "P", kt["P"]["genMs"], 0 if chained["P"] else kt["P"]["timedBatches"], 0, kt["P"]["genTimed"]),
             kernel_line("sparse_tables_kernel (not timed)" if args.sparse else "transpose_kernel (sync)", "A+P", tot["syncMs"], tot["syncTimed"], tot["syncBytes"], tot["syncTimed"]),
         ]
+        for i_, w_ in ((2, "A"), (3, "P")):
+            if chained[w_]: kernels[i_]["kernel"] = "(none: the generator is the last workgroup of chain_kernel)"
         for i_, fused_ in ((0, fusedA), (1, fusedP)):
             if not fused_ and not args.sparse:
                 # one-launch split evaluation: the A*P updates this kernel's proposals owe (12N bytes each, counted in bytes_per_launch by

@@ -1,0 +1,52 @@
+// chain_kernel.h -- the chained launch: ONE launch per batch for a sampler whose evaluation is the fused form.
+//
+// AsynchronousGibbsSampler::update (AsynchronousGibbsSampler.h:88-122) alternates populate and the evaluation of the queue; as two
+// launches per batch (gen_kernel, eval_kernel<EVAL_FUSED>) every batch pays two kernel boundaries and the generator's prologue --
+// kernel arguments, the sampler's record, the PCG jump coefficients, 80 KB of conflict table to empty, the seeds and the
+// death-probability rows of its window -- between the last decision and the first attempt of the next batch.  Here workgroups
+// 0 .. gridDim-2 evaluate batch n exactly as eval_kernel<EVAL_FUSED> does, and the LAST workgroup is the generator of batch n + 1: it
+// runs its prologue and fetches everything the decisions will rewrite while the evaluation workgroups work, receives each decision as a
+// pair of tagged 8-byte granules (one write-through store each, polled past its caches: MI355X guide, handoff-1to1), carries the
+// decisions out on the atomic domain and the factor matrix itself (gen_populate.h, chain_apply) and goes straight into the
+// classification.  The evaluation workgroups write nothing but the granules and their A*P rows; the A*P updates run beside the
+// generator, off the decide -> generate chain.
+//
+// What an evaluation workgroup reads when it starts -- its queue record, the queue length, the batch tag -- exists in two copies, one
+// per launch PARITY (a kernel argument: consecutive launches alternate): a launch of parity p evaluates copy p and its generator writes
+// copy 1 - p, so nothing in a launch reads what the same launch writes, however late a workgroup starts.  The generator workgroup is
+// the last one so that every evaluation workgroup has been dispatched when it begins to wait (and so that the test-only emulator, which
+// runs workgroups in index order, never spins); the grid is kept at one workgroup per compute unit or less, all resident at once.
+// Bit-identical to the two-launch form: the same reductions, decisions and stores, and the erase cache's order does not matter (the
+// flush sorts it by position, ConcurrentAtomicDomain.cpp:71-79).
+#pragma once
+#include "eval_kernel.h"
+
+#define CHAIN_MAX_THREADS 512        // 8 waves of up to 256 VGPRs: one workgroup per compute unit, whichever role it plays
+#define CHAIN_EVAL_GRID 240u         // evaluation workgroups of a chained launch (+ the generator: 241 <= 256 compute units)
+
+#if defined(GEN_TIMELINE)
+// dev: one chained launch on the chip-wide 100 MHz clock -- per workgroup {entry, decision published, end}; the generator workgroup's marks in g_chain_gen
+__device__ unsigned long long g_chain_rt[256 * 4];
+#endif
+template <int WIN>
+CG_KERNEL void CG_LAUNCH_BOUNDS(CHAIN_MAX_THREADS) chain_kernel(const uint64_t *lcgMul, const uint64_t *lcgInc, GenScalars *gs, PropRec *queue, unsigned long long *grans, ChainSlot *slots,
+                                                                uint32_t queueCap, uint32_t parity, const SamplerDev CG_CONSTANT *sp)
+{
+    if (cg_bid() + 1u == cg_gdim()) {
+        if (cg_tid() >= (unsigned)WIN + 64u) return;      // (the launch's workgroups have the evaluation's size; whole waves leave)
+        GenHot hot; hot.lcgMul = lcgMul; hot.lcgInc = lcgInc; hot.gs = gs; hot.eraseList = nullptr; hot.queueUnits = nullptr; hot.eraseCap = 0; hot.queueCap = queueCap;
+        hot.queueRd = queue + (size_t)parity * queueCap; hot.queueWr = queue + (size_t)(1u - parity) * queueCap; hot.grans = grans; hot.slotWr = &slots[1u - parity];
+        gen_body<WIN, true, true>(sp, hot);
+        return;
+    }
+    EvalHot hot; hot.queue = queue + (size_t)parity * queueCap; hot.gs = gs; hot.queueCap = queueCap; hot.slot = &slots[parity]; hot.grans = grans;
+#if defined(GEN_TIMELINE)
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const EvalFirst first = eval_first<EVAL_CHAIN>(hot, 1u, cg_bid());
+    const SamplerDev &S = eval_record<EVAL_CHAIN>(sp);
+    eval_body<EVAL_CHAIN, true>(S, 1u, cg_bid(), cg_gdim() - 1u, hot, first);
+#if defined(GEN_TIMELINE)
+    if (cg_tid() == 0u && first.qlen >= 140u && gs->nSteps - gs->nDone >= 512u && cg_bid() < 255u) { g_chain_rt[cg_bid() * 4u] = rt0; g_chain_rt[cg_bid() * 4u + 2u] = __builtin_amdgcn_s_memrealtime(); g_chain_rt[cg_bid() * 4u + 3u] = first.qlen; }
+#endif
+}

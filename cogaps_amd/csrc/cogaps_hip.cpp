@@ -11,6 +11,7 @@
 #include "gen_kernel.h"
 #include "file_reader.h"
 #include "eval_kernel.h"
+#include "chain_kernel.h"
 #include "aux_kernels.h"
 #include "sparse_kernels.h"
 
@@ -176,6 +177,10 @@ struct HostSampler {
     float anneal = 1.f;           // annealing temperature of the next update
     rt_graph graph;               // GRAPH_PAIRS (generate, evaluate) pairs, replayed while the kernel parameters stay the same
     SamplerDev graphKey; bool graphValid = false;    // proposals per batch in the last update (chunk-size predictor)
+    // chained launch (chain_kernel.h): one launch per batch; consecutive launches alternate the parity they carry as a kernel argument, so
+    // a captured run of launches exists once per starting parity
+    bool chain = false; uint32_t chainParity = 0;
+    rt_graph chainGraph[2]; bool chainGraphValid[2] = {false, false};
     size_t traceCap = 0;
     char name = 'A';
     // perf accounting
@@ -208,6 +213,7 @@ struct cogaps_session {
     uint64_t totalUpdates = 0; double samplerSeconds = 0; double syncMs = 0; uint64_t syncTimed = 0, syncBytes = 0;
     bool timing = false; bool evInit = false;
     bool noGraph = getenv("COGAPS_NO_GRAPH") != nullptr;     // diagnostics: every launch as a plain call (counter collection tools)
+    bool noChain = getenv("COGAPS_NO_CHAIN") != nullptr;     // A/B and tests: two launches per batch (gen_kernel, eval_kernel<EVAL_FUSED>) where the chained launch would serve
     std::vector<rt_event_pair> evPool; std::vector<int> evKind; std::vector<HostSampler *> evOwner; std::vector<uint64_t> evOrd; size_t evUsed = 0;
     GenScalars *hGs = nullptr;    // pinned staging
 };
@@ -232,7 +238,7 @@ static void free_sampler(HostSampler &h)
     rt_free(d.seqScratch); rt_free((void *)d.deathProb);
     rt_free((void *)d.D); rt_free((void *)d.S2); rt_free(d.AP); rt_free(d.mat); rt_free(d.colPos);
     rt_free(d.atoms); rt_free(d.vec); rt_free(d.freeHandles); rt_free(d.binHead);
-    rt_free(d.bits0); rt_free(d.bits1); rt_free(d.bits2); rt_free(d.eraseList); rt_free(d.queue); rt_free(d.queueUnits); rt_free(d.partials); rt_free(d.grans); rt_free(d.dec);
+    rt_free(d.bits0); rt_free(d.bits1); rt_free(d.bits2); rt_free(d.eraseList); rt_free(d.queue); rt_free(d.queueUnits); rt_free(d.chainSlots); rt_free(d.partials); rt_free(d.grans); rt_free(d.dec);
     rt_free(d.rowStamp); rt_free(d.atomStamp); rt_free(d.gapStamp); rt_free(d.inlineStamp); rt_free(d.atomDest);
     rt_free(d.gs); rt_free(d.trace); rt_free(d.traceBatchNproc); rt_free(d.traceBatchQlen);
     rt_free(h.Sraw); rt_free(h.seeds); rt_free_host(h.hSeeds); rt_free(h.partial); rt_free(h.dRecord);
@@ -338,7 +344,7 @@ static void build_sampler(cogaps_session *s, HostSampler &h, char name, const fl
     d.nWords0 = (uint32_t)((nBins + 63) / 64); d.nWords1 = (d.nWords0 + 63) / 64; d.nWords2 = (d.nWords1 + 63) / 64;
     d.bits0 = dalloc<unsigned long long>(d.nWords0); d.bits1 = dalloc<unsigned long long>(d.nWords1); d.bits2 = dalloc<unsigned long long>(d.nWords2);
     d.queueCap = d.M + 8; d.eraseCap = d.queueCap;
-    d.eraseList = dalloc<unsigned long long>(d.eraseCap); d.queue = dalloc<PropRec>(d.queueCap); d.queueUnits = dalloc<uint32_t>(d.queueCap); d.partials = dalloc<float>((size_t)d.queueCap * 64); d.grans = dalloc<unsigned long long>((size_t)d.queueCap * 64); d.dec = dalloc<DecRec>(d.queueCap);
+    d.eraseList = dalloc<unsigned long long>(d.eraseCap); d.queue = dalloc<PropRec>((size_t)2 * d.queueCap); d.chainSlots = dalloc<ChainSlot>(2); d.queueUnits = dalloc<uint32_t>(d.queueCap); d.partials = dalloc<float>((size_t)d.queueCap * 64); d.grans = dalloc<unsigned long long>((size_t)d.queueCap * 64); d.dec = dalloc<DecRec>(d.queueCap);
     d.rowStamp = dalloc<unsigned long long>(d.M);
     d.atomStamp = dalloc<unsigned long long>(d.atomCap); d.gapStamp = dalloc<unsigned long long>((size_t)d.atomCap + 1);
     d.inlineStamp = dalloc<unsigned long long>(d.atomCap); d.atomDest = dalloc<uint64_t>(d.atomCap);
@@ -459,6 +465,19 @@ static uint32_t apply_grid()
 #endif
     return g < 1u ? 1u : g;
 }
+// The chained launch serves the one-chain fused evaluation (dense model, product arithmetic) whose workgroups are at least as large as
+// the generator's and small enough for the generator's register budget (chain_kernel.h); everything else keeps two launches per batch.
+static bool chain_eligible(const cogaps_session *s, const HostSampler &h);
+static void launch_chain(cogaps_session *s, HostSampler &h)
+{
+    const int slot = timing_slot(s, h, 1, h.evalLaunches);
+    const SamplerDev CG_CONSTANT *rec = (const SamplerDev CG_CONSTANT *)h.dRecord;
+    const uint32_t grid = std::min<uint32_t>(h.d.queueCap, CHAIN_EVAL_GRID) + 1u;
+    const uint32_t parity = h.chainParity; h.chainParity ^= 1u;
+    if (h.genWin == (uint32_t)GEN_WIN) LAUNCH_MAYBE_TIMED(slot, chain_kernel<GEN_WIN>, grid, h.d.redW, h.d.lcgMul, h.d.lcgInc, h.d.gs, h.d.queue, h.d.grans, h.d.chainSlots, h.d.queueCap, parity, rec);
+    else LAUNCH_MAYBE_TIMED(slot, chain_kernel<GEN_WIN_HALF>, grid, h.d.redW, h.d.lcgMul, h.d.lcgInc, h.d.gs, h.d.queue, h.d.grans, h.d.chainSlots, h.d.queueCap, parity, rec);
+    h.evalLaunches++;      // (one launch per batch: counted with the evaluation launches, as its time is)
+}
 static void launch_gen(cogaps_session *s, HostSampler &h)
 {
     const int slot = timing_slot(s, h, 0, h.genLaunches);
@@ -518,10 +537,42 @@ static void launch_eval(cogaps_session *s, HostSampler &h)
 // kernels take their whole state through SamplerDev (by value), so one graph serves until a pointer in it
 // changes (atom arrays regrown, seed buffer reallocated).
 static const uint32_t GRAPH_PAIRS = 64;
+static bool chain_eligible(const cogaps_session *s, const HostSampler &h)
+{
+    return !s->noChain && !h.d.seq && !h.d.sparse && h.d.redW <= (uint32_t)CHAIN_MAX_THREADS && h.d.redW >= h.genWin + 64u;
+}
+// one batch step: the chained launch, or a generator launch and an evaluation launch
+static void launch_pair(cogaps_session *s, HostSampler &h)
+{
+    if (h.chain) launch_chain(s, h); else { launch_gen(s, h); launch_eval(s, h); }
+}
+static void drop_graphs(HostSampler &h)
+{
+    if (h.graphValid) { rt_graph_destroy(h.graph); h.graphValid = false; }
+    for (int k = 0; k < 2; ++k) if (h.chainGraphValid[k]) { rt_graph_destroy(h.chainGraph[k]); h.chainGraphValid[k] = false; }
+}
+// the captured run of GRAPH_PAIRS batch steps that starts at the sampler's current parity (an even number of launches: the parity after
+// a replay is the parity before it)
+static rt_graph &ensure_chain_graph(cogaps_session *s, HostSampler &h)
+{
+    static_assert(GRAPH_PAIRS % 2u == 0u, "a replay must leave the parity as it found it");
+    if ((h.chainGraphValid[0] || h.chainGraphValid[1]) && memcmp(&h.graphKey, &h.d, sizeof(SamplerDev)) != 0) drop_graphs(h);
+    const uint32_t k = h.chainParity;
+    if (!h.chainGraphValid[k]) {
+        const bool timing = s->timing; s->timing = false;
+        const uint64_t g0 = h.genLaunches, e0 = h.evalLaunches;
+        rt_capture_begin(s->stream);
+        for (uint32_t b = 0; b < GRAPH_PAIRS; ++b) launch_chain(s, h);
+        rt_capture_end(s->stream, h.chainGraph[k]);
+        h.genLaunches = g0; h.evalLaunches = e0; s->timing = timing;
+        memcpy(&h.graphKey, &h.d, sizeof(SamplerDev)); h.chainGraphValid[k] = true;
+    }
+    return h.chainGraph[k];
+}
 static void ensure_graph(cogaps_session *s, HostSampler &h)
 {
     if (h.graphValid && memcmp(&h.graphKey, &h.d, sizeof(SamplerDev)) == 0) return;
-    if (h.graphValid) { rt_graph_destroy(h.graph); h.graphValid = false; }
+    drop_graphs(h);
     const bool timing = s->timing; s->timing = false;              // no event records inside a capture
     const uint64_t g0 = h.genLaunches, e0 = h.evalLaunches;
     rt_capture_begin(s->stream);
@@ -561,9 +612,12 @@ static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool t
     g.traceOn = trace ? 1u : 0u; g.traceCount = 0; g.traceCap = trace ? traceCap : 0; g.traceBatchCount = 0;
     *s->hGs = g;
     rt_h2d(d.gs, s->hGs, sizeof(GenScalars), s->stream);
+    const ChainSlot emptySlots[2] = {{0u, 0u}, {0u, 0u}};
+    rt_h2d(d.chainSlots, emptySlots, sizeof(emptySlots), s->stream);      // (chained launch: both parities start from an empty queue)
     rt_sync(s->stream);
     if (nSteps == 0) return 0;
     sync_record(s, h);
+    h.chain = chain_eligible(s, h);
     h.updLaunches = 0;
     // proposals per batch: the previous update of this sampler is the best predictor
     float avgq = h.stepsPerBatch > 1.f ? h.stepsPerBatch : (g.avgQueue > 1.f ? g.avgQueue : 1.f);
@@ -578,7 +632,7 @@ static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool t
         firstChunk = false;
         uint32_t plain = chunk;
         if (rt_graphs_supported() && !s->noGraph && !trace && plain >= GRAPH_PAIRS) {
-            ensure_graph(s, h);
+            if (!h.chain) ensure_graph(s, h);
             // HIP events cannot ride on replayed launches.  While timing is on, one replay of every chunk -- its position moves
             // through the chunk from update to update -- is issued as plain launches that carry events, so that the sample covers
             // the whole population of batches and not only the tail of each chunk (the remainder below).
@@ -586,11 +640,11 @@ static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool t
             const uint64_t rot = s->timing ? h.plainRotor++ : 0;                       // (every fourth chunk: the plain launches leave longer gaps than a replay)
             const uint32_t timedRep = (s->timing && (rot & 3u) == 0u) ? (uint32_t)(((rot >> 2) * 7u) % nRep) : 0xFFFFFFFFu;
             for (uint32_t r = 0; plain >= GRAPH_PAIRS; plain -= GRAPH_PAIRS, ++r) {
-                if (r == timedRep) { for (uint32_t b = 0; b < GRAPH_PAIRS; ++b) { launch_gen(s, h); launch_eval(s, h); h.updLaunches++; } continue; }
-                rt_graph_launch(h.graph, s->stream); h.genLaunches += GRAPH_PAIRS; h.evalLaunches += GRAPH_PAIRS; h.updLaunches += GRAPH_PAIRS;
+                if (r == timedRep) { for (uint32_t b = 0; b < GRAPH_PAIRS; ++b) { launch_pair(s, h); h.updLaunches++; } continue; }
+                rt_graph_launch(h.chain ? ensure_chain_graph(s, h) : h.graph, s->stream); if (!h.chain) h.genLaunches += GRAPH_PAIRS; h.evalLaunches += GRAPH_PAIRS; h.updLaunches += GRAPH_PAIRS;
             }
         }
-        for (uint32_t b = 0; b < plain; ++b) { launch_gen(s, h); launch_eval(s, h); h.updLaunches++; }
+        for (uint32_t b = 0; b < plain; ++b) { launch_pair(s, h); h.updLaunches++; }
         // while the GPU works: the seeds of the next update (the other sampler's, about one per atom it holds; Poisson spread + margin)
         if (!topped) { HostSampler &o = (&h == &s->A) ? s->P : s->A; seed_top_up(s, (size_t)std::max(o.nAtoms, 10u) + (size_t)(6.0 * sqrt((double)std::max(o.nAtoms, 10u))) + 64u); topped = true; }
         read_gs(s, h);
@@ -602,7 +656,7 @@ static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool t
     h.nAtoms = s->hGs->nAtoms; h.avgQueue = s->hGs->avgQueue; h.batches += s->hGs->nBatches;
     if (s->hGs->nBatches >= 8u) h.stepsPerBatch = (float)nSteps / (float)s->hGs->nBatches;
     const uint32_t win = gen_window_for(h.genWin, h.stepsPerBatch);
-    if (win != h.genWin) { h.genWin = win; if (h.graphValid) { rt_graph_destroy(h.graph); h.graphValid = false; } }      // (the captured launches carry the window)
+    if (win != h.genWin) { h.genWin = win; drop_graphs(h); }      // (the captured launches carry the window)
     return 0;
 }
 
@@ -819,6 +873,7 @@ void cogaps_session_destroy(cogaps_session *s)
 {
     if (!s) return;
     rt_graph_destroy(s->A.graph); rt_graph_destroy(s->P.graph);
+    for (int k = 0; k < 2; ++k) { rt_graph_destroy(s->A.chainGraph[k]); rt_graph_destroy(s->P.chainGraph[k]); }
     free_sampler(s->A); free_sampler(s->P);
     rt_free(s->dErf); rt_free(s->dErfinv); rt_free(s->dQgamma); rt_free(s->dLcgMul); rt_free(s->dLcgInc);
     rt_free(s->Asum); rt_free(s->Asq); rt_free(s->Psum); rt_free(s->Psq); rt_free(s->pump);
@@ -1159,8 +1214,7 @@ cogaps_batch *cogaps_batch_create(cogaps_session **sessions, uint32_t n)
         for (int w = 0; w < 2; ++w) { b->dev[w] = dalloc<SamplerDev>(n); b->host[w].resize(n); memset(b->host[w].data(), 0, sizeof(SamplerDev) * n); }
         for (cogaps_session *s : b->ss) rt_sync(s->stream);
         for (cogaps_session *s : b->ss) {      // from here on the sessions run on the batch's stream, one after the other (nothing below throws)
-            if (s->A.graphValid) { rt_graph_destroy(s->A.graph); s->A.graphValid = false; }
-            if (s->P.graphValid) { rt_graph_destroy(s->P.graph); s->P.graphValid = false; }
+            drop_graphs(s->A); drop_graphs(s->P);
             rt_stream_destroy(s->stream); s->stream = b->stream; s->ownsStream = false;
         }
         return b;
@@ -1424,6 +1478,11 @@ extern "C" int cogaps_debug_timeline(unsigned long long *out, int n)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * (size_t)n);
 }
+extern "C" int cogaps_debug_chain_timeline(unsigned long long *wgs, unsigned long long *gen)
+{
+    if (hipMemcpyFromSymbol(wgs, HIP_SYMBOL(g_chain_rt), sizeof(unsigned long long) * 1024) != hipSuccess) return 1;
+    return (int)hipMemcpyFromSymbol(gen, HIP_SYMBOL(g_chain_gen), sizeof(unsigned long long) * 8);
+}
 extern "C" int cogaps_debug_eval_timeline(unsigned long long *out, int n)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_eval_timeline), sizeof(unsigned long long) * (size_t)n);
@@ -1474,6 +1533,14 @@ int cogaps_session_perf_sampler(cogaps_session *s, char which, cogaps_perf *out)
     SESSION_TRY
     memset(out, 0, sizeof(*out));
     add_perf(s, &pick(s, which), out);
+    SESSION_END
+}
+
+int cogaps_session_chained(cogaps_session *s, char which, int *chained)
+{
+    SESSION_TRY
+    if (!chained) return fail("null argument");
+    *chained = pick(s, which).chain ? 1 : 0;
     SESSION_END
 }
 

@@ -42,11 +42,12 @@ struct EvalAcc { float s, m; };
 #define EVAL_MODE_SAME 2     // v = other[:,c1] - other[:,c2], one row (DenseNormalModel.cpp:200-212)
 
 #if defined(GEN_TIMELINE)
+extern __device__ unsigned long long g_chain_rt[256 * 4];      // (chain_kernel.h)
 // dev: timestamps of the first 16 workgroups of a launch (lane 0 of the first and of the last wave)
 __device__ unsigned long long g_eval_timeline[2 * 16 * 2 * 12];     // [narrow | wide workgroups]
 #define EVAL_TS(id) do { if ((t & 63u) == 0u && ets_n < 11u) { ets[ets_n++] = ((unsigned long long)cg_clock() << 8) | (unsigned long long)(id); } } while (0)
-#define EVAL_TS_DUMP(ty) do { const uint32_t lastW_ = (cg_bdim() - 1u) >> 6; if (cg_bid() < 16u && (t & 63u) == 0u && ((t >> 6) == 0u || (t >> 6) == lastW_) && qlen >= 40u) { \
-    unsigned long long *o_ = &g_eval_timeline[((PHASE != EVAL_FUSED ? 16u : 0u) * 2u + cg_bid() * 2u + ((t >> 6) ? 1u : 0u)) * 12u]; o_[0] = (unsigned long long)(ty); for (uint32_t i_ = 0; i_ < 11u; ++i_) o_[1 + i_] = i_ < ets_n ? ets[i_] : 0ull; } } while (0)
+#define EVAL_TS_DUMP(ty) do { const uint32_t lastW_ = (cg_bdim() - 1u) >> 6; if (cg_bid() < 16u && (t & 63u) == 0u && ((t >> 6) == 0u || (t >> 6) == lastW_) && qlen >= 40u && (PHASE != EVAL_CHAIN || (qlen >= 140u && hot.gs->nSteps - hot.gs->nDone >= 512u))) { \
+    unsigned long long *o_ = &g_eval_timeline[((PHASE != EVAL_FUSED && PHASE != EVAL_CHAIN ? 16u : 0u) * 2u + cg_bid() * 2u + ((t >> 6) ? 1u : 0u)) * 12u]; o_[0] = (unsigned long long)(ty); for (uint32_t i_ = 0; i_ < 11u; ++i_) o_[1 + i_] = i_ < ets_n ? ets[i_] : 0ull; } } while (0)
 #define EVAL_PIN(x) asm volatile("" : "+v"(x) :: "memory")
 #define EVAL_TS_PARAMS , unsigned long long (&ets)[11], uint32_t &ets_n
 #define EVAL_TS_ARGS , ets, ets_n
@@ -385,6 +386,8 @@ CG_DEVICE EvalAtoms eval_atoms_load(const SamplerDev &S, const PropRec &p, bool 
 #define EVAL_ALPHA 1     // split evaluation, first kernel: `slices` workgroups per proposal, per-slice alpha partials
 #define EVAL_APPLY 2     // split evaluation, second kernel: combine the partials, decide, update the slice
 #define EVAL_SEQ 3       // verification mode: one workgroup per proposal, sums in the reference's scalar order, session math mode
+#define EVAL_CHAIN 5     // the fused form inside the chained launch (chain_kernel.h): the decision goes to the next batch's generator workgroup of the SAME launch as
+                         // two tagged granules and that workgroup applies it to the domain and the matrix; this workgroup only updates its A*P row(s)
 #define EVAL_DECIDE 4    // split evaluation in ONE launch (one-chain form): the slices' workgroups hand their totals to the proposal's last slice
                          // workgroup, which decides and records what the A*P cache owes (DecRec); eval_apply_items carries that out beside the
                          // NEXT generator launch (gen_apply_kernel), off the generate -> decide -> generate chain
@@ -399,16 +402,17 @@ CG_DEVICE EvalAtoms eval_atoms_load(const SamplerDev &S, const PropRec &p, bool 
 // hot: the three values a workgroup's first memory trip needs, passed as leading scalar kernel arguments so that the dispatcher preloads
 // them into SGPRs (-amdgpu-kernarg-preload-count): the queue record is requested at once, the lines of the sampler's record come in
 // under the same trip (eval_first / eval_record).
-struct EvalHot { const PropRec *queue; const GenScalars *gs; uint32_t queueCap; };
+struct EvalHot { const PropRec *queue; const GenScalars *gs; uint32_t queueCap; const ChainSlot *slot; unsigned long long *grans; };      // slot, grans: chained launch only
 // The first memory trip of an evaluation workgroup: its first queue record, the queue length, the annealing temperature.  The
 // addresses need only `hot` and the workgroup index, so the one-chain kernels issue it before they have seen the sampler's record.
 struct EvalFirst { PropRec p; uint32_t qlen; float T; uint32_t tag; };      // tag: the batch's number (low word), what the in-launch hand-off marks its granules with
 template <int PHASE>
 CG_DEVICE EvalFirst eval_first(const EvalHot hot, uint32_t slices, uint32_t vbid)
 {
-    const uint32_t qFirst = (PHASE == EVAL_FUSED || PHASE == EVAL_SEQ) ? vbid : vbid / slices;
-    EvalFirst f; f.p = hot.queue[qFirst < hot.queueCap ? qFirst : 0u]; f.qlen = hot.gs->qlen; f.T = hot.gs->annealTemp;
-    f.tag = (PHASE == EVAL_DECIDE) ? (uint32_t)hot.gs->batchEpoch : 0u;
+    const uint32_t qFirst = (PHASE == EVAL_FUSED || PHASE == EVAL_SEQ || PHASE == EVAL_CHAIN) ? vbid : vbid / slices;
+    EvalFirst f; f.p = hot.queue[qFirst < hot.queueCap ? qFirst : 0u]; f.T = hot.gs->annealTemp;
+    if (PHASE == EVAL_CHAIN) { const ChainSlot cs = *hot.slot; f.qlen = cs.qlen; f.tag = cs.tag; }      // (this launch's parity: nothing in this launch writes it)
+    else { f.qlen = hot.gs->qlen; f.tag = (PHASE == EVAL_DECIDE) ? (uint32_t)hot.gs->batchEpoch : 0u; }
     return f;
 }
 // The one-chain kernels read the sampler's record through a pointer in the constant address space (scalar loads), requested behind
@@ -431,14 +435,16 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
 #if defined(GEN_TIMELINE)
     unsigned long long ets[11]; uint32_t ets_n = 0;
 #endif
-    const uint32_t qFirst = (PHASE == EVAL_FUSED || PHASE == EVAL_SEQ) ? vbid : vbid / slices;
+    constexpr bool CHAIN = PHASE == EVAL_CHAIN;
+    constexpr bool FUSEDF = PHASE == EVAL_FUSED || CHAIN;      // the fused form: one workgroup reduces, decides and updates
+    const uint32_t qFirst = (FUSEDF || PHASE == EVAL_SEQ) ? vbid : vbid / slices;
     PropRec pNext = first.p;
     const uint32_t qlen = first.qlen;
     const float T = first.T;
     CG_SHARED float lds[16 * 4];
     CG_SHARED float decf; CG_SHARED uint32_t deci;     // decision of wave 0, broadcast to the other waves
     CG_SHARED float seqTerm[PHASE == EVAL_SEQ ? 4 * 4 * EVAL_SEQ_BS : 1];
-    constexpr bool WHOLE = PHASE == EVAL_FUSED || PHASE == EVAL_SEQ;      // one workgroup owns the whole proposal
+    constexpr bool WHOLE = FUSEDF || PHASE == EVAL_SEQ;      // one workgroup owns the whole proposal
     const uint32_t mm = (PHASE == EVAL_SEQ) ? S.mathMode : GM_MATH_PORTABLE;
     const uint32_t t = cg_tid(), BS = cg_bdim();
 #if defined(GEN_PROFILE) && !defined(GEN_SUBMARKS) && !defined(GEN_ROUNDMARKS)
@@ -455,7 +461,17 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
     const uint32_t chunk0 = slice * BS, stride = WHOLE ? BS : S.redW;
     constexpr bool DECIDE = PHASE == EVAL_DECIDE;
     const bool decider = DECIDE && slice + 1u == slices;      // the proposal's last slice: it is dispatched last, so its siblings are on the machine when it waits for their totals
-    const bool writer = (DECIDE ? decider : slice == 0u) && t == 0u;          // the one thread that stores the proposal's scalar results
+    const bool writer = !CHAIN && (DECIDE ? decider : slice == 0u) && t == 0u;          // the one thread that stores the proposal's scalar results (chained launch: nobody here)
+    // chained launch: thread 0 hands the decision to the generator workgroup of this launch the moment it is made, before the broadcast
+    // and the A*P update -- {code | units << 8, tag} and {value, tag}, one write-through store each (gaps_state.h, CHAIN_*)
+#if defined(GEN_TIMELINE)
+#define EVAL_PUBLISH_RT() do { if (CHAIN && t == 0u && q < 255u && qlen >= 140u && hot.gs->nSteps - hot.gs->nDone >= 512u) g_chain_rt[q * 4u + 1u] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define EVAL_PUBLISH_RT() do { } while (0)
+#endif
+#define EVAL_PUBLISH(CODE, VAL, NUPD) do { EVAL_TS(7); EVAL_PUBLISH_RT(); if (CHAIN && t == 0u) { unsigned long long *gr_ = hot.grans + (size_t)q * 64u; const uint32_t units_ = (NUPD) * 3u + alphaUnits; \
+        cg_store_agent_u64(&gr_[0], ((unsigned long long)first.tag << 32) | (unsigned long long)((CODE) | (units_ << 8))); \
+        cg_store_agent_u64(&gr_[1], ((unsigned long long)first.tag << 32) | (unsigned long long)gm_f2u(VAL)); } } while (0)
     // (the deciding workgroup's other waves have nothing to do with the decision: no broadcast)
 #define EVAL_BCAST(F0, I0) do { if (multiWave && !DECIDE) { if (t == 0) { decf = (F0); deci = (I0); } cg_sync(); (F0) = decf; (I0) = deci; } } while (0)
     if (DECIDE && vbid == 0u && t == 0u) S.gs->applyCount = qlen;      // what the next generator launch's update workgroups will find in S.dec (0: this launch found no queue)
@@ -469,7 +485,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
 #if defined(EVAL_ATOMS_LATE)
         EvalAtoms ea = eval_atoms_load(S, p, writer && PHASE == EVAL_SEQ);      // dev A/B: the fused form asks for the writer's atom record behind the reduction (below), with the update's chunks
 #else
-        EvalAtoms ea = eval_atoms_load(S, p, writer && (PHASE == EVAL_FUSED || PHASE == EVAL_SEQ));
+        EvalAtoms ea = eval_atoms_load(S, p, writer && (PHASE == EVAL_FUSED || PHASE == EVAL_SEQ));      // (chained launch: writer is false, the generator fetches them)
 #endif      // (split evaluation: requested after the slices' totals, below -- asked for at once by the one-launch form's decider it cost 0.6 us: 7.2 -> 7.8 us per launch, the rows' wait then includes it)
         bool eaLoaded = false;
         const bool two = (p.type == 'M' || p.type == 'E');
@@ -487,10 +503,11 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
         if (S.dbg & 16u) need = false;     // timing experiment: no reduction at all
 #endif
         const bool diff = two && p.r1 != p.r2;
+        const uint32_t alphaUnits = need ? (!two ? 4u : (diff ? 8u : 5u)) : 0u;      // roofline bookkeeping, units of 4N bytes (below)
         float s = 0.f, smu = 0.f;          // un-annealed sums, valid in wave 0
         // the one-chain fused launch only: the batched one is throughput bound and at its register budget, and the split form's APPLY
         // launch got slower with it (10.3 -> 12 us: 80 KB rows fetched for every rejected proposal, registers at the launch bound)
-        constexpr bool PRE = PHASE == EVAL_FUSED && SINGLE;
+        constexpr bool PRE = FUSEDF && SINGLE;
         EvalPre pre; pre.v1 = f4_zero(); pre.p1 = f4_zero(); pre.v2 = f4_zero(); pre.p2 = f4_zero();
         const uint32_t jPre = chunk0 + t;
 #define EVAL_PREFETCH() do { if (PRE && jPre < (S.Npad >> 2)) { \
@@ -502,7 +519,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
             else if (PRE) eval_update_pre1(S, (ROW), (COL), (DELTA), chunk0, stride, pre.v1, pre.p1); else eval_update_ap(S, (ROW), (COL), (DELTA), chunk0, stride); } while (0)
 #define EVAL_UPD2(R1, C1, D1, R2, C2, D2) do { if (DECIDE) { owe.n = 2u; owe.r1 = (R1); owe.c1 = (C1); owe.d1 = (D1); owe.r2 = (R2); owe.c2 = (C2); owe.d2 = (D2); } \
             else if (PRE) eval_update_pre2(S, (R1), (C1), (D1), (R2), (C2), (D2), chunk0, stride, pre); else eval_update_ap2(S, (R1), (C1), (D1), (R2), (C2), (D2), chunk0, stride); } while (0)
-        constexpr bool AHEAD = (PHASE == EVAL_FUSED && SINGLE) || DECIDE;       // (the batched fused kernel is at its register budget)
+        constexpr bool AHEAD = (FUSEDF && SINGLE) || DECIDE;       // (the batched fused kernel is at its register budget)
         EvalSpec spec; spec.rng = rng; spec.mm = mm; spec.l1 = 0.f; spec.l2 = 0.f;
         spec.n = (AHEAD && scalarLane && need && (p.type == 'D' || p.type == 'M')) ? ((p.type == 'D' && gibbs1) ? 2u : 1u) : 0u;
         if (need) {
@@ -575,7 +592,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
             if (AHEAD && spec.n) eval_spec_run(spec);      // (a lane of wave 0 without a chunk: vectors shorter than 256 elements)
         }
         EVAL_PIN(s); EVAL_TS(3);
-        if (PHASE == EVAL_FUSED) EVAL_PREFETCH();                    // (after the reduction: the registers are free again)
+        if (FUSEDF) EVAL_PREFETCH();                    // (after the reduction: the registers are free again)
 #if defined(EVAL_ATOMS_LATE)
         if (PHASE == EVAL_FUSED) ea = eval_atoms_load(S, p, writer);
 #endif
@@ -591,6 +608,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
             if (scalarLane) {
                 if (gibbs1) { OptF g = gm_gibbs_mass(s, smu, 0.f, S.maxGibbsMass, rng, S.luts, true, lambda); bv = g.v; bhas = g.has ? 1u : 0u; }
                 else { bv = pcg_exponential(rng, lambda, mm); bhas = 1u; }
+                if (bhas != 0u && bv >= GAPS_EPSILON) EVAL_PUBLISH(CHAIN_APPLY, bv, 1u); else EVAL_PUBLISH(CHAIN_ERASE, 0.f, 0u);
             }
             EVAL_PIN(bv); EVAL_TS(4);
             EVAL_BCAST(bv, bhas);
@@ -614,6 +632,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
                 const float deltaLL = rebirth * (smu - s * rebirth / 2.f);
                 const float logU = (AHEAD && need) ? (drew ? spec.l2 : spec.l1) : gm_logf_m(pcg_uniform(rng), mm);      // (need is always true here; a dev build that switches the reduction off -- dbg & 16 -- never ran the look-ahead)
                 acc = (logU < deltaLL) ? 1u : 0u;
+                if (acc != 0u) { if (rebirth != m1) EVAL_PUBLISH(CHAIN_APPLY, rebirth, 1u); else EVAL_PUBLISH(CHAIN_NONE, 0.f, 0u); } else EVAL_PUBLISH(CHAIN_ERASE, 0.f, 1u);
             }
             EVAL_PIN(acc); EVAL_TS(4);
             EVAL_BCAST(rebirth, acc);
@@ -636,7 +655,8 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
         } else if (p.type == 'M') {
             // ---------------------------------------------------------------- move (:184-196)
             uint32_t acc = 0; float unused = 0.f;
-            if (scalarLane) { const float deltaLL = -1.f * m1 * (smu + s * m1 / 2.f); const float logU = (AHEAD && need) ? spec.l1 : gm_logf_m(pcg_uniform(rng), mm); acc = (logU < deltaLL) ? 1u : 0u; }
+            if (scalarLane) { const float deltaLL = -1.f * m1 * (smu + s * m1 / 2.f); const float logU = (AHEAD && need) ? spec.l1 : gm_logf_m(pcg_uniform(rng), mm); acc = (logU < deltaLL) ? 1u : 0u;
+                              if (acc) EVAL_PUBLISH(CHAIN_APPLY, 0.f, 2u); else EVAL_PUBLISH(CHAIN_NONE, 0.f, 0u); }
             EVAL_PIN(acc); EVAL_TS(4);
             EVAL_BCAST(unused, acc);
             EVAL_TS(5);
@@ -653,7 +673,8 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
         } else if (need) {
             // ---------------------------------------------------------------- exchange (:201-219)
             float gv = 0.f; uint32_t gh = 0;
-            if (scalarLane) { OptF g0 = gm_gibbs_mass(s, smu, -m1, m2, rng, S.luts, false, 0.f); gv = g0.v; gh = g0.has ? 1u : 0u; }
+            if (scalarLane) { OptF g0 = gm_gibbs_mass(s, smu, -m1, m2, rng, S.luts, false, 0.f); gv = g0.v; gh = g0.has ? 1u : 0u;
+                              if (gh != 0u && m1 + gv > GAPS_EPSILON && m2 - gv > GAPS_EPSILON) EVAL_PUBLISH(CHAIN_APPLY, gv, 2u); else EVAL_PUBLISH(CHAIN_NONE, 0.f, 0u); }
             EVAL_PIN(gv); EVAL_TS(4);
             EVAL_BCAST(gv, gh);
             EVAL_TS(5);
@@ -670,6 +691,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
                 }
             }
         }
+        else EVAL_PUBLISH(CHAIN_NONE, 0.f, 0u);      // an exchange that cannot use Gibbs (:201-206): nothing happens, the generator still waits for its word
         EVAL_TS(6);
         EVAL_TS_DUMP(p.type | (nUpd << 8) | ((p.r1 == p.r2 ? 1u : 0u) << 16));
         if (DECIDE && writer) S.dec[q] = owe;
@@ -692,7 +714,7 @@ template <int PHASE>
 #endif
 CG_KERNEL void CG_LAUNCH_BOUNDS2((PHASE == EVAL_SEQ ? EVAL_SEQ_BS : 1024), (PHASE == EVAL_FUSED || PHASE == EVAL_SEQ ? 4 : (PHASE == EVAL_APPLY || PHASE == EVAL_DECIDE ? EVAL_APPLY_WAVES : 8))) eval_kernel(const PropRec *hotQueue, const GenScalars *hotGs, uint32_t hotCap, uint32_t slices, const SamplerDev CG_CONSTANT *sp)
 {
-    EvalHot hot; hot.queue = hotQueue; hot.gs = hotGs; hot.queueCap = hotCap;
+    EvalHot hot; hot.queue = hotQueue; hot.gs = hotGs; hot.queueCap = hotCap; hot.slot = nullptr; hot.grans = nullptr;
     const EvalFirst first = eval_first<PHASE>(hot, slices, cg_bid());
     const SamplerDev &S = eval_record<PHASE>(sp);
     eval_body<PHASE, true>(S, slices, cg_bid(), cg_gdim(), hot, first);
@@ -711,7 +733,7 @@ CG_KERNEL void CG_LAUNCH_BOUNDS2(1024, (PHASE == EVAL_FUSED ? EVAL_MULTI_FUSED_W
     const SamplerDev CG_CONSTANT *sp = arr + chain;
     cg_const_warm<sizeof(SamplerDev)>(sp);
     const SamplerDev &S = *(const SamplerDev *)sp;
-    EvalHot hot; hot.queue = S.queue; hot.gs = S.gs; hot.queueCap = S.queueCap;
+    EvalHot hot; hot.queue = S.queue; hot.gs = S.gs; hot.queueCap = S.queueCap; hot.slot = nullptr; hot.grans = nullptr;
     const uint32_t vbid = cg_bid() - chain * wgPerChain;
     eval_body<PHASE, false>(S, slices, vbid, wgPerChain, hot, eval_first<PHASE>(hot, slices, vbid));
 }

@@ -52,6 +52,17 @@ struct alignas(16) PropRec {
 // 2: ... then AP[:,r2] += d2 * other[:,c2] (an accepted move / exchange; r1 == r2 allowed: the second continues from the first).
 struct alignas(16) DecRec { uint32_t n, r1, c1; float d1; uint32_t r2, c2; float d2; uint32_t pad; };
 
+// The chained launch (chain_kernel.h: one launch evaluates batch n and generates batch n + 1) keeps the queue and its length in two
+// copies, one per launch parity: a launch of parity p evaluates queue copy p / slot p and its generator workgroup writes copy 1 - p, so
+// nothing an evaluation workgroup reads at its start can change while its launch runs.  tag: the batch's number (low word), what the
+// evaluation marks its decision granules with.
+struct alignas(8) ChainSlot { uint32_t qlen, tag; };
+// decision of one evaluated proposal, handed to the next batch's generator inside the launch as two {value, tag} granules
+// (grans[q * 64 + 0] = code | units << 8, grans[q * 64 + 1] = one float): what the generator's lane applies to the atomic domain
+#define CHAIN_NONE 0u        // nothing to change (rejected move / exchange, a death's rebirth with the old mass)
+#define CHAIN_APPLY 1u       // B: mass = value; D: rebirth mass = value; M: the move; E: delta = value
+#define CHAIN_ERASE 2u       // B: rejected, D: the atom dies -- the atom goes to the erase cache
+
 // Mutable scalars of the proposal generator, one cache line region in HBM.
 struct GenScalars {
     uint64_t qrng;            // ProposalQueue::mRng state
@@ -119,6 +130,7 @@ struct SamplerDev {
     DecRec *dec;          // [queueCap] what each evaluated proposal does to the A*P cache (one-chain split form: carried out beside the next generator launch)
     uint32_t *queueUnits; // [queueCap] algorithmic traffic of each evaluated proposal, in units of 4N bytes
     uint32_t queueCap;
+    ChainSlot *chainSlots;  // [2] chained launch: queue length and batch tag per launch parity (the queue then holds 2 * queueCap records)
     const uint64_t *seeds;  // seeder outputs for this update(): candidate k of the update uses seeds[k]
     // conflict stamps, one 64-bit word per key: [batch epoch:40][round:12][priority:12], written with
     // atomicMax.  priority 4094-t for attempt t of the current window (earliest attempt wins), 0xFFFFFF

@@ -31,12 +31,19 @@ __device__ unsigned long long g_timeline[(GEN_WIN / 64 + 1) * 64];
 #define GEN_TS_DUMP_WAVE() do { if ((t & 63u) == 0u && ts_ok && (t >> 6) <= (unsigned)(GEN_WIN / 64)) { for (uint32_t i_ = 0; i_ < 64u; ++i_) g_timeline[(t & ~63u) + i_] = i_ < ts_n ? sh.ts[(t & ~63u) + i_] : 0ull; } } while (0)
 #define GEN_TS_INIT() uint32_t ts_n = 0
 #define GEN_TS_RESUME(k) ts_n = (k)
+#define GEN_TS_ZERO(a, b) do { if ((t & 63u) == 0u) for (uint32_t i_ = (a); i_ < (b); ++i_) sh.ts[(t & ~63u) + i_] = 0ull; } while (0)
 #define GEN_PIN(x) asm volatile("" : "+v"(x) :: "memory")      // the value is computed before the next timestamp
+__device__ unsigned long long g_chain_gen[8];      // the chained launch's generator workgroup on the chip-wide 100 MHz clock (chain_kernel.h)
+#define GEN_RT(i) do { if (t == 0u) sh.rt[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define GEN_RT_DUMP() do { if (t == 0u && sh.rtOn) { for (int i_ = 0; i_ < 8; ++i_) g_chain_gen[i_] = sh.rt[i_]; } } while (0)
 #else
 #define GEN_TS(id) do { } while (0)
 #define GEN_TS_INIT() do { } while (0)
 #define GEN_TS_RESUME(k) do { } while (0)
+#define GEN_TS_ZERO(a, b) do { } while (0)
 #define GEN_PIN(x) do { } while (0)
+#define GEN_RT(i) do { } while (0)
+#define GEN_RT_DUMP() do { } while (0)
 #define GEN_TS_DUMP_WAVE() do { } while (0)
 #endif
 
@@ -101,6 +108,7 @@ struct GenShared {
     uint32_t freeTop[16];                // the free-handle stack's top entries as the launch found them (below what its own flush pushes): a committing birth's handle without a memory trip
 #if defined(GEN_TIMELINE)
     unsigned long long ts[(WIN / 64 + 1) * 64];
+    unsigned long long rt[8]; uint32_t rtOn;
 #endif
     alignas(16) uint32_t bkey[4 * GEN_TAB_NB];      // conflict sets of round 1: keys, bucket-major
     alignas(16) GenTabVal bval[4 * GEN_TAB_NB];     // ... and the ordinals registered under each key
@@ -111,6 +119,10 @@ struct GenShared {
     uint32_t roundNo, stopKey;
     uint32_t nR, minAtoms, processed, qlen, skip, remaining;
     uint32_t nWork, updBase; float u1c, u2c;
+    // chained launch (chain_kernel.h): the erase cache as the generator's own lanes fill it from the decisions they apply, and the window
+    // of the death-probability table this launch can need (staged while the evaluation workgroups of the same launch still run)
+    unsigned long long eraseTmp[FLUSH_MAX]; uint32_t eraseN, specBad;
+    float dpWin[4 * WIN];
 };
 
 // bin index = pos / binLength, exact: double-precision reciprocal estimate (off by at most one), then a

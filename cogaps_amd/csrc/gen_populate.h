@@ -125,15 +125,17 @@ CG_DEVICE void gen_flush_part(const SamplerDev &S, GenShared<WIN> &sh, const Gen
 // hot: what the launch's first memory trip reads, passed as leading scalar kernel arguments so that the dispatcher preloads them into
 // SGPRs (-amdgpu-kernarg-preload-count): the trip starts at once and the by-value SamplerDev's kernel-argument lines (WARM
 // bytes; 0 = the caller warmed them) come in under it instead of before it.
-struct GenHot { const uint64_t *lcgMul, *lcgInc; GenScalars *gs; const unsigned long long *eraseList; const uint32_t *queueUnits; uint32_t eraseCap, queueCap; };
+struct GenHot { const uint64_t *lcgMul, *lcgInc; GenScalars *gs; const unsigned long long *eraseList; const uint32_t *queueUnits; uint32_t eraseCap, queueCap;
+                // chained launch only: the queue copy the previous batch sits in, the copy and slot this launch writes, the decision granules
+                const PropRec *queueRd; PropRec *queueWr; const unsigned long long *grans; ChainSlot *slotWr; };
 
 // ---- the helper wave: flush, table presets, round bookkeeping, write-back.  Mirrors the attempt waves' barriers one for one. ----
 template <int WIN>
 CG_DEVICE void gen_helper(const SamplerDev &S, GenShared<WIN> &sh, GenScalars *gs, const unsigned ht, const unsigned long long specE,
-                          const uint32_t e_m, const uint32_t e_n, const uint32_t e_fc, const uint32_t e_prevQ, const uint32_t e_nDone, const uint32_t e_nSteps)
+                          const uint32_t e_m, const uint32_t e_n, const uint32_t e_fc, const uint32_t e_prevQ, const uint32_t e_nDone, const uint32_t e_nSteps, ChainSlot *slotWr, const bool specDone = false)
 {
     const unsigned t = (unsigned)WIN + ht;
-    GEN_TS_INIT(); GEN_TS_RESUME(7);      // (marks 0, 0, 26-29, 1 were left by gen_body)
+    GEN_TS_INIT(); GEN_TS_RESUME(13);      // (marks 0, 0, 26-29, 1 and the chained launch's 30-35 were left by gen_body)
     GenFlushRegs fr;
     gen_flush_fetch<WIN>(S, fr, ht, e_m, e_n, specE, e_fc);          // the flush's one memory trip: under the attempt waves' A1
     const uint32_t n0 = e_n - e_m;                              // the domain holds this many atoms after the flush
@@ -154,10 +156,12 @@ CG_DEVICE void gen_helper(const SamplerDev &S, GenShared<WIN> &sh, GenScalars *g
         // ---- A1's two barriers (the classification's one count exchange, then the sorted slots); round 1: the flush goes on between them
         // (the sort -- it waits for the records -- while the attempt waves draw and guess; the list surgery and the index replay during
         // the type sort; the write-back during the first stage of A2)
+        // (specDone: the chained launch classified this window before the decisions arrived and executed A1's two barriers then -- the
+        // flush runs straight through to the join)
         if (first) { gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 0); if (ht < 16u) sh.freeTop[ht] = fr.freeTop; }
-        cg_sync_lds();
+        if (!(first && specDone)) cg_sync_lds(); else cg_wave_sync();
         if (first) { gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 1); gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 2); }
-        cg_sync_lds();
+        if (!(first && specDone)) cg_sync_lds(); else cg_wave_sync();
         if (first) { gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 3); GEN_TS(3); cg_sync(); }      // the join: the flush's stores are acknowledged (vmcnt(0)) before any lane reads the domain
         // ---- B1 / B2 barriers
         if (ldsRound) cg_sync_lds(); else cg_sync();
@@ -221,6 +225,8 @@ CG_DEVICE void gen_helper(const SamplerDev &S, GenShared<WIN> &sh, GenScalars *g
             const uint32_t frontWord = (uint32_t)(offsetof(GenScalars, front) / 4u);
             for (uint32_t w = ht; w < GEN_GS_WORDS; w += 64u)
                 if (w != GEN_GS_ERROR_WORD && !(frontPending && w == frontWord)) reinterpret_cast<uint32_t *>(gs)[w] = reinterpret_cast<const uint32_t *>(&sh.g)[w];
+            // chained launch: what the next launch's evaluation workgroups start from (the queue copy they read was filled by this launch's commit)
+            if (slotWr && ht == 0) { ChainSlot cs; cs.qlen = sh.g.qlen; cs.tag = (uint32_t)batchEpoch; *slotWr = cs; }
             GEN_TS(24);
             { const bool ts_ok = e_prevQ >= 140u && remaining >= 512u && GEN_TS_ROUND_OK(roundNo); (void)ts_ok; GEN_TS_DUMP_WAVE(); }
             return;
@@ -242,16 +248,84 @@ CG_DEVICE void gen_helper(const SamplerDev &S, GenShared<WIN> &sh, GenScalars *g
 struct GenRoundCtx {
     unsigned t; uint64_t jm0, ji0, jm1, ji1, seed1, batchEpoch, g_qrng; uint32_t n0, updBase, remaining, K, g_skip, e_prevQ; float dp0, g_u1, g_u2; GenScalars *gs;
     float tabHi, tabLo;      // round 1: this lane's entries of the window's death-probability rows, on their way from SamplerDev::deathProb
+    PropRec *queueOut;       // where the batch's queue records go (S.queue; the chained launch: the copy of the other parity)
+    uint32_t dpBase;         // chained launch: first entry of the death-probability table's window in sh.dpWin
 };
-template <int WIN, bool FIRST>
-CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRoundCtx &c, const uint32_t roundNo)
+// The chained launch classifies and sorts its first window BEFORE the previous batch's decisions are in (gen_spec_a1, while the
+// evaluation workgroups of the same launch run): what the lane keeps of that in registers.  First half: lane = attempt; second half:
+// lane = sorted slot.
+struct GenSpec {
+    uint32_t bBefore, dBefore, guess, active; float u1, u2;
+    uint32_t go, ct, info; uint64_t rng, pos; uint32_t bin, r1, c1;
+};
+// A1 of round 1 without the domain's size (chained launch).  The type of an attempt depends on the atom count n only through the
+// birth / death threshold deathProb(n) (ProposalQueue.cpp:129-160), which is monotone in n and moves by ~1e-9 per atom; the count
+// after the flush lies in [nLo, nHi] = [nAtoms - queue length, nAtoms] (a proposal erases at most one atom).  The lanes classify with
+// both ends' thresholds: where every attempt gets the same type from both -- practically always -- that is its type for the true
+// count too, and the count exchange, the sorted slots, the attempt's generator state and a birth's position follow without it.  A
+// window with an attempt between the two thresholds (sh.specBad) is classified again the usual way once the count is known.
+template <int WIN>
+CG_DEVICE void gen_spec_a1(const SamplerDev &S, GenShared<WIN> &sh, const GenRoundCtx &c, const uint32_t nLo, const uint32_t nHi, const float dpAtLo, const float dpAtHi, GenSpec &sp)
 {
+    const unsigned t = c.t;
+    const uint32_t winN = c.remaining < (uint32_t)WIN ? c.remaining : (uint32_t)WIN;
+    const uint32_t active = t < winN;
+    uint64_t s = (c.g_skip ? c.jm1 : c.jm0) * c.g_qrng + (c.g_skip ? c.ji1 : c.ji0);
+    float u1 = pcg_uniform(s), u2 = pcg_uniform(s);
+    const uint32_t cached = (c.g_skip != 0u) & (uint32_t)(t == 0u);       // attempt 0 replays the cached pair
+    u1 = cached ? c.g_u1 : u1; u2 = cached ? c.g_u2 : u2;
+    const uint32_t gLo = gen_decide(u1, u2, nLo, nLo, dpAtLo, dpAtLo), gHi = gen_decide(u1, u2, nHi, nHi, dpAtHi, dpAtHi);
+    if (cg_ballot(active && gLo != gHi) != 0ull && (t & 63u) == 0u) sh.specBad = 1u;
+#if defined(GEN_SPEC_BAD_EVERY)
+    if (t == 0u && (sh.g.batchEpoch % (uint64_t)GEN_SPEC_BAD_EVERY) == 0ull) sh.specBad = 1u;      // test-only variant: the fall-back path, regularly
+#endif
+    const uint32_t guess = active ? gHi : (uint32_t)GEN_T_NONE;
+    sh.u1[t] = u1; sh.u2[t] = u2;
+    uint32_t eX[4], tX[4];
+    gen_count4<WIN>(sh.wtot4, t, guess == 'B', guess == 'D', guess == 'M', guess == 'E', eX, tX);
+    sp.bBefore = eX[0]; sp.dBefore = eX[1]; sp.u1 = u1; sp.u2 = u2; sp.guess = guess; sp.active = active;
+    const uint32_t goA = (uint32_t)(guess != GEN_T_NONE);
+    const uint32_t k0 = (uint32_t)(guess == 'B') | (uint32_t)(guess == 'D'), k1 = (uint32_t)(guess == 'M');
+    const uint32_t T0 = tX[0] + tX[1], T1 = tX[2], T2 = tX[3];
+    if (goA) {
+        uint32_t slot = T0 + T1 + eX[3];
+        slot = k1 ? T0 + eX[2] : slot;
+        slot = k0 ? eX[0] + eX[1] : slot;
+        sh.perm[slot] = (uint16_t)t;
+        sh.info[t] = guess | (eX[0] << 8);
+    }
+    if (t == 0) sh.nWork = T0 + T1 + T2;
+    // (the caller parks the attempt's seed in sh.seed[t] once the trip that brings it has landed, then closes with the second barrier)
+}
+// ... second half (lane = sorted slot): the attempt's generator state, a birth's position
+template <int WIN>
+CG_DEVICE void gen_spec_slot(const SamplerDev &S, GenShared<WIN> &sh, const GenRoundCtx &c, GenSpec &sp)
+{
+    const unsigned t = c.t;
+    const bool go = t < sh.nWork;
+    sp.go = go ? 1u : 0u;
+    sp.ct = go ? (uint32_t)sh.perm[t] : 0u;
+    sp.info = go ? sh.info[sp.ct] : 0u;
+    sp.rng = go ? pcg_from_seed(sh.seed[sp.ct]) : 0ull;
+    sp.pos = 0; sp.bin = 0; sp.r1 = 0; sp.c1 = 0;
+    if (go && (sp.info & 0xFFu) == 'B') {
+        uint64_t x = pcg_u64(sp.rng);
+        while (x >= S.limitL) x = pcg_u64(sp.rng);
+        sp.pos = (S.iPartL == 1ull ? x : x / S.iPartL) + 1ull;
+        sp.bin = gen_bin_of(S, sp.pos); sp.r1 = gen_div_k(S, sp.bin); sp.c1 = sp.bin - sp.r1 * c.K;
+    }
+}
+
+template <int WIN, bool FIRST, bool SPEC = false>
+CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRoundCtx &c, const uint32_t roundNo, const GenSpec *spec = nullptr)
+{
+    static_assert(FIRST || !SPEC, "only a batch's first window is classified ahead of the decisions");
     const unsigned t = c.t;
     const uint64_t jm0 = c.jm0, ji0 = c.ji0, jm1 = c.jm1, ji1 = c.ji1, seed1 = c.seed1, batchEpoch = c.batchEpoch;
     const uint32_t updBase = c.updBase, remaining = c.remaining, K = c.K;
     GenScalars *gs = c.gs;
     constexpr bool first = FIRST;
-    GEN_TS_INIT(); GEN_TS_RESUME(FIRST ? 7u : 40u);
+    GEN_TS_INIT(); GEN_TS_RESUME(FIRST ? 13u : 40u);
     GEN_TS(4);
     const uint32_t nR = first ? c.n0 : sh.nR, minR = first ? c.n0 : sh.minAtoms, skip = first ? c.g_skip : sh.skip, processed = first ? 0u : sh.processed;
     const uint64_t qrngRound = first ? c.g_qrng : sh.qrngRound;
@@ -262,7 +336,8 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
 
     // ------------------------------------------------------------------ A1 (lane = attempt): (u1,u2), B/D/M/E
     uint32_t bBeforeA1 = 0, dBeforeA1 = 0, guessA1 = 0, activeA1 = 0; float u1A1 = 0.f, u2A1 = 0.f;      // the lane's OWN attempt, for its exact decision below
-    {
+    if (SPEC) { bBeforeA1 = spec->bBefore; dBeforeA1 = spec->dBefore; guessA1 = spec->guess; activeA1 = spec->active; u1A1 = spec->u1; u2A1 = spec->u2; }
+    else {
         // (0/1 words and selects instead of short-circuit logic: with one wave per SIMD a branch costs more
         // than the arithmetic it would skip)
         const uint32_t active = t < winN;
@@ -302,18 +377,18 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
         GEN_TS(8);
         if (t == 0) sh.nWork = T0 + T1 + T2;
     }
-    cg_sync_lds();
+    if (!SPEC) cg_sync_lds();
     GEN_TS(9);
 
     // ------------------------------------------------------------------ A2 (lane = sorted slot): populate-phase draws
-    const bool go = t < sh.nWork;
-    const uint32_t ct = go ? (uint32_t)sh.perm[t] : 0u;          // this lane's attempt ordinal in the window
-    const uint32_t info = go ? sh.info[ct] : 0u;
+    const bool go = SPEC ? spec->go != 0u : t < sh.nWork;
+    const uint32_t ct = SPEC ? spec->ct : (go ? (uint32_t)sh.perm[t] : 0u);          // this lane's attempt ordinal in the window
+    const uint32_t info = SPEC ? spec->info : (go ? sh.info[ct] : 0u);
     const uint32_t type = info & 0xFFu, bBefore = info >> 8;
     uint32_t flags = 0;
     const bool isB = go && type == 'B';
     bool pick = go && type != 'B';                 // D/M/E: picks an existing atom
-    uint64_t rng = go ? pcg_from_seed(sh.seed[ct]) : 0ull;   // AtomicProposal ctor, ProposalQueue.cpp:12-15
+    uint64_t rng = SPEC ? spec->rng : (go ? pcg_from_seed(sh.seed[ct]) : 0ull);   // AtomicProposal ctor, ProposalQueue.cpp:12-15
     const uint32_t nT = nR + bBefore;              // domain size this attempt sees
     uint64_t pos = 0, cpos = 0, lbpos = 0, rbpos = 0;
     uint32_t h1 = CG_NONE, h2 = CG_NONE, i1 = CG_NONE, i2 = CG_NONE, hl = CG_NONE, hr = CG_NONE;
@@ -322,11 +397,14 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
 
     // stage 1 ---------------------------------------------------------------------------------
     if (isB) {
-        // uniform64(1, L) (Random.cpp:105-123) with the constant range's iPart precomputed
-        uint64_t x = pcg_u64(rng);
-        while (x >= S.limitL) x = pcg_u64(rng);
-        pos = (S.iPartL == 1ull ? x : x / S.iPartL) + 1ull;
-        bin = gen_bin_of(S, pos); r1 = gen_div_k(S, bin); c1 = bin - r1 * K;
+        if (SPEC) { pos = spec->pos; bin = spec->bin; r1 = spec->r1; c1 = spec->c1; }      // (drawn ahead: gen_spec_a1)
+        else {
+            // uniform64(1, L) (Random.cpp:105-123) with the constant range's iPart precomputed
+            uint64_t x = pcg_u64(rng);
+            while (x >= S.limitL) x = pcg_u64(rng);
+            pos = (S.iPartL == 1ull ? x : x / S.iPartL) + 1ull;
+            bin = gen_bin_of(S, pos); r1 = gen_div_k(S, bin); c1 = bin - r1 * K;
+        }
         i1 = nT;
     } else if (pick) {
         i1 = pcg_uniform32(rng, 0u, nT - 1u);
@@ -352,7 +430,10 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
     {   // the exact B/D/indeterminate decision of this lane's own attempt (ProposalQueue.cpp:129-160 with the atom bounds as the births /
         // deaths before it leave them), while the trip above is on its way: a guess that does not hold is a hazard (the window is cut
         // there and redrawn with exact bounds), an indeterminate attempt ends the batch -- the smallest such attempt is the stop key
-        const uint32_t exact = gen_decide(u1A1, u2A1, (uint64_t)minR - dBeforeA1, (uint64_t)nR + bBeforeA1, sh.dpLo[dBeforeA1], sh.dpHi[bBeforeA1]);
+        // (SPEC: the rows were never parked -- the table's window staged in LDS holds them: deathProb(n0 - d), deathProb(n0 + b))
+        const float dpLoX = SPEC ? (nR >= dBeforeA1 ? sh.dpWin[nR - dBeforeA1 - c.dpBase] : 0.f) : sh.dpLo[dBeforeA1];
+        const float dpHiX = SPEC ? sh.dpWin[nR + bBeforeA1 - c.dpBase] : sh.dpHi[bBeforeA1];
+        const uint32_t exact = gen_decide(u1A1, u2A1, (uint64_t)minR - dBeforeA1, (uint64_t)nR + bBeforeA1, dpLoX, dpHiX);
         const uint32_t hazA = activeA1 & (uint32_t)(exact != guessA1);
         const uint32_t failA = activeA1 & (hazA ^ 1u) & (uint32_t)(guessA1 == GEN_T_NONE);   // indeterminate: batch ends, no seed used
         if (hazA | failA) cg_atomic_min_u32(&sh.stopKey, 2u * t + (hazA ^ 1u));
@@ -783,7 +864,7 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
                 p.gibbs = (gib1 > 0u ? 1u : 0u) | ((two && gib2 > 0u) ? 2u : 0u);
                 p.m1 = (type == 'B') ? 0.f : a.mass; p.m2 = (type == 'E') ? m2x : 0.f;
                 p.old1 = old1; p.old2 = two ? old2 : 0.f; p.curPos = (type == 'M') ? cpos : 0ull;
-                S.queue[slot] = p;
+                c.queueOut[slot] = p;
                 if (c_traceOn) { const uint32_t ti = c_traceCount + slot; if (ti < c_traceCap) { p.batch = c_nBatches; S.trace[ti] = p; } }
             }
         }
@@ -810,14 +891,135 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
         }
     }
     GEN_TS(21);
-    if (endB) { GEN_TS(22); { const bool ts_ok = c.e_prevQ >= 140u && c.remaining >= 512u && GEN_TS_ROUND_OK(roundNo); (void)ts_ok; GEN_TS_DUMP_WAVE(); } }
+    if (endB) { GEN_TS(22); GEN_RT(5); GEN_RT_DUMP(); { const bool ts_ok = c.e_prevQ >= 140u && c.remaining >= 512u && GEN_TS_ROUND_OK(roundNo); (void)ts_ok; GEN_TS_DUMP_WAVE(); } }
     return endB;
+}
+
+// ---- chained launch (chain_kernel.h): the generator applies the previous batch's decisions itself -----------------------------------------
+// One launch evaluates batch n (its other workgroups) and generates batch n + 1 (this workgroup).  The evaluation workgroups write
+// nothing the generator reads except one pair of tagged granules per proposal -- {code, traffic units} and one float -- and the
+// generator's lane q carries the decision out on the atomic domain and the factor matrix: the stores the evaluation's writer thread
+// makes in the two-launch form (eval_kernel.h: atom_set_mass, eval_store_matrix, eval_domain_move, eval_cache_erase), the same values
+// from the same operations.  Everything those stores need that does not depend on the decision -- the queue record, the atom's record
+// (its links name the holders of the cached copies, as the evaluation looks them up when it runs), the old bin's head and the bitmap's
+// upper words of a move -- is fetched while the evaluation workgroups still run.
+// The lane's part of the hand-over is split in two.  chain_fetch (before the wait) turns the record into ADDRESSES and old values: every
+// word a decision can rewrite, as a pointer held in vector registers (null: nothing to write there).  chain_apply (behind the wait, on the
+// decide -> generate chain) only computes the new values and stores -- no field of the sampler's record is read there: the compiler
+// re-loads such fields through the scalar cache wherever they are used, and two dozen of those loads, each waited for, in the four
+// type branches a wave walks through one after the other cost the first version 3 k cycles per launch.
+struct ChainItem {
+    uint32_t type; float m1, m2, old1, old2; uint64_t pos; unsigned long long eraseEntry;
+    float *mass1, *rm1, *mass2, *rm2;        // atoms[h1].mass and the copy its left neighbour caches; exchange: the same for the partner
+    float *mat1, *mat2; uint32_t *col1, *col2;      // mMatrix(r1,c1), mMatrix(r2,c2), the columns' counts of positive entries
+    // move (ConcurrentAtomicDomain.cpp:126-132 across bins, as eval_domain_move decides it: the atom's own record is current -- births queued
+    // after the move may have changed the links, nothing moves next to a moving atom, ProposalQueue.cpp:167,218)
+    uint64_t *pos1, *rposL, *lposR;          // atoms[h1].pos, atoms[left].rpos, atoms[right].lpos
+    uint32_t *head1, *head2; uint32_t head1Val, h1;      // old bin's head word (null: the atom is not the head) and what it becomes; new bin's head word (null: stays)
+    unsigned long long *b0clr, *b0set, *b1set, *b2set; uint32_t bit1, bit2, bit1w, bit2w;      // bitmap words (null: nothing to do) and bit numbers
+};
+CG_DEVICE void chain_item_clear(ChainItem &it)
+{
+    it.type = 0; it.m1 = 0.f; it.m2 = 0.f; it.old1 = 0.f; it.old2 = 0.f; it.pos = 0; it.eraseEntry = 0ull;
+    it.mass1 = nullptr; it.rm1 = nullptr; it.mass2 = nullptr; it.rm2 = nullptr; it.mat1 = nullptr; it.mat2 = nullptr; it.col1 = nullptr; it.col2 = nullptr;
+    it.pos1 = nullptr; it.rposL = nullptr; it.lposR = nullptr; it.head1 = nullptr; it.head2 = nullptr; it.head1Val = CG_NONE; it.h1 = 0;
+    it.b0clr = nullptr; it.b0set = nullptr; it.b1set = nullptr; it.b2set = nullptr; it.bit1 = 0; it.bit2 = 0; it.bit1w = 0; it.bit2w = 0;
+}
+// what the second trip brings: the atom's record, the partner's left link, a move's old bin head and upper bitmap words
+struct ChainMid { AtomRec a; uint32_t l2, head1, b1, b2; unsigned long long x1, x2; };
+CG_DEVICE ChainMid chain_fetch_mid(const SamplerDev &S, const PropRec &p)
+{
+    // every lane issues every load (a lane without a proposal, or of another type, reads harmless words: handle 0, bin 0): loads inside
+    // divergent branches made the compiler wait for the whole trip where the branches join, before the work meant to run under it
+    ChainMid m;
+    const uint32_t hE = p.type == 'E' ? p.h2 : p.h1;
+    m.b1 = gen_bin_of(S, p.curPos); m.b2 = gen_bin_of(S, p.pos);
+    const uint32_t w0 = m.b2 >> 6, w1 = w0 >> 6, w2 = w1 >> 6;
+    m.a = S.atoms[p.h1];
+    m.l2 = S.atoms[hE].left;
+    m.head1 = S.binHead[m.b1];
+    m.x1 = S.bits1[w1]; m.x2 = S.bits2[w2];
+    return m;
+}
+CG_DEVICE void chain_fetch_build(const SamplerDev &S, const PropRec &p, const ChainMid &m, ChainItem &it);
+CG_DEVICE void chain_fetch(const SamplerDev &S, const PropRec *queueRd, uint32_t q, ChainItem &it)
+{
+    const PropRec p = queueRd[q];
+    const ChainMid m = chain_fetch_mid(S, p);
+    chain_fetch_build(S, p, m, it);
+}
+CG_DEVICE void chain_fetch_build(const SamplerDev &S, const PropRec &p, const ChainMid &m, ChainItem &it)
+{
+    chain_item_clear(it);
+    it.type = p.type; it.m1 = p.m1; it.m2 = p.m2; it.old1 = p.old1; it.old2 = p.old2; it.pos = p.pos; it.h1 = p.h1;
+    it.eraseEntry = ((unsigned long long)(p.r1 * S.K + p.c1) << 32) | (unsigned long long)p.h1;
+    const AtomRec a = m.a;
+    it.mass1 = &S.atoms[p.h1].mass; it.rm1 = a.left != CG_NONE ? &S.atoms[a.left].rmass : nullptr;
+    it.mat1 = &S.mat[(size_t)p.c1 * S.Mpad + p.r1]; it.col1 = &S.colPos[p.c1];
+    const bool two = p.type == 'M' || p.type == 'E';
+    if (two) { it.mat2 = &S.mat[(size_t)p.c2 * S.Mpad + p.r2]; it.col2 = &S.colPos[p.c2]; }
+    if (p.type == 'E') { const uint32_t l2 = m.l2; it.mass2 = &S.atoms[p.h2].mass; it.rm2 = l2 != CG_NONE ? &S.atoms[l2].rmass : nullptr; }
+    if (p.type == 'M') {
+        const uint32_t b1 = m.b1, b2 = m.b2;
+        const uint32_t head1 = m.head1;
+        const uint32_t w0 = b2 >> 6, w1 = w0 >> 6, w2 = w1 >> 6;
+        const unsigned long long x1 = m.x1, x2 = m.x2;
+        it.pos1 = &S.atoms[p.h1].pos; it.rposL = a.left != CG_NONE ? &S.atoms[a.left].rpos : nullptr; it.lposR = a.right != CG_NONE ? &S.atoms[a.right].lpos : nullptr;
+        if (head1 == p.h1) {      // the old bin loses its lowest atom: the right neighbour takes over if it lies in the same bin, else the bin is empty
+            it.head1 = &S.binHead[b1];
+            if (a.right != CG_NONE && gen_bin_of(S, a.rpos) == b1) it.head1Val = a.right; else { it.head1Val = CG_NONE; it.b0clr = &S.bits0[b1 >> 6]; it.bit1 = b1 & 63u; }
+        }
+        if (a.left == CG_NONE || gen_bin_of(S, a.lpos) != b2) it.head2 = &S.binHead[b2];
+        it.b0set = &S.bits0[w0]; it.bit2 = b2 & 63u;      // bm_set, the upper levels' words read ahead
+        if (!((x1 >> (w0 & 63u)) & 1ull)) { it.b1set = &S.bits1[w1]; it.bit1w = w0 & 63u; }
+        if (!((x2 >> (w1 & 63u)) & 1ull)) { it.b2set = &S.bits2[w2]; it.bit2w = w1 & 63u; }
+    }
+}
+// mMatrix entry = newv with the per-column count of positive entries (eval_store_matrix)
+CG_DEVICE void chain_store_matrix(float *cell, uint32_t *col, float oldv, float newv)
+{
+    *cell = newv;
+    const bool was = oldv > 0.f, is = newv > 0.f;
+    if (was != is) { if (is) cg_atomic_add_u32(col, 1u); else cg_atomic_sub_u32(col, 1u); }
+}
+// Carries the decision out (the stores of eval_kernel.h's writer thread: atom_set_mass, eval_store_matrix, eval_domain_move); returns
+// whether the atom goes to the erase cache.  AsynchronousGibbsSampler.h:127-144 birth, :148-180 death / rebirth, :184-196 move, :201-219 exchange.
+CG_DEVICE bool chain_apply(const ChainItem &it, uint32_t code, float val)
+{
+    const uint32_t tB = it.type == 'B', tD = it.type == 'D', tM = it.type == 'M', tE = it.type == 'E';
+    const bool app = code == CHAIN_APPLY, era = code == CHAIN_ERASE;
+    // new masses: B: val, D: the rebirth mass val, E: m1 + val and m2 - val
+    const float n1 = tE ? it.m1 + val : val, n2 = it.m2 - val;
+    // new matrix entries (safelyChangeMatrix: gm_max(old + delta, 0); changeMatrix for a birth and a move's destination)
+    float d1 = tB ? val : (tD ? (val - it.m1) : (tM ? -it.m1 : (n1 - it.m1)));
+    d1 = (era && tD) ? -1.f * it.m1 : d1;
+    const float s1 = it.old1 + d1;
+    const float nv1 = tB ? s1 : gm_max(s1, 0.f);
+    const float s2 = it.old2 + (tM ? it.m1 : (n2 - it.m2));
+    const float nv2 = tM ? s2 : gm_max(s2, 0.f);
+    const bool doMat1 = app || (era && tD != 0u), doMat2 = app && (tM | tE) != 0u;
+    const bool doMass1 = app && tM == 0u, doMass2 = app && tE != 0u;
+    if (doMass1) { *it.mass1 = n1; if (it.rm1) *it.rm1 = n1; }
+    if (doMass2) { *it.mass2 = n2; if (it.rm2) *it.rm2 = n2; }
+    if (doMat1) chain_store_matrix(it.mat1, it.col1, it.old1, nv1);
+    if (doMat2) chain_store_matrix(it.mat2, it.col2, it.old2, nv2);
+    if (app && tM != 0u) {
+        *it.pos1 = it.pos; if (it.rposL) *it.rposL = it.pos; if (it.lposR) *it.lposR = it.pos;
+        if (it.head1) *it.head1 = it.head1Val;
+        if (it.b0clr) cg_atomic_and_u64(it.b0clr, ~(1ull << it.bit1));
+        if (it.head2) *it.head2 = it.h1;
+        cg_atomic_or_u64(it.b0set, 1ull << it.bit2);
+        if (it.b1set) cg_atomic_or_u64(it.b1set, 1ull << it.bit1w);
+        if (it.b2set) cg_atomic_or_u64(it.b2set, 1ull << it.bit2w);
+    }
+    return era;
 }
 
 // sp: the sampler's record in device memory (constant address space: scalar loads).  ASYNC: the launch's hot pointers arrived as
 // preloaded kernel arguments, the record's lines are requested behind the first trip and waited for after the conflict table has been
 // emptied (one-chain launch); otherwise the caller has read the record already (batched launch: the hot pointers come from it).
-template <int WIN, bool ASYNC>
+// CHAIN: the chained launch's generator workgroup (above; chain_kernel.h).
+template <int WIN, bool ASYNC, bool CHAIN = false>
 CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
 {
     CG_SHARED GenShared<WIN> sh;
@@ -828,13 +1030,18 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
     GenScalars *gs = hot.gs;
 
     GEN_TS_INIT(); GEN_TS(0); GEN_TS(0);
+    GEN_RT(0);
     // k-step PCG jumps for this lane's (u1,u2): k = 2t, or 2(t-1) when attempt 0 replays cached values
     const uint64_t jm0 = hot.lcgMul[2u * ta], ji0 = hot.lcgInc[2u * ta];
     const uint64_t jm1 = hot.lcgMul[ta ? 2u * (ta - 1u) : 0u], ji1 = hot.lcgInc[ta ? 2u * (ta - 1u) : 0u];
     // first memory trip of the launch, everything independent: the scalars every lane needs (one lane per word into LDS, where they
     // live for the whole launch), the erase cache (helper lanes) and the traffic-unit slots (attempt lanes) read speculatively
-    const unsigned long long specE = (helper && ht < (unsigned)FLUSH_MAX && ht < hot.eraseCap) ? hot.eraseList[ht] : 0ull;
-    uint32_t units = (!helper && t < hot.queueCap) ? hot.queueUnits[t] : 0u;
+    // (the chained launch has neither: its lanes collect both from the decisions they apply)
+    unsigned long long specE = (!CHAIN && helper && ht < (unsigned)FLUSH_MAX && ht < hot.eraseCap) ? hot.eraseList[ht] : 0ull;
+    // chained launch: the lane's queue record of the batch being evaluated (slot t always exists), with the launch's first trip
+    PropRec p0; p0.type = 0; p0.h1 = 0; p0.h2 = 0; p0.pos = 0; p0.curPos = 0; p0.r1 = 0; p0.c1 = 0; p0.r2 = 0; p0.c2 = 0; p0.m1 = 0.f; p0.m2 = 0.f; p0.old1 = 0.f; p0.old2 = 0.f;
+    if (CHAIN && !helper && t < hot.queueCap) p0 = hot.queueRd[t];
+    uint32_t units = (!CHAIN && !helper && t < hot.queueCap) ? hot.queueUnits[t] : 0u;
     const uint64_t jmW = hot.lcgMul[2 * WIN], jiW = hot.lcgInc[2 * WIN];
     constexpr uint32_t GSW = (uint32_t)(sizeof(GenScalars) / 4u);
     static_assert(GSW <= 2u * TPB, "at most two words of GenScalars per lane");
@@ -863,25 +1070,156 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
     GEN_TS(28);
     if (t < GSW) reinterpret_cast<uint32_t *>(&sh.g)[t] = gword;
     if (t + TPB < GSW) reinterpret_cast<uint32_t *>(&sh.g)[t + TPB] = gword2;
-    if (t == 0) { sh.newFront = CG_KEEP; sh.unitSum = 0; sh.jmul[WIN] = jmW; sh.jinc[WIN] = jiW; }
+    if (t == 0) { sh.newFront = CG_KEEP; sh.unitSum = 0; sh.jmul[WIN] = jmW; sh.jinc[WIN] = jiW; if (CHAIN) { sh.eraseN = 0; sh.specBad = 0; } }
     if (!helper) { sh.jmul[t] = jm0; sh.jinc[t] = ji0; }        // even-step PCG jumps, for the round bookkeeping
     GEN_TS(29);
     cg_sync_lds();
     // the scalars every lane needs, from the LDS copy (wave-uniform: kept in scalar registers)
-    const uint32_t e_m = cg_uniform_u32(sh.g.eraseCount), e_n = cg_uniform_u32(sh.g.nAtoms), e_fc = cg_uniform_u32(sh.g.freeCount), e_prevQ = cg_uniform_u32(sh.g.qlen),
+    uint32_t e_m = CHAIN ? 0u : cg_uniform_u32(sh.g.eraseCount);
+    const uint32_t e_n = cg_uniform_u32(sh.g.nAtoms), e_fc = cg_uniform_u32(sh.g.freeCount), e_prevQ = cg_uniform_u32(sh.g.qlen),
                    e_nDone = cg_uniform_u32(sh.g.nDone), e_nSteps = cg_uniform_u32(sh.g.nSteps);
     GEN_TS(1);
     const bool updateDone = e_nDone >= e_nSteps;
-    if (!helper) {   // roofline bookkeeping: add up the traffic units the evaluation kernel left per queue slot (the helper wave adds
-        // the sum to evalBytes at the end of the batch)
-        if (t >= e_prevQ) units = 0;
-        for (uint32_t q = t + WIN; q < e_prevQ; q += WIN) units += S.queueUnits[q];
-        const uint32_t waveUnits = cg_wave_sum_u32(units);
-        if ((t & 63u) == 0u && waveUnits) cg_atomic_add_u32(&sh.unitSum, waveUnits);
+    uint64_t seedC = 0ull; bool dpStaged = false, trySpec = false, specDone = false; uint32_t dpBase = 0;
+    GenSpec specKeep; specKeep.bBefore = 0; specKeep.dBefore = 0; specKeep.guess = 0; specKeep.active = 0; specKeep.u1 = 0.f; specKeep.u2 = 0.f; specKeep.go = 0; specKeep.ct = 0; specKeep.info = 0;
+    specKeep.rng = 0; specKeep.pos = 0; specKeep.bin = 0; specKeep.r1 = 0; specKeep.c1 = 0;
+    if (!CHAIN) {
+        GEN_TS_ZERO(7u, 13u);
+#if defined(GEN_TIMELINE)
+        if (t == 0u) sh.rtOn = 0u;
+#endif
+        if (!helper) {   // roofline bookkeeping: add up the traffic units the evaluation kernel left per queue slot (the helper wave adds
+            // the sum to evalBytes at the end of the batch)
+            if (t >= e_prevQ) units = 0;
+            for (uint32_t q = t + WIN; q < e_prevQ; q += WIN) units += S.queueUnits[q];
+            const uint32_t waveUnits = cg_wave_sum_u32(units);
+            if ((t & 63u) == 0u && waveUnits) cg_atomic_add_u32(&sh.unitSum, waveUnits);
+        }
+    } else {
+        // ---- everything that does not depend on the previous batch's decisions, while its evaluation workgroups run: the lane's proposal
+        // and what its decision will rewrite, this round's seeds, the window of the death-probability table (after the flush the domain
+        // holds between nAtoms - qlen and nAtoms atoms: every proposal erases at most one), and the classification of the next window
+        // itself (gen_spec_a1) -- ordered so that the two memory trips of the fetch run under the classification's barriers and arithmetic
+        ChainItem it; chain_item_clear(it);
+        unsigned long long *const eraseList = S.eraseList; const uint32_t eraseCap = S.eraseCap;      // (read here: nothing of the record is read behind the wait)
+        GEN_TS(30);
+        GEN_RT(1);
+#if defined(GEN_TIMELINE)
+        if (t == 0u) sh.rtOn = (e_prevQ >= 140u && e_nSteps - e_nDone >= 512u) ? 1u : 0u;
+#endif
+        const bool have0 = !helper && t < e_prevQ;
+        // second trip (the first brought the scalars and the lane's record): what the decision will rewrite, the seeds, the table's window
+        ChainMid mid0; mid0.l2 = CG_NONE; mid0.head1 = CG_NONE; mid0.b1 = 0; mid0.b2 = 0; mid0.x1 = 0ull; mid0.x2 = 0ull;
+        mid0.a.pos = 0; mid0.a.lpos = 0; mid0.a.rpos = 0; mid0.a.left = CG_NONE; mid0.a.right = CG_NONE; mid0.a.mass = 0.f; mid0.a.rmass = 0.f; mid0.a.idx = 0; mid0.a.pad0 = 0;
+        mid0 = chain_fetch_mid(S, p0);      // (p0 of a lane without a proposal: slot t of the queue copy, whatever it holds -- handles and positions of an older batch: valid addresses)
+        if (!updateDone) seedC = S.seeds[e_nDone + t < e_nSteps ? e_nDone + t : e_nSteps - 1u];
+        const uint32_t span = e_prevQ + (uint32_t)(WIN - 1);
+        dpBase = e_n > span ? e_n - span : 0u;
+        const uint32_t dpCnt = e_n + (uint32_t)WIN - dpBase;                  // entries dpBase .. nAtoms + WIN - 1
+        dpStaged = !updateDone && dpCnt <= 4u * (uint32_t)WIN;
+        const uint32_t nLo = e_n > e_prevQ ? e_n - e_prevQ : 0u, nHi = e_n;
+        trySpec = dpStaged && nLo >= 2u;                                      // (tiny domains: the type also depends on the count itself)
+        float dpw[4] = {0.f, 0.f, 0.f, 0.f};
+        if (dpStaged) {
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) { const uint32_t i = t + k * TPB; dpw[k] = S.deathProb[dpBase + (i < dpCnt ? i : dpCnt - 1u)]; }
+        }
+        cg_sched_fence();
+        GEN_TS(31);
+        // ... and under it: the classification (the two thresholds computed -- the table's entries would arrive with the trip)
+        GenRoundCtx rcS; GenSpec spS;
+        if (trySpec && !helper) {
+            const float dpAtLo = gm_death_prob((double)(uint64_t)nLo, S.domainLenD, S.alphaD, S.numBins), dpAtHi = gm_death_prob((double)(uint64_t)nHi, S.domainLenD, S.alphaD, S.numBins);
+            rcS.t = t; rcS.jm0 = jm0; rcS.ji0 = ji0; rcS.jm1 = jm1; rcS.ji1 = ji1; rcS.seed1 = 0ull; rcS.g_qrng = sh.g.qrng; rcS.g_skip = sh.g.useCached ? 1u : 0u;
+            rcS.g_u1 = sh.g.u1; rcS.g_u2 = sh.g.u2; rcS.remaining = e_nSteps - e_nDone; rcS.K = S.K;
+            gen_spec_a1<WIN>(S, sh, rcS, nLo, nHi, dpAtLo, dpAtHi, spS);      // (the first of A1's two barriers inside)
+        } else if (trySpec) cg_sync_lds();
+        // the trip has landed: the attempt's seed and the table's window go to LDS; A1's second barrier
+        if (dpStaged) {
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) { const uint32_t i = t + k * TPB; if (i < dpCnt) sh.dpWin[i] = dpw[k]; }
+        }
+        if (trySpec) {
+            if (!helper && spS.guess != (uint32_t)GEN_T_NONE) sh.seed[t] = seedC;      // consumed after the type sort
+            cg_sync_lds();
+            if (!helper) gen_spec_slot<WIN>(S, sh, rcS, spS);
+        }
+        if (have0) chain_fetch_build(S, p0, mid0, it);
+        GEN_PIN(it.type); GEN_PIN(it.bit2);
+        GEN_TS(32);
+        GEN_RT(2);
+        const uint32_t tag = (uint32_t)sh.g.batchEpoch;      // the batch in the queue: the one this workgroup generated in the previous launch
+#if defined(COGAPS_EMUL)
+        if (t == 0 && e_prevQ) cg_atomic_add_u64(&gs->prof[13], 1ull);      // test-only build: batches whose decisions arrived inside a chained launch
+#endif
+        uint32_t unitAcc = 0;
+        if (!helper) {
+            // one proposal: wait for its two granules (read past this workgroup's caches until both carry the batch's tag), note an erased atom
+            // in the erase cache, carry the decision out
+            auto take = [&](const uint32_t q, const bool have) {
+                const unsigned long long *gr = hot.grans + (size_t)q * 64u;
+                unsigned long long g0 = 0ull, g1 = 0ull; uint32_t spins = 0;
+                for (;;) {
+                    if (have) { g0 = cg_load_l2_u64(&gr[0]); g1 = cg_load_l2_u64(&gr[1]); }
+                    const bool ok = !have || ((uint32_t)(g0 >> 32) == tag && (uint32_t)(g1 >> 32) == tag);
+                    if (cg_ballot(!ok) == 0ull) break;
+                    if (++spins > (1u << 20)) { if ((t & 63u) == 0u) gs->error = GAPS_ERR_SPIN; break; }      // (bounded: a launch never hangs the GPU)
+                    cg_poll_pause();
+                }
+                GEN_TS(33);
+                GEN_RT(3);
+                const uint32_t code = have ? ((uint32_t)g0 & 0xFFu) : CHAIN_NONE;
+                if (have) unitAcc += ((uint32_t)g0 >> 8) & 0xFFFFu;
+                // erase cache (ConcurrentAtomicDomain.cpp:62-69): one slot per erased atom, in any order -- the flush sorts by position.
+                // (Before the stores: what the barrier below waits for is LDS traffic only.)
+                const bool er = have && code == CHAIN_ERASE;
+                const unsigned long long em = cg_ballot(er);
+                if (em) {
+                    const uint32_t cntE = (uint32_t)cg_popc64(em);
+                    uint32_t b0 = 0;
+                    if ((t & 63u) == 0u) b0 = cg_atomic_add_u32(&sh.eraseN, cntE);
+                    b0 = cg_wave_bcast_u32(b0, 0);
+                    if (er) {
+                        const uint32_t k = b0 + (uint32_t)cg_popc64(em & ((1ull << (t & 63u)) - 1ull));
+                        const unsigned long long e = it.eraseEntry;
+                        if (k < (uint32_t)FLUSH_MAX) sh.eraseTmp[k] = e;
+                        if (k < eraseCap) eraseList[k] = e; else gs->error = GAPS_ERR_ERASE_CAP;
+                    }
+                }
+                if (have) chain_apply(it, code, gm_u2f((uint32_t)g1));
+            };
+            // a batch of several rounds may have queued more than a window (rare): those proposals first, so that the usual case -- and the
+            // last stores before the barrier -- is straight-line code (a loop's exit made the compiler wait for every store's acknowledgement)
+            if (e_prevQ > (uint32_t)WIN) {
+                ChainItem keep = it;
+                for (uint32_t base = (uint32_t)WIN; base < e_prevQ; base += (uint32_t)WIN) {
+                    const uint32_t q = base + t;
+                    const bool have = q < e_prevQ;
+                    if (have) chain_fetch(S, hot.queueRd, q, it);
+                    take(q, have);
+                }
+                it = keep;
+            }
+            take(t, have0);
+            const uint32_t waveUnits = cg_wave_sum_u32(unitAcc);
+            if ((t & 63u) == 0u && waveUnits) cg_atomic_add_u32(&sh.unitSum, waveUnits);
+        }
+        GEN_TS(34);
+        cg_sync();      // the decisions are in the domain (stores issued by this workgroup are seen by its later loads), the erase cache and the unit sum are complete
+        GEN_TS(35);
+        GEN_RT(4);
+        e_m = cg_uniform_u32(sh.eraseN);
+        if (e_m > eraseCap) e_m = eraseCap;
+        if (helper) specE = (ht < (unsigned)FLUSH_MAX && ht < e_m) ? sh.eraseTmp[ht] : 0ull;
+        specDone = trySpec && cg_uniform_u32(sh.specBad) == 0u;
+#if defined(COGAPS_EMUL)
+        if (t == 0 && !updateDone) cg_atomic_add_u64(&gs->prof[specDone ? 12 : 11], 1ull);      // test-only build: windows classified ahead of the decisions / the usual way
+#endif
+        if (specDone) specKeep = spS;
     }
     if (updateDone) {
         // a launch past the end of the update: the last erase cache is flushed (by the helper wave alone) and the progress words reported
-        cg_sync_lds();                          // (the unit sum is complete)
+        if (!CHAIN) cg_sync_lds();              // (the unit sum is complete)
         if (!helper) return;
         GenFlushRegs fr;
         gen_flush_fetch<WIN>(S, fr, ht, e_m, e_n, specE, e_fc);
@@ -889,32 +1227,37 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
         cg_wave_sync();
         for (int part = 0; part < 4; ++part) { gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, part); cg_wave_sync(); }
         if (ht == 0) { gs->nAtoms = sh.g.nAtoms; gs->front = sh.g.front; gs->freeCount = sh.g.freeCount; gs->eraseCount = 0; gs->qlen = 0; gs->batchNproc = 0; gs->updateFlushed = 1;
-                       gs->evalBytes = sh.g.evalBytes + (unsigned long long)sh.unitSum * S.unitBytes; gs->evalProps = sh.g.evalProps + e_prevQ; }
+                       gs->evalBytes = sh.g.evalBytes + (unsigned long long)sh.unitSum * S.unitBytes; gs->evalProps = sh.g.evalProps + e_prevQ;
+                       if (CHAIN) { ChainSlot cs; cs.qlen = 0; cs.tag = (uint32_t)sh.g.batchEpoch; *hot.slotWr = cs; } }
         return;
     }
-    if (helper) { gen_helper<WIN>(S, sh, gs, ht, specE, e_m, e_n, e_fc, e_prevQ, e_nDone, e_nSteps); return; }
+    if (helper) { gen_helper<WIN>(S, sh, gs, ht, specE, e_m, e_n, e_fc, e_prevQ, e_nDone, e_nSteps, CHAIN ? hot.slotWr : nullptr, CHAIN && specDone); return; }
 
     // ================================================================================ attempt lanes
     // second trip (addresses from the first): this round's seeds
-    const uint64_t seed1 = (e_nDone + t < e_nSteps) ? S.seeds[e_nDone + t] : 0ull;
+    const uint64_t seed1 = CHAIN ? seedC : ((e_nDone + t < e_nSteps) ? S.seeds[e_nDone + t] : 0ull);
     const uint32_t n0 = e_n - e_m;                  // after the flush (which the helper wave runs meanwhile) the domain holds this many atoms
     // death probability (ProposalQueue::deathProb) for every atom count an attempt of this window can see: lane t takes the entries for
     // t births / t deaths ahead of it from the session's table (the same gm_death_prob, evaluated once per session).  They are needed
     // after the first count of the classification, and are parked in LDS just before it: the trip runs under the draws and the
     // first guess, which needs only the entry of the count itself (computed here: the load would be on the critical path).
-    const float tabHi = S.deathProb[n0 + t], tabLo = (n0 >= t) ? S.deathProb[n0 - t] : 0.f;
+    // (The chained launch staged the table's window in LDS while it waited for the decisions: no trip, no division.)
+    const bool fromWin = CHAIN && dpStaged;
+    const float tabHi = fromWin ? sh.dpWin[n0 + t - dpBase] : S.deathProb[n0 + t], tabLo = (n0 >= t) ? (fromWin ? sh.dpWin[n0 - t - dpBase] : S.deathProb[n0 - t]) : 0.f;
     const uint64_t batchEpoch = sh.g.batchEpoch + 1;
     const uint32_t updBase = e_nDone;           // attempts consumed by earlier batches of this update
     const uint32_t remaining = e_nSteps - e_nDone;
     const uint32_t K = S.K;
     // round 1 takes its scalars from the LDS copy of GenScalars (complete since the first barrier); the helper wave writes the round
     // variables' LDS copies, which later phases and rounds read
-    const float dp0 = gm_death_prob((double)(uint64_t)n0, S.domainLenD, S.alphaD, S.numBins);
+    const float dp0 = fromWin ? sh.dpWin[n0 - dpBase] : gm_death_prob((double)(uint64_t)n0, S.domainLenD, S.alphaD, S.numBins);
     const uint64_t g_qrng = sh.g.qrng; const uint32_t g_skip = sh.g.useCached ? 1u : 0u; const float g_u1 = sh.g.u1, g_u2 = sh.g.u2;
 
     GenRoundCtx rc; rc.t = t; rc.jm0 = jm0; rc.ji0 = ji0; rc.jm1 = jm1; rc.ji1 = ji1; rc.seed1 = seed1; rc.batchEpoch = batchEpoch; rc.g_qrng = g_qrng; rc.n0 = n0; rc.updBase = updBase;
     rc.remaining = remaining; rc.K = K; rc.g_skip = g_skip; rc.e_prevQ = e_prevQ; rc.dp0 = dp0; rc.g_u1 = g_u1; rc.g_u2 = g_u2; rc.gs = gs; rc.tabHi = tabHi; rc.tabLo = tabLo;
-    if (gen_round<WIN, true>(S, sh, rc, 1u)) return;
+    rc.queueOut = CHAIN ? hot.queueWr : S.queue; rc.dpBase = dpBase;
+    if (CHAIN && specDone) { if (gen_round<WIN, true, true>(S, sh, rc, 1u, &specKeep)) return; }
+    else if (gen_round<WIN, true>(S, sh, rc, 1u)) return;
     for (uint32_t roundNo = 2; ; ++roundNo) {
         // ------------------------------------------------------------------ set-up of the next round of this batch (the helper wave has published
         // sh.nR / sh.minAtoms and resets the masks and the stop key between the two barriers)
@@ -936,6 +1279,7 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(WIN + 64) gen_kernel(const uint64_t *lcgMul, con
                                                     uint32_t eraseCap, uint32_t queueCap, const SamplerDev CG_CONSTANT *sp)
 {
     GenHot hot; hot.lcgMul = lcgMul; hot.lcgInc = lcgInc; hot.gs = gs; hot.eraseList = eraseList; hot.queueUnits = queueUnits; hot.eraseCap = eraseCap; hot.queueCap = queueCap;
+    hot.queueRd = nullptr; hot.queueWr = nullptr; hot.grans = nullptr; hot.slotWr = nullptr;
     gen_body<WIN, true>(sp, hot);
 }
 // batched multi-chain launch (eval_kernel.h): one workgroup per chain
@@ -946,5 +1290,6 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(WIN + 64) gen_kernel_multi(const SamplerDev CG_C
     cg_const_warm<sizeof(SamplerDev)>(sp);
     const SamplerDev &S = *(const SamplerDev *)sp;
     GenHot hot; hot.lcgMul = S.lcgMul; hot.lcgInc = S.lcgInc; hot.gs = S.gs; hot.eraseList = S.eraseList; hot.queueUnits = S.queueUnits; hot.eraseCap = S.eraseCap; hot.queueCap = S.queueCap;
+    hot.queueRd = nullptr; hot.queueWr = nullptr; hot.grans = nullptr; hot.slotWr = nullptr;
     gen_body<WIN, false>(sp, hot);
 }

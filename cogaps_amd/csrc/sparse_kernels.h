@@ -778,7 +778,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
 }
 CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_kernel(const PropRec *hotQueue, const GenScalars *hotGs, uint32_t hotCap, const SamplerDev CG_CONSTANT *sp)
 {
-    EvalHot hot; hot.queue = hotQueue; hot.gs = hotGs; hot.queueCap = hotCap;
+    EvalHot hot; hot.queue = hotQueue; hot.gs = hotGs; hot.queueCap = hotCap; hot.slot = nullptr; hot.grans = nullptr;
     const EvalFirst first = eval_first<EVAL_FUSED>(hot, 1u, cg_bid());
     const SamplerDev &S = eval_record<EVAL_FUSED>(sp);
     eval_sparse_body<false, false>(S, cg_bid(), cg_gdim(), hot, first);
@@ -786,7 +786,7 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_kernel(const PropRec *hotQueue,
 // data vectors of more than one round of flag words (more than 16384 elements): the rounds' common non-zeros listed together (sp_partial_merged)
 CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_kernel_wide(const PropRec *hotQueue, const GenScalars *hotGs, uint32_t hotCap, const SamplerDev CG_CONSTANT *sp)
 {
-    EvalHot hot; hot.queue = hotQueue; hot.gs = hotGs; hot.queueCap = hotCap;
+    EvalHot hot; hot.queue = hotQueue; hot.gs = hotGs; hot.queueCap = hotCap; hot.slot = nullptr; hot.grans = nullptr;
     const EvalFirst first = eval_first<EVAL_FUSED>(hot, 1u, cg_bid());
     const SamplerDev &S = eval_record<EVAL_FUSED>(sp);
     eval_sparse_body<false, true>(S, cg_bid(), cg_gdim(), hot, first);
@@ -797,14 +797,14 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_kernel_multi(const SamplerDev C
     const SamplerDev CG_CONSTANT *sp = arr + chain;
     cg_const_warm<sizeof(SamplerDev)>(sp);
     const SamplerDev &S = *(const SamplerDev *)sp;
-    EvalHot hot; hot.queue = S.queue; hot.gs = S.gs; hot.queueCap = S.queueCap;
+    EvalHot hot; hot.queue = S.queue; hot.gs = S.gs; hot.queueCap = S.queueCap; hot.slot = nullptr; hot.grans = nullptr;
     const uint32_t vbid = cg_bid() - chain * wgPerChain;
     eval_sparse_body<false, false>(S, vbid, wgPerChain, hot, eval_first<EVAL_FUSED>(hot, 1u, vbid));
 }
 CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_seq_kernel(SamplerDev S)
 {
     cg_kernarg_warm<sizeof(SamplerDev)>();
-    EvalHot hot; hot.queue = S.queue; hot.gs = S.gs; hot.queueCap = S.queueCap;
+    EvalHot hot; hot.queue = S.queue; hot.gs = S.gs; hot.queueCap = S.queueCap; hot.slot = nullptr; hot.grans = nullptr;
     eval_sparse_body<true, false>(S, cg_bid(), cg_gdim(), hot, eval_first<EVAL_FUSED>(hot, 1u, cg_bid()));
 }
 

@@ -209,6 +209,10 @@ typedef struct cogaps_perf {
 int cogaps_session_set_timing(cogaps_session *s, int on);
 int cogaps_session_perf(cogaps_session *s, cogaps_perf *out);                      /* both samplers */
 int cogaps_session_perf_sampler(cogaps_session *s, char which, cogaps_perf *out);   /* the 'A' or the 'P' sampler alone */
+/* 1 when the sampler's last update ran as chained launches (csrc/chain_kernel.h: ONE launch evaluates batch n and generates batch n + 1;
+ * its time is reported as evalMs, genMs stays 0), 0 for a generator launch and an evaluation launch per batch.  The chained form serves
+ * the one-chain fused evaluation (AsynchronousGibbsSampler.h:88-122, same results); environment COGAPS_NO_CHAIN=1 switches it off. */
+int cogaps_session_chained(cogaps_session *s, char which, int *chained);
 
 /* ------------------------------------------------------------------------------------------------
  * Batched multi-chain launches: the sessions of a batch -- the subsets of a GWCoGAPS / scCoGAPS job that share one GPU

@@ -13,7 +13,8 @@ S.run_iterations(1, 0, int(sys.argv[1]) if len(sys.argv) > 1 else 40)
 names = {0: 'entry', 1: 'entry loads+sync (B0)', 2: 'helper: round vars set, flush loads issued', 3: 'helper: flush written back (before join)', 4: 'round top', 5: 'A1 pcg+guess', 6: 'A1 count3 #1 (C1)',
          7: 'A1 exact decide', 8: 'A1 count3 #2+perm (C2)', 9: 'A1 sync (C3)', 10: 'A2 stage1 rng/addr', 25: 'A2 join with the flush', 11: 'A2 stage2 (vec/bits0 used)', 12: 'A2 stage3 (atoms/binHead used)',
          13: 'A2 neighbour loads issued', 14: 'A2 finish', 15: 'B1 registrations', 16: 'B1 sync', 17: 'B2 lookups', 18: 'B2 logic', 19: 'B2 sync (Bp)', 20: 'C masks sync (Bc1)', 21: 'C commit issued',
-         22: 'attempt wave ends', 26: 'entry: loads issued', 27: 'entry: conflict table preset', 28: 'entry: kernel arguments in', 29: 'entry: first trip landed, scalars in LDS', 23: 'helper: bookkeeping done', 24: 'helper: write-back issued'}
+         22: 'attempt wave ends', 26: 'entry: loads issued', 27: 'entry: conflict table preset', 28: 'entry: kernel arguments in', 29: 'entry: first trip landed, scalars in LDS', 23: 'helper: bookkeeping done', 24: 'helper: write-back issued',
+         30: 'chain: before the fetch', 31: 'chain: record + atoms fetched', 32: 'chain: seeds / table window issued', 33: 'chain: granules in (poll done)', 34: 'chain: decisions applied (stores issued)', 35: 'chain: stores acknowledged + barrier'}
 WAVES = 5
 buf = (ctypes.c_uint64 * (WAVES * 64))()
 PL.cogaps_debug_timeline.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -42,8 +43,10 @@ ebuf = (ctypes.c_uint64 * (2 * 16 * 2 * 12))()
 PL.cogaps_debug_eval_timeline.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert PL.cogaps_debug_eval_timeline(ebuf, 2 * 16 * 2 * 12) == 0
 ea = np.array(ebuf).reshape(2, 16, 2, 12)
-en = {0: 'entry', 1: 'record', 2: 'scalars', 3: 'reduced', 4: 'scalar math', 5: 'broadcast', 6: 'AP update', 10: 'partials', 11: 'parked', 12: 'barrier'}
-if SPARSE: en = {0: 'entry', 1: 'record', 2: 'rows in LDS', 3: 'terms folded', 4: 'totals', 5: 's, s_mu', 6: 'decision + update'}
+en = {7: 'published', 0: 'entry', 1: 'record', 2: 'scalars', 3: 'reduced', 4: 'scalar math', 5: 'broadcast', 6: 'AP update', 10: 'partials', 11: 'parked', 12: 'barrier'}
+if SPARSE: en = {7: 'published', 0: 'entry', 1: 'record', 2: 'rows in LDS', 3: 'terms folded', 4: 'totals', 5: 's, s_mu', 6: 'decision + update'}
+g0 = min(seq[w][0][1] for w in range(WAVES) if seq[w])
+print('generator waves: first mark, absolute (minus the earliest):', [seq[w][0][1] - g0 for w in range(WAVES) if seq[w]])
 for which, e in (('narrow workgroups (A sampler)', ea[0]), ('wide workgroups (P sampler)', ea[1])):
     print()
     print('evaluation kernel, %s, cycles since workgroup entry:' % which)
@@ -54,4 +57,4 @@ for which, e in (('narrow workgroups (A sampler)', ea[0]), ('wide workgroups (P 
             ts = [(int(x) & 0xFF, int(x) >> 8) for x in e[b, w, 1:] if x]
             if not ts: continue
             t0 = ts[0][1]
-            print('  wg %2d %s nUpd %d sameRow %d wave %s: ' % (b, chr(ty & 0xFF), (ty >> 8) & 0xFF, ty >> 16, 'first' if w == 0 else 'last ') + '  '.join('%s %d' % (en.get(i, str(i)), c - t0) for i, c in ts[1:]))
+            print('  wg %2d %s nUpd %d sameRow %d wave %s (entry %+d vs the generator workgroup\'s): ' % (b, chr(ty & 0xFF), (ty >> 8) & 0xFF, ty >> 16, 'first' if w == 0 else 'last ', t0 - g0) + '  '.join('%s %d' % (en.get(i, str(i)), c - t0) for i, c in ts[1:]))
