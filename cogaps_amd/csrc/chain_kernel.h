@@ -22,7 +22,11 @@
 #include "eval_kernel.h"
 
 #define CHAIN_MAX_THREADS 512        // 8 waves of up to 256 VGPRs: one workgroup per compute unit, whichever role it plays
+#if defined(COGAPS_EMUL)
+#define CHAIN_EVAL_GRID 7u           // (test-only emulator: a workgroup is a set of fibers; few of them keep the tests quick and make every workgroup evaluate several proposals)
+#else
 #define CHAIN_EVAL_GRID 240u         // evaluation workgroups of a chained launch (+ the generator: 241 <= 256 compute units)
+#endif
 
 #if defined(GEN_TIMELINE)
 // dev: one chained launch on the chip-wide 100 MHz clock -- per workgroup {entry, decision published, end}; the generator workgroup's marks in g_chain_gen

@@ -1483,6 +1483,11 @@ extern "C" int cogaps_debug_chain_timeline(unsigned long long *wgs, unsigned lon
     if (hipMemcpyFromSymbol(wgs, HIP_SYMBOL(g_chain_rt), sizeof(unsigned long long) * 1024) != hipSuccess) return 1;
     return (int)hipMemcpyFromSymbol(gen, HIP_SYMBOL(g_chain_gen), sizeof(unsigned long long) * 8);
 }
+extern "C" int cogaps_debug_chain_log(unsigned long long *out, unsigned int *n)
+{
+    if (hipMemcpyFromSymbol(n, HIP_SYMBOL(g_chain_log_n), sizeof(unsigned int)) != hipSuccess) return 1;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_log), sizeof(unsigned long long) * (size_t)GEN_LOG_N * 8);
+}
 extern "C" int cogaps_debug_eval_timeline(unsigned long long *out, int n)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_eval_timeline), sizeof(unsigned long long) * (size_t)n);

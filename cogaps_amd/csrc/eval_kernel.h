@@ -443,6 +443,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
     const float T = first.T;
     CG_SHARED float lds[16 * 4];
     CG_SHARED float decf; CG_SHARED uint32_t deci;     // decision of wave 0, broadcast to the other waves
+
     CG_SHARED float seqTerm[PHASE == EVAL_SEQ ? 4 * 4 * EVAL_SEQ_BS : 1];
     constexpr bool WHOLE = FUSEDF || PHASE == EVAL_SEQ;      // one workgroup owns the whole proposal
     const uint32_t mm = (PHASE == EVAL_SEQ) ? S.mathMode : GM_MATH_PORTABLE;

@@ -35,7 +35,11 @@ __device__ unsigned long long g_timeline[(GEN_WIN / 64 + 1) * 64];
 #define GEN_PIN(x) asm volatile("" : "+v"(x) :: "memory")      // the value is computed before the next timestamp
 __device__ unsigned long long g_chain_gen[8];      // the chained launch's generator workgroup on the chip-wide 100 MHz clock (chain_kernel.h)
 #define GEN_RT(i) do { if (t == 0u) sh.rt[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#define GEN_RT_DUMP() do { if (t == 0u && sh.rtOn) { for (int i_ = 0; i_ < 8; ++i_) g_chain_gen[i_] = sh.rt[i_]; } } while (0)
+#define GEN_LOG_N 65536
+__device__ unsigned long long g_chain_log[GEN_LOG_N * 8]; __device__ unsigned int g_chain_log_n;      // one record per chained launch of a well filled queue
+#define GEN_RT_DUMP() do { if (t == 0u && sh.rtOn) { for (int i_ = 0; i_ < 8; ++i_) g_chain_gen[i_] = sh.rt[i_]; } \
+    if (t == 0u && sh.rtLog) { const unsigned int k_ = atomicAdd(&g_chain_log_n, 1u) % GEN_LOG_N; for (int i_ = 0; i_ < 6; ++i_) g_chain_log[k_ * 8 + i_] = sh.rt[i_]; \
+        g_chain_log[k_ * 8 + 6] = sh.rtInfo; g_chain_log[k_ * 8 + 7] = (unsigned long long)roundNo; } } while (0)
 #else
 #define GEN_TS(id) do { } while (0)
 #define GEN_TS_INIT() do { } while (0)
@@ -64,6 +68,7 @@ __device__ unsigned long long g_chain_gen[8];      // the chained launch's gener
 #define GEN_F_BINEMPTY 128u // birth's bin had no atom
 #define GEN_F_WORDZERO 256u // ... and its whole level-0 bitmap word was empty (hints must be set)
 
+#define GEN_SPEC_INVALID 0xFFFFFFFEu   // gen_spec_births: no look-up was made for this slot
 #define GEN_STAMP_COMMITTED 0xFFFFFFull
 // buckets of the LDS conflict table (round 1 of a batch), 4 slots each: 1024 for a window of 256 attempts (at most 768 registrations:
 // 19 % of the slots), half of that for the 128-lane window -- the table is emptied at every launch (80 KB / 40 KB of LDS stores).
@@ -108,7 +113,7 @@ struct GenShared {
     uint32_t freeTop[16];                // the free-handle stack's top entries as the launch found them (below what its own flush pushes): a committing birth's handle without a memory trip
 #if defined(GEN_TIMELINE)
     unsigned long long ts[(WIN / 64 + 1) * 64];
-    unsigned long long rt[8]; uint32_t rtOn;
+    unsigned long long rt[8]; uint32_t rtOn, rtLog; unsigned long long rtInfo;
 #endif
     alignas(16) uint32_t bkey[4 * GEN_TAB_NB];      // conflict sets of round 1: keys, bucket-major
     alignas(16) GenTabVal bval[4 * GEN_TAB_NB];     // ... and the ordinals registered under each key
@@ -118,11 +123,15 @@ struct GenShared {
     uint64_t qrngRound, batchEpoch;
     uint32_t roundNo, stopKey;
     uint32_t nR, minAtoms, processed, qlen, skip, remaining;
-    uint32_t nWork, updBase; float u1c, u2c;
+    uint32_t nWork, nBD, updBase; float u1c, u2c;      // nBD: births + deaths of the window by the first guess (their sorted slots come first)
     // chained launch (chain_kernel.h): the erase cache as the generator's own lanes fill it from the decisions they apply, and the window
     // of the death-probability table this launch can need (staged while the evaluation workgroups of the same launch still run)
     unsigned long long eraseTmp[FLUSH_MAX]; uint32_t eraseN, specBad;
     float dpWin[4 * WIN];
+    // ... and the births of the window classified ahead (gen_spec_births, by the helper wave while the attempt lanes wait for the decisions):
+    // the bitmap words and the successor bin's head each birth will need, per sorted slot; `dirty`: one bit per level-0 bitmap word
+    // (mod 16384) that the decisions being applied or the flush change -- a birth whose words are marked looks them up again
+    unsigned long long bw0[WIN], bw0n[WIN]; uint32_t bv2[WIN], bhb[WIN]; uint32_t bslot[64]; uint32_t dirty[512];
 };
 
 // bin index = pos / binLength, exact: double-precision reciprocal estimate (off by at most one), then a

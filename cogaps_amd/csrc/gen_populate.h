@@ -294,7 +294,8 @@ CG_DEVICE void gen_spec_a1(const SamplerDev &S, GenShared<WIN> &sh, const GenRou
         sh.perm[slot] = (uint16_t)t;
         sh.info[t] = guess | (eX[0] << 8);
     }
-    if (t == 0) sh.nWork = T0 + T1 + T2;
+    if (t == 0) { sh.nWork = T0 + T1 + T2; sh.nBD = T0; }
+    sh.bv2[t] = GEN_SPEC_INVALID;
     // (the caller parks the attempt's seed in sh.seed[t] once the trip that brings it has landed, then closes with the second barrier)
 }
 // ... second half (lane = sorted slot): the attempt's generator state, a birth's position
@@ -314,6 +315,56 @@ CG_DEVICE void gen_spec_slot(const SamplerDev &S, GenShared<WIN> &sh, const GenR
         sp.pos = (S.iPartL == 1ull ? x : x / S.iPartL) + 1ull;
         sp.bin = gen_bin_of(S, sp.pos); sp.r1 = gen_div_k(S, sp.bin); sp.c1 = sp.bin - sp.r1 * c.K;
     }
+}
+
+// The births of the window classified ahead, looked up ahead -- by the helper wave, which has nothing to do until the decisions are
+// applied.  A birth is the one attempt type with three dependent memory trips in front of its conflict registration (bitmap word ->
+// successor bin's head -> that atom's record; a pick has two) and its wave held every other wave at the registration barrier for the
+// length of a trip or two.  The first two trips only read the bitmap and the bin heads, which change where an accepted move or an
+// erased atom touches a bin: the lanes that apply the decisions mark those bitmap words in sh.dirty, and a birth whose two words are
+// unmarked takes the words and the head found here and goes straight to the record (gen_round, stage 1).
+template <int WIN>
+CG_DEVICE void gen_spec_births(const SamplerDev &S, GenShared<WIN> &sh, const unsigned ht)
+{
+    // the births' sorted slots, compacted (births and deaths share the slots [0, nBD) in attempt order)
+    const uint32_t nBD = sh.nBD;
+    uint32_t nb = 0;
+    for (uint32_t base = 0; base < nBD; base += 64u) {
+        const uint32_t j = base + ht;
+        const bool isB = j < nBD && (sh.info[sh.perm[j]] & 0xFFu) == 'B';
+        const unsigned long long m = cg_ballot(isB);
+        const uint32_t k = nb + (uint32_t)cg_popc64(m & ((1ull << ht) - 1ull));
+        if (isB && k < 64u) sh.bslot[k] = j;
+        nb += (uint32_t)cg_popc64(m);
+    }
+    cg_wave_sync();
+    if (nb > 64u) nb = 64u;
+    if (ht < nb) {
+        const uint32_t slot = sh.bslot[ht], ct = sh.perm[slot];
+        uint64_t rng = pcg_from_seed(sh.seed[ct]);
+        uint64_t x = pcg_u64(rng);
+        while (x >= S.limitL) x = pcg_u64(rng);
+        const uint64_t pos = (S.iPartL == 1ull ? x : x / S.iPartL) + 1ull;
+        const uint32_t bin = gen_bin_of(S, pos), wd = bin >> 6, bit = bin & 63u;
+        const unsigned long long w0 = S.bits0[wd], w0n = (wd + 1u < S.nWords0) ? S.bits0[wd + 1u] : 0ull;
+        uint32_t headBin = bin; bool ok = true;
+        if (!((w0 >> bit) & 1ull)) {
+            const unsigned long long m = (bit == 63u) ? 0ull : (w0 & ~((2ull << bit) - 1ull));
+            if (m) headBin = (bin & ~63u) + (uint32_t)cg_ctz64(m); else if (w0n) headBin = (bin & ~63u) + 64u + (uint32_t)cg_ctz64(w0n);
+            else {
+                // an empty stretch of the domain: the search through the bitmap's upper levels (half a dozen dependent trips: every wave of the
+                // launch waited for the one birth that needed it) is made here, ahead, as well; the birth checks every word up to the successor's
+                headBin = bm_next_bin(S, bin);
+                ok = headBin != CG_NONE;      // (past the last atom: the usual way)
+            }
+        }
+        if (ok) { const uint32_t v2 = S.binHead[headBin]; sh.bw0[slot] = w0; sh.bw0n[slot] = w0n; sh.bhb[slot] = headBin; sh.bv2[slot] = v2; }
+    }
+}
+CG_DEVICE void gen_mark_dirty(uint32_t *dirty, uint32_t bin)
+{
+    const uint32_t w = (bin >> 6) & 16383u;
+    cg_atomic_or_u32(&dirty[w >> 5], 1u << (w & 31u));
 }
 
 template <int WIN, bool FIRST, bool SPEC = false>
@@ -422,7 +473,32 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
     // headline shape's occupancy -- the successor bin is nearly always in the next 64, and the full search through the bitmap's upper
     // levels, half a dozen dependent trips that the whole wave waits for, stays for the domain's sparse stretches)
     unsigned long long w0n = 0ull;
-    if (isB) { w0 = S.bits0[bin >> 6]; w0n = ((bin >> 6) + 1u < S.nWords0) ? S.bits0[(bin >> 6) + 1u] : 0ull; }
+    // (SPEC: a birth whose bitmap words were not touched by the decisions just applied takes the words and the successor bin's head the
+    // helper wave looked up ahead -- gen_spec_births -- and asks for that atom's record at once, two trips ahead of the others)
+    bool specB = false; uint32_t v2 = CG_NONE;
+    AtomRec b3; b3.pos = 0; b3.lpos = 0; b3.rpos = 0; b3.left = CG_NONE; b3.right = CG_NONE; b3.mass = 0.f; b3.rmass = 0.f; b3.idx = 0;
+    uint32_t specHead = 0;
+    if (SPEC && isB) {
+        const uint32_t sv2 = sh.bv2[t];
+        specHead = sh.bhb[t];
+        // the look-up holds if none of the bitmap words it read -- the bin's own, the next, and every further one up to the successor bin's --
+        // is marked
+        const uint32_t wFirst = bin >> 6;
+        uint32_t wLast = specHead >> 6; wLast = wLast > wFirst + 1u ? wLast : wFirst + 1u;
+        uint32_t dd = (sv2 == GEN_SPEC_INVALID || wLast - wFirst >= 16384u) ? 1u : 0u;
+        for (uint32_t w = wFirst; !dd && w <= wLast; ) {
+            const uint32_t wm = w & 16383u, n = 32u - (wm & 31u), left = wLast - w + 1u, take = n < left ? n : left;
+            const uint32_t bits = sh.dirty[wm >> 5] >> (wm & 31u);
+            dd = bits & (take >= 32u ? 0xFFFFFFFFu : ((1u << take) - 1u));
+            w += take;
+        }
+        specB = dd == 0u;
+#if defined(COGAPS_EMUL)
+        cg_atomic_add_u64(&gs->prof[specB ? 10 : (sv2 != GEN_SPEC_INVALID ? 9 : 8)], 1ull);      // test-only build: births that used the look-up made ahead / found their words marked / had none
+#endif
+        if (specB) { w0 = sh.bw0[t]; w0n = sh.bw0n[t]; v2 = sv2; b3 = S.atoms[v2]; }
+    }
+    if (isB && !specB) { w0 = S.bits0[bin >> 6]; w0n = ((bin >> 6) + 1u < S.nWords0) ? S.bits0[(bin >> 6) + 1u] : 0ull; }
     if (pick) v1 = S.vec[i1];
 #if defined(GEN_SUBMARKS)
     if (v1 == 12345678u || w0 == 0x123456789ull) flags |= 0x80000000u;
@@ -449,11 +525,13 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
         else {
             flags |= GEN_F_BINEMPTY; if (w0 == 0ull) flags |= GEN_F_WORDZERO;
             const unsigned long long m = (bit == 63u) ? 0ull : (w0 & ~((2ull << bit) - 1ull));
-            if (m) headBin = (bin & ~63u) + (uint32_t)cg_ctz64(m); else if (w0n) headBin = (bin & ~63u) + 64u + (uint32_t)cg_ctz64(w0n); else slowB = true;
+            if (m) headBin = (bin & ~63u) + (uint32_t)cg_ctz64(m); else if (w0n) headBin = (bin & ~63u) + 64u + (uint32_t)cg_ctz64(w0n);
+            else if (specB) headBin = specHead;      // (an empty stretch: the successor bin the helper wave's search found, gen_spec_births)
+            else slowB = true;
         }
     }
-    uint32_t v2 = CG_NONE; AtomRec a; a.pos = 0; a.lpos = 0; a.rpos = 0; a.left = CG_NONE; a.right = CG_NONE; a.mass = 0.f; a.rmass = 0.f; a.idx = 0;
-    if (isB && !slowB) v2 = S.binHead[headBin];
+    AtomRec a; a.pos = 0; a.lpos = 0; a.rpos = 0; a.left = CG_NONE; a.right = CG_NONE; a.mass = 0.f; a.rmass = 0.f; a.idx = 0;
+    if (isB && !slowB && !specB) v2 = S.binHead[headBin];
     if (pick) { h1 = v1; a = S.atoms[h1]; }
 #if defined(GEN_SUBMARKS)
     if (v2 == 12345678u || a.pos == 0x123456789ull) flags |= 0x80000000u;
@@ -464,7 +542,6 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
     // A picked atom's record carries its neighbours' positions and the right neighbour's mass (gaps_state.h): a move's bounds and
     // an exchange's partner need no trip to the neighbours' records -- every pick goes from its record straight to the matrix
     // entries.  (The one exception: the highest atom's exchange partner is front(), whose record is fetched.)
-    AtomRec b3; b3.pos = 0; b3.lpos = 0; b3.rpos = 0; b3.left = CG_NONE; b3.right = CG_NONE; b3.mass = 0.f; b3.rmass = 0.f; b3.idx = 0;
     uint64_t lp = 0, rp = 0;
     float m2x = 0.f;                        // exchange: the partner's mass
     bool frontE = false;                    // exchange of the highest atom: the partner is front()
@@ -480,10 +557,11 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
             else { h2 = sh.g.front; frontE = true; }
         }
     }
-    if (isB && !slowB) b3 = S.atoms[v2];
-    if (frontE) b3 = S.atoms[h2];
     // the scalars the evaluation starts from travel in the queue record (consumed at commit)
     float old1 = 0.f, old2 = 0.f; uint32_t gib1 = 0, gib2 = 0;
+    uint64_t lposB = 0, rposB = 0; float rmassB = 0.f;        // birth: what the new atom's record caches of its neighbours
+    if (isB && !slowB && !specB) b3 = S.atoms[v2];
+    if (frontE) b3 = S.atoms[h2];
     if (isB || pick) { old1 = S.sparse ? S.rows[(size_t)r1 * S.Kpad + c1] : S.mat[(size_t)c1 * S.Mpad + r1]; gib1 = S.otherColPos[c1]; }
     if (pick && type == 'M') {
         if (hl != CG_NONE) { flags |= GEN_F_HASLEFT; lbpos = lp; } else lbpos = 0;
@@ -505,7 +583,6 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
     GEN_PIN(b3.pos); GEN_PIN(lp); GEN_PIN(rp);
     GEN_TS(13);
     // finish ----------------------------------------------------------------------------------
-    uint64_t lposB = 0, rposB = 0; float rmassB = 0.f;        // birth: what the new atom's record caches of its neighbours
     if (isB) {
         if (!slowB) {
             if ((flags & GEN_F_BINEMPTY) || b3.pos > pos) { hr = v2; hl = b3.left; lposB = b3.lpos; rposB = b3.pos; rmassB = b3.mass; flags |= GEN_F_NEWHEAD; }
@@ -524,6 +601,9 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
                 hl = cur; hr = nxt; lposB = curPos; rposB = nxtPos; rmassB = nxtMass;
             }
         }
+#if defined(GEN_TIMELINE)
+        if (FIRST) { cg_atomic_add_u64(&sh.rt[6], specB ? 1ull : 0x10000ull); if (slowB) cg_atomic_add_u64(&sh.rt[7], 1ull); }
+#endif
         if (slowB) {
             bool occ, nh;
             gen_find_gap(S, pos, bin, &hl, &hr, &occ, &nh);
@@ -915,6 +995,7 @@ struct ChainItem {
     // move (ConcurrentAtomicDomain.cpp:126-132 across bins, as eval_domain_move decides it: the atom's own record is current -- births queued
     // after the move may have changed the links, nothing moves next to a moving atom, ProposalQueue.cpp:167,218)
     uint64_t *pos1, *rposL, *lposR;          // atoms[h1].pos, atoms[left].rpos, atoms[right].lpos
+    uint32_t mb1, mb2;                       // the move's old and new bin (sh.dirty marks)
     uint32_t *head1, *head2; uint32_t head1Val, h1;      // old bin's head word (null: the atom is not the head) and what it becomes; new bin's head word (null: stays)
     unsigned long long *b0clr, *b0set, *b1set, *b2set; uint32_t bit1, bit2, bit1w, bit2w;      // bitmap words (null: nothing to do) and bit numbers
 };
@@ -922,6 +1003,7 @@ CG_DEVICE void chain_item_clear(ChainItem &it)
 {
     it.type = 0; it.m1 = 0.f; it.m2 = 0.f; it.old1 = 0.f; it.old2 = 0.f; it.pos = 0; it.eraseEntry = 0ull;
     it.mass1 = nullptr; it.rm1 = nullptr; it.mass2 = nullptr; it.rm2 = nullptr; it.mat1 = nullptr; it.mat2 = nullptr; it.col1 = nullptr; it.col2 = nullptr;
+    it.mb1 = 0; it.mb2 = 0;
     it.pos1 = nullptr; it.rposL = nullptr; it.lposR = nullptr; it.head1 = nullptr; it.head2 = nullptr; it.head1Val = CG_NONE; it.h1 = 0;
     it.b0clr = nullptr; it.b0set = nullptr; it.b1set = nullptr; it.b2set = nullptr; it.bit1 = 0; it.bit2 = 0; it.bit1w = 0; it.bit2w = 0;
 }
@@ -961,6 +1043,7 @@ CG_DEVICE void chain_fetch_build(const SamplerDev &S, const PropRec &p, const Ch
     if (p.type == 'E') { const uint32_t l2 = m.l2; it.mass2 = &S.atoms[p.h2].mass; it.rm2 = l2 != CG_NONE ? &S.atoms[l2].rmass : nullptr; }
     if (p.type == 'M') {
         const uint32_t b1 = m.b1, b2 = m.b2;
+        it.mb1 = b1; it.mb2 = b2;
         const uint32_t head1 = m.head1;
         const uint32_t w0 = b2 >> 6, w1 = w0 >> 6, w2 = w1 >> 6;
         const unsigned long long x1 = m.x1, x2 = m.x2;
@@ -1086,7 +1169,7 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
     if (!CHAIN) {
         GEN_TS_ZERO(7u, 13u);
 #if defined(GEN_TIMELINE)
-        if (t == 0u) sh.rtOn = 0u;
+        if (t == 0u) { sh.rtOn = 0u; sh.rtLog = 0u; }
 #endif
         if (!helper) {   // roofline bookkeeping: add up the traffic units the evaluation kernel left per queue slot (the helper wave adds
             // the sum to evalBytes at the end of the batch)
@@ -1105,7 +1188,7 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
         GEN_TS(30);
         GEN_RT(1);
 #if defined(GEN_TIMELINE)
-        if (t == 0u) sh.rtOn = (e_prevQ >= 140u && e_nSteps - e_nDone >= 512u) ? 1u : 0u;
+        if (t == 0u) { sh.rtOn = (e_prevQ >= 140u && e_nSteps - e_nDone >= 512u) ? 1u : 0u; sh.rt[6] = 0ull; sh.rt[7] = 0ull; sh.rtLog = (WIN == 256 && e_prevQ >= 100u && e_nSteps - e_nDone >= 512u) ? 1u : 0u; }
 #endif
         const bool have0 = !helper && t < e_prevQ;
         // second trip (the first brought the scalars and the lane's record): what the decision will rewrite, the seeds, the table's window
@@ -1134,6 +1217,7 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
             rcS.g_u1 = sh.g.u1; rcS.g_u2 = sh.g.u2; rcS.remaining = e_nSteps - e_nDone; rcS.K = S.K;
             gen_spec_a1<WIN>(S, sh, rcS, nLo, nHi, dpAtLo, dpAtHi, spS);      // (the first of A1's two barriers inside)
         } else if (trySpec) cg_sync_lds();
+        if (trySpec) { for (uint32_t i = t; i < 512u; i += TPB) sh.dirty[i] = 0u; }
         // the trip has landed: the attempt's seed and the table's window go to LDS; A1's second barrier
         if (dpStaged) {
 #pragma unroll
@@ -1142,7 +1226,7 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
         if (trySpec) {
             if (!helper && spS.guess != (uint32_t)GEN_T_NONE) sh.seed[t] = seedC;      // consumed after the type sort
             cg_sync_lds();
-            if (!helper) gen_spec_slot<WIN>(S, sh, rcS, spS);
+            if (!helper) gen_spec_slot<WIN>(S, sh, rcS, spS); else gen_spec_births<WIN>(S, sh, ht);
         }
         if (have0) chain_fetch_build(S, p0, mid0, it);
         GEN_PIN(it.type); GEN_PIN(it.bit2);
@@ -1173,6 +1257,9 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
                 // erase cache (ConcurrentAtomicDomain.cpp:62-69): one slot per erased atom, in any order -- the flush sorts by position.
                 // (Before the stores: what the barrier below waits for is LDS traffic only.)
                 const bool er = have && code == CHAIN_ERASE;
+                // bitmap words whose bits or bins' heads this decision (or the flush, for an erased atom) changes: the births looked up ahead check them
+                if (er) gen_mark_dirty(sh.dirty, (uint32_t)(it.eraseEntry >> 32));
+                if (have && code == CHAIN_APPLY && it.type == 'M') { gen_mark_dirty(sh.dirty, it.mb1); gen_mark_dirty(sh.dirty, it.mb2); }
                 const unsigned long long em = cg_ballot(er);
                 if (em) {
                     const uint32_t cntE = (uint32_t)cg_popc64(em);
@@ -1212,6 +1299,9 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
         if (e_m > eraseCap) e_m = eraseCap;
         if (helper) specE = (ht < (unsigned)FLUSH_MAX && ht < e_m) ? sh.eraseTmp[ht] : 0ull;
         specDone = trySpec && cg_uniform_u32(sh.specBad) == 0u;
+#if defined(GEN_TIMELINE)
+        if (t == 0u) sh.rtInfo = (unsigned long long)e_prevQ | ((unsigned long long)e_m << 16) | ((unsigned long long)(specDone ? 1u : 0u) << 32);
+#endif
 #if defined(COGAPS_EMUL)
         if (t == 0 && !updateDone) cg_atomic_add_u64(&gs->prof[specDone ? 12 : 11], 1ull);      // test-only build: windows classified ahead of the decisions / the usual way
 #endif

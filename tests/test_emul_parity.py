@@ -48,6 +48,35 @@ def test_batches_of_several_rounds_use_the_lds_table_then_the_stamp_tables(emul_
         assert n_lds > 100, (n_lds, n_hbm)
 
 
+@pytest.mark.parametrize("variant", ["chained", "chained_fallback", "two_launches"])
+def test_chained_launch_against_the_oracle(emul_lib, monkeypatch, variant):
+    """csrc/chain_kernel.h: one launch evaluates batch n and generates batch n + 1 -- the generator workgroup applies the decisions it
+    receives as tagged granules, classifies its window and looks its births up ahead of them.  1200 x 300: both samplers take the chained
+    form at the 64-attempt window (workgroups of 128 / 512 threads), the domains are large enough for the look-ups made ahead to survive
+    and small enough for some to be invalidated by an accepted move or an erased atom in the same bitmap word.  Stepwise against the
+    oracle (every proposal of every batch, the state after every update), then the test-only build's counters: every path was taken.
+    `chained_fallback`: a build variant that declares every third window's classification unusable (the path a window takes when an
+    attempt falls between the two birth / death thresholds -- too rare to meet otherwise); `two_launches`: COGAPS_NO_CHAIN=1."""
+    from cogaps_amd import _capi
+    if variant == "two_launches": monkeypatch.setenv("COGAPS_NO_CHAIN", "1")
+    lib = emul_lib(64, extra="-DGEN_SPEC_BAD_EVERY=3", tag="_specbad") if variant == "chained_fallback" else emul_lib(64)
+    data = pu.synthetic(1200, 300, seed=7)
+    pu.run_stepwise(lib, data, 24, nPatterns=3, seed=123, total_iter=40, check_every=4)
+    S = _capi.Session(data, lib=lib, nPatterns=3, seed=123, nIterations=40)
+    S.run_iterations(1, 0, 24)
+    tot = np.zeros(16, dtype=np.int64)
+    for w in "AP":
+        assert S.chained(w) == (variant != "two_launches")
+        tot += np.array(S.debug_prof(w), dtype=np.int64)
+    S.close()
+    ahead, marked, none, usual, spec, chain_batches = (int(tot[i]) for i in (10, 9, 8, 11, 12, 13))
+    if variant == "two_launches":
+        assert chain_batches == 0 and spec == 0 and ahead == 0
+    else:
+        assert chain_batches > 300 and spec > 200 and usual > 20 and ahead > 300 and marked > 3 and none > 3, (chain_batches, spec, usual, ahead, marked, none)
+        if variant == "chained_fallback": assert usual > spec // 3
+
+
 def test_tiny_domain_hazards(emul_lib):
     """5 rows x 2 patterns: every window is full of row conflicts, same-bin moves and neighbour hazards"""
     data = pu.synthetic(5, 6, rank=2, seed=3)

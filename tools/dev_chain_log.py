@@ -1,0 +1,36 @@
+"""dev: distribution of the phases of the chained launch's generator workgroup over thousands of launches (profile build, chip-wide 100 MHz clock):
+entry -> first barrier -> ahead-of-the-decisions work done -> granules in -> decisions applied + barrier -> attempt wave 0 ends; by number of rounds."""
+import sys, os, ctypes, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cogaps_amd import _capi
+from bench import synthetic_dense
+PL = _capi.bind(ctypes.CDLL(os.path.join(os.path.dirname(_capi.LIB_PATH), 'libcogaps_hip_PROFILE_DEV.so')))
+data = synthetic_dense(20000, 2000)
+S = _capi.Session(data, lib=PL, nPatterns=50, nIterations=100, seed=42)
+S.run_iterations(1, 0, int(sys.argv[1]) if len(sys.argv) > 1 else 60)
+N = 65536
+buf = (ctypes.c_uint64 * (N * 8))(); n = ctypes.c_uint32()
+PL.cogaps_debug_chain_log.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+assert PL.cogaps_debug_chain_log(buf, ctypes.byref(n)) == 0
+a = np.array(buf, dtype=np.int64).reshape(N, 8)[:min(n.value, N)]
+a = a[a[:, 0] > 0]
+t = (a[:, 1:6] - a[:, 0:5]) / 100.0            # phase lengths, us
+tot = (a[:, 5] - a[:, 0]) / 100.0
+prevq = a[:, 6] & 0xFFFF; em = (a[:, 6] >> 16) & 0xFFFF; spec = (a[:, 6] >> 32) & 1; rounds = a[:, 7]
+names = ['entry -> first barrier', 'work ahead of the decisions', 'wait for the granules', 'apply + barrier', 'round(s) of the next batch']
+def line(name, v): print('  %-32s mean %6.2f  p10 %6.2f  p50 %6.2f  p75 %6.2f  p90 %6.2f  p99 %6.2f' % (name, v.mean(), *np.percentile(v, [10, 50, 75, 90, 99])))
+print('%d launches logged (queue >= 100); rounds: %s; classified ahead: %.3f' % (len(a), dict(zip(*np.unique(rounds, return_counts=True))), spec.mean()))
+for sel, nm in ((rounds >= 1, 'all'), (rounds == 1, 'one round'), (rounds == 2, 'two rounds')):
+    if sel.sum() < 10: continue
+    print(nm, '(%d)' % sel.sum())
+    line('whole workgroup', tot[sel])
+    for i, n_ in enumerate(names): line(n_, t[sel, i])
+one = rounds == 1
+r = t[one, 4]
+print('one-round launches, the round by quartile of its length: queue %s erased %s' % (
+    [round(float(prevq[one][(r >= lo) & (r <= hi)].mean()), 1) for lo, hi in zip(np.percentile(r, [0, 25, 50, 75]), np.percentile(r, [25, 50, 75, 100]))],
+    [round(float(em[one][(r >= lo) & (r <= hi)].mean()), 1) for lo, hi in zip(np.percentile(r, [0, 25, 50, 75]), np.percentile(r, [25, 50, 75, 100]))]))
+w = t[:, 2]
+for lo, hi in ((100, 200), (200, 240), (240, 256), (256, 2000)):
+    sel = (prevq > lo) & (prevq <= hi)
+    if sel.sum(): print('  queue in (%d, %d]: %5d launches, wait for the granules mean %.2f p50 %.2f p90 %.2f; apply mean %.2f' % (lo, hi, sel.sum(), w[sel].mean(), np.median(w[sel]), np.percentile(w[sel], 90), t[sel, 3].mean()))

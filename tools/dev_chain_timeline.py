@@ -24,3 +24,4 @@ for name, a in (('entry', ent), ('published', pub), ('end', end)):
 names = ['entry', 'first barrier passed, fetch begins', 'record + atoms fetched, window staged', 'granules in (poll done)', 'decisions applied + barrier', 'attempt wave 0 ends']
 for i, n in enumerate(names):
     print('  generator  %-40s %.2f us' % (n, us(g[i])))
+print('  births of the window: looked up ahead %d, the usual way %d, slow path %d' % (int(g[6]) & 0xFFFF, int(g[6]) >> 16, int(g[7])))
