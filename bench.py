@@ -476,7 +476,7 @@ def main():
                 traffic_stale = traffic_measured_on != lib_hash
                 traffic_kernels = {k: v["hbm_bytes_per_launch"] for k, v in pk.items()}
                 tb = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in pk.values())
-                nb = sum(v["launches"] for k, v in pk.items() if k.startswith("gen_kernel"))
+                nb = sum(v["launches"] for k, v in pk.items() if k.startswith("gen_kernel") or k.startswith("chain_kernel"))      # one generator (or chained) launch per batch
                 if nb and not traffic_stale:
                     traffic = tb / nb
                 if nb:
@@ -506,7 +506,7 @@ def main():
                                                "eval": (1e3 * kt[w]["evalNoopMs"] / kt[w]["evalNoopTimed"]) if kt[w]["evalNoopTimed"] else None} for w in "AP"}},
             # roofline.achieved = B_alg / (sum of kernel time) over the whole path -- generator, evaluation and sync
             # kernels of the timed region -- with each kernel's own figure alongside.  One "launch" of the path = one batch.
-            "roofline": {"bound": "hbm", "kernel": "path: gen_kernel + evaluation kernels + sync, per batch (dominant by time: %s, sampler %s)" % (dominant["kernel"], dominant["sampler"]),
+            "roofline": {"bound": "hbm", "kernel": "path: generator + evaluation launches (one chained launch per batch where the fused evaluation serves) + sync, per batch (dominant by time: %s, sampler %s)" % (dominant["kernel"], dominant["sampler"]),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved is not None else None,
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_bytes_per_launch_by_kernel": (traffic_kernels if not traffic_stale else None),
                          # the committed counter pass names the library build it measured; another build -> no figure, no ratio, re-run tools/r4_pmc_pass.sh

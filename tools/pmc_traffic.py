@@ -14,6 +14,7 @@ def per_kernel(d, counter):
             if r['Counter_Name'] == counter:
                 name = r['Kernel_Name'].split('(')[0]
                 if 'gen_kernel<' in name or 'gen_apply_kernel<' in name: name = 'gen_kernel'          # (both window instantiations, with or without the update workgroups: one generator launch per batch)
+                if 'chain_kernel<' in name: name = 'chain_kernel'      # (chained launch: evaluation of batch n + generator of batch n+1, one launch per batch)
                 rows[name].append((int(r['Dispatch_Id']), float(r['Counter_Value'])))
     for v in rows.values():
         v.sort()
@@ -25,6 +26,8 @@ bench = json.load(open(sys.argv[3]))
 ks = bench['roofline']['kernels']        # [evaluation A, evaluation P, generator A, generator P, sync]
 want = {'eval_kernel<0>': ks[0]['launches'], 'eval_kernel<1>': ks[1]['launches'], 'eval_kernel<2>': ks[1]['launches'], 'eval_kernel<4>': ks[1]['launches'],
         'gen_kernel': ks[2]['launches'] + ks[3]['launches']}      # (<1> + <2>: the two-launch split form of rounds 1-3; <4>: the one-launch form, whose updates are counted with the generator launch)
+for i_, w_ in ((0, 'A'), (1, 'P')):
+    if ks[i_]['kernel'].startswith('chain_kernel'): want['chain_kernel'] = want.get('chain_kernel', 0) + ks[i_]['launches']
 if 'sparse' in ks[0]['kernel']:      # the sparse model: one evaluation kernel per sampler (the wide form where a vector has more flag words than word owners)
     names = sorted({k for k in fetch if 'eval_sparse_kernel' in k})
     want = {'gen_kernel': ks[2]['launches'] + ks[3]['launches']}
@@ -38,7 +41,7 @@ for name, n in want.items():
     f, w = fetch[fk[0]], write[wk[0]]
     n = n or len(f)
     # the same dispatches in both passes (deterministic run): select on the fetch pass, by position
-    idx = [i for i, (_, v) in enumerate(f) if v >= 64.0 or name.startswith('gen')][-n:]      # (generator: the last n launches, empty-queue ones included)
+    idx = [i for i, (_, v) in enumerate(f) if v >= 64.0 or name.startswith('gen') or name.startswith('chain')][-n:]      # (generator: the last n launches, empty-queue ones included)
     fb = sum(f[i][1] for i in idx) / len(idx) * 1024.0 * 2.0
     wb = sum(w[i][1] for i in idx if i < len(w)) / len(idx) * 1024.0
     out[name] = {'launches': len(idx), 'fetch_bytes_per_launch_corrected_x2': fb, 'write_bytes_per_launch': wb, 'hbm_bytes_per_launch': fb + wb,
