@@ -470,7 +470,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
 #else
 #define EVAL_PUBLISH_RT() do { } while (0)
 #endif
-#define EVAL_PUBLISH(CODE, VAL, NUPD) do { EVAL_TS(7); EVAL_PUBLISH_RT(); if (CHAIN && t == 0u) { unsigned long long *gr_ = hot.grans + (size_t)q * 64u; const uint32_t units_ = (NUPD) * 3u + alphaUnits; \
+#define EVAL_PUBLISH(CODE, VAL, NUPD) do { EVAL_TS(7); EVAL_PUBLISH_RT(); if (CHAIN && t == 0u) { unsigned long long *gr_ = hot.grans + (size_t)q * CHAIN_GRAN_STRIDE; const uint32_t units_ = (NUPD) * 3u + alphaUnits; \
         cg_store_agent_u64(&gr_[0], ((unsigned long long)first.tag << 32) | (unsigned long long)((CODE) | (units_ << 8))); \
         cg_store_agent_u64(&gr_[1], ((unsigned long long)first.tag << 32) | (unsigned long long)gm_f2u(VAL)); } } while (0)
     // (the deciding workgroup's other waves have nothing to do with the decision: no broadcast)

@@ -58,7 +58,9 @@ struct alignas(16) DecRec { uint32_t n, r1, c1; float d1; uint32_t r2, c2; float
 // evaluation marks its decision granules with.
 struct alignas(8) ChainSlot { uint32_t qlen, tag; };
 // decision of one evaluated proposal, handed to the next batch's generator inside the launch as two {value, tag} granules
-// (grans[q * 64 + 0] = code | units << 8, grans[q * 64 + 1] = one float): what the generator's lane applies to the atomic domain
+// (grans[q * CHAIN_GRAN_STRIDE + 0] = code | units << 8, + 1 = one float): what the generator's lane applies to the atomic domain
+#define CHAIN_GRAN_STRIDE 2u  // 64-bit words per proposal in the granule array: the two granules side by side, four proposals per 64-byte line (a wave's poll
+                             // touches 16 lines; at the split evaluation's stride of 64 words it touched 128 and took that much longer to return)
 #define CHAIN_NONE 0u        // nothing to change (rejected move / exchange, a death's rebirth with the old mass)
 #define CHAIN_APPLY 1u       // B: mass = value; D: rebirth mass = value; M: the move; E: delta = value
 #define CHAIN_ERASE 2u       // B: rejected, D: the atom dies -- the atom goes to the erase cache

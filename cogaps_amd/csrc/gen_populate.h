@@ -1241,7 +1241,7 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
             // one proposal: wait for its two granules (read past this workgroup's caches until both carry the batch's tag), note an erased atom
             // in the erase cache, carry the decision out
             auto take = [&](const uint32_t q, const bool have) {
-                const unsigned long long *gr = hot.grans + (size_t)q * 64u;
+                const unsigned long long *gr = hot.grans + (size_t)q * CHAIN_GRAN_STRIDE;
                 unsigned long long g0 = 0ull, g1 = 0ull; uint32_t spins = 0;
                 for (;;) {
                     if (have) { g0 = cg_load_l2_u64(&gr[0]); g1 = cg_load_l2_u64(&gr[1]); }
