@@ -25,3 +25,5 @@ names = ['entry', 'first barrier passed, fetch begins', 'record + atoms fetched,
 for i, n in enumerate(names):
     print('  generator  %-40s %.2f us' % (n, us(g[i])))
 print('  births of the window: looked up ahead %d, the usual way %d, slow path %d' % (int(g[6]) & 0xFFFF, int(g[6]) >> 16, int(g[7])))
+sec = [b for b in range(240, 255) if w[b, 1] and abs(int(w[b, 1]) - int(g[0])) < 5000]
+if sec: print('  second-pass proposals (queue slots 240..254) published: ' + ' '.join('%.2f' % us(w[b, 1]) for b in sec) + ' us')
