@@ -376,6 +376,201 @@ CG_DEVICE EvalAtoms eval_atoms_load(const SamplerDev &S, const PropRec &p, bool 
     return e;
 }
 
+// ---- chained launch: two proposals evaluated side by side by the halves of a workgroup ------------------------------------------------
+// A chained launch has at most one evaluation workgroup per compute unit (chain_kernel.h), 240 of them; a batch that queued more
+// proposals -- the batch after a generator launch of two rounds, 18 % of the headline chain's launches -- used to give some
+// workgroups a second proposal AFTER their first, and the launch's generator workgroup, which needs the LAST decision, waited 4 us
+// longer.  Here such a workgroup evaluates its two proposals at once: half h (threads h*H .. h*H+H-1, H = BS / 2) takes proposal h,
+// thread u of a half holds the virtual lanes u and u + H of the W = BS lanes (one chunk each), the half's first wave makes the decision.
+// The sums are the reduction contract's: each slot's lanes are folded by the wave butterfly and the tree over the half's waves --
+// exactly the lower and the upper half of the whole workgroup's tree -- and the two slots are added last, which is the butterfly's
+// last stage (x[L] + x[L ^ H]).  Both halves execute the same three barriers whatever their proposals' types.  Decisions, draws and
+// the A*P updates are eval_body's, operation for operation.
+template <int NC>
+CG_DEVICE void eval_pair_fold(const float *lds, const uint32_t tv, const uint32_t nw, float (&tot)[NC])
+{
+    constexpr int NV = NC * 2;
+    if (tv < 64u) {
+        const uint32_t i = tv < (uint32_t)NV ? tv : 0u;
+        float y[16];
+#pragma unroll
+        for (uint32_t w = 0; w < 16; ++w) y[w] = lds[w * NV + i];
+#pragma unroll
+        for (uint32_t w = 0; w < 16; ++w) y[w] = w < nw ? y[w] : 0.f;
+#pragma unroll
+        for (uint32_t stride = 1; stride < 16u; stride <<= 1) {
+#pragma unroll
+            for (uint32_t k = 0; k + stride < 16u; k += 2u * stride) y[k] = y[k] + y[k + stride];
+        }
+        float z = y[0];
+        z = z + cg_shfl_xor_f32(z, 1);      // lanes 2c, 2c+1: the two slots of component c
+#pragma unroll
+        for (int c = 0; c < NC; ++c) tot[c] = cg_lane_read_f32(z, c * 2);
+    }
+}
+// alpha parameters of NR rows over the half's two slots; tot valid in the half's first wave.  lds: this half's [16][2 * NR * 2] scratch.
+// (The barrier between the parking and the fold is the caller's: both halves share it.)
+template <int NR, int MODE>
+CG_DEVICE void eval_pair_alpha(const SamplerDev &S, const uint32_t (&row)[NR], const uint32_t (&col)[NR], uint32_t col2, float ch, const uint32_t u, const uint32_t H, float *lds, EvalSpec &spec)
+{
+    constexpr int NC = 2 * NR;
+    const uint32_t nq = S.Npad >> 2;
+    float ps[NR][2], pm[NR][2];
+    cg_f4 v[2][NR], w2[2], d[2][NR], sq[2][NR], pp[2][NR];
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        const uint32_t j = u + (uint32_t)sl * H, jj = j < nq ? j : nq - 1u;      // (a lane past the row reads its last chunk and adds nothing)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const float *Dr = S.D + (size_t)row[r] * S.Npad, *Ar = S.AP + (size_t)row[r] * S.Npad, *Vr = S.other + (size_t)col[r] * S.Npad;
+            v[sl][r] = ld4(Vr, jj); d[sl][r] = ld4_stream(Dr, jj); pp[sl][r] = ld4(Ar, jj);
+            if (!S.defaultS) sq[sl][r] = ld4_stream(S.S2 + (size_t)row[r] * S.Npad, jj);
+        }
+        w2[sl] = (MODE == EVAL_MODE_SAME) ? ld4(S.other + (size_t)col2 * S.Npad, jj) : f4_zero();
+    }
+    if (spec.n) { cg_sched_fence(); eval_spec_run(spec); cg_sched_fence(); }      // (wave-uniform; the loads above are out)
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        const uint32_t j = u + (uint32_t)sl * H;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (S.defaultS) {
+                const float sx = gm_max(d[sl][r].x * 0.1f, 0.1f), sy = gm_max(d[sl][r].y * 0.1f, 0.1f), sz = gm_max(d[sl][r].z * 0.1f, 0.1f), sw = gm_max(d[sl][r].w * 0.1f, 0.1f);
+                sq[sl][r].x = sx * sx; sq[sl][r].y = sy * sy; sq[sl][r].z = sz * sz; sq[sl][r].w = sw * sw;
+            }
+            EvalAcc a; a.s = 0.f; a.m = 0.f;
+            if (j < nq) {
+                const cg_f4 vv = v[sl][r], dd = d[sl][r], ss = sq[sl][r], aa = pp[sl][r], ww = w2[sl];
+                if (MODE == EVAL_MODE_CH) { EVAL_ELEM_CH(vv.x, dd.x, ss.x, aa.x) EVAL_ELEM_CH(vv.y, dd.y, ss.y, aa.y) EVAL_ELEM_CH(vv.z, dd.z, ss.z, aa.z) EVAL_ELEM_CH(vv.w, dd.w, ss.w, aa.w) }
+                else if (MODE == EVAL_MODE_SAME) {
+                    { float x = vv.x - ww.x; EVAL_ELEM(x, dd.x, ss.x, aa.x) }
+                    { float x = vv.y - ww.y; EVAL_ELEM(x, dd.y, ss.y, aa.y) }
+                    { float x = vv.z - ww.z; EVAL_ELEM(x, dd.z, ss.z, aa.z) }
+                    { float x = vv.w - ww.w; EVAL_ELEM(x, dd.w, ss.w, aa.w) }
+                } else { EVAL_ELEM(vv.x, dd.x, ss.x, aa.x) EVAL_ELEM(vv.y, dd.y, ss.y, aa.y) EVAL_ELEM(vv.z, dd.z, ss.z, aa.z) EVAL_ELEM(vv.w, dd.w, ss.w, aa.w) }
+            }
+            ps[r][sl] = a.s; pm[r][sl] = a.m;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) { ps[r][sl] = cg_wave_allsum_f32(ps[r][sl]); pm[r][sl] = cg_wave_allsum_f32(pm[r][sl]); }
+    }
+    if ((u & 63u) == 0u) {
+        float *o = lds + (u >> 6) * (NC * 2);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) { o[(2 * r) * 2 + 0] = ps[r][0]; o[(2 * r) * 2 + 1] = ps[r][1]; o[(2 * r + 1) * 2 + 0] = pm[r][0]; o[(2 * r + 1) * 2 + 1] = pm[r][1]; }
+    }
+}
+// AP[:,row] += delta * other[:,col] over the half's two slots (eval_update_ap's operations); a second site continues from the first in
+// registers when it is the same row (eval_update_ap2)
+CG_DEVICE void eval_pair_update(const SamplerDev &S, const DecRec &d, const uint32_t u, const uint32_t H)
+{
+    const uint32_t nq = S.Npad >> 2;
+    if (d.n == 0u) return;
+    float *AP1 = S.AP + (size_t)d.r1 * S.Npad; const float *V1 = S.other + (size_t)d.c1 * S.Npad;
+    const bool second = d.n == 2u, same = second && d.r1 == d.r2;
+    float *AP2 = S.AP + (size_t)(second ? d.r2 : d.r1) * S.Npad; const float *V2 = S.other + (size_t)(second ? d.c2 : d.c1) * S.Npad;
+    cg_f4 v1[2], p1[2], v2[2], p2[2];
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        const uint32_t j = u + (uint32_t)sl * H, jj = j < nq ? j : nq - 1u;
+        v1[sl] = ld4(V1, jj); p1[sl] = ld4(AP1, jj); v2[sl] = ld4(V2, jj); p2[sl] = ld4(AP2, jj);
+    }
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        const uint32_t j = u + (uint32_t)sl * H;
+        if (j < nq) {
+            cg_f4 q = p1[sl];
+            q.x = q.x + d.d1 * v1[sl].x; q.y = q.y + d.d1 * v1[sl].y; q.z = q.z + d.d1 * v1[sl].z; q.w = q.w + d.d1 * v1[sl].w;
+            if (same) { q.x = q.x + d.d2 * v2[sl].x; q.y = q.y + d.d2 * v2[sl].y; q.z = q.z + d.d2 * v2[sl].z; q.w = q.w + d.d2 * v2[sl].w; }
+            st4(AP1, j, q);
+            if (second && !same) {
+                cg_f4 w = p2[sl];
+                w.x = w.x + d.d2 * v2[sl].x; w.y = w.y + d.d2 * v2[sl].y; w.z = w.z + d.d2 * v2[sl].z; w.w = w.w + d.d2 * v2[sl].w;
+                st4(AP2, j, w);
+            }
+        }
+    }
+}
+// proposals qA (first half) and qB (second half) of the queue; every thread of the workgroup calls it
+CG_DEVICE void eval_chain_pair(const SamplerDev &S, unsigned long long *grans, const uint32_t tag, const float T, const PropRec &pA, const PropRec &pB, const uint32_t qA, const uint32_t qB)
+{
+    CG_SHARED float ldsP[2][16 * 8];
+    CG_SHARED DecRec decP[2];
+    const uint32_t t = cg_tid(), H = cg_bdim() >> 1, h = t >= H ? 1u : 0u, u = t - h * H, nwH = H >> 6;
+    const PropRec p = h ? pB : pA;
+    const uint32_t q = h ? qB : qA;
+    const uint32_t mm = GM_MATH_PORTABLE;
+    const float lambda = S.lambda;
+    const bool scalarLane = u < 64u;
+    uint64_t rng = p.rng;
+    const bool two = (p.type == 'M' || p.type == 'E');
+    const float m1 = p.m1, m2 = p.m2, old1 = p.old1, old2 = p.old2;
+    const bool gibbs1 = (p.gibbs & 1u) != 0u, gibbs2 = (p.gibbs & 2u) != 0u;
+    const bool need = (p.type == 'B') ? gibbs1 : ((p.type == 'D' || p.type == 'M') ? true : (gibbs1 || gibbs2));
+    const bool diff = two && p.r1 != p.r2;
+    const uint32_t alphaUnits = need ? (!two ? 4u : (diff ? 8u : 5u)) : 0u;
+    EvalSpec spec; spec.rng = rng; spec.mm = mm; spec.l1 = 0.f; spec.l2 = 0.f;
+    spec.n = (scalarLane && need && (p.type == 'D' || p.type == 'M')) ? ((p.type == 'D' && gibbs1) ? 2u : 1u) : 0u;
+    float *lds = &ldsP[h][0];
+    if (need) {
+        const uint32_t rowA[1] = {p.r1}, colA[1] = {p.c1};
+        if (diff) { const uint32_t rowAB[2] = {p.r1, p.r2}, colAB[2] = {p.c1, p.c2}; eval_pair_alpha<2, EVAL_MODE_ONE>(S, rowAB, colAB, 0u, 0.f, u, H, lds, spec); }
+        else if (p.type == 'D') eval_pair_alpha<1, EVAL_MODE_CH>(S, rowA, colA, 0u, -1.f * m1, u, H, lds, spec);
+        else if (two) eval_pair_alpha<1, EVAL_MODE_SAME>(S, rowA, colA, p.c2, 0.f, u, H, lds, spec);
+        else eval_pair_alpha<1, EVAL_MODE_ONE>(S, rowA, colA, 0u, 0.f, u, H, lds, spec);
+    }
+    cg_sync();                                  // barrier 1: the waves' partials are parked
+    float s = 0.f, smu = 0.f;
+    if (need) {
+        if (diff) { float tot[4] = {0.f, 0.f, 0.f, 0.f}; eval_pair_fold<4>(lds, u, nwH, tot); s = tot[0] + tot[2]; smu = tot[1] - tot[3]; }      // AlphaParameters.cpp:11-14
+        else { float t2[2] = {0.f, 0.f}; eval_pair_fold<2>(lds, u, nwH, t2); s = t2[0]; smu = t2[1]; }
+        if (spec.n) eval_spec_run(spec);
+    }
+    s = s * T; smu = smu * T;
+    DecRec owe; owe.n = 0; owe.r1 = 0; owe.c1 = 0; owe.d1 = 0.f; owe.r2 = 0; owe.c2 = 0; owe.d2 = 0.f; owe.pad = 0;
+    if (scalarLane) {
+        uint32_t code = CHAIN_NONE, nUpd = 0; float val = 0.f;
+        if (p.type == 'B') {                                                   // AsynchronousGibbsSampler.h:127-144
+            float bv = 0.f; uint32_t bhas = 0;
+            if (gibbs1) { OptF g = gm_gibbs_mass(s, smu, 0.f, S.maxGibbsMass, rng, S.luts, true, lambda); bv = g.v; bhas = g.has ? 1u : 0u; }
+            else { bv = pcg_exponential(rng, lambda, mm); bhas = 1u; }
+            if (bhas != 0u && bv >= GAPS_EPSILON) { code = CHAIN_APPLY; val = bv; nUpd = 1u; owe.n = 1u; owe.r1 = p.r1; owe.c1 = p.c1; owe.d1 = bv; }
+            else code = CHAIN_ERASE;
+        } else if (p.type == 'D') {                                            // :148-180
+            float rebirth = m1; bool drew = false;
+            if (gibbs1) { OptF g = gm_gibbs_mass(s, smu, 0.f, S.maxGibbsMass, rng, S.luts, true, lambda); if (g.has) { rebirth = g.v; drew = true; } }
+            const float deltaLL = rebirth * (smu - s * rebirth / 2.f);
+            const float logU = drew ? spec.l2 : spec.l1;
+            if (logU < deltaLL) {
+                if (rebirth != m1) { const float nv = gm_max(old1 + (rebirth - m1), 0.f); code = CHAIN_APPLY; val = rebirth; nUpd = 1u; owe.n = 1u; owe.r1 = p.r1; owe.c1 = p.c1; owe.d1 = nv - old1; }
+            } else { const float nv = gm_max(old1 + (-1.f * m1), 0.f); code = CHAIN_ERASE; nUpd = 1u; owe.n = 1u; owe.r1 = p.r1; owe.c1 = p.c1; owe.d1 = nv - old1; }
+        } else if (p.type == 'M') {                                            // :184-196
+            const float deltaLL = -1.f * m1 * (smu + s * m1 / 2.f);
+            if (spec.l1 < deltaLL) { const float nv1 = gm_max(old1 + (-m1), 0.f); code = CHAIN_APPLY; nUpd = 2u; owe.n = 2u; owe.r1 = p.r1; owe.c1 = p.c1; owe.d1 = nv1 - old1; owe.r2 = p.r2; owe.c2 = p.c2; owe.d2 = m1; }
+        } else if (need) {                                                     // exchange, :201-219
+            OptF g0 = gm_gibbs_mass(s, smu, -m1, m2, rng, S.luts, false, 0.f);
+            const float gv = g0.v, n1 = m1 + gv, n2 = m2 - gv;
+            if (g0.has && n1 > GAPS_EPSILON && n2 > GAPS_EPSILON) {
+                const float nv1 = gm_max(old1 + (n1 - m1), 0.f), nv2 = gm_max(old2 + (n2 - m2), 0.f);
+                code = CHAIN_APPLY; val = gv; nUpd = 2u; owe.n = 2u; owe.r1 = p.r1; owe.c1 = p.c1; owe.d1 = nv1 - old1; owe.r2 = p.r2; owe.c2 = p.c2; owe.d2 = nv2 - old2;
+            }
+        }
+        if (u == 0u) {
+            unsigned long long *gr = grans + (size_t)q * CHAIN_GRAN_STRIDE; const uint32_t units = nUpd * 3u + alphaUnits;
+            cg_store_agent_u64(&gr[0], ((unsigned long long)tag << 32) | (unsigned long long)(code | (units << 8)));
+            cg_store_agent_u64(&gr[1], ((unsigned long long)tag << 32) | (unsigned long long)gm_f2u(val));
+            decP[h] = owe;
+        }
+    }
+    cg_sync();                                  // barrier 2: the decisions are in LDS
+    const DecRec d = decP[h];
+    eval_pair_update(S, d, u, H);
+    cg_sync();                                  // barrier 3: the scratch is free again
+}
+
 #if defined(GEN_PROFILE) && !defined(GEN_SUBMARKS) && !defined(GEN_ROUNDMARKS)
 #define EVAL_PROF(i) do { if (t == 0 && cg_bid() == 0) { unsigned long long now_ = cg_clock(); cg_atomic_add_u64(&S.gs->prof[8 + (i)], now_ - eprof_last); eprof_last = now_; } } while (0)
 #else
@@ -480,6 +675,20 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
         // one trip: the record (slot q always exists: q < queueCap), the queue length, the annealing temperature
         const PropRec p = pNext;
         if (q >= qlen) break;
+        if (CHAIN && q + qStep < qlen && (S.Npad >> 2) <= BS && BS >= 128u) {
+            // a queue longer than the launch has evaluation workgroups: this workgroup's next two proposals side by side (eval_chain_pair)
+            const uint32_t qB = q + qStep;
+            const PropRec pB = hot.queue[qB < hot.queueCap ? qB : 0u];
+            const uint32_t qN = qB + qStep;
+            if (qN < qlen) pNext = hot.queue[qN < hot.queueCap ? qN : 0u];
+#if defined(COGAPS_EMUL)
+            if (t == 0u) cg_atomic_add_u64(&S.gs->prof[7], 1ull);      // test-only build: proposals evaluated in pairs
+#endif
+            eval_chain_pair(S, hot.grans, first.tag, T, p, pB, q, qB);
+            if (qN >= qlen) break;
+            q = qB;      // (the loop's step adds the second)
+            continue;
+        }
         { uint32_t ty_ = p.type; EVAL_PIN(ty_); }
         EVAL_TS(1);
         uint64_t rng = p.rng; uint32_t nUpd = 0;

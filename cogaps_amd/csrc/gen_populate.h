@@ -1124,6 +1124,7 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
     // chained launch: the lane's queue record of the batch being evaluated (slot t always exists), with the launch's first trip
     PropRec p0; p0.type = 0; p0.h1 = 0; p0.h2 = 0; p0.pos = 0; p0.curPos = 0; p0.r1 = 0; p0.c1 = 0; p0.r2 = 0; p0.c2 = 0; p0.m1 = 0.f; p0.m2 = 0.f; p0.old1 = 0.f; p0.old2 = 0.f;
     if (CHAIN && !helper && t < hot.queueCap) p0 = hot.queueRd[t];
+
     uint32_t units = (!CHAIN && !helper && t < hot.queueCap) ? hot.queueUnits[t] : 0u;
     const uint64_t jmW = hot.lcgMul[2 * WIN], jiW = hot.lcgInc[2 * WIN];
     constexpr uint32_t GSW = (uint32_t)(sizeof(GenScalars) / 4u);
@@ -1194,6 +1195,9 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
         // second trip (the first brought the scalars and the lane's record): what the decision will rewrite, the seeds, the table's window
         ChainMid mid0; mid0.l2 = CG_NONE; mid0.head1 = CG_NONE; mid0.b1 = 0; mid0.b2 = 0; mid0.x1 = 0ull; mid0.x2 = 0ull;
         mid0.a.pos = 0; mid0.a.lpos = 0; mid0.a.rpos = 0; mid0.a.left = CG_NONE; mid0.a.right = CG_NONE; mid0.a.mass = 0.f; mid0.a.rmass = 0.f; mid0.a.idx = 0; mid0.a.pad0 = 0;
+        // a queue longer than the window (the batch after a generator launch of two rounds, 14 % of the headline chain's launches; its
+        // evaluation takes longer as well: the workgroups evaluate pairs): the lane's second proposal is fetched ahead like the first
+        const bool have1 = !helper && t + (unsigned)WIN < e_prevQ;
         mid0 = chain_fetch_mid(S, p0);      // (p0 of a lane without a proposal: slot t of the queue copy, whatever it holds -- handles and positions of an older batch: valid addresses)
         if (!updateDone) seedC = S.seeds[e_nDone + t < e_nSteps ? e_nDone + t : e_nSteps - 1u];
         const uint32_t span = e_prevQ + (uint32_t)(WIN - 1);
@@ -1229,6 +1233,9 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
             if (!helper) gen_spec_slot<WIN>(S, sh, rcS, spS); else gen_spec_births<WIN>(S, sh, ht);
         }
         if (have0) chain_fetch_build(S, p0, mid0, it);
+        // (last of the work ahead: behind a branch the compiler waits for every load in flight, and here they have all landed)
+        ChainItem it1; chain_item_clear(it1);
+        if (e_prevQ > (uint32_t)WIN) { const uint32_t q1 = t + (unsigned)WIN; chain_fetch(S, hot.queueRd, q1 < hot.queueCap ? q1 : 0u, it1); }
         GEN_PIN(it.type); GEN_PIN(it.bit2);
         GEN_TS(32);
         GEN_RT(2);
@@ -1240,7 +1247,7 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
         if (!helper) {
             // one proposal: wait for its two granules (read past this workgroup's caches until both carry the batch's tag), note an erased atom
             // in the erase cache, carry the decision out
-            auto take = [&](const uint32_t q, const bool have) {
+            auto take = [&](const uint32_t q, const bool have, const ChainItem &it) {
                 const unsigned long long *gr = hot.grans + (size_t)q * CHAIN_GRAN_STRIDE;
                 unsigned long long g0 = 0ull, g1 = 0ull; uint32_t spins = 0;
                 for (;;) {
@@ -1277,17 +1284,18 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
             };
             // a batch of several rounds may have queued more than a window (rare): those proposals first, so that the usual case -- and the
             // last stores before the barrier -- is straight-line code (a loop's exit made the compiler wait for every store's acknowledgement)
-            if (e_prevQ > (uint32_t)WIN) {
-                ChainItem keep = it;
-                for (uint32_t base = (uint32_t)WIN; base < e_prevQ; base += (uint32_t)WIN) {
+            if (e_prevQ > 2u * (uint32_t)WIN) {
+                for (uint32_t base = 2u * (uint32_t)WIN; base < e_prevQ; base += (uint32_t)WIN) {
                     const uint32_t q = base + t;
                     const bool have = q < e_prevQ;
-                    if (have) chain_fetch(S, hot.queueRd, q, it);
-                    take(q, have);
+                    ChainItem itX; chain_item_clear(itX);
+                    if (have) chain_fetch(S, hot.queueRd, q, itX);
+                    take(q, have, itX);
                 }
-                it = keep;
             }
-            take(t, have0);
+            // (the second window's worth of a long queue -- the batch after a generator launch of two rounds -- was fetched ahead like the first)
+            if (e_prevQ > (uint32_t)WIN) take((uint32_t)WIN + t, have1, it1);
+            take(t, have0, it);
             const uint32_t waveUnits = cg_wave_sum_u32(unitAcc);
             if ((t & 63u) == 0u && waveUnits) cg_atomic_add_u32(&sh.unitSum, waveUnits);
         }

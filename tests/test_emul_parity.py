@@ -55,6 +55,7 @@ def test_chained_launch_against_the_oracle(emul_lib, monkeypatch, variant):
     form at the 64-attempt window (workgroups of 128 / 512 threads), the domains are large enough for the look-ups made ahead to survive
     and small enough for some to be invalidated by an accepted move or an erased atom in the same bitmap word.  Stepwise against the
     oracle (every proposal of every batch, the state after every update), then the test-only build's counters: every path was taken.
+    Workgroups with several proposals evaluate them in pairs, one per half (eval_chain_pair).
     `chained_fallback`: a build variant that declares every third window's classification unusable (the path a window takes when an
     attempt falls between the two birth / death thresholds -- too rare to meet otherwise); `two_launches`: COGAPS_NO_CHAIN=1."""
     from cogaps_amd import _capi
@@ -69,12 +70,13 @@ def test_chained_launch_against_the_oracle(emul_lib, monkeypatch, variant):
         assert S.chained(w) == (variant != "two_launches")
         tot += np.array(S.debug_prof(w), dtype=np.int64)
     S.close()
-    ahead, marked, none, usual, spec, chain_batches = (int(tot[i]) for i in (10, 9, 8, 11, 12, 13))
+    ahead, marked, none, usual, spec, chain_batches, pairs = (int(tot[i]) for i in (10, 9, 8, 11, 12, 13, 7))
     if variant == "two_launches":
-        assert chain_batches == 0 and spec == 0 and ahead == 0
+        assert chain_batches == 0 and spec == 0 and ahead == 0 and pairs == 0
     else:
         assert chain_batches > 300 and spec > 200 and usual > 20 and ahead > 300 and marked > 3 and none > 3, (chain_batches, spec, usual, ahead, marked, none)
         if variant == "chained_fallback": assert usual > spec // 3
+        assert pairs > 300, pairs        # (seven evaluation workgroups per launch in this build: most proposals are evaluated two at a time, eval_chain_pair)
 
 
 def test_tiny_domain_hazards(emul_lib):

@@ -1,5 +1,6 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-export CONFIGS="ab_libs/chain13.so;ab_libs/chain_g248.so;ab_libs/chain_g255.so" TAG=chaingrid
-export TESTS="-k 'headline_shape_stepwise'"
+export CONFIGS="${CONFIGS:-ab_libs/chain18.so;ab_libs/chain13.so}" TAG=${TAG:-chain18}
+export TESTS="-k headline_shape_stepwise"
+export TEST_TIMEOUT=1500
 bash tools/r4_chain_ab.sh
