@@ -214,6 +214,7 @@ struct cogaps_session {
     bool timing = false; bool evInit = false;
     bool noGraph = getenv("COGAPS_NO_GRAPH") != nullptr;     // diagnostics: every launch as a plain call (counter collection tools)
     bool noChain = getenv("COGAPS_NO_CHAIN") != nullptr;     // A/B and tests: two launches per batch (gen_kernel, eval_kernel<EVAL_FUSED>) where the chained launch would serve
+    unsigned computeUnits = 0;      // of the session's device: the chained launch wants all its workgroups resident at once, one per compute unit
     std::vector<rt_event_pair> evPool; std::vector<int> evKind; std::vector<HostSampler *> evOwner; std::vector<uint64_t> evOrd; size_t evUsed = 0;
     GenScalars *hGs = nullptr;    // pinned staging
 };
@@ -539,7 +540,10 @@ static void launch_eval(cogaps_session *s, HostSampler &h)
 static const uint32_t GRAPH_PAIRS = 64;
 static bool chain_eligible(const cogaps_session *s, const HostSampler &h)
 {
-    return !s->noChain && !h.d.seq && !h.d.sparse && h.d.redW <= (uint32_t)CHAIN_MAX_THREADS && h.d.redW >= h.genWin + 64u;
+    // (a device with fewer compute units than the launch has workgroups -- a partitioned GPU -- would run them in turns, the generator
+    // workgroup last: correct, and slower than two launches)
+    return !s->noChain && !h.d.seq && !h.d.sparse && h.d.redW <= (uint32_t)CHAIN_MAX_THREADS && h.d.redW >= h.genWin + 64u
+           && s->computeUnits >= std::min<uint32_t>(h.d.queueCap, CHAIN_EVAL_GRID) + 1u;
 }
 // one batch step: the chained launch, or a generator launch and an evaluation launch
 static void launch_pair(cogaps_session *s, HostSampler &h)
@@ -781,7 +785,7 @@ cogaps_session *cogaps_session_create(const float *data, uint32_t nrow, uint32_t
                 if (p.dataIndicesSubset[i] < 1u || p.dataIndicesSubset[i] > dim) { fail("dataIndicesSubset holds an index outside 1 .. " + std::to_string(dim)); return nullptr; }
         }
         rt_set_device(p.device);
-        s = new cogaps_session();
+        s = new cogaps_session(); s->computeUnits = rt_compute_units();
         s->p = p;
         s->p.device = rt_get_device();            // (-1 resolved: later calls from other host threads select the same GPU)
         s->startTime = now_s();

@@ -30,6 +30,7 @@ inline void rt_sync(rt_stream_t) {}
 inline void rt_set_device(int) {}
 inline int rt_get_device() { return 0; }
 inline void rt_mem_info(size_t *freeB, size_t *totalB) { *freeB = *totalB = (size_t)1 << 40; }
+inline unsigned rt_compute_units() { const char *e = getenv("COGAPS_TEST_COMPUTE_UNITS"); return e ? (unsigned)atoi(e) : (1u << 20); }      // (test-only build: a small device on request)
 inline rt_stream_t rt_stream_create() { return 0; }
 inline void rt_stream_destroy(rt_stream_t) {}
 #define RT_LAUNCH(kernel, grid, block, stream, ...) cgemu::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })
@@ -86,6 +87,8 @@ inline void rt_set_device(int d) { if (d >= 0) RT_CHECK(hipSetDevice(d)); }
 // (hipGetDevice as a process's FIRST runtime call reports "no ROCm-capable device" on ROCm 7.2: initialise explicitly)
 inline int rt_get_device() { int d = 0; RT_CHECK(hipInit(0)); RT_CHECK(hipGetDevice(&d)); return d; }
 inline void rt_mem_info(size_t *freeB, size_t *totalB) { RT_CHECK(hipMemGetInfo(freeB, totalB)); }
+// compute units of the current device (a partitioned MI355X shows a fraction of the 256)
+inline unsigned rt_compute_units() { int d = 0, n = 0; RT_CHECK(hipGetDevice(&d)); RT_CHECK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d)); return n > 0 ? (unsigned)n : 0u; }
 inline rt_stream_t rt_stream_create() { hipStream_t s; RT_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); return s; }
 inline void rt_stream_destroy(rt_stream_t s) { (void)hipStreamDestroy(s); }
 #define RT_LAUNCH(kernel, grid, block, stream, ...) do { hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (stream), __VA_ARGS__); RT_CHECK(hipGetLastError()); } while (0)

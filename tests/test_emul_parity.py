@@ -48,7 +48,7 @@ def test_batches_of_several_rounds_use_the_lds_table_then_the_stamp_tables(emul_
         assert n_lds > 100, (n_lds, n_hbm)
 
 
-@pytest.mark.parametrize("variant", ["chained", "chained_fallback", "two_launches"])
+@pytest.mark.parametrize("variant", ["chained", "chained_fallback", "two_launches", "few_compute_units"])
 def test_chained_launch_against_the_oracle(emul_lib, monkeypatch, variant):
     """csrc/chain_kernel.h: one launch evaluates batch n and generates batch n + 1 -- the generator workgroup applies the decisions it
     receives as tagged granules, classifies its window and looks its births up ahead of them.  1200 x 300: both samplers take the chained
@@ -57,9 +57,11 @@ def test_chained_launch_against_the_oracle(emul_lib, monkeypatch, variant):
     oracle (every proposal of every batch, the state after every update), then the test-only build's counters: every path was taken.
     Workgroups with several proposals evaluate them in pairs, one per half (eval_chain_pair).
     `chained_fallback`: a build variant that declares every third window's classification unusable (the path a window takes when an
-    attempt falls between the two birth / death thresholds -- too rare to meet otherwise); `two_launches`: COGAPS_NO_CHAIN=1."""
+    attempt falls between the two birth / death thresholds -- too rare to meet otherwise); `two_launches`: COGAPS_NO_CHAIN=1; `few_compute_units`: a device with
+    fewer compute units than the chained launch has workgroups keeps two launches per batch."""
     from cogaps_amd import _capi
     if variant == "two_launches": monkeypatch.setenv("COGAPS_NO_CHAIN", "1")
+    if variant == "few_compute_units": monkeypatch.setenv("COGAPS_TEST_COMPUTE_UNITS", "4")      # (a partitioned GPU: fewer compute units than the chained launch has workgroups)
     lib = emul_lib(64, extra="-DGEN_SPEC_BAD_EVERY=3", tag="_specbad") if variant == "chained_fallback" else emul_lib(64)
     data = pu.synthetic(1200, 300, seed=7)
     pu.run_stepwise(lib, data, 24, nPatterns=3, seed=123, total_iter=40, check_every=4)
@@ -67,11 +69,11 @@ def test_chained_launch_against_the_oracle(emul_lib, monkeypatch, variant):
     S.run_iterations(1, 0, 24)
     tot = np.zeros(16, dtype=np.int64)
     for w in "AP":
-        assert S.chained(w) == (variant != "two_launches")
+        assert S.chained(w) == (variant in ("chained", "chained_fallback"))
         tot += np.array(S.debug_prof(w), dtype=np.int64)
     S.close()
     ahead, marked, none, usual, spec, chain_batches, pairs = (int(tot[i]) for i in (10, 9, 8, 11, 12, 13, 7))
-    if variant == "two_launches":
+    if variant in ("two_launches", "few_compute_units"):
         assert chain_batches == 0 and spec == 0 and ahead == 0 and pairs == 0
     else:
         assert chain_batches > 300 and spec > 200 and usual > 20 and ahead > 300 and marked > 3 and none > 3, (chain_batches, spec, usual, ahead, marked, none)
