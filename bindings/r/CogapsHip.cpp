@@ -37,7 +37,11 @@ static Rcpp::CharacterVector splitLines(const std::string &joined) {         // 
     for (std::string line; std::getline(in, line); ) out.push_back(line);
     return out;
 }
-static int pollInterrupt(void *) { try { Rcpp::checkUserInterrupt(); } catch (...) { return 1; } return 0; }   // GapsRunner.cpp:280
+// GapsRunner.cpp:280 calls Rcpp::checkUserInterrupt() once per iteration and lets its exception unwind.  A C callback cannot throw through
+// the library: the interrupt is noted here, the library ends the run with an error code, and cogaps_cpp raises the interrupt again (below)
+static bool g_userInterrupt = false;
+static int pollInterrupt(void *) { try { Rcpp::checkUserInterrupt(); } catch (...) { g_userInterrupt = true; return 1; } return 0; }
+static void reraiseInterrupt() { if (g_userInterrupt) { g_userInterrupt = false; Rcpp::checkUserInterrupt(); Rcpp::stop("CoGAPS interrupted by the user"); } }
 
 // ---- allParams -> cogaps_params (getGapsParameters, Cogaps.cpp:64-139) -------------------------------------------------
 struct ParamStore { cogaps_params p; std::vector<uint32_t> subset; std::vector<float> fixed; };   // keeps what p points to alive
@@ -95,7 +99,7 @@ static Rcpp::List resultToList(const cogaps_result &r, const cogaps_params &p, c
             Rcpp::Named("samplingSnapshotsA") = snapshotList(r.samplingSnapshotsA, r.nSamplingSnapshots, r.nGenes, r.nPatterns),
             Rcpp::Named("samplingSnapshotsP") = snapshotList(r.samplingSnapshotsP, r.nSamplingSnapshots, r.nSamples, r.nPatterns)));
 }
-static void failWithLibraryMessage() { Rcpp::stop(std::string("CoGAPS terminated: ") + cogaps_last_error()); }   // GAPS_ERROR -> Rcpp::stop
+static void failWithLibraryMessage() { reraiseInterrupt(); Rcpp::stop(std::string("CoGAPS terminated: ") + cogaps_last_error()); }   // GAPS_ERROR -> Rcpp::stop
 
 // ---- the six functions of the package (Cogaps.cpp:191-254) ---------------------------------------------------------------
 Rcpp::List cogaps_cpp(const Rcpp::NumericMatrix &data, const Rcpp::List &allParams, const Rcpp::Nullable<Rcpp::NumericMatrix> &uncertainty) {
@@ -126,7 +130,13 @@ Rcpp::List getFileInfo_cpp(const std::string &path) {                           
     return Rcpp::List::create(Rcpp::Named("dimensions") = Rcpp::NumericVector::create(nr, nc),
                               Rcpp::Named("rowNames") = splitLines(rows), Rcpp::Named("colNames") = splitLines(cols));
 }
-bool compiledWithOpenMPSupport_cpp() { return true; }                         // see the note above: FALSE would make CoGAPS() force the sequential sampler
+// R/CoGAPS.R:120-124 forces asynchronousUpdates = FALSE -- the reference's SingleThreadedGibbsSampler -- when this reports FALSE ("requesting
+// multi-threaded version of CoGAPS but compiler did not support OpenMP"); the library only has the asynchronous sampler, which is what the
+// OpenMP build runs, so the honest answer for "can nThreads > 1 be honoured" is TRUE: the asynchronous sampler's result does not depend
+// on the thread count (tests/testthat/test_seed_consistency.R:41-70) and the GPU runs its queue in parallel.  A caller that asks for
+// asynchronousUpdates = FALSE outside a distributed run (the scCoGAPS / GWCoGAPS wrappers' default, R/CoGAPS.R:176,216, applies to their
+// workers, which the library accepts) gets the library's error text through failWithLibraryMessage -- see bindings/r/README.md.
+bool compiledWithOpenMPSupport_cpp() { return true; }
 bool checkpointsEnabled_cpp() { return cogaps_checkpoints_enabled() != 0; }
 std::string getBuildReport_cpp() { return cogaps_build_report(); }
 

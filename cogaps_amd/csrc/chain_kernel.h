@@ -47,8 +47,10 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(CHAIN_MAX_THREADS) chain_kernel(const uint64_t *
 #if defined(GEN_TIMELINE)
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    const unsigned long long clk0 = (cg_bid() == 0u && cg_tid() == 0u) ? cg_realtime() : 0ull;
     const EvalFirst first = eval_first<EVAL_CHAIN>(hot, 1u, cg_bid());
     const SamplerDev &S = eval_record<EVAL_CHAIN>(sp);
+    if (cg_bid() == 0u && cg_tid() == 0u && S.launchClock) S.launchClock[2u * (first.tag % GAPS_CLOCK_RING)] = clk0;      // (launch clock: gaps_state.h)
     eval_body<EVAL_CHAIN, true>(S, 1u, cg_bid(), cg_gdim() - 1u, hot, first);
 #if defined(GEN_TIMELINE)
     if (cg_tid() == 0u && first.qlen >= 140u && gs->nSteps - gs->nDone >= 512u && cg_bid() < 255u) { g_chain_rt[cg_bid() * 4u] = rt0; g_chain_rt[cg_bid() * 4u + 2u] = __builtin_amdgcn_s_memrealtime(); g_chain_rt[cg_bid() * 4u + 3u] = first.qlen; }

@@ -158,6 +158,18 @@ extern "C" uint32_t cogaps_sparse_width(uint32_t N)
                          case 4: RT_LAUNCH(KERNEL<4>, grid, bs_, stream, __VA_ARGS__); break; case 8: RT_LAUNCH(KERNEL<8>, grid, bs_, stream, __VA_ARGS__); break; \
                          default: RT_LAUNCH(KERNEL<16>, grid, bs_, stream, __VA_ARGS__); break; } } while (0)
 
+// Switches that change what is MEASURED and never a result (launch sizes, the two-launch split form, reading S instead of recomputing it)
+// exist in development builds only (-DCOGAPS_DEV, -DGEN_PROFILE): the product library does not look at them.  What the product library
+// does read from the environment, on purpose, is documented in include/cogaps_hip.h: COGAPS_NO_GRAPH (every launch as a plain call --
+// counter collection hangs on replayed graphs) and COGAPS_NO_CHAIN (two launches per batch: the A/B and the equality test of the chained launch).
+static const char *dev_env(const char *name)
+{
+#if defined(COGAPS_DEV) || defined(GEN_PROFILE) || defined(COGAPS_EMUL)
+    return getenv(name);
+#else
+    (void)name; return nullptr;
+#endif
+}
 static const uint32_t SEQ_SPARSE_GRID = 256;      // workgroups of the sparse model's verification-mode evaluation (one scratch region each)
 
 // ------------------------------------------------------------------------------------------------
@@ -190,6 +202,8 @@ struct HostSampler {
     uint64_t updLaunches = 0;    // (generator, evaluation) pairs enqueued in the current update
     uint64_t batchesAtTimingOn = 0;   // `batches` when event timing was switched on: the sampled times are scaled to the batches since then
     uint64_t plainRotor = 0;     // which graph replay of a chunk runs as plain, event-carrying launches while timing is on
+    // launch clock of the chained launches (gaps_state.h): durations in 0.1 us bins since timing was switched on, their sum and count
+    std::vector<unsigned long long> clockHost; uint64_t clockSeen = 0; std::vector<uint64_t> clockHist; double clockSumUs = 0; uint64_t clockN = 0;
 };
 
 struct cogaps_session {
@@ -217,6 +231,7 @@ struct cogaps_session {
     unsigned computeUnits = 0;      // of the session's device: the chained launch wants all its workgroups resident at once, one per compute unit
     std::vector<rt_event_pair> evPool; std::vector<int> evKind; std::vector<HostSampler *> evOwner; std::vector<uint64_t> evOrd; size_t evUsed = 0;
     GenScalars *hGs = nullptr;    // pinned staging
+    bool poisoned = false;        // a device error ended an update half way (capacity, a hand-over inside a launch that never arrived): the chain's state is not a state of the chain
 };
 
 static double now_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
@@ -236,7 +251,7 @@ static void build_death_prob_table(cogaps_session *s, SamplerDev &d)
 static void free_sampler(HostSampler &h)
 {
     SamplerDev &d = h.d;
-    rt_free(d.seqScratch); rt_free((void *)d.deathProb);
+    rt_free(d.seqScratch); rt_free((void *)d.deathProb); rt_free(d.launchClock);
     rt_free((void *)d.D); rt_free((void *)d.S2); rt_free(d.AP); rt_free(d.mat); rt_free(d.colPos);
     rt_free(d.atoms); rt_free(d.vec); rt_free(d.freeHandles); rt_free(d.binHead);
     rt_free(d.bits0); rt_free(d.bits1); rt_free(d.bits2); rt_free(d.eraseList); rt_free(d.queue); rt_free(d.queueUnits); rt_free(d.chainSlots); rt_free(d.partials); rt_free(d.grans); rt_free(d.dec);
@@ -266,7 +281,7 @@ static void build_sampler(cogaps_session *s, HostSampler &h, char name, const fl
     // With the default uncertainty the evaluation kernel recomputes S*S = max(0.1 D, 0.1)^2 from the D value it loads anyway
     // (bit-identical: the same three fp32 operations as the fill below): no S2 array, one row less per proposal from HBM.
     // (COGAPS_READ_S: diagnostics, keeps the array and the loads.)
-    const bool defaultS = !sparse && unc == nullptr && !getenv("COGAPS_READ_S");
+    const bool defaultS = !sparse && unc == nullptr && !dev_env("COGAPS_READ_S");
     float *dD = dalloc<float>(tot), *dS2 = defaultS ? nullptr : dalloc<float>(tot); h.Sraw = dalloc<float>(tot);
     if (sparse) {
         if (d.K > SP_KMAX) throw std::runtime_error("useSparseOptimization supports at most 512 patterns");
@@ -345,7 +360,7 @@ static void build_sampler(cogaps_session *s, HostSampler &h, char name, const fl
     d.nWords0 = (uint32_t)((nBins + 63) / 64); d.nWords1 = (d.nWords0 + 63) / 64; d.nWords2 = (d.nWords1 + 63) / 64;
     d.bits0 = dalloc<unsigned long long>(d.nWords0); d.bits1 = dalloc<unsigned long long>(d.nWords1); d.bits2 = dalloc<unsigned long long>(d.nWords2);
     d.queueCap = d.M + 8; d.eraseCap = d.queueCap;
-    d.eraseList = dalloc<unsigned long long>(d.eraseCap); d.queue = dalloc<PropRec>((size_t)2 * d.queueCap); d.chainSlots = dalloc<ChainSlot>(2); d.queueUnits = dalloc<uint32_t>(d.queueCap); d.partials = dalloc<float>((size_t)d.queueCap * 64); d.grans = dalloc<unsigned long long>((size_t)d.queueCap * 64); d.dec = dalloc<DecRec>(d.queueCap);
+    d.eraseList = dalloc<unsigned long long>(d.eraseCap); d.queue = dalloc<PropRec>((size_t)2 * d.queueCap); d.chainSlots = dalloc<ChainSlot>(2); d.launchClock = dalloc<unsigned long long>(2u * GAPS_CLOCK_RING); d.queueUnits = dalloc<uint32_t>(d.queueCap); d.partials = dalloc<float>((size_t)d.queueCap * 64); d.grans = dalloc<unsigned long long>((size_t)d.queueCap * 64); d.dec = dalloc<DecRec>(d.queueCap);
     d.rowStamp = dalloc<unsigned long long>(d.M);
     d.atomStamp = dalloc<unsigned long long>(d.atomCap); d.gapStamp = dalloc<unsigned long long>((size_t)d.atomCap + 1);
     d.inlineStamp = dalloc<unsigned long long>(d.atomCap); d.atomDest = dalloc<uint64_t>(d.atomCap);
@@ -454,7 +469,7 @@ static void sync_record(cogaps_session *s, HostSampler &h)
 // (gen_apply_kernel) -- see eval_kernel.h.  The batched multi-chain launches keep the two-launch form (alpha, apply).
 static bool split_one_launch(const HostSampler &h)
 {
-    static const bool twoLaunches = getenv("COGAPS_SPLIT_TWO_LAUNCHES") != nullptr;      // dev: A/B against the two-launch form (alpha kernel, apply kernel)
+    static const bool twoLaunches = dev_env("COGAPS_SPLIT_TWO_LAUNCHES") != nullptr;      // dev builds: A/B against the two-launch form (alpha kernel, apply kernel)
     return !twoLaunches && !h.d.seq && !h.d.sparse && h.d.redW > 1024u;
 }
 static uint32_t apply_grid()
@@ -462,7 +477,7 @@ static uint32_t apply_grid()
 #if defined(COGAPS_EMUL)
     static const uint32_t g = 5u;        // (test-only emulator: a workgroup is a set of fibers, few of them keep the tests quick; 5 does not divide the items evenly)
 #else
-    static const uint32_t g = getenv("COGAPS_APPLY_GRID") ? (uint32_t)atoi(getenv("COGAPS_APPLY_GRID")) : 127u;      // dev: A/B of the update workgroups' number
+    static const uint32_t g = dev_env("COGAPS_APPLY_GRID") ? (uint32_t)atoi(dev_env("COGAPS_APPLY_GRID")) : 127u;      // dev builds: A/B of the update workgroups' number
 #endif
     return g < 1u ? 1u : g;
 }
@@ -509,7 +524,7 @@ static void launch_eval(cogaps_session *s, HostSampler &h)
         else LAUNCH_MAYBE_TIMED(slot, eval_sparse_kernel, grid, W, (const PropRec *)h.d.queue, (const GenScalars *)h.d.gs, h.d.queueCap, rec);
     } else if (h.d.redW <= 1024u) {
         // one workgroup of W threads per proposal
-        static const uint32_t fusedGrid = getenv("COGAPS_FUSED_GRID") ? (uint32_t)atoi(getenv("COGAPS_FUSED_GRID")) : 512u;      // dev: A/B of the launch size
+        static const uint32_t fusedGrid = dev_env("COGAPS_FUSED_GRID") ? (uint32_t)atoi(dev_env("COGAPS_FUSED_GRID")) : 512u;      // dev builds: A/B of the launch size
         const uint32_t grid = std::min<uint32_t>(h.d.queueCap, fusedGrid);
         LAUNCH_MAYBE_TIMED(slot, eval_kernel<EVAL_FUSED>, grid, h.d.redW, (const PropRec *)h.d.queue, (const GenScalars *)h.d.gs, h.d.queueCap, 1u, rec);
     } else {
@@ -586,6 +601,29 @@ static void ensure_graph(cogaps_session *s, HostSampler &h)
     memcpy(&h.graphKey, &h.d, sizeof(SamplerDev)); h.graphValid = true;
 }
 
+// Launch clock of the chained launches (gaps_state.h): the ring holds {entry of the first workgroup, end of the generator workgroup} of
+// every chained launch, slot = tag of the batch it evaluated.  Read back with the progress word of a chunk (at most 4096 launches, the ring
+// holds 8192): the launches that evaluated batches (clockSeen, upTo] are complete -- the batch generated last is evaluated by the next
+// launch, unless the update is over.
+static void clock_collect(cogaps_session *s, HostSampler &h, uint64_t epoch, bool flushed)
+{
+    const uint64_t upTo = flushed ? epoch : (epoch ? epoch - 1u : 0u);
+    if (!s->timing || !h.d.launchClock) { h.clockSeen = upTo; return; }
+    if (upTo <= h.clockSeen) return;
+    h.clockHost.resize(2u * GAPS_CLOCK_RING);
+    rt_d2h(h.clockHost.data(), h.d.launchClock, sizeof(unsigned long long) * 2u * GAPS_CLOCK_RING, s->stream); rt_sync(s->stream);
+    if (h.clockHist.empty()) h.clockHist.assign(2048, 0);
+    const uint64_t from = upTo - h.clockSeen > GAPS_CLOCK_RING ? upTo - GAPS_CLOCK_RING : h.clockSeen;
+    for (uint64_t e = from + 1u; e <= upTo; ++e) {
+        const unsigned long long b = h.clockHost[2u * (uint32_t)(e % GAPS_CLOCK_RING)], en = h.clockHost[2u * (uint32_t)(e % GAPS_CLOCK_RING) + 1u];
+        if (!b || en <= b || en - b > 100000000ull) continue;      // (an entry whose halves belong to different launches: a stale slot)
+        const double us = 0.01 * (double)(en - b);
+        h.clockSumUs += us; h.clockN++;
+        h.clockHist[std::min<size_t>(h.clockHist.size() - 1u, (size_t)(us * 10.0))]++;
+    }
+    h.clockSeen = upTo;
+}
+
 // AsynchronousGibbsSampler::update (AsynchronousGibbsSampler.h:88-122): batches of generate + evaluate
 // until nSteps proposals have been processed.  The number of batches is data dependent, so (generate,
 // evaluate) pairs are enqueued in chunks and the generator's progress word is read back per chunk;
@@ -594,6 +632,7 @@ static void ensure_graph(cogaps_session *s, HostSampler &h)
 static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool trace, uint32_t traceCap)
 {
     SamplerDev &d = h.d;
+    if (s->poisoned) return fail("this session was ended by a device error in an earlier update; its chain cannot be continued");
     read_gs(s, h);
     GenScalars g = *s->hGs;
     grow_atoms(s, h, g.nAtoms + nSteps + 1024u);
@@ -623,6 +662,7 @@ static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool t
     sync_record(s, h);
     h.chain = chain_eligible(s, h);
     h.updLaunches = 0;
+    h.clockSeen = g.batchEpoch;      // (launch clock: the batches of this update carry the tags behind this one)
     // proposals per batch: the previous update of this sampler is the best predictor
     float avgq = h.stepsPerBatch > 1.f ? h.stepsPerBatch : (g.avgQueue > 1.f ? g.avgQueue : 1.f);
     bool firstChunk = true, topped = false;
@@ -653,7 +693,8 @@ static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool t
         if (!topped) { HostSampler &o = (&h == &s->A) ? s->P : s->A; seed_top_up(s, (size_t)std::max(o.nAtoms, 10u) + (size_t)(6.0 * sqrt((double)std::max(o.nAtoms, 10u))) + 64u); topped = true; }
         read_gs(s, h);
         timing_resolve(s, s->hGs->nBatches);
-        if (s->hGs->error) return fail(std::string("device error code ") + std::to_string(s->hGs->error) + " in sampler " + h.name);
+        if (h.chain) clock_collect(s, h, s->hGs->batchEpoch, s->hGs->updateFlushed != 0);
+        if (s->hGs->error) { s->poisoned = true; return fail(std::string("device error code ") + std::to_string(s->hGs->error) + " in sampler " + h.name); }
         if (s->hGs->updateFlushed) break;
         if (s->hGs->nBatches > 0) avgq = std::max(1.f, (float)s->hGs->nDone / (float)s->hGs->nBatches);
     }
@@ -1172,7 +1213,7 @@ static int run_update_multi(cogaps_batch *b, int w, const std::vector<uint32_t> 
         bool all = true;
         for (uint32_t c = 0; c < C; ++c) {
             const GenScalars &g = b->hGs[c];
-            if (g.error) return fail(std::string("device error code ") + std::to_string(g.error) + " in sampler " + (w ? 'P' : 'A') + " of chain " + std::to_string(c));
+            if (g.error) { b->ss[c]->poisoned = true; return fail(std::string("device error code ") + std::to_string(g.error) + " in sampler " + (w ? 'P' : 'A') + " of chain " + std::to_string(c)); }
             if (g.updateFlushed) done[c] = 1; else all = false;
             if (g.nBatches > 0) avgq[c] = std::max(1.f, (float)g.nDone / (float)g.nBatches);
         }
@@ -1219,7 +1260,7 @@ cogaps_batch *cogaps_batch_create(cogaps_session **sessions, uint32_t n)
         for (cogaps_session *s : b->ss) rt_sync(s->stream);
         for (cogaps_session *s : b->ss) {      // from here on the sessions run on the batch's stream, one after the other (nothing below throws)
             drop_graphs(s->A); drop_graphs(s->P);
-            rt_stream_destroy(s->stream); s->stream = b->stream; s->ownsStream = false;
+            rt_stream_destroy(s->stream); s->stream = b->stream; s->ownsStream = false; s->A.chain = false; s->P.chain = false;      // (the batched launches keep two launches per step: cogaps_session_chained reports what runs)
         }
         return b;
     } catch (const std::exception &e) {
@@ -1509,6 +1550,7 @@ int cogaps_session_set_timing(cogaps_session *s, int on)
         for (HostSampler *h : {&s->A, &s->P}) {
             h->batchesAtTimingOn = h->batches;
             h->evalMs = h->genMs = h->evalNoopMs = h->genNoopMs = 0; h->evalTimed = h->genTimed = h->evalNoopTimed = h->genNoopTimed = 0;
+            h->clockHist.assign(2048, 0); h->clockSumUs = 0; h->clockN = 0;
         }
         s->syncMs = 0; s->syncTimed = 0; s->syncBytes = 0;
     }
@@ -1545,6 +1587,21 @@ int cogaps_session_perf_sampler(cogaps_session *s, char which, cogaps_perf *out)
     SESSION_END
 }
 
+int cogaps_session_launch_clock(cogaps_session *s, char which, double *meanUs, double *percentilesUs, uint64_t *launches)
+{
+    SESSION_TRY
+    if (!meanUs || !percentilesUs || !launches) return fail("null argument");
+    HostSampler &h = pick(s, which);
+    *launches = h.clockN; *meanUs = h.clockN ? h.clockSumUs / (double)h.clockN : 0.0;
+    static const double q[5] = {0.10, 0.50, 0.75, 0.90, 0.99};
+    for (int k = 0; k < 5; ++k) {
+        percentilesUs[k] = 0.0;
+        if (!h.clockN) continue;
+        const uint64_t want = (uint64_t)(q[k] * (double)h.clockN); uint64_t acc = 0;
+        for (size_t b = 0; b < h.clockHist.size(); ++b) { acc += h.clockHist[b]; if (acc > want) { percentilesUs[k] = 0.1 * ((double)b + 0.5); break; } }
+    }
+    SESSION_END
+}
 int cogaps_session_chained(cogaps_session *s, char which, int *chained)
 {
     SESSION_TRY

@@ -773,12 +773,14 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
                         ea = eval_atoms_load(S, p, writer); eaLoaded = true;
                         const uint32_t comp = t >> 4, sl = t & 15u;
                         const bool want = sl + 1u < slices;
-                        unsigned long long g = 0ull; uint32_t spins = 0;
+                        unsigned long long g = 0ull; uint32_t spins = 0; const unsigned long long pollT0 = cg_poll_begin();
                         for (;;) {
                             if (want) g = cg_load_l2_u64(&gr[sl * 4u + comp]);
                             const bool ok = !want || (uint32_t)(g >> 32) == first.tag;
                             if (cg_ballot(!ok) == 0ull) break;
-                            if (++spins > (1u << 20)) { if (t == 0u) S.gs->error = GAPS_ERR_SPIN; break; }      // (bounded: a launch never hangs the GPU)
+                            // bounded by time (platform.h), never a hang; a bound that is hit decides NOTHING from stale totals: the deciding wave
+                            // leaves (the error word ends the update on the host), the workgroup's other waves have no part in the decision
+                            if (cg_poll_expired(pollT0, ++spins)) { if (t == 0u) S.gs->error = GAPS_ERR_SPIN; return; }
                             cg_poll_pause();
                         }
                         const float own = comp == 0u ? tot[0] : (comp == 1u ? tot[1] : (comp == 2u ? tot[2] : tot[3]));

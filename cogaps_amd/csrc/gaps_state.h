@@ -175,4 +175,10 @@ struct SamplerDev {
     PropRec *trace;        // [traceCap] copies of queued proposals
     uint32_t *traceBatchNproc, *traceBatchQlen; // [traceCap]
     uint32_t dbg;          // GEN_PROFILE builds: skip parts of the evaluation kernel (timing experiments)
+    // ---- launch clock (chained launch) ---------------------------------------------------------
+    // [GAPS_CLOCK_RING][2] chip-wide 100 MHz clock (s_memrealtime) at the entry of a chained launch's first workgroup and at the end of
+    // its generator workgroup (the launch's last to finish), slot = the evaluated batch's tag mod the ring: the duration of EVERY launch
+    // of the timed region, replayed graphs included, where HIP events can only ride on plain launches.  Null: not recorded.
+    unsigned long long *launchClock;
 };
+#define GAPS_CLOCK_RING 8192u

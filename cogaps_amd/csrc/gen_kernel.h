@@ -126,7 +126,7 @@ struct GenShared {
     uint32_t nWork, nBD, updBase; float u1c, u2c;      // nBD: births + deaths of the window by the first guess (their sorted slots come first)
     // chained launch (chain_kernel.h): the erase cache as the generator's own lanes fill it from the decisions they apply, and the window
     // of the death-probability table this launch can need (staged while the evaluation workgroups of the same launch still run)
-    unsigned long long eraseTmp[FLUSH_MAX]; uint32_t eraseN, specBad;
+    unsigned long long eraseTmp[FLUSH_MAX]; uint32_t eraseN, specBad, spinFail;
     float dpWin[4 * WIN];
     // ... and the births of the window classified ahead (gen_spec_births, by the helper wave while the attempt lanes wait for the decisions):
     // the bitmap words and the successor bin's head each birth will need, per sorted slot; `dirty`: one bit per level-0 bitmap word

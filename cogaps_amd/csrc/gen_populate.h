@@ -1102,10 +1102,18 @@ CG_DEVICE bool chain_apply(const ChainItem &it, uint32_t code, float val)
 // preloaded kernel arguments, the record's lines are requested behind the first trip and waited for after the conflict table has been
 // emptied (one-chain launch); otherwise the caller has read the record already (batched launch: the hot pointers come from it).
 // CHAIN: the chained launch's generator workgroup (above; chain_kernel.h).
+// launch clock (gaps_state.h): every wave of the chained launch's generator workgroup leaves the chip-wide clock at its own end in the
+// launch's ring slot (a non-returning maximum: the waves end without a closing barrier, the last one's stamp stays)
+struct GenClockEnd {
+    unsigned long long *slot; unsigned t;
+    CG_DEVICE GenClockEnd(unsigned t_) : slot(nullptr), t(t_) {}
+    CG_DEVICE ~GenClockEnd() { if (slot && (t & 63u) == 0u) cg_atomic_max_u64(slot, cg_realtime()); }
+};
 template <int WIN, bool ASYNC, bool CHAIN = false>
 CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
 {
     CG_SHARED GenShared<WIN> sh;
+    GenClockEnd clockEnd(cg_tid());
     constexpr unsigned TPB = (unsigned)WIN + 64u;       // attempt lanes + the helper wave
     const unsigned t = cg_tid();
     const bool helper = t >= (unsigned)WIN;             // wave-uniform
@@ -1154,7 +1162,7 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
     GEN_TS(28);
     if (t < GSW) reinterpret_cast<uint32_t *>(&sh.g)[t] = gword;
     if (t + TPB < GSW) reinterpret_cast<uint32_t *>(&sh.g)[t + TPB] = gword2;
-    if (t == 0) { sh.newFront = CG_KEEP; sh.unitSum = 0; sh.jmul[WIN] = jmW; sh.jinc[WIN] = jiW; if (CHAIN) { sh.eraseN = 0; sh.specBad = 0; } }
+    if (t == 0) { sh.newFront = CG_KEEP; sh.unitSum = 0; sh.jmul[WIN] = jmW; sh.jinc[WIN] = jiW; if (CHAIN) { sh.eraseN = 0; sh.specBad = 0; sh.spinFail = 0; } }
     if (!helper) { sh.jmul[t] = jm0; sh.jinc[t] = ji0; }        // even-step PCG jumps, for the round bookkeeping
     GEN_TS(29);
     cg_sync_lds();
@@ -1240,6 +1248,7 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
         GEN_TS(32);
         GEN_RT(2);
         const uint32_t tag = (uint32_t)sh.g.batchEpoch;      // the batch in the queue: the one this workgroup generated in the previous launch
+        if (S.launchClock) clockEnd.slot = S.launchClock + 2u * (tag % GAPS_CLOCK_RING) + 1u;
 #if defined(COGAPS_EMUL)
         if (t == 0 && e_prevQ) cg_atomic_add_u64(&gs->prof[13], 1ull);      // test-only build: batches whose decisions arrived inside a chained launch
 #endif
@@ -1247,14 +1256,18 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
         if (!helper) {
             // one proposal: wait for its two granules (read past this workgroup's caches until both carry the batch's tag), note an erased atom
             // in the erase cache, carry the decision out
-            auto take = [&](const uint32_t q, const bool have, const ChainItem &it) {
+            auto take = [&](const uint32_t q, const bool haveIn, const ChainItem &it) {
                 const unsigned long long *gr = hot.grans + (size_t)q * CHAIN_GRAN_STRIDE;
-                unsigned long long g0 = 0ull, g1 = 0ull; uint32_t spins = 0;
+                unsigned long long g0 = 0ull, g1 = 0ull; uint32_t spins = 0; const unsigned long long pollT0 = cg_poll_begin();
+                bool have = haveIn;
                 for (;;) {
                     if (have) { g0 = cg_load_l2_u64(&gr[0]); g1 = cg_load_l2_u64(&gr[1]); }
                     const bool ok = !have || ((uint32_t)(g0 >> 32) == tag && (uint32_t)(g1 >> 32) == tag);
                     if (cg_ballot(!ok) == 0ull) break;
-                    if (++spins > (1u << 20)) { if ((t & 63u) == 0u) gs->error = GAPS_ERR_SPIN; break; }      // (bounded: a launch never hangs the GPU)
+                    // bounded by time (platform.h), never a hang.  A bound that is hit applies NOTHING: a granule without this batch's tag is an
+                    // older batch's decision -- the lane drops its proposal, the error word ends the update on the host (the session is then
+                    // marked unusable: its domain lacks decisions) and the workgroup leaves behind the barrier below without generating
+                    if (cg_poll_expired(pollT0, ++spins)) { if (!ok) have = false; if ((t & 63u) == 0u) { gs->error = GAPS_ERR_SPIN; sh.spinFail = 1u; } break; }
                     cg_poll_pause();
                 }
                 GEN_TS(33);
@@ -1303,6 +1316,7 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
         cg_sync();      // the decisions are in the domain (stores issued by this workgroup are seen by its later loads), the erase cache and the unit sum are complete
         GEN_TS(35);
         GEN_RT(4);
+        if (cg_uniform_u32(sh.spinFail) != 0u) return;      // a decision never arrived (GAPS_ERR_SPIN is set): every wave leaves, nothing is generated
         e_m = cg_uniform_u32(sh.eraseN);
         if (e_m > eraseCap) e_m = eraseCap;
         if (helper) specE = (ht < (unsigned)FLUSH_MAX && ht < e_m) ? sh.eraseTmp[ht] : 0ull;

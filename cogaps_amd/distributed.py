@@ -24,7 +24,30 @@ import numpy as np
 
 from . import _capi
 
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # see distributedCogaps
+
+def _ipc_mode_for_rccl():
+    """RCCL between the ranks' processes needs dmabuf IPC on this driver (HSA_ENABLE_IPC_MODE_LEGACY=0, read when HIP initialises).  The
+    launcher or the rank's entry point exports it (bench.py does); a rank of a multi-process job that arrives here without it gets it
+    set now -- nothing is touched on import or in a single-process call -- and is told when HIP is already up and will not see it."""
+    try:
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    except Exception:
+        multi = False
+    if not multi or os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0":
+        return
+    import warnings
+    had = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+    if had is None:
+        os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    try:
+        import torch
+        up = torch.cuda.is_initialized()
+    except Exception:
+        up = False
+    if had is not None or up:
+        warnings.warn("HSA_ENABLE_IPC_MODE_LEGACY is %s and HIP is %s: RCCL between processes needs it to be 0 before HIP initialises "
+                      "(export it in the launcher)" % (repr(had), "already initialised" if up else "not yet initialised"))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -373,9 +396,7 @@ class _Source:
 
 def distributedCogaps(data, params, uncertainty=None, messages=False, outputFrequency=1000, transposeData=False,
                       device=-1, run_fn=None, comm_device=None, shardsInFlight=16, nSnapshots=0, snapshotPhase="sampling", shape=None):
-    # RCCL between the ranks' processes needs dmabuf IPC on this driver; the variable is read when HIP initialises, so it is set here (and at
-    # import, below the imports) for callers whose launcher did not export it -- a process that initialised HIP earlier keeps what it had
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    _ipc_mode_for_rccl()
     run_fn = run_fn or _capi.run
     shardsInFlight = max(1, int(shardsInFlight))
     genome_wide = params.distributed == "genome-wide"

@@ -213,6 +213,11 @@ int cogaps_session_perf_sampler(cogaps_session *s, char which, cogaps_perf *out)
  * its time is reported as evalMs, genMs stays 0), 0 for a generator launch and an evaluation launch per batch.  The chained form serves
  * the one-chain fused evaluation (AsynchronousGibbsSampler.h:88-122, same results); environment COGAPS_NO_CHAIN=1 switches it off. */
 int cogaps_session_chained(cogaps_session *s, char which, int *chained);
+/* Durations of the sampler's chained launches since cogaps_session_set_timing(1), EVERY launch -- replayed graphs included, where HIP
+ * events cannot ride --, from the chip-wide 100 MHz clock read inside the launch (entry of its first workgroup to the end of its generator
+ * workgroup, the last to finish: what rocprofv3 --kernel-trace reports as the dispatch's duration, minus the dispatcher's fill / drain).
+ * meanUs; percentilesUs[5] = 10th, 50th, 75th, 90th, 99th (0.1 us bins); launches = how many were measured (0: the sampler does not chain). */
+int cogaps_session_launch_clock(cogaps_session *s, char which, double *meanUs, double *percentilesUs, uint64_t *launches);
 
 /* ------------------------------------------------------------------------------------------------
  * Batched multi-chain launches: the sessions of a batch -- the subsets of a GWCoGAPS / scCoGAPS job that share one GPU

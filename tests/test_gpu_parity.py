@@ -207,7 +207,68 @@ def test_headline_shape_stepwise(hip_lib):
         assert (S.natoms("A"), S.natoms("P")) == (O.natoms("A"), O.natoms("P")), it
     assert props > 300000 and S.natoms("A") > 40000
     pu.assert_state_equal(S, O, "headline")
+    # which launch form was tested: the A sampler (2000-element vectors, 512 evaluation threads) steps by chained launches
+    # (csrc/chain_kernel.h), the P sampler (split evaluation) by gen_apply_kernel + eval_kernel<EVAL_DECIDE>
+    assert S.chained("A") == 1 and S.chained("P") == 0
     S.close(), O.close()
+
+
+def _chain_state(S):
+    import hashlib
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    out = []
+    for w in "AP":
+        a = S.atoms(w)
+        out += [sha(a["pos"]), sha(a["mass"]), sha(a["left"]), sha(a["right"]), sha(S.matrix(w)), sha(S.ap(w)), str(S.natoms(w)), str(S.check_domain(w))]
+    return out
+
+
+_CHAIN_AB = dict(genes=4000, samples=1600, nPatterns=20, nIterations=40, seed=11, iters=10)
+
+
+def _chain_ab_run(lib):
+    """4000 x 1600, K = 20: the A sampler's vectors have 1600 elements (512 evaluation threads: chained where the library allows it)"""
+    from cogaps_amd import _capi
+    c = _CHAIN_AB
+    S = _capi.Session(pu.synthetic(c["genes"], c["samples"], rank=5, seed=3), lib=lib, nPatterns=c["nPatterns"], nIterations=c["nIterations"], seed=c["seed"])
+    for it in range(c["iters"]):
+        S.set_annealing(min(1.0, 2.0 * it / c["nIterations"]))
+        nA, nP = S.draw_steps()
+        S.iterate(nA, nP)
+    st = _chain_state(S), S.chained("A")
+    S.close()
+    return st
+
+
+def test_chained_equals_two_launches_on_the_gpu(hip_lib, monkeypatch):
+    """The chained launch (one launch per batch: evaluation of batch b + generator of batch b + 1, csrc/chain_kernel.h) against the same
+    chain stepped by two launches per batch (COGAPS_NO_CHAIN=1: gen_kernel, eval_kernel<EVAL_FUSED>) ON THE HARDWARE: atoms (positions,
+    masses, links), factor matrices and A*P caches bit-equal, the domain consistent, and each session reports the form it ran."""
+    chained, formA = _chain_ab_run(hip_lib)
+    assert formA == 1, "the chained launch did not run: the hot path of the headline chain is untested on this device"
+    monkeypatch.setenv("COGAPS_NO_CHAIN", "1")
+    plain, formB = _chain_ab_run(hip_lib)
+    assert formB == 0
+    assert chained == plain
+
+
+def test_chained_launch_with_half_the_compute_units(hip_lib):
+    """`Correct and slower, never a hang` as a hardware fact: the same chain in a process whose queues may use 120 of the 256 compute
+    units (HSA_CU_MASK), so that the 241 workgroups of a chained launch are NOT all resident at once and the generator workgroup -- the
+    launch's last -- starts when evaluation workgroups have left.  Must finish and must equal the unmasked run bit for bit."""
+    import subprocess, sys, json
+    ref, formA = _chain_ab_run(hip_lib)
+    code = ("import sys, json; sys.path[:0] = [%r, %r]\n"
+            "import test_gpu_parity as T\nfrom cogaps_amd import _capi\nimport time\nt0 = time.time()\n"
+            "st, form = T._chain_ab_run(_capi.load())\nprint(json.dumps({'state': st, 'form': form, 'seconds': time.time() - t0}))\n"
+            % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    env = dict(os.environ, HSA_CU_MASK="0:0-119", ROC_GLOBAL_CU_MASK="0x" + "f" * 30)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    print("masked run: %.1f s, chained=%d" % (rec["seconds"], rec["form"]))
+    assert rec["form"] == formA == 1
+    assert rec["state"] == ref
 
 
 def test_plain_c_client_equals_the_ctypes_path(hip_lib, gist):
@@ -771,6 +832,7 @@ def test_benchmarked_chain_end_to_end_against_the_golden(hip_lib):
         assert sha(S.matrix(w)) == str(g["sha256_matrix_" + w]), "final factor matrix " + w
         assert sha(S.ap(w)) == str(g["sha256_ap_" + w]), "final A*P cache " + w
         assert S.check_domain(w) == 0
+    assert S.chained("A") == 1 and S.chained("P") == 0      # (the launch forms the bench times: chained A side, gen_apply + deciding evaluation on the P side)
     r = S.finish()
     S.close()
     assert r["totalUpdates"] == int(g["totalUpdates"]) == 52906603
