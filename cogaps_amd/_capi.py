@@ -143,7 +143,8 @@ def bind(L):
     L.cogaps_session_perf.argtypes = [vp, C.POINTER(CogapsPerfC)]
     L.cogaps_session_perf_sampler.argtypes = [vp, C.c_char, C.POINTER(CogapsPerfC)]
     L.cogaps_session_chained.argtypes = [vp, C.c_char, C.POINTER(C.c_int)]
-    L.cogaps_session_launch_clock.argtypes = [vp, C.c_char, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    if hasattr(L, "cogaps_session_launch_clock"):      # (an A/B build of an older source tree may lack it: launch_clock() then reports no launches)
+        L.cogaps_session_launch_clock.argtypes = [vp, C.c_char, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.cogaps_session_debug_prof.argtypes = [vp, C.c_char, C.POINTER(C.c_uint64)]
     L.cogaps_session_debug_replay.argtypes = [vp, C.c_char, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
     L.cogaps_reduction_width.restype = C.c_uint32
@@ -403,6 +404,8 @@ class Session:
         """durations of the sampler's chained launches since set_timing(1), every launch (device clock): mean, percentiles, count"""
         m, n = C.c_double(0), C.c_uint64(0)
         pc = (C.c_double * 5)()
+        if not hasattr(self.L, "cogaps_session_launch_clock"):
+            return {"mean_us": 0.0, "p10_us": 0.0, "p50_us": 0.0, "p75_us": 0.0, "p90_us": 0.0, "p99_us": 0.0, "launches": 0}
         self._ck(self.L.cogaps_session_launch_clock(self.h, which.encode(), C.byref(m), pc, C.byref(n)))
         return {"mean_us": m.value, "p10_us": pc[0], "p50_us": pc[1], "p75_us": pc[2], "p90_us": pc[3], "p99_us": pc[4], "launches": int(n.value)}
 

@@ -161,7 +161,8 @@ extern "C" uint32_t cogaps_sparse_width(uint32_t N)
 // Switches that change what is MEASURED and never a result (launch sizes, the two-launch split form, reading S instead of recomputing it)
 // exist in development builds only (-DCOGAPS_DEV, -DGEN_PROFILE): the product library does not look at them.  What the product library
 // does read from the environment, on purpose, is documented in include/cogaps_hip.h: COGAPS_NO_GRAPH (every launch as a plain call --
-// counter collection hangs on replayed graphs) and COGAPS_NO_CHAIN (two launches per batch: the A/B and the equality test of the chained launch).
+// counter collection hangs on replayed graphs), COGAPS_NO_CHAIN (two launches per batch: the A/B and the equality test of the chained launch) and
+// COGAPS_FORCE_CHAIN (tests: the chained launch on a device with fewer compute units than the launch has workgroups).
 static const char *dev_env(const char *name)
 {
 #if defined(COGAPS_DEV) || defined(GEN_PROFILE) || defined(COGAPS_EMUL)
@@ -228,6 +229,7 @@ struct cogaps_session {
     bool timing = false; bool evInit = false;
     bool noGraph = getenv("COGAPS_NO_GRAPH") != nullptr;     // diagnostics: every launch as a plain call (counter collection tools)
     bool noChain = getenv("COGAPS_NO_CHAIN") != nullptr;     // A/B and tests: two launches per batch (gen_kernel, eval_kernel<EVAL_FUSED>) where the chained launch would serve
+    bool forceChain = getenv("COGAPS_FORCE_CHAIN") != nullptr;      // tests: the chained launch also where the device shows fewer compute units than the launch has workgroups (they then run in turns, the generator last)
     unsigned computeUnits = 0;      // of the session's device: the chained launch wants all its workgroups resident at once, one per compute unit
     std::vector<rt_event_pair> evPool; std::vector<int> evKind; std::vector<HostSampler *> evOwner; std::vector<uint64_t> evOrd; size_t evUsed = 0;
     GenScalars *hGs = nullptr;    // pinned staging
@@ -558,7 +560,7 @@ static bool chain_eligible(const cogaps_session *s, const HostSampler &h)
     // (a device with fewer compute units than the launch has workgroups -- a partitioned GPU -- would run them in turns, the generator
     // workgroup last: correct, and slower than two launches)
     return !s->noChain && !h.d.seq && !h.d.sparse && h.d.redW <= (uint32_t)CHAIN_MAX_THREADS && h.d.redW >= h.genWin + 64u
-           && s->computeUnits >= std::min<uint32_t>(h.d.queueCap, CHAIN_EVAL_GRID) + 1u;
+           && (s->forceChain || s->computeUnits >= std::min<uint32_t>(h.d.queueCap, CHAIN_EVAL_GRID) + 1u);
 }
 // one batch step: the chained launch, or a generator launch and an evaluation launch
 static void launch_pair(cogaps_session *s, HostSampler &h)

@@ -715,6 +715,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
         const bool diff = two && p.r1 != p.r2;
         const uint32_t alphaUnits = need ? (!two ? 4u : (diff ? 8u : 5u)) : 0u;      // roofline bookkeeping, units of 4N bytes (below)
         float s = 0.f, smu = 0.f;          // un-annealed sums, valid in wave 0
+        uint32_t typeX = p.type;           // the step that is decided below (0: none -- a hand-over inside the launch that never arrived)
         // the one-chain fused launch only: the batched one is throughput bound and at its register budget, and the split form's APPLY
         // launch got slower with it (10.3 -> 12 us: 80 KB rows fetched for every rejected proposal, registers at the launch bound)
         constexpr bool PRE = FUSEDF && SINGLE;
@@ -773,14 +774,14 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
                         ea = eval_atoms_load(S, p, writer); eaLoaded = true;
                         const uint32_t comp = t >> 4, sl = t & 15u;
                         const bool want = sl + 1u < slices;
-                        unsigned long long g = 0ull; uint32_t spins = 0; const unsigned long long pollT0 = cg_poll_begin();
+                        unsigned long long g = 0ull; uint32_t spins = 0;
                         for (;;) {
                             if (want) g = cg_load_l2_u64(&gr[sl * 4u + comp]);
                             const bool ok = !want || (uint32_t)(g >> 32) == first.tag;
                             if (cg_ballot(!ok) == 0ull) break;
-                            // bounded by time (platform.h), never a hang; a bound that is hit decides NOTHING from stale totals: the deciding wave
-                            // leaves (the error word ends the update on the host), the workgroup's other waves have no part in the decision
-                            if (cg_poll_expired(pollT0, ++spins)) { if (t == 0u) S.gs->error = GAPS_ERR_SPIN; return; }
+                            // bounded (platform.h: two seconds at least), never a hang; a bound that is hit decides NOTHING from stale totals: the
+                            // proposal is dropped (typeX: no branch below matches, nothing is stored), the error word ends the update on the host
+                            if (cg_poll_expired(++spins)) { if (t == 0u) S.gs->error = GAPS_ERR_SPIN; typeX = 0u; break; }
                             cg_poll_pause();
                         }
                         const float own = comp == 0u ? tot[0] : (comp == 1u ? tot[1] : (comp == 2u ? tot[2] : tot[3]));
@@ -814,7 +815,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
 #if defined(GEN_PROFILE)
         if (S.dbg & 8u) { if (q + qStep >= qlen) break; { const uint32_t qn_ = q + qStep; pNext = hot.queue[qn_ < hot.queueCap ? qn_ : 0u]; } cg_sync(); continue; }    // timing experiment: stop before the scalar step
 #endif
-        if (p.type == 'B') {
+        if (typeX == 'B') {
             // ---------------------------------------------------------------- birth (:127-144)
             float bv = 0.f; uint32_t bhas = 0;
             if (scalarLane) {
@@ -830,7 +831,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
                 ++nUpd;                          // changeMatrix
                 if (writer) { atom_set_mass(S, p.h1, ea.a1.left, bv); eval_store_matrix(S, p.r1, p.c1, old1, old1 + bv); }
             } else if (writer) eval_cache_erase(S, p.h1, p.r1, p.c1);
-        } else if (p.type == 'D') {
+        } else if (typeX == 'D') {
             // ---------------------------------------------------------------- death / rebirth (:148-180)
             float rebirth = m1;
             EVAL_PROF(1);
@@ -864,7 +865,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
                 if (writer) { eval_store_matrix(S, p.r1, p.c1, old1, nv); eval_cache_erase(S, p.h1, p.r1, p.c1); }
             }
             EVAL_PROF(3);
-        } else if (p.type == 'M') {
+        } else if (typeX == 'M') {
             // ---------------------------------------------------------------- move (:184-196)
             uint32_t acc = 0; float unused = 0.f;
             if (scalarLane) { const float deltaLL = -1.f * m1 * (smu + s * m1 / 2.f); const float logU = (AHEAD && need) ? spec.l1 : gm_logf_m(pcg_uniform(rng), mm); acc = (logU < deltaLL) ? 1u : 0u;
@@ -882,7 +883,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
                     eval_store_matrix(S, p.r2, p.c2, old2, old2 + m1);
                 }
             }
-        } else if (need) {
+        } else if (need && typeX == 'E') {
             // ---------------------------------------------------------------- exchange (:201-219)
             float gv = 0.f; uint32_t gh = 0;
             if (scalarLane) { OptF g0 = gm_gibbs_mass(s, smu, -m1, m2, rng, S.luts, false, 0.f); gv = g0.v; gh = g0.has ? 1u : 0u;

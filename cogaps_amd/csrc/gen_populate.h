@@ -367,10 +367,195 @@ CG_DEVICE void gen_mark_dirty(uint32_t *dirty, uint32_t bin)
     cg_atomic_or_u32(&dirty[w >> 5], 1u << (w & 31u));
 }
 
-template <int WIN, bool FIRST, bool SPEC = false>
-CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRoundCtx &c, const uint32_t roundNo, const GenSpec *spec = nullptr)
+// ---- the populate-phase draws of one attempt (ProposalQueue.cpp:162-283: birth / death / move / exchange up to the conflict rules) ------
+// What an attempt's lane knows once it has drawn: the proposal as it will be queued, the atoms and matrix entries it read, and -- for the
+// chained launch, which draws a window AHEAD of the previous batch's decisions and must know which lanes to draw again -- what it read
+// them from.
+struct GenDraw {
+    uint32_t go, flags; bool isB, pick;
+    uint64_t rng, rngPick, pos, cpos;          // rngPick: the lane's generator behind the pick of its atom (uniform32 over the domain's size)
+    uint32_t h1, h2, i1, hl, hr, r1, c1, r2, c2, bin;
+    float nm1, nm2, amass, m2x, old1, old2; uint32_t gib1, gib2;
+    uint64_t lposB, rposB; float rmassB;
+    // drawn ahead only: the successor bin a birth found and the atom at its head; `redo`: the lane took (or would have taken) one of the
+    // rare long ways -- the full gap search, a walk along a bin, front() as an exchange partner -- and draws again behind the decisions
+    uint32_t headBin, v2; bool redo;
+};
+CG_DEVICE void gen_draw_clear(GenDraw &d)
+{
+    d.go = 0; d.flags = 0; d.isB = false; d.pick = false; d.rng = 0; d.rngPick = 0; d.pos = 0; d.cpos = 0;
+    d.h1 = CG_NONE; d.h2 = CG_NONE; d.i1 = CG_NONE; d.hl = CG_NONE; d.hr = CG_NONE; d.r1 = 0; d.c1 = 0; d.r2 = 0; d.c2 = 0; d.bin = 0;
+    d.nm1 = 0.f; d.nm2 = 0.f; d.amass = 0.f; d.m2x = 0.f; d.old1 = 0.f; d.old2 = 0.f; d.gib1 = 0; d.gib2 = 0; d.lposB = 0; d.rposB = 0; d.rmassB = 0.f;
+    d.headBin = 0; d.v2 = CG_NONE; d.redo = false;
+}
+// first part: what needs only the window's scalars -- a birth's position and bin (SPEC: drawn with the classification, gen_spec_slot),
+// a pick's index into the unsorted vector.  nR: the domain's size at the start of the round; an attempt sees nR + (births before it).
+template <int WIN, bool SPEC>
+CG_DEVICE void gen_draw_a(const SamplerDev &S, const GenRoundCtx &c, const GenSpec *spec, const bool go, const uint32_t type, const uint32_t bBefore, const uint64_t rng0, const uint32_t nR, GenDraw &d)
+{
+    gen_draw_clear(d);
+    d.go = go ? 1u : 0u;
+    d.isB = go && type == 'B';
+    d.pick = go && type != 'B';                 // D/M/E: picks an existing atom
+    d.rng = rng0;                                  // AtomicProposal ctor, ProposalQueue.cpp:12-15
+    const uint32_t nT = nR + bBefore;              // domain size this attempt sees
+    if (d.isB) {
+        if (SPEC) { d.pos = spec->pos; d.bin = spec->bin; d.r1 = spec->r1; d.c1 = spec->c1; }      // (drawn ahead: gen_spec_slot)
+        else {
+            // uniform64(1, L) (Random.cpp:105-123) with the constant range's iPart precomputed
+            uint64_t x = pcg_u64(d.rng);
+            while (x >= S.limitL) x = pcg_u64(d.rng);
+            d.pos = (S.iPartL == 1ull ? x : x / S.iPartL) + 1ull;
+            d.bin = gen_bin_of(S, d.pos); d.r1 = gen_div_k(S, d.bin); d.c1 = d.bin - d.r1 * c.K;
+        }
+        d.i1 = nT;
+    } else if (d.pick) {
+        d.i1 = pcg_uniform32(d.rng, 0u, nT - 1u);
+        if (d.i1 >= nR) { d.flags |= GEN_F_FAIL; d.pick = false; }   // an atom born earlier in this window: its row is in use
+    }
+    d.rngPick = d.rng;
+}
+// second part: the staged dependent loads (B: bitmap word -> bin head -> atom; D/M/E: vec -> atom record, which carries the neighbours'
+// positions and the right neighbour's mass -> matrix entries) and what follows from them.  underTrip(): the caller's work for the
+// first trip's shadow.  AHEAD: drawn before the previous batch's decisions are in -- the long ways are not taken, the lane is marked.
+template <int WIN, bool AHEAD, class F>
+CG_DEVICE void gen_draw_b(const SamplerDev &S, GenShared<WIN> &sh, const GenRoundCtx &c, const uint32_t type, GenDraw &d, F underTrip)
+{
+    const uint32_t K = c.K;
+    const bool isB = d.isB, pick = d.pick;
+    uint32_t flags = d.flags;
+    uint64_t rng = d.rng, pos = d.pos, cpos = 0, lbpos = 0, rbpos = 0;
+    uint32_t h1 = CG_NONE, h2 = CG_NONE, hl = CG_NONE, hr = CG_NONE;
+    uint32_t r1 = d.r1, c1 = d.c1, r2 = 0, c2 = 0; float nm1 = 0.f, nm2 = 0.f;
+    uint32_t bin = d.bin, headBin = 0; unsigned long long w0 = 0;
+    const uint32_t i1 = d.i1;
+    // stage 1 ---------------------------------------------------------------------------------
+    uint32_t v1 = CG_NONE;
+    // (the word after the bin's own travels in the same trip: when the rest of the bin's word is empty -- one birth in twenty-five at the
+    // headline shape's occupancy -- the successor bin is nearly always in the next 64, and the full search through the bitmap's upper
+    // levels, half a dozen dependent trips that the whole wave waits for, stays for the domain's sparse stretches)
+    unsigned long long w0n = 0ull;
+    uint32_t v2 = CG_NONE;
+    AtomRec b3; b3.pos = 0; b3.lpos = 0; b3.rpos = 0; b3.left = CG_NONE; b3.right = CG_NONE; b3.mass = 0.f; b3.rmass = 0.f; b3.idx = 0;
+    if (isB) { w0 = S.bits0[bin >> 6]; w0n = ((bin >> 6) + 1u < S.nWords0) ? S.bits0[(bin >> 6) + 1u] : 0ull; }
+    if (pick) v1 = S.vec[i1];
+    underTrip();
+    // stage 2 ---------------------------------------------------------------------------------
+    bool slowB = false;
+    if (isB) {
+        const uint32_t bit = bin & 63u;
+        if ((w0 >> bit) & 1ull) headBin = bin;
+        else {
+            flags |= GEN_F_BINEMPTY; if (w0 == 0ull) flags |= GEN_F_WORDZERO;
+            const unsigned long long m = (bit == 63u) ? 0ull : (w0 & ~((2ull << bit) - 1ull));
+            if (m) headBin = (bin & ~63u) + (uint32_t)cg_ctz64(m); else if (w0n) headBin = (bin & ~63u) + 64u + (uint32_t)cg_ctz64(w0n);
+            else slowB = true;
+        }
+    }
+    AtomRec a; a.pos = 0; a.lpos = 0; a.rpos = 0; a.left = CG_NONE; a.right = CG_NONE; a.mass = 0.f; a.rmass = 0.f; a.idx = 0;
+    if (isB && !slowB) v2 = S.binHead[headBin];
+    if (pick) { h1 = v1; a = S.atoms[h1]; }
+    // stage 3 ---------------------------------------------------------------------------------
+    // A picked atom's record carries its neighbours' positions and the right neighbour's mass (gaps_state.h): a move's bounds and
+    // an exchange's partner need no trip to the neighbours' records -- every pick goes from its record straight to the matrix
+    // entries.  (The one exception: the highest atom's exchange partner is front(), whose record is fetched.)
+    uint64_t lp = 0, rp = 0;
+    float m2x = 0.f;                        // exchange: the partner's mass
+    bool frontE = false;                    // exchange of the highest atom: the partner is front()
+    if (pick) {
+        cpos = a.pos;
+        const uint32_t b1 = gen_bin_of(S, cpos);
+        r1 = gen_div_k(S, b1); c1 = b1 - r1 * K;
+        hl = a.left;
+        if (type == 'M') { hr = a.right; lp = a.lpos; rp = a.rpos; }
+        else if (type == 'E') {
+            hr = a.right;
+            if (hr != CG_NONE) { h2 = hr; rbpos = a.rpos; m2x = a.rmass; }
+            else { h2 = sh.g.front; frontE = true; }
+        }
+    }
+    if (AHEAD && frontE) { d.redo = true; frontE = false; h2 = h1; }      // (front() may be another atom behind the decisions: drawn again)
+    // the scalars the evaluation starts from travel in the queue record (consumed at commit)
+    float old1 = 0.f, old2 = 0.f; uint32_t gib1 = 0, gib2 = 0;
+    uint64_t lposB = 0, rposB = 0; float rmassB = 0.f;        // birth: what the new atom's record caches of its neighbours
+    if (isB && !slowB) b3 = S.atoms[v2];
+    if (frontE) b3 = S.atoms[h2];
+    if (isB || pick) { old1 = S.sparse ? S.rows[(size_t)r1 * S.Kpad + c1] : S.mat[(size_t)c1 * S.Mpad + r1]; gib1 = S.otherColPos[c1]; }
+    if (pick && type == 'M') {
+        if (hl != CG_NONE) { flags |= GEN_F_HASLEFT; lbpos = lp; } else lbpos = 0;
+        if (hr != CG_NONE) { flags |= GEN_F_HASRIGHT; rbpos = rp; } else rbpos = S.rboundNone;
+        pos = pcg_uniform64(rng, lbpos + 1ull, rbpos - 1ull);
+        const uint32_t bin2 = gen_bin_of(S, pos);
+        r2 = gen_div_k(S, bin2); c2 = bin2 - r2 * K;
+        if (r1 == r2 && c1 == c2) flags |= GEN_F_INLINE;
+    }
+    if (pick && type == 'E' && !frontE) {
+        flags |= GEN_F_HASRIGHT;
+        const uint32_t bin2 = gen_bin_of(S, rbpos);
+        r2 = gen_div_k(S, bin2); c2 = bin2 - r2 * K;
+    }
+    if (pick && (type == 'M' || (type == 'E' && !frontE))) { old2 = S.sparse ? S.rows[(size_t)r2 * S.Kpad + c2] : S.mat[(size_t)c2 * S.Mpad + r2]; gib2 = S.otherColPos[c2]; }
+    // finish ----------------------------------------------------------------------------------
+    if (isB) {
+        if (!slowB) {
+            if ((flags & GEN_F_BINEMPTY) || b3.pos > pos) { hr = v2; hl = b3.left; lposB = b3.lpos; rposB = b3.pos; rmassB = b3.mass; flags |= GEN_F_NEWHEAD; }
+            else if (b3.pos == pos) slowB = true;      // position already taken: the retry loop below
+            else {
+                // the bin's lowest atom lies below pos: go on to the right; the record in hand knows its right neighbour's
+                // position, so the usual case (a bin holds 1.3 atoms on average) needs no further trip
+                uint32_t cur = v2, nxt = b3.right; uint64_t curPos = b3.pos, nxtPos = b3.rpos; float nxtMass = b3.rmass;
+                for (;;) {
+                    if (nxt == CG_NONE) break;
+                    if (nxtPos == pos) { slowB = true; break; }
+                    if (nxtPos > pos) break;
+                    if (AHEAD) { d.redo = true; break; }      // (a walk along the bin reads records the validation does not know of)
+                    const AtomRec w = S.atoms[nxt];
+                    cur = nxt; curPos = nxtPos; nxt = w.right; nxtPos = w.rpos; nxtMass = w.rmass;
+                }
+                hl = cur; hr = nxt; lposB = curPos; rposB = nxtPos; rmassB = nxtMass;
+            }
+        }
+        if (AHEAD && slowB) { d.redo = true; slowB = false; }
+        if (slowB) {
+            bool occ, nh;
+            gen_find_gap(S, pos, bin, &hl, &hr, &occ, &nh);
+            while (occ) {           // randomFreePosition retry (ConcurrentAtomicDomain.cpp:46-54)
+                pos = pcg_uniform64(rng, 1ull, S.domainLenU);
+                bin = gen_bin_of(S, pos); r1 = gen_div_k(S, bin); c1 = bin - r1 * K;
+                gen_find_gap(S, pos, bin, &hl, &hr, &occ, &nh);
+            }
+            flags &= ~(GEN_F_BINEMPTY | GEN_F_WORDZERO | GEN_F_NEWHEAD);
+            if (nh) flags |= GEN_F_NEWHEAD;
+            if (S.binHead[bin] == CG_NONE) { flags |= GEN_F_BINEMPTY; if (S.bits0[bin >> 6] == 0ull) flags |= GEN_F_WORDZERO; }
+            old1 = S.sparse ? S.rows[(size_t)r1 * S.Kpad + c1] : S.mat[(size_t)c1 * S.Mpad + r1]; gib1 = S.otherColPos[c1];      // the retry may have moved the birth to another bin
+            lposB = (hl != CG_NONE) ? S.atoms[hl].pos : 0ull;
+            if (hr != CG_NONE) { rposB = S.atoms[hr].pos; rmassB = S.atoms[hr].mass; } else { rposB = 0ull; rmassB = 0.f; }
+        }
+    } else if (pick && type == 'E') {
+        if (frontE) {
+            rbpos = b3.pos; m2x = b3.mass;
+            const uint32_t bin2 = gen_bin_of(S, rbpos);
+            r2 = gen_div_k(S, bin2); c2 = bin2 - r2 * K;
+            old2 = S.sparse ? S.rows[(size_t)r2 * S.Kpad + c2] : S.mat[(size_t)c2 * S.Mpad + r2]; gib2 = S.otherColPos[c2];
+        }
+        if (r1 == r2 && c1 == c2 && !(AHEAD && d.redo)) {
+            flags |= GEN_F_INLINE;
+            const float m1 = a.mass, m2 = m2x;
+            const float newMass = pcg_trunc_gamma_upper(rng, S.luts, m1 + m2, 1.f / S.lambda, S.mathMode);
+            const float delta = (m1 > m2) ? newMass - m1 : m2 - newMass;
+            if (m1 + delta > GAPS_EPSILON && m2 - delta > GAPS_EPSILON) { flags |= GEN_F_APPLY; nm1 = m1 + delta; nm2 = m2 - delta; }
+        }
+    }
+    d.flags = flags; d.rng = rng; d.pos = pos; d.cpos = cpos; d.h1 = h1; d.h2 = h2; d.hl = hl; d.hr = hr; d.r1 = r1; d.c1 = c1; d.r2 = r2; d.c2 = c2; d.bin = bin;
+    d.nm1 = nm1; d.nm2 = nm2; d.amass = a.mass; d.m2x = m2x; d.old1 = old1; d.old2 = old2; d.gib1 = gib1; d.gib2 = gib2; d.lposB = lposB; d.rposB = rposB; d.rmassB = rmassB;
+    d.headBin = headBin; d.v2 = v2;
+}
+
+template <int WIN, bool FIRST, bool SPEC = false, bool AHEAD = false>
+CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRoundCtx &c, const uint32_t roundNo, const GenSpec *spec = nullptr, const GenDraw *ahead = nullptr, const bool aheadValid = true)
 {
     static_assert(FIRST || !SPEC, "only a batch's first window is classified ahead of the decisions");
+    static_assert(SPEC || !AHEAD, "only a window classified ahead is drawn ahead");
     const unsigned t = c.t;
     const uint64_t jm0 = c.jm0, ji0 = c.ji0, jm1 = c.jm1, ji1 = c.ji1, seed1 = c.seed1, batchEpoch = c.batchEpoch;
     const uint32_t updBase = c.updBase, remaining = c.remaining, K = c.K;
@@ -431,82 +616,16 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
     if (!SPEC) cg_sync_lds();
     GEN_TS(9);
 
-    // ------------------------------------------------------------------ A2 (lane = sorted slot): populate-phase draws
+    // ------------------------------------------------------------------ A2 (lane = sorted slot): populate-phase draws (gen_draw_a / gen_draw_b)
     const bool go = SPEC ? spec->go != 0u : t < sh.nWork;
     const uint32_t ct = SPEC ? spec->ct : (go ? (uint32_t)sh.perm[t] : 0u);          // this lane's attempt ordinal in the window
     const uint32_t info = SPEC ? spec->info : (go ? sh.info[ct] : 0u);
     const uint32_t type = info & 0xFFu, bBefore = info >> 8;
-    uint32_t flags = 0;
-    const bool isB = go && type == 'B';
-    bool pick = go && type != 'B';                 // D/M/E: picks an existing atom
-    uint64_t rng = SPEC ? spec->rng : (go ? pcg_from_seed(sh.seed[ct]) : 0ull);   // AtomicProposal ctor, ProposalQueue.cpp:12-15
-    const uint32_t nT = nR + bBefore;              // domain size this attempt sees
-    uint64_t pos = 0, cpos = 0, lbpos = 0, rbpos = 0;
-    uint32_t h1 = CG_NONE, h2 = CG_NONE, i1 = CG_NONE, i2 = CG_NONE, hl = CG_NONE, hr = CG_NONE;
-    uint32_t r1 = 0, c1 = 0, r2 = 0, c2 = 0; float nm1 = 0.f, nm2 = 0.f;
-    uint32_t bin = 0, headBin = 0; unsigned long long w0 = 0;
-
-    // stage 1 ---------------------------------------------------------------------------------
-    if (isB) {
-        if (SPEC) { pos = spec->pos; bin = spec->bin; r1 = spec->r1; c1 = spec->c1; }      // (drawn ahead: gen_spec_a1)
-        else {
-            // uniform64(1, L) (Random.cpp:105-123) with the constant range's iPart precomputed
-            uint64_t x = pcg_u64(rng);
-            while (x >= S.limitL) x = pcg_u64(rng);
-            pos = (S.iPartL == 1ull ? x : x / S.iPartL) + 1ull;
-            bin = gen_bin_of(S, pos); r1 = gen_div_k(S, bin); c1 = bin - r1 * K;
-        }
-        i1 = nT;
-    } else if (pick) {
-        i1 = pcg_uniform32(rng, 0u, nT - 1u);
-        if (i1 >= nR) { flags |= GEN_F_FAIL; pick = false; }   // an atom born earlier in this window: its row is in use
-    }
-    GEN_PIN(i1); GEN_PIN(bin); GEN_PIN(pos);
-    GEN_TS(10);
-    // Everything above needed only the window's scalars.  From here on the lanes read the domain (index vector, records, bitmap,
-    // bin heads), which the helper wave's flush has been rewriting meanwhile: join it (its stores are acknowledged: cg_sync waits
-    // for every wave's own outstanding memory operations).  Later rounds of a batch ended with such a barrier already.
-    if (FIRST) cg_sync();
-    GEN_TS(25);
-    uint32_t v1 = CG_NONE;
-    // (the word after the bin's own travels in the same trip: when the rest of the bin's word is empty -- one birth in twenty-five at the
-    // headline shape's occupancy -- the successor bin is nearly always in the next 64, and the full search through the bitmap's upper
-    // levels, half a dozen dependent trips that the whole wave waits for, stays for the domain's sparse stretches)
-    unsigned long long w0n = 0ull;
-    // (SPEC: a birth whose bitmap words were not touched by the decisions just applied takes the words and the successor bin's head the
-    // helper wave looked up ahead -- gen_spec_births -- and asks for that atom's record at once, two trips ahead of the others)
-    bool specB = false; uint32_t v2 = CG_NONE;
-    AtomRec b3; b3.pos = 0; b3.lpos = 0; b3.rpos = 0; b3.left = CG_NONE; b3.right = CG_NONE; b3.mass = 0.f; b3.rmass = 0.f; b3.idx = 0;
-    uint32_t specHead = 0;
-    if (SPEC && isB) {
-        const uint32_t sv2 = sh.bv2[t];
-        specHead = sh.bhb[t];
-        // the look-up holds if none of the bitmap words it read -- the bin's own, the next, and every further one up to the successor bin's --
-        // is marked
-        const uint32_t wFirst = bin >> 6;
-        uint32_t wLast = specHead >> 6; wLast = wLast > wFirst + 1u ? wLast : wFirst + 1u;
-        uint32_t dd = (sv2 == GEN_SPEC_INVALID || wLast - wFirst >= 16384u) ? 1u : 0u;
-        for (uint32_t w = wFirst; !dd && w <= wLast; ) {
-            const uint32_t wm = w & 16383u, n = 32u - (wm & 31u), left = wLast - w + 1u, take = n < left ? n : left;
-            const uint32_t bits = sh.dirty[wm >> 5] >> (wm & 31u);
-            dd = bits & (take >= 32u ? 0xFFFFFFFFu : ((1u << take) - 1u));
-            w += take;
-        }
-        specB = dd == 0u;
-#if defined(COGAPS_EMUL)
-        cg_atomic_add_u64(&gs->prof[specB ? 10 : (sv2 != GEN_SPEC_INVALID ? 9 : 8)], 1ull);      // test-only build: births that used the look-up made ahead / found their words marked / had none
-#endif
-        if (specB) { w0 = sh.bw0[t]; w0n = sh.bw0n[t]; v2 = sv2; b3 = S.atoms[v2]; }
-    }
-    if (isB && !specB) { w0 = S.bits0[bin >> 6]; w0n = ((bin >> 6) + 1u < S.nWords0) ? S.bits0[(bin >> 6) + 1u] : 0ull; }
-    if (pick) v1 = S.vec[i1];
-#if defined(GEN_SUBMARKS)
-    if (v1 == 12345678u || w0 == 0x123456789ull) flags |= 0x80000000u;
-#endif
-    {   // the exact B/D/indeterminate decision of this lane's own attempt (ProposalQueue.cpp:129-160 with the atom bounds as the births /
-        // deaths before it leave them), while the trip above is on its way: a guess that does not hold is a hazard (the window is cut
-        // there and redrawn with exact bounds), an indeterminate attempt ends the batch -- the smallest such attempt is the stop key
-        // (SPEC: the rows were never parked -- the table's window staged in LDS holds them: deathProb(n0 - d), deathProb(n0 + b))
+    // the exact B/D/indeterminate decision of this lane's own attempt (ProposalQueue.cpp:129-160 with the atom bounds as the births /
+    // deaths before it leave them): a guess that does not hold is a hazard (the window is cut there and redrawn with exact bounds), an
+    // indeterminate attempt ends the batch -- the smallest such attempt is the stop key.  Made while the draws' first memory trip is on
+    // its way (SPEC: the rows were never parked -- the table's window staged in LDS holds them: deathProb(n0 - d), deathProb(n0 + b))
+    auto exactDecide = [&]() {
         const float dpLoX = SPEC ? (nR >= dBeforeA1 ? sh.dpWin[nR - dBeforeA1 - c.dpBase] : 0.f) : sh.dpLo[dBeforeA1];
         const float dpHiX = SPEC ? sh.dpWin[nR + bBeforeA1 - c.dpBase] : sh.dpHi[bBeforeA1];
         const uint32_t exact = gen_decide(u1A1, u2A1, (uint64_t)minR - dBeforeA1, (uint64_t)nR + bBeforeA1, dpLoX, dpHiX);
@@ -514,127 +633,41 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
         const uint32_t failA = activeA1 & (hazA ^ 1u) & (uint32_t)(guessA1 == GEN_T_NONE);   // indeterminate: batch ends, no seed used
         if (hazA | failA) cg_atomic_min_u32(&sh.stopKey, 2u * t + (hazA ^ 1u));
         GEN_TS(7);
-    }
-    GEN_PIN(v1); GEN_PIN(w0);
-    GEN_TS(11);
-    // stage 2 ---------------------------------------------------------------------------------
-    bool slowB = false;
-    if (isB) {
-        const uint32_t bit = bin & 63u;
-        if ((w0 >> bit) & 1ull) headBin = bin;
-        else {
-            flags |= GEN_F_BINEMPTY; if (w0 == 0ull) flags |= GEN_F_WORDZERO;
-            const unsigned long long m = (bit == 63u) ? 0ull : (w0 & ~((2ull << bit) - 1ull));
-            if (m) headBin = (bin & ~63u) + (uint32_t)cg_ctz64(m); else if (w0n) headBin = (bin & ~63u) + 64u + (uint32_t)cg_ctz64(w0n);
-            else if (specB) headBin = specHead;      // (an empty stretch: the successor bin the helper wave's search found, gen_spec_births)
-            else slowB = true;
-        }
-    }
-    AtomRec a; a.pos = 0; a.lpos = 0; a.rpos = 0; a.left = CG_NONE; a.right = CG_NONE; a.mass = 0.f; a.rmass = 0.f; a.idx = 0;
-    if (isB && !slowB && !specB) v2 = S.binHead[headBin];
-    if (pick) { h1 = v1; a = S.atoms[h1]; }
-#if defined(GEN_SUBMARKS)
-    if (v2 == 12345678u || a.pos == 0x123456789ull) flags |= 0x80000000u;
-#endif
-    GEN_PIN(v2); GEN_PIN(a.pos); GEN_PIN(a.left);
-    GEN_TS(12);
-    // stage 3 ---------------------------------------------------------------------------------
-    // A picked atom's record carries its neighbours' positions and the right neighbour's mass (gaps_state.h): a move's bounds and
-    // an exchange's partner need no trip to the neighbours' records -- every pick goes from its record straight to the matrix
-    // entries.  (The one exception: the highest atom's exchange partner is front(), whose record is fetched.)
-    uint64_t lp = 0, rp = 0;
-    float m2x = 0.f;                        // exchange: the partner's mass
-    bool frontE = false;                    // exchange of the highest atom: the partner is front()
-    if (pick) {
-        cpos = a.pos;
-        const uint32_t b1 = gen_bin_of(S, cpos);
-        r1 = gen_div_k(S, b1); c1 = b1 - r1 * K;
-        hl = a.left;
-        if (type == 'M') { hr = a.right; lp = a.lpos; rp = a.rpos; }
-        else if (type == 'E') {
-            hr = a.right;
-            if (hr != CG_NONE) { h2 = hr; rbpos = a.rpos; m2x = a.rmass; }
-            else { h2 = sh.g.front; frontE = true; }
-        }
-    }
-    // the scalars the evaluation starts from travel in the queue record (consumed at commit)
-    float old1 = 0.f, old2 = 0.f; uint32_t gib1 = 0, gib2 = 0;
-    uint64_t lposB = 0, rposB = 0; float rmassB = 0.f;        // birth: what the new atom's record caches of its neighbours
-    if (isB && !slowB && !specB) b3 = S.atoms[v2];
-    if (frontE) b3 = S.atoms[h2];
-    if (isB || pick) { old1 = S.sparse ? S.rows[(size_t)r1 * S.Kpad + c1] : S.mat[(size_t)c1 * S.Mpad + r1]; gib1 = S.otherColPos[c1]; }
-    if (pick && type == 'M') {
-        if (hl != CG_NONE) { flags |= GEN_F_HASLEFT; lbpos = lp; } else lbpos = 0;
-        if (hr != CG_NONE) { flags |= GEN_F_HASRIGHT; rbpos = rp; } else rbpos = S.rboundNone;
-        pos = pcg_uniform64(rng, lbpos + 1ull, rbpos - 1ull);
-        const uint32_t bin2 = gen_bin_of(S, pos);
-        r2 = gen_div_k(S, bin2); c2 = bin2 - r2 * K;
-        if (r1 == r2 && c1 == c2) flags |= GEN_F_INLINE;
-    }
-    if (pick && type == 'E' && !frontE) {
-        flags |= GEN_F_HASRIGHT;
-        const uint32_t bin2 = gen_bin_of(S, rbpos);
-        r2 = gen_div_k(S, bin2); c2 = bin2 - r2 * K;
-    }
-    if (pick && (type == 'M' || (type == 'E' && !frontE))) { old2 = S.sparse ? S.rows[(size_t)r2 * S.Kpad + c2] : S.mat[(size_t)c2 * S.Mpad + r2]; gib2 = S.otherColPos[c2]; }
-#if defined(GEN_SUBMARKS)
-    if (b3.pos == 12345678u || lp == 0x123456789ull || rp == 0x123456789ull) flags |= 0x80000000u;
-#endif
-    GEN_PIN(b3.pos); GEN_PIN(lp); GEN_PIN(rp);
-    GEN_TS(13);
-    // finish ----------------------------------------------------------------------------------
-    if (isB) {
-        if (!slowB) {
-            if ((flags & GEN_F_BINEMPTY) || b3.pos > pos) { hr = v2; hl = b3.left; lposB = b3.lpos; rposB = b3.pos; rmassB = b3.mass; flags |= GEN_F_NEWHEAD; }
-            else if (b3.pos == pos) slowB = true;      // position already taken: the retry loop below
-            else {
-                // the bin's lowest atom lies below pos: go on to the right; the record in hand knows its right neighbour's
-                // position, so the usual case (a bin holds 1.3 atoms on average) needs no further trip
-                uint32_t cur = v2, nxt = b3.right; uint64_t curPos = b3.pos, nxtPos = b3.rpos; float nxtMass = b3.rmass;
-                for (;;) {
-                    if (nxt == CG_NONE) break;
-                    if (nxtPos == pos) { slowB = true; break; }
-                    if (nxtPos > pos) break;
-                    const AtomRec w = S.atoms[nxt];
-                    cur = nxt; curPos = nxtPos; nxt = w.right; nxtPos = w.rpos; nxtMass = w.rmass;
-                }
-                hl = cur; hr = nxt; lposB = curPos; rposB = nxtPos; rmassB = nxtMass;
+    };
+    GenDraw d;
+    if (AHEAD) {
+        // (chained launch: the window was drawn ahead of the decisions -- gen_body -- against the domain as the previous batch's commit left
+        // it; the lanes whose reads the decisions or the flush touched draw again, now, against the domain as it is: the same code, the
+        // same results as if every lane had waited.  The join with the flush precedes both: gen_body.)
+        d = *ahead;
+        if (cg_ballot(go && !aheadValid) != 0ull) {
+            if (go && !aheadValid) {
+                GenDraw r; gen_draw_a<WIN, SPEC>(S, c, spec, go, type, bBefore, SPEC ? spec->rng : pcg_from_seed(sh.seed[ct]), nR, r);
+                gen_draw_b<WIN, false>(S, sh, c, type, r, [&]() {});
+                d = r;
             }
-        }
-#if defined(GEN_TIMELINE)
-        if (FIRST) { cg_atomic_add_u64(&sh.rt[6], specB ? 1ull : 0x10000ull); if (slowB) cg_atomic_add_u64(&sh.rt[7], 1ull); }
-#endif
-        if (slowB) {
-            bool occ, nh;
-            gen_find_gap(S, pos, bin, &hl, &hr, &occ, &nh);
-            while (occ) {           // randomFreePosition retry (ConcurrentAtomicDomain.cpp:46-54)
-                pos = pcg_uniform64(rng, 1ull, S.domainLenU);
-                bin = gen_bin_of(S, pos); r1 = gen_div_k(S, bin); c1 = bin - r1 * K;
-                gen_find_gap(S, pos, bin, &hl, &hr, &occ, &nh);
-            }
-            flags &= ~(GEN_F_BINEMPTY | GEN_F_WORDZERO | GEN_F_NEWHEAD);
-            if (nh) flags |= GEN_F_NEWHEAD;
-            if (S.binHead[bin] == CG_NONE) { flags |= GEN_F_BINEMPTY; if (S.bits0[bin >> 6] == 0ull) flags |= GEN_F_WORDZERO; }
-            old1 = S.sparse ? S.rows[(size_t)r1 * S.Kpad + c1] : S.mat[(size_t)c1 * S.Mpad + r1]; gib1 = S.otherColPos[c1];      // the retry may have moved the birth to another bin
-            lposB = (hl != CG_NONE) ? S.atoms[hl].pos : 0ull;
-            if (hr != CG_NONE) { rposB = S.atoms[hr].pos; rmassB = S.atoms[hr].mass; } else { rposB = 0ull; rmassB = 0.f; }
-        }
-    } else if (pick && type == 'E') {
-        if (frontE) {
-            rbpos = b3.pos; m2x = b3.mass;
-            const uint32_t bin2 = gen_bin_of(S, rbpos);
-            r2 = gen_div_k(S, bin2); c2 = bin2 - r2 * K;
-            old2 = S.sparse ? S.rows[(size_t)r2 * S.Kpad + c2] : S.mat[(size_t)c2 * S.Mpad + r2]; gib2 = S.otherColPos[c2];
-        }
-        if (r1 == r2 && c1 == c2) {
-            flags |= GEN_F_INLINE;
-            const float m1 = a.mass, m2 = m2x;
-            const float newMass = pcg_trunc_gamma_upper(rng, S.luts, m1 + m2, 1.f / S.lambda, S.mathMode);
-            const float delta = (m1 > m2) ? newMass - m1 : m2 - newMass;
-            if (m1 + delta > GAPS_EPSILON && m2 - delta > GAPS_EPSILON) { flags |= GEN_F_APPLY; nm1 = m1 + delta; nm2 = m2 - delta; }
-        }
+        } else if (d.isB) d.i1 = nR + bBefore;      // (a birth's index in the unsorted vector: the domain's size, known now)
+        exactDecide();
+    } else {
+        gen_draw_a<WIN, SPEC>(S, c, spec, go, type, bBefore, SPEC ? spec->rng : (go ? pcg_from_seed(sh.seed[ct]) : 0ull), nR, d);
+        GEN_PIN(d.i1); GEN_PIN(d.bin); GEN_PIN(d.pos);
+        GEN_TS(10);
+        // Everything above needed only the window's scalars.  From here on the lanes read the domain (index vector, records, bitmap,
+        // bin heads), which the helper wave's flush has been rewriting meanwhile: join it (its stores are acknowledged: cg_sync waits
+        // for every wave's own outstanding memory operations).  Later rounds of a batch ended with such a barrier already.
+        if (FIRST) cg_sync();
+        GEN_TS(25);
+        gen_draw_b<WIN, false>(S, sh, c, type, d, exactDecide);
     }
-    GEN_PIN(pos); GEN_PIN(flags); GEN_PIN(r2); GEN_PIN(c2); GEN_PIN(rbpos); GEN_PIN(nm1);
+    uint32_t flags = d.flags;
+    const bool isB = d.isB, pick = d.pick;
+    const uint64_t rng = d.rng, pos = d.pos, cpos = d.cpos;
+    uint32_t h1 = d.h1, h2 = d.h2, i1 = d.i1, i2 = CG_NONE; const uint32_t hl = d.hl, hr = d.hr;
+    const uint32_t r1 = d.r1, c1 = d.c1, r2 = d.r2, c2 = d.c2, bin = d.bin; const float nm1 = d.nm1, nm2 = d.nm2;
+    const float old1 = d.old1, old2 = d.old2, m2x = d.m2x; const uint32_t gib1 = d.gib1, gib2 = d.gib2;
+    const uint64_t lposB = d.lposB, rposB = d.rposB; const float rmassB = d.rmassB;
+    struct { float mass; } a; a.mass = d.amass;
+    (void)isB; (void)pick;
     GEN_TS(14);
 
     // ------------------------------------------------------------------ B1: register rows / atoms / gaps
@@ -1258,16 +1291,16 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
             // in the erase cache, carry the decision out
             auto take = [&](const uint32_t q, const bool haveIn, const ChainItem &it) {
                 const unsigned long long *gr = hot.grans + (size_t)q * CHAIN_GRAN_STRIDE;
-                unsigned long long g0 = 0ull, g1 = 0ull; uint32_t spins = 0; const unsigned long long pollT0 = cg_poll_begin();
+                unsigned long long g0 = 0ull, g1 = 0ull; uint32_t spins = 0;
                 bool have = haveIn;
                 for (;;) {
                     if (have) { g0 = cg_load_l2_u64(&gr[0]); g1 = cg_load_l2_u64(&gr[1]); }
                     const bool ok = !have || ((uint32_t)(g0 >> 32) == tag && (uint32_t)(g1 >> 32) == tag);
                     if (cg_ballot(!ok) == 0ull) break;
-                    // bounded by time (platform.h), never a hang.  A bound that is hit applies NOTHING: a granule without this batch's tag is an
+                    // bounded (platform.h: two seconds at least), never a hang.  A bound that is hit applies NOTHING: a granule without this batch's tag is an
                     // older batch's decision -- the lane drops its proposal, the error word ends the update on the host (the session is then
                     // marked unusable: its domain lacks decisions) and the workgroup leaves behind the barrier below without generating
-                    if (cg_poll_expired(pollT0, ++spins)) { if (!ok) have = false; if ((t & 63u) == 0u) { gs->error = GAPS_ERR_SPIN; sh.spinFail = 1u; } break; }
+                    if (cg_poll_expired(++spins)) { if (!ok) have = false; if ((t & 63u) == 0u) { gs->error = GAPS_ERR_SPIN; sh.spinFail = 1u; } break; }
                     cg_poll_pause();
                 }
                 GEN_TS(33);

@@ -143,11 +143,12 @@ CG_DEVICE unsigned long long cg_load_l2_u64(const unsigned long long *p) { retur
 // (MI355X_MICROARCH.md, persistent-kernel price list, handoff-1to1: ~0.8 us on an idle chip).
 CG_DEVICE void cg_store_agent_u64(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 CG_DEVICE void cg_poll_pause() { __builtin_amdgcn_s_sleep(1); }
-// A poll inside a launch is bounded by TIME, generously (two seconds of the chip-wide 100 MHz clock): a waiting workgroup may share the GPU
-// with a foreign kernel, a debugger or a preempted queue, and a bound that is hit is an error of the whole update (GAPS_ERR_SPIN), never a hang.
 CG_DEVICE unsigned long long cg_realtime() { return __builtin_amdgcn_s_memrealtime(); }      // chip-wide constant 100 MHz clock
-CG_DEVICE unsigned long long cg_poll_begin() { return __builtin_amdgcn_s_memrealtime(); }
-CG_DEVICE bool cg_poll_expired(unsigned long long begin, uint32_t) { return __builtin_amdgcn_s_memrealtime() - begin > 200000000ull; }
+// A poll inside a launch is bounded, generously: every turn is a load past the caches (>= 0.5 us while the word is not there) plus a
+// sleep, so 2^22 turns are at least two seconds -- a waiting workgroup may share the GPU with a foreign kernel, a debugger or a preempted
+// queue -- and a bound that is hit is an error of the whole update (GAPS_ERR_SPIN), never a hang.  (Reading the clock inside the loop
+// cost the deciding evaluation kernel ten spilled vector registers and 2.8 us per launch: the turn count is the clock.)
+CG_DEVICE bool cg_poll_expired(uint32_t spins) { return spins > (1u << 22); }
 CG_DEVICE float cg_shfl_xor_f32(float v, int mask) { return __shfl_xor(v, mask, 64); }
 CG_DEVICE float cg_shfl_f32(float v, int lane) { return __shfl(v, lane, 64); }
 // the value lane `lane` holds (lane: the same in every lane of the wave) -- a lane read instead of an LDS-crossbar permute

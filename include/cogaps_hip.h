@@ -211,7 +211,12 @@ int cogaps_session_perf(cogaps_session *s, cogaps_perf *out);                   
 int cogaps_session_perf_sampler(cogaps_session *s, char which, cogaps_perf *out);   /* the 'A' or the 'P' sampler alone */
 /* 1 when the sampler's last update ran as chained launches (csrc/chain_kernel.h: ONE launch evaluates batch n and generates batch n + 1;
  * its time is reported as evalMs, genMs stays 0), 0 for a generator launch and an evaluation launch per batch.  The chained form serves
- * the one-chain fused evaluation (AsynchronousGibbsSampler.h:88-122, same results); environment COGAPS_NO_CHAIN=1 switches it off. */
+ * the one-chain fused evaluation (AsynchronousGibbsSampler.h:88-122, same results); environment COGAPS_NO_CHAIN=1 switches it off.  It is taken
+ * only where the device shows a compute unit per workgroup of the launch (241; hipDeviceAttributeMultiprocessorCount, which honours
+ * HSA_CU_MASK): the evaluation workgroups never wait for anything, so with fewer units the launch is still correct -- the workgroups run in
+ * turns, the generator last -- but slower than two launches; COGAPS_FORCE_CHAIN=1 (tests) takes it there anyway.  The hand-over inside the
+ * launch relies on the dispatcher starting workgroups in index order (observed, not promised by HIP): a generator that started before an
+ * evaluation workgroup could be scheduled would wait for it, bounded by two seconds, and end the update with an error, never with a hang. */
 int cogaps_session_chained(cogaps_session *s, char which, int *chained);
 /* Durations of the sampler's chained launches since cogaps_session_set_timing(1), EVERY launch -- replayed graphs included, where HIP
  * events cannot ride --, from the chip-wide 100 MHz clock read inside the launch (entry of its first workgroup to the end of its generator

@@ -64,8 +64,7 @@ inline unsigned long long cg_load_l2_u64(const unsigned long long *p) { return *
 inline void cg_store_agent_u64(unsigned long long *p, unsigned long long v) { *p = v; }
 inline void cg_poll_pause() {}
 inline unsigned long long cg_realtime() { return 0ull; }
-inline unsigned long long cg_poll_begin() { return 0ull; }
-inline bool cg_poll_expired(unsigned long long, uint32_t spins) { return spins > (1u << 16); }      // (no clock here: the emulator's producers have always finished)
+inline bool cg_poll_expired(uint32_t spins) { return spins > (1u << 16); }      // (no clock here: the emulator's producers have always finished)
 inline float cg_shfl_xor_f32(float v, int mask) { return cgemu::wave_exchange_f32(v, mask); }
 inline float cg_wave_allsum_f32(float x) { for (int off = 1; off < 64; off <<= 1) x = x + cgemu::wave_exchange_f32(x, off); return x; }
 inline float cg_shfl_f32(float v, int lane) { return cgemu::wave_read_f32(v, lane); }

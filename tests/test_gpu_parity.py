@@ -253,22 +253,30 @@ def test_chained_equals_two_launches_on_the_gpu(hip_lib, monkeypatch):
 
 
 def test_chained_launch_with_half_the_compute_units(hip_lib):
-    """`Correct and slower, never a hang` as a hardware fact: the same chain in a process whose queues may use 120 of the 256 compute
-    units (HSA_CU_MASK), so that the 241 workgroups of a chained launch are NOT all resident at once and the generator workgroup -- the
-    launch's last -- starts when evaluation workgroups have left.  Must finish and must equal the unmasked run bit for bit."""
+    """`Correct and slower, never a hang` as a hardware fact.  The same chain in processes whose queues may use 120 of the 256 compute
+    units (HSA_CU_MASK): (1) as the library decides; (2) with COGAPS_FORCE_CHAIN=1 the chained launch whatever the runtime reports --
+    its 241 workgroups are then NOT all resident at once, the generator workgroup, the launch's last, starts when evaluation workgroups
+    have left.  Both must finish and equal the unmasked run bit for bit."""
     import subprocess, sys, json
     ref, formA = _chain_ab_run(hip_lib)
-    code = ("import sys, json; sys.path[:0] = [%r, %r]\n"
+    assert formA == 1
+    here = os.path.dirname(os.path.abspath(__file__)); root = os.path.dirname(here)
+    code = ("import sys, json; sys.path[:0] = [%r, %r, %r]\n"
             "import test_gpu_parity as T\nfrom cogaps_amd import _capi\nimport time\nt0 = time.time()\n"
             "st, form = T._chain_ab_run(_capi.load())\nprint(json.dumps({'state': st, 'form': form, 'seconds': time.time() - t0}))\n"
-            % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-    env = dict(os.environ, HSA_CU_MASK="0:0-119", ROC_GLOBAL_CU_MASK="0x" + "f" * 30)
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-2000:]
-    rec = json.loads(out.stdout.strip().splitlines()[-1])
-    print("masked run: %.1f s, chained=%d" % (rec["seconds"], rec["form"]))
-    assert rec["form"] == formA == 1
-    assert rec["state"] == ref
+            % (here, root, os.path.join(root, "oracle")))
+    for force in (False, True):
+        env = dict(os.environ, HSA_CU_MASK="0:0-119")
+        env.pop("COGAPS_NO_CHAIN", None)
+        if force: env["COGAPS_FORCE_CHAIN"] = "1"
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        rec = json.loads(out.stdout.strip().splitlines()[-1])
+        print("120 compute units, force=%s: %.1f s, chained=%d" % (force, rec["seconds"], rec["form"]))
+        # (whether the mask lowers the compute-unit count the runtime reports -- and so closes the library's gate -- depends on the driver:
+        # unforced, either form may run; forced, the chained one must)
+        assert rec["form"] == 1 or not force
+        assert rec["state"] == ref
 
 
 def test_plain_c_client_equals_the_ctypes_path(hip_lib, gist):
