@@ -37,7 +37,6 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(CHAIN_MAX_THREADS) chain_kernel(const uint64_t *
                                                                 uint32_t queueCap, uint32_t parity, const SamplerDev CG_CONSTANT *sp)
 {
     if (cg_bid() + 1u == cg_gdim()) {
-        if (cg_tid() >= (unsigned)WIN + 64u) return;      // (the launch's workgroups have the evaluation's size; whole waves leave)
         GenHot hot; hot.lcgMul = lcgMul; hot.lcgInc = lcgInc; hot.gs = gs; hot.eraseList = nullptr; hot.queueUnits = nullptr; hot.eraseCap = 0; hot.queueCap = queueCap;
         hot.queueRd = queue + (size_t)parity * queueCap; hot.queueWr = queue + (size_t)(1u - parity) * queueCap; hot.grans = grans; hot.slotWr = &slots[1u - parity];
         gen_body<WIN, true, true>(sp, hot);

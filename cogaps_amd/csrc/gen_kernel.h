@@ -25,16 +25,17 @@
 
 #if defined(GEN_TIMELINE)
 // per-wave timeline of one typical launch (lane 0 of every wave -- the attempt waves and the helper wave -- records (clock << 8 | id)); dev tool only
-__device__ unsigned long long g_timeline[(GEN_WIN / 64 + 1) * 64];
+__device__ unsigned long long g_timeline[8 * 64];      // (up to eight waves: the chained launch's generator workgroup has the evaluation's size)
 #define GEN_TS(id) do { if ((t & 63u) == 0u && ts_n < 64u) { sh.ts[(t & ~63u) + ts_n] = ((unsigned long long)cg_clock() << 8) | (unsigned long long)(id); ++ts_n; } } while (0)
 // every wave leaves its own marks when it ends (a launch that found a well filled queue: the populated chain)
-#define GEN_TS_DUMP_WAVE() do { if ((t & 63u) == 0u && ts_ok && (t >> 6) <= (unsigned)(GEN_WIN / 64)) { for (uint32_t i_ = 0; i_ < 64u; ++i_) g_timeline[(t & ~63u) + i_] = i_ < ts_n ? sh.ts[(t & ~63u) + i_] : 0ull; } } while (0)
+#define GEN_TS_DUMP_WAVE() do { if ((t & 63u) == 0u && ts_ok && (t >> 6) < 8u) { for (uint32_t i_ = 0; i_ < 64u; ++i_) g_timeline[(t & ~63u) + i_] = i_ < ts_n ? sh.ts[(t & ~63u) + i_] : 0ull; } } while (0)
 #define GEN_TS_INIT() uint32_t ts_n = 0
 #define GEN_TS_RESUME(k) ts_n = (k)
 #define GEN_TS_ZERO(a, b) do { if ((t & 63u) == 0u) for (uint32_t i_ = (a); i_ < (b); ++i_) sh.ts[(t & ~63u) + i_] = 0ull; } while (0)
 #define GEN_PIN(x) asm volatile("" : "+v"(x) :: "memory")      // the value is computed before the next timestamp
 __device__ unsigned long long g_chain_gen[8];      // the chained launch's generator workgroup on the chip-wide 100 MHz clock (chain_kernel.h)
 #define GEN_RT(i) do { if (t == 0u) sh.rt[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define GEN_RT_AT(i, lane) do { if (t == (unsigned)(lane)) sh.rt[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define GEN_LOG_N 65536
 __device__ unsigned long long g_chain_log[GEN_LOG_N * 8]; __device__ unsigned int g_chain_log_n;      // one record per chained launch of a well filled queue
 #define GEN_RT_DUMP() do { if (t == 0u && sh.rtOn) { for (int i_ = 0; i_ < 8; ++i_) g_chain_gen[i_] = sh.rt[i_]; } \
@@ -47,6 +48,7 @@ __device__ unsigned long long g_chain_log[GEN_LOG_N * 8]; __device__ unsigned in
 #define GEN_TS_ZERO(a, b) do { } while (0)
 #define GEN_PIN(x) do { } while (0)
 #define GEN_RT(i) do { } while (0)
+#define GEN_RT_AT(i, lane) do { } while (0)
 #define GEN_RT_DUMP() do { } while (0)
 #define GEN_TS_DUMP_WAVE() do { } while (0)
 #endif
@@ -93,6 +95,8 @@ __device__ unsigned long long g_chain_log[GEN_LOG_N * 8]; __device__ unsigned in
 #endif
 #define CG_KEEP 0xFFFFFFFEu          // "front unchanged" marker
 
+#define GEN_DIRTY_ATOMS 4096      // 32-bit words of the note bit sets (a batch's decisions touch ~3 atom records and ~1.5 cells each: ~600 of 131072 bits)
+#define GEN_DIRTY_CELLS 2048
 struct GenTabVal { uint32_t used, gap, inl, pad; };
 struct GenTabKeys { uint32_t k[4]; };
 
@@ -112,7 +116,7 @@ struct GenShared {
     uint32_t nLow, newFront, flushM, flushBase, unitSum, frontPending;
     uint32_t freeTop[16];                // the free-handle stack's top entries as the launch found them (below what its own flush pushes): a committing birth's handle without a memory trip
 #if defined(GEN_TIMELINE)
-    unsigned long long ts[(WIN / 64 + 1) * 64];
+    unsigned long long ts[8 * 64];
     unsigned long long rt[8]; uint32_t rtOn, rtLog; unsigned long long rtInfo;
 #endif
     alignas(16) uint32_t bkey[4 * GEN_TAB_NB];      // conflict sets of round 1: keys, bucket-major
@@ -132,6 +136,9 @@ struct GenShared {
     // the bitmap words and the successor bin's head each birth will need, per sorted slot; `dirty`: one bit per level-0 bitmap word
     // (mod 16384) that the decisions being applied or the flush change -- a birth whose words are marked looks them up again
     unsigned long long bw0[WIN], bw0n[WIN]; uint32_t bv2[WIN], bhb[WIN]; uint32_t bslot[64]; uint32_t dirty[512];
+    // ... and (round 5) the whole window DRAWN ahead: what the decisions being applied change, noted by the lanes that apply them --
+    // atom records (handles), matrix cells (bins), the vector slots the flush refills (gen_populate.h, gen_draw_valid)
+    alignas(16) uint32_t dAtom[GEN_DIRTY_ATOMS]; uint32_t dCell[GEN_DIRTY_CELLS]; uint32_t anyRedo;      // (bit sets, two hash positions per key; anyRedo: some lane of the window draws again)
 };
 
 // bin index = pos / binLength, exact: double-precision reciprocal estimate (off by at most one), then a

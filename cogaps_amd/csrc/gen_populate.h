@@ -29,11 +29,11 @@
 struct GenFlushRegs { uint32_t myH, myBin, myHead; AtomRec rec; uint32_t vtail, freeTop; };
 // step 1: request the erased atoms' records, their bins' heads and the tail of the unsorted vector (no wait)
 template <int WIN>
-CG_DEVICE void gen_flush_fetch(const SamplerDev &S, GenFlushRegs &f, const unsigned ht, const uint32_t m, const uint32_t n, const unsigned long long specE, const uint32_t fc)
+CG_DEVICE void gen_flush_fetch(const SamplerDev &S, GenFlushRegs &f, const unsigned ht, const uint32_t m, const uint32_t n, const unsigned long long specE, const uint32_t fc, const bool haveFreeTop = false)
 {
     // (the stack's top sixteen entries ride along: half of the launches commit a birth that pops below what the flush pushed, and its
     // wave -- the launch's last phase -- waited a memory trip for the handle)
-    f.freeTop = (ht < 16u && ht < fc) ? S.freeHandles[fc - 1u - ht] : CG_NONE;
+    f.freeTop = (!haveFreeTop && ht < 16u && ht < fc) ? S.freeHandles[fc - 1u - ht] : CG_NONE;      // (haveFreeTop: the chained launch parked them in sh.freeTop ahead of the decisions)
     f.myH = 0; f.myBin = 0; f.myHead = CG_NONE; f.vtail = CG_NONE;
     f.rec.pos = 0; f.rec.lpos = 0; f.rec.rpos = 0; f.rec.left = CG_NONE; f.rec.right = CG_NONE; f.rec.mass = 0.f; f.rec.rmass = 0.f; f.rec.idx = 0; f.rec.pad0 = 0;
     // (the bin travels with the handle in the erase cache: the bin's head is asked for in the same trip as the record)
@@ -137,7 +137,7 @@ CG_DEVICE void gen_helper(const SamplerDev &S, GenShared<WIN> &sh, GenScalars *g
     const unsigned t = (unsigned)WIN + ht;
     GEN_TS_INIT(); GEN_TS_RESUME(13);      // (marks 0, 0, 26-29, 1 and the chained launch's 30-35 were left by gen_body)
     GenFlushRegs fr;
-    gen_flush_fetch<WIN>(S, fr, ht, e_m, e_n, specE, e_fc);          // the flush's one memory trip: under the attempt waves' A1
+    gen_flush_fetch<WIN>(S, fr, ht, e_m, e_n, specE, e_fc, specDone);          // the flush's one memory trip: under the attempt waves' A1
     const uint32_t n0 = e_n - e_m;                              // the domain holds this many atoms after the flush
     const uint64_t batchEpoch = sh.g.batchEpoch + 1;
     const uint32_t remaining = e_nSteps - e_nDone;
@@ -158,14 +158,28 @@ CG_DEVICE void gen_helper(const SamplerDev &S, GenShared<WIN> &sh, GenScalars *g
         // the type sort; the write-back during the first stage of A2)
         // (specDone: the chained launch classified this window before the decisions arrived and executed A1's two barriers then -- the
         // flush runs straight through to the join)
-        if (first) { gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 0); if (ht < 16u) sh.freeTop[ht] = fr.freeTop; }
-        if (!(first && specDone)) cg_sync_lds(); else cg_wave_sync();
-        if (first) { gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 1); gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 2); }
-        if (!(first && specDone)) cg_sync_lds(); else cg_wave_sync();
-        if (first) { gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 3); GEN_TS(3); cg_sync(); }      // the join: the flush's stores are acknowledged (vmcnt(0)) before any lane reads the domain
-        // ---- B1 / B2 barriers
-        if (ldsRound) cg_sync_lds(); else cg_sync();
-        if (ldsRound) cg_sync_lds(); else cg_sync();
+        if (first && specDone) {
+            // Chained launch, the window drawn ahead of the decisions (gen_body): the attempt lanes have validated their draws when they
+            // arrive at the first barrier.  No lane draws again (every second launch): the domain is not read before the commit, and the
+            // flush runs BESIDE the conflict phases -- sort, list surgery and index replay before the registration barrier (the commit
+            // reads their LDS results), the write-back before the look-up barrier, acknowledged (cg_sync waits for this wave's stores).
+            // Some lane draws again: it reads the domain as the flush leaves it -- the whole flush, then the join, as in the other forms.
+            gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 0);
+            cg_sync_lds();
+            const bool anyRedo = cg_uniform_u32(sh.anyRedo) != 0u;
+            gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 1); gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 2);
+            if (anyRedo) { gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 3); GEN_TS(3); cg_sync(); cg_sync_lds(); cg_sync_lds(); }
+            else { cg_sync_lds(); gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 3); GEN_TS(3); cg_sync(); }
+        } else {
+            if (first) { gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 0); if (ht < 16u) sh.freeTop[ht] = fr.freeTop; }
+            cg_sync_lds();
+            if (first) { gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 1); gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 2); }
+            cg_sync_lds();
+            if (first) { gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 3); GEN_TS(3); cg_sync(); }      // the join: the flush's stores are acknowledged (vmcnt(0)) before any lane reads the domain
+            // ---- B1 / B2 barriers
+            if (ldsRound) cg_sync_lds(); else cg_sync();
+            if (ldsRound) cg_sync_lds(); else cg_sync();
+        }
         // ---- C: masks complete behind this barrier; the attempt lanes commit, this wave keeps the books
         const uint32_t nR = sh.nR, minR = sh.minAtoms, skip = sh.skip, processed = sh.processed;
         const uint32_t left_ = remaining - processed;
@@ -367,6 +381,29 @@ CG_DEVICE void gen_mark_dirty(uint32_t *dirty, uint32_t bin)
     cg_atomic_or_u32(&dirty[w >> 5], 1u << (w & 31u));
 }
 
+// ---- notes of what the previous batch's decisions change (chained launch) ------------------------------------------------------------
+// Two bit sets in LDS -- atom records (by handle; the vector slots the flush refills share it under complemented keys) and matrix cells
+// (by bin) --, two hash positions per key: the lanes that apply the decisions set bits with non-returning LDS atomics (nothing to wait
+// for; an exact hash set's compare-and-swap chains cost the applying waves 3 k cycles per launch), the lanes that drew the next window
+// ahead read their keys' bits behind the join.  A key that was never noted reads as noted with probability ~2e-5 (two of ~600 set bits
+// among 131072): the lane then draws again, which is always correct.
+template <int WORDS>
+CG_DEVICE void gen_note_add(uint32_t *bits, uint32_t key)
+{
+    constexpr uint32_t LOG2 = WORDS == 4096 ? 17u : 16u;
+    static_assert(WORDS == 4096 || WORDS == 2048, "bit positions are the hashes' top 17 / 16 bits");
+    const uint32_t a = (key * 2654435761u) >> (32u - LOG2), b = (key * 0x85EBCA6Bu + 0x27D4EB2Fu) >> (32u - LOG2);
+    cg_atomic_or_u32(&bits[a >> 5], 1u << (a & 31u));
+    cg_atomic_or_u32(&bits[b >> 5], 1u << (b & 31u));
+}
+template <int WORDS>
+CG_DEVICE uint32_t gen_note_has(const uint32_t *bits, uint32_t key)
+{
+    constexpr uint32_t LOG2 = WORDS == 4096 ? 17u : 16u;
+    const uint32_t a = (key * 2654435761u) >> (32u - LOG2), b = (key * 0x85EBCA6Bu + 0x27D4EB2Fu) >> (32u - LOG2);
+    return (bits[a >> 5] >> (a & 31u)) & (bits[b >> 5] >> (b & 31u)) & 1u;
+}
+
 // ---- the populate-phase draws of one attempt (ProposalQueue.cpp:162-283: birth / death / move / exchange up to the conflict rules) ------
 // What an attempt's lane knows once it has drawn: the proposal as it will be queued, the atoms and matrix entries it read, and -- for the
 // chained launch, which draws a window AHEAD of the previous batch's decisions and must know which lanes to draw again -- what it read
@@ -379,18 +416,18 @@ struct GenDraw {
     uint64_t lposB, rposB; float rmassB;
     // drawn ahead only: the successor bin a birth found and the atom at its head; `redo`: the lane took (or would have taken) one of the
     // rare long ways -- the full gap search, a walk along a bin, front() as an exchange partner -- and draws again behind the decisions
-    uint32_t headBin, v2; bool redo;
+    uint32_t headBin, v2, v3, xPick; bool redo;      // v3: the one further record a birth read along its bin; xPick: the 32 random bits the pick was made from
 };
 CG_DEVICE void gen_draw_clear(GenDraw &d)
 {
     d.go = 0; d.flags = 0; d.isB = false; d.pick = false; d.rng = 0; d.rngPick = 0; d.pos = 0; d.cpos = 0;
     d.h1 = CG_NONE; d.h2 = CG_NONE; d.i1 = CG_NONE; d.hl = CG_NONE; d.hr = CG_NONE; d.r1 = 0; d.c1 = 0; d.r2 = 0; d.c2 = 0; d.bin = 0;
     d.nm1 = 0.f; d.nm2 = 0.f; d.amass = 0.f; d.m2x = 0.f; d.old1 = 0.f; d.old2 = 0.f; d.gib1 = 0; d.gib2 = 0; d.lposB = 0; d.rposB = 0; d.rmassB = 0.f;
-    d.headBin = 0; d.v2 = CG_NONE; d.redo = false;
+    d.headBin = 0; d.v2 = CG_NONE; d.v3 = CG_NONE; d.xPick = 0; d.redo = false;
 }
 // first part: what needs only the window's scalars -- a birth's position and bin (SPEC: drawn with the classification, gen_spec_slot),
 // a pick's index into the unsorted vector.  nR: the domain's size at the start of the round; an attempt sees nR + (births before it).
-template <int WIN, bool SPEC>
+template <int WIN, bool SPEC, bool AHEAD = false>
 CG_DEVICE void gen_draw_a(const SamplerDev &S, const GenRoundCtx &c, const GenSpec *spec, const bool go, const uint32_t type, const uint32_t bBefore, const uint64_t rng0, const uint32_t nR, GenDraw &d)
 {
     gen_draw_clear(d);
@@ -410,6 +447,12 @@ CG_DEVICE void gen_draw_a(const SamplerDev &S, const GenRoundCtx &c, const GenSp
         }
         d.i1 = nT;
     } else if (d.pick) {
+        if (AHEAD) {
+            // (drawn ahead: the pick is checked later against the size the flush leaves -- gen_draw_valid -- from the 32 bits it was made from;
+            // a pick that needed a second draw, one in ten thousand, is simply drawn again)
+            uint64_t r2 = d.rng; d.xPick = pcg_u32(r2);
+            if (d.xPick >= nT * (0xFFFFFFFFu / nT)) d.redo = true;
+        }
         d.i1 = pcg_uniform32(d.rng, 0u, nT - 1u);
         if (d.i1 >= nR) { d.flags |= GEN_F_FAIL; d.pick = false; }   // an atom born earlier in this window: its row is in use
     }
@@ -508,7 +551,7 @@ CG_DEVICE void gen_draw_b(const SamplerDev &S, GenShared<WIN> &sh, const GenRoun
                     if (nxt == CG_NONE) break;
                     if (nxtPos == pos) { slowB = true; break; }
                     if (nxtPos > pos) break;
-                    if (AHEAD) { d.redo = true; break; }      // (a walk along the bin reads records the validation does not know of)
+                    if (AHEAD) { if (d.v3 != CG_NONE) { d.redo = true; break; } d.v3 = nxt; }      // (ahead: one further record, which the validation knows of; a longer walk is made again)
                     const AtomRec w = S.atoms[nxt];
                     cur = nxt; curPos = nxtPos; nxt = w.right; nxtPos = w.rpos; nxtMass = w.rmass;
                 }
@@ -516,6 +559,9 @@ CG_DEVICE void gen_draw_b(const SamplerDev &S, GenShared<WIN> &sh, const GenRoun
             }
         }
         if (AHEAD && slowB) { d.redo = true; slowB = false; }
+#if defined(EXP_NO_SLOW)
+        slowB = false;
+#endif
         if (slowB) {
             bool occ, nh;
             gen_find_gap(S, pos, bin, &hl, &hr, &occ, &nh);
@@ -541,14 +587,65 @@ CG_DEVICE void gen_draw_b(const SamplerDev &S, GenShared<WIN> &sh, const GenRoun
         if (r1 == r2 && c1 == c2 && !(AHEAD && d.redo)) {
             flags |= GEN_F_INLINE;
             const float m1 = a.mass, m2 = m2x;
+#if defined(EXP_NO_GAMMA)
+            const float newMass = m1;
+#else
             const float newMass = pcg_trunc_gamma_upper(rng, S.luts, m1 + m2, 1.f / S.lambda, S.mathMode);
+#endif
             const float delta = (m1 > m2) ? newMass - m1 : m2 - newMass;
             if (m1 + delta > GAPS_EPSILON && m2 - delta > GAPS_EPSILON) { flags |= GEN_F_APPLY; nm1 = m1 + delta; nm2 = m2 - delta; }
         }
     }
     d.flags = flags; d.rng = rng; d.pos = pos; d.cpos = cpos; d.h1 = h1; d.h2 = h2; d.hl = hl; d.hr = hr; d.r1 = r1; d.c1 = c1; d.r2 = r2; d.c2 = c2; d.bin = bin;
     d.nm1 = nm1; d.nm2 = nm2; d.amass = a.mass; d.m2x = m2x; d.old1 = old1; d.old2 = old2; d.gib1 = gib1; d.gib2 = gib2; d.lposB = lposB; d.rposB = rposB; d.rmassB = rmassB;
-    d.headBin = headBin; d.v2 = v2;
+    d.headBin = headBin; d.v2 = v2;      // (v3, xPick, redo: set where they arise)
+}
+
+// Did the lane, drawing ahead of the decisions, read only what they and the flush left alone?  nR: the domain's size behind the flush
+// (the draw assumed that nothing is erased), m: atoms erased.  A pick is uniform32(0, size - 1) (Random.cpp:79-96): x / iPart with
+// iPart = UINT32_MAX / size, x below size * iPart -- the same index from both sizes unless iPart or the rejection differs, which is
+// recomputed here from the 32 bits the pick was made from.  All reads are independent: one LDS trip.
+template <int WIN>
+CG_DEVICE bool gen_draw_valid(const SamplerDev &S, GenShared<WIN> &sh, const GenSpec &sp, const GenDraw &d, const uint32_t nR, const uint32_t m, const uint32_t K)
+{
+    const uint32_t type = sp.info & 0xFFu, bBefore = sp.info >> 8;
+    uint32_t bad = d.redo ? 1u : 0u;
+#if defined(GEN_AHEAD_BAD_EVERY)
+    if (((sp.ct + (uint32_t)sh.g.batchEpoch) % (uint32_t)GEN_AHEAD_BAD_EVERY) == 0u) bad = 1u;      // test-only variant: lanes drawn again, regularly
+#endif
+    const bool isB = type == 'B';
+    // the matrix cells (a birth: its bin; a pick: its atom's bin and, for a move / exchange, the other site's), the atom record(s)
+    const uint32_t cellA = isB ? d.bin : d.r1 * K + d.c1, cellB = d.r2 * K + d.c2;
+    const uint32_t atomA = isB ? d.v2 : d.h1, atomB = d.v3;
+    const bool reads = isB || d.pick;       // (a lane without an attempt, or whose pick fell on an atom born in this window, read nothing)
+    const uint32_t nA = gen_note_has<GEN_DIRTY_ATOMS>(sh.dAtom, atomA), nB = gen_note_has<GEN_DIRTY_ATOMS>(sh.dAtom, atomB), nS = gen_note_has<GEN_DIRTY_ATOMS>(sh.dAtom, ~d.i1);
+    const uint32_t cA = gen_note_has<GEN_DIRTY_CELLS>(sh.dCell, cellA), cB = gen_note_has<GEN_DIRTY_CELLS>(sh.dCell, cellB);
+    if (reads) bad |= nA | cA;
+    if (isB && d.v3 != CG_NONE) bad |= nB;
+    if (d.pick && (type == 'M' || type == 'E')) bad |= cB;
+    if (isB) {
+        // the bitmap words it read -- the bin's own, the next, and every further one up to the successor bin's
+        const uint32_t wFirst = d.bin >> 6;
+        uint32_t wLast = d.headBin >> 6; wLast = wLast > wFirst + 1u ? wLast : wFirst + 1u;
+        uint32_t dd = (wLast - wFirst >= 16384u) ? 1u : 0u;
+        for (uint32_t w = wFirst; !dd && w <= wLast; ) {
+            const uint32_t wm = w & 16383u, n = 32u - (wm & 31u), left = wLast - w + 1u, take = n < left ? n : left;
+            const uint32_t bits = sh.dirty[wm >> 5] >> (wm & 31u);
+            dd = bits & (take >= 32u ? 0xFFFFFFFFu : ((1u << take) - 1u));
+            w += take;
+        }
+        bad |= dd ? 1u : 0u;
+    } else if (m != 0u && type != 0u) {
+        // the pick again, from the size the flush leaves; its slot must not be one the flush refills from the vector's tail
+        const uint32_t nT = nR + bBefore, iPart = 0xFFFFFFFFu / nT;
+        const uint32_t same = (uint32_t)(d.xPick < nT * iPart) & (uint32_t)(d.xPick / iPart == d.i1) & (uint32_t)(!(d.pick && d.i1 >= nR));
+        bad |= (same ^ 1u) | (d.pick ? nS : 0u);
+    }
+    const bool ok = !(d.go != 0u && bad != 0u);
+#if defined(COGAPS_EMUL)
+    if (d.go) cg_atomic_add_u64(&S.gs->prof[ok ? 8 : 9], 1ull);      // test-only build: lanes whose draw ahead held / that drew again
+#endif
+    return ok;
 }
 
 template <int WIN, bool FIRST, bool SPEC = false, bool AHEAD = false>
@@ -561,7 +658,7 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
     const uint32_t updBase = c.updBase, remaining = c.remaining, K = c.K;
     GenScalars *gs = c.gs;
     constexpr bool first = FIRST;
-    GEN_TS_INIT(); GEN_TS_RESUME(FIRST ? 13u : 40u);
+    GEN_TS_INIT(); GEN_TS_RESUME(FIRST ? (AHEAD ? 16u : 13u) : 40u);
     GEN_TS(4);
     const uint32_t nR = first ? c.n0 : sh.nR, minR = first ? c.n0 : sh.minAtoms, skip = first ? c.g_skip : sh.skip, processed = first ? 0u : sh.processed;
     const uint64_t qrngRound = first ? c.g_qrng : sh.qrngRound;
@@ -640,13 +737,15 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
         // it; the lanes whose reads the decisions or the flush touched draw again, now, against the domain as it is: the same code, the
         // same results as if every lane had waited.  The join with the flush precedes both: gen_body.)
         d = *ahead;
-        if (cg_ballot(go && !aheadValid) != 0ull) {
-            if (go && !aheadValid) {
-                GenDraw r; gen_draw_a<WIN, SPEC>(S, c, spec, go, type, bBefore, SPEC ? spec->rng : pcg_from_seed(sh.seed[ct]), nR, r);
-                gen_draw_b<WIN, false>(S, sh, c, type, r, [&]() {});
-                d = r;
-            }
-        } else if (d.isB) d.i1 = nR + bBefore;      // (a birth's index in the unsorted vector: the domain's size, known now)
+        if (d.isB) d.i1 = nR + bBefore;      // (a birth's index in the unsorted vector: the domain's size, known now)
+#if !defined(EXP_NO_REDO)
+        const bool again = go && !aheadValid;
+        if (cg_ballot(again) != 0ull) {      // (wave-uniform: the wave's other lanes walk through with nothing to draw, as lanes without an attempt do)
+            GenDraw r; gen_draw_a<WIN, SPEC>(S, c, spec, again, type, bBefore, SPEC ? spec->rng : 0ull, nR, r);
+            gen_draw_b<WIN, false>(S, sh, c, type, r, [&]() {});
+            if (again) d = r;
+        }
+#endif
         exactDecide();
     } else {
         gen_draw_a<WIN, SPEC>(S, c, spec, go, type, bBefore, SPEC ? spec->rng : (go ? pcg_from_seed(sh.seed[ct]) : 0ull), nR, d);
@@ -1031,6 +1130,9 @@ struct ChainItem {
     uint32_t mb1, mb2;                       // the move's old and new bin (sh.dirty marks)
     uint32_t *head1, *head2; uint32_t head1Val, h1;      // old bin's head word (null: the atom is not the head) and what it becomes; new bin's head word (null: stays)
     unsigned long long *b0clr, *b0set, *b1set, *b2set; uint32_t bit1, bit2, bit1w, bit2w;      // bitmap words (null: nothing to do) and bit numbers
+    // what the decision touches, by name (the notes for the window drawn ahead): the neighbours, the partner and its left neighbour, the
+    // two matrix cells (bins), the atom's slot in the unsorted vector
+    uint32_t hL, hR, h2, l2, cell1, cell2, idx;
 };
 CG_DEVICE void chain_item_clear(ChainItem &it)
 {
@@ -1039,6 +1141,7 @@ CG_DEVICE void chain_item_clear(ChainItem &it)
     it.mb1 = 0; it.mb2 = 0;
     it.pos1 = nullptr; it.rposL = nullptr; it.lposR = nullptr; it.head1 = nullptr; it.head2 = nullptr; it.head1Val = CG_NONE; it.h1 = 0;
     it.b0clr = nullptr; it.b0set = nullptr; it.b1set = nullptr; it.b2set = nullptr; it.bit1 = 0; it.bit2 = 0; it.bit1w = 0; it.bit2w = 0;
+    it.hL = CG_NONE; it.hR = CG_NONE; it.h2 = CG_NONE; it.l2 = CG_NONE; it.cell1 = 0; it.cell2 = 0; it.idx = 0;
 }
 // what the second trip brings: the atom's record, the partner's left link, a move's old bin head and upper bitmap words
 struct ChainMid { AtomRec a; uint32_t l2, head1, b1, b2; unsigned long long x1, x2; };
@@ -1069,6 +1172,7 @@ CG_DEVICE void chain_fetch_build(const SamplerDev &S, const PropRec &p, const Ch
     it.type = p.type; it.m1 = p.m1; it.m2 = p.m2; it.old1 = p.old1; it.old2 = p.old2; it.pos = p.pos; it.h1 = p.h1;
     it.eraseEntry = ((unsigned long long)(p.r1 * S.K + p.c1) << 32) | (unsigned long long)p.h1;
     const AtomRec a = m.a;
+    it.hL = a.left; it.hR = a.right; it.idx = a.idx; it.cell1 = p.r1 * S.K + p.c1; it.cell2 = p.r2 * S.K + p.c2; it.h2 = p.h2; it.l2 = m.l2;
     it.mass1 = &S.atoms[p.h1].mass; it.rm1 = a.left != CG_NONE ? &S.atoms[a.left].rmass : nullptr;
     it.mat1 = &S.mat[(size_t)p.c1 * S.Mpad + p.r1]; it.col1 = &S.colPos[p.c1];
     const bool two = p.type == 'M' || p.type == 'E';
@@ -1149,8 +1253,10 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
     GenClockEnd clockEnd(cg_tid());
     constexpr unsigned TPB = (unsigned)WIN + 64u;       // attempt lanes + the helper wave
     const unsigned t = cg_tid();
-    const bool helper = t >= (unsigned)WIN;             // wave-uniform
-    const unsigned ht = t - (unsigned)WIN, ta = helper ? 0u : t;
+    // wave-uniform roles: attempt lanes, the helper wave, and -- chained launch only, which has the evaluation's workgroup size -- the
+    // waves beyond it, which with the helper wave apply the previous batch's decisions
+    const bool attempt = t < (unsigned)WIN, helper = t >= (unsigned)WIN && t < TPB, spare = t >= TPB, applier = CHAIN && !attempt;
+    const unsigned ht = t - (unsigned)WIN, ta = attempt ? t : 0u;
     GenScalars *gs = hot.gs;
 
     GEN_TS_INIT(); GEN_TS(0); GEN_TS(0);
@@ -1164,9 +1270,9 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
     unsigned long long specE = (!CHAIN && helper && ht < (unsigned)FLUSH_MAX && ht < hot.eraseCap) ? hot.eraseList[ht] : 0ull;
     // chained launch: the lane's queue record of the batch being evaluated (slot t always exists), with the launch's first trip
     PropRec p0; p0.type = 0; p0.h1 = 0; p0.h2 = 0; p0.pos = 0; p0.curPos = 0; p0.r1 = 0; p0.c1 = 0; p0.r2 = 0; p0.c2 = 0; p0.m1 = 0.f; p0.m2 = 0.f; p0.old1 = 0.f; p0.old2 = 0.f;
-    if (CHAIN && !helper && t < hot.queueCap) p0 = hot.queueRd[t];
+    if (applier && ht < hot.queueCap) p0 = hot.queueRd[ht];
 
-    uint32_t units = (!CHAIN && !helper && t < hot.queueCap) ? hot.queueUnits[t] : 0u;
+    uint32_t units = (!CHAIN && attempt && t < hot.queueCap) ? hot.queueUnits[t] : 0u;
     const uint64_t jmW = hot.lcgMul[2 * WIN], jiW = hot.lcgInc[2 * WIN];
     constexpr uint32_t GSW = (uint32_t)(sizeof(GenScalars) / 4u);
     static_assert(GSW <= 2u * TPB, "at most two words of GenScalars per lane");
@@ -1187,7 +1293,13 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
         constexpr uint32_t UNITS = 5u * (uint32_t)GEN_TAB_NB, ROUNDS = (UNITS + TPB - 1u) / TPB;
         GenTabKeys *tab = reinterpret_cast<GenTabKeys *>(&sh.bkey[0]) + t;
 #pragma unroll
-        for (uint32_t k = 0; k < ROUNDS; ++k) { if ((k + 1u) * TPB <= UNITS || t + k * TPB < UNITS) tab[k * TPB] = none; }
+        for (uint32_t k = 0; k < ROUNDS; ++k) { if (!spare && ((k + 1u) * TPB <= UNITS || t + k * TPB < UNITS)) tab[k * TPB] = none; }
+        if (CHAIN) {      // ... and the notes of what the decisions change (atom records, matrix cells), by every lane of the launch's workgroup
+            static_assert(offsetof(GenShared<WIN>, dCell) == offsetof(GenShared<WIN>, dAtom) + 4u * (size_t)GEN_DIRTY_ATOMS, "the two note tables are contiguous");
+            GenTabKeys *dt = reinterpret_cast<GenTabKeys *>(&sh.dAtom[0]);
+            GenTabKeys zero; zero.k[0] = zero.k[1] = zero.k[2] = zero.k[3] = 0u;
+            for (uint32_t i = t; i < (uint32_t)(GEN_DIRTY_ATOMS + GEN_DIRTY_CELLS) / 4u; i += cg_bdim()) dt[i] = zero;
+        }
     }
     GEN_TS(27);
     if (ASYNC) sp = cg_const_warm_end(sp, lines);
@@ -1195,8 +1307,8 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
     GEN_TS(28);
     if (t < GSW) reinterpret_cast<uint32_t *>(&sh.g)[t] = gword;
     if (t + TPB < GSW) reinterpret_cast<uint32_t *>(&sh.g)[t + TPB] = gword2;
-    if (t == 0) { sh.newFront = CG_KEEP; sh.unitSum = 0; sh.jmul[WIN] = jmW; sh.jinc[WIN] = jiW; if (CHAIN) { sh.eraseN = 0; sh.specBad = 0; sh.spinFail = 0; } }
-    if (!helper) { sh.jmul[t] = jm0; sh.jinc[t] = ji0; }        // even-step PCG jumps, for the round bookkeeping
+    if (t == 0) { sh.newFront = CG_KEEP; sh.unitSum = 0; sh.jmul[WIN] = jmW; sh.jinc[WIN] = jiW; if (CHAIN) { sh.eraseN = 0; sh.specBad = 0; sh.spinFail = 0; sh.anyRedo = 0; } }
+    if (attempt) { sh.jmul[t] = jm0; sh.jinc[t] = ji0; }        // even-step PCG jumps, for the round bookkeeping
     GEN_TS(29);
     cg_sync_lds();
     // the scalars every lane needs, from the LDS copy (wave-uniform: kept in scalar registers)
@@ -1208,12 +1320,13 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
     uint64_t seedC = 0ull; bool dpStaged = false, trySpec = false, specDone = false; uint32_t dpBase = 0;
     GenSpec specKeep; specKeep.bBefore = 0; specKeep.dBefore = 0; specKeep.guess = 0; specKeep.active = 0; specKeep.u1 = 0.f; specKeep.u2 = 0.f; specKeep.go = 0; specKeep.ct = 0; specKeep.info = 0;
     specKeep.rng = 0; specKeep.pos = 0; specKeep.bin = 0; specKeep.r1 = 0; specKeep.c1 = 0;
+    GenDraw drawKeep; gen_draw_clear(drawKeep);      // chained launch: the lane's attempt of the next window, drawn ahead of the decisions
     if (!CHAIN) {
         GEN_TS_ZERO(7u, 13u);
 #if defined(GEN_TIMELINE)
         if (t == 0u) { sh.rtOn = 0u; sh.rtLog = 0u; }
 #endif
-        if (!helper) {   // roofline bookkeeping: add up the traffic units the evaluation kernel left per queue slot (the helper wave adds
+        if (attempt) {   // roofline bookkeeping: add up the traffic units the evaluation kernel left per queue slot (the helper wave adds
             // the sum to evalBytes at the end of the batch)
             if (t >= e_prevQ) units = 0;
             for (uint32_t q = t + WIN; q < e_prevQ; q += WIN) units += S.queueUnits[q];
@@ -1221,26 +1334,28 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
             if ((t & 63u) == 0u && waveUnits) cg_atomic_add_u32(&sh.unitSum, waveUnits);
         }
     } else {
-        // ---- everything that does not depend on the previous batch's decisions, while its evaluation workgroups run: the lane's proposal
-        // and what its decision will rewrite, this round's seeds, the window of the death-probability table (after the flush the domain
-        // holds between nAtoms - qlen and nAtoms atoms: every proposal erases at most one), and the classification of the next window
-        // itself (gen_spec_a1) -- ordered so that the two memory trips of the fetch run under the classification's barriers and arithmetic
-        ChainItem it; chain_item_clear(it);
+        // ---- Everything that does not depend on the previous batch's decisions, while its evaluation workgroups run.  The workgroup's
+        // waves split (round 5): the ATTEMPT waves classify the next window (gen_spec_a1) and DRAW it -- picks, records, matrix entries,
+        // a birth's gap: the three dependent memory trips of a round -- against the domain as this workgroup's own commit left it;
+        // the APPLIER waves (the helper wave and the waves beyond it: the launch has the evaluation's workgroup size) fetch what the
+        // decisions will rewrite, receive the decisions, carry them out and note every atom record, matrix cell, vector slot and
+        // bitmap word they or the flush change (sh.dAtom / dCell / dSlot / dirty).  Behind the join an attempt lane whose reads
+        // touched none of these has drawn exactly what it would draw now; the others draw again (gen_round<.., AHEAD>).
         unsigned long long *const eraseList = S.eraseList; const uint32_t eraseCap = S.eraseCap;      // (read here: nothing of the record is read behind the wait)
         GEN_TS(30);
         GEN_RT(1);
 #if defined(GEN_TIMELINE)
         if (t == 0u) { sh.rtOn = (e_prevQ >= 140u && e_nSteps - e_nDone >= 512u) ? 1u : 0u; sh.rt[6] = 0ull; sh.rt[7] = 0ull; sh.rtLog = (WIN == 256 && e_prevQ >= 100u && e_nSteps - e_nDone >= 512u) ? 1u : 0u; }
 #endif
-        const bool have0 = !helper && t < e_prevQ;
-        // second trip (the first brought the scalars and the lane's record): what the decision will rewrite, the seeds, the table's window
+        const uint32_t NA = cg_bdim() - (uint32_t)WIN, al = t - (uint32_t)WIN;      // applier lanes (al: this lane's number among them)
+        const bool have0 = applier && al < e_prevQ;
+        // second trip (the first brought the scalars and an applier's record): what the decision will rewrite; the seeds, the table's window
         ChainMid mid0; mid0.l2 = CG_NONE; mid0.head1 = CG_NONE; mid0.b1 = 0; mid0.b2 = 0; mid0.x1 = 0ull; mid0.x2 = 0ull;
         mid0.a.pos = 0; mid0.a.lpos = 0; mid0.a.rpos = 0; mid0.a.left = CG_NONE; mid0.a.right = CG_NONE; mid0.a.mass = 0.f; mid0.a.rmass = 0.f; mid0.a.idx = 0; mid0.a.pad0 = 0;
-        // a queue longer than the window (the batch after a generator launch of two rounds, 14 % of the headline chain's launches; its
-        // evaluation takes longer as well: the workgroups evaluate pairs): the lane's second proposal is fetched ahead like the first
-        const bool have1 = !helper && t + (unsigned)WIN < e_prevQ;
-        mid0 = chain_fetch_mid(S, p0);      // (p0 of a lane without a proposal: slot t of the queue copy, whatever it holds -- handles and positions of an older batch: valid addresses)
-        if (!updateDone) seedC = S.seeds[e_nDone + t < e_nSteps ? e_nDone + t : e_nSteps - 1u];
+        // (the free-handle stack's top entries, which a committing birth pops: nothing the decisions change -- only the flush pushes)
+        const uint32_t freeTopAhead = (helper && ht < 16u && ht < e_fc) ? S.freeHandles[e_fc - 1u - ht] : CG_NONE;
+        if (applier) mid0 = chain_fetch_mid(S, p0);      // (p0 of a lane without a proposal: a slot of the queue copy, whatever it holds -- handles and positions of an older batch: valid addresses)
+        if (!updateDone && attempt) seedC = S.seeds[e_nDone + t < e_nSteps ? e_nDone + t : e_nSteps - 1u];
         const uint32_t span = e_prevQ + (uint32_t)(WIN - 1);
         dpBase = e_n > span ? e_n - span : 0u;
         const uint32_t dpCnt = e_n + (uint32_t)WIN - dpBase;                  // entries dpBase .. nAtoms + WIN - 1
@@ -1248,7 +1363,7 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
         const uint32_t nLo = e_n > e_prevQ ? e_n - e_prevQ : 0u, nHi = e_n;
         trySpec = dpStaged && nLo >= 2u;                                      // (tiny domains: the type also depends on the count itself)
         float dpw[4] = {0.f, 0.f, 0.f, 0.f};
-        if (dpStaged) {
+        if (dpStaged && !spare) {
 #pragma unroll
             for (uint32_t k = 0; k < 4u; ++k) { const uint32_t i = t + k * TPB; dpw[k] = S.deathProb[dpBase + (i < dpCnt ? i : dpCnt - 1u)]; }
         }
@@ -1256,63 +1371,88 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
         GEN_TS(31);
         // ... and under it: the classification (the two thresholds computed -- the table's entries would arrive with the trip)
         GenRoundCtx rcS; GenSpec spS;
-        if (trySpec && !helper) {
+        rcS.t = t; rcS.jm0 = jm0; rcS.ji0 = ji0; rcS.jm1 = jm1; rcS.ji1 = ji1; rcS.seed1 = 0ull; rcS.g_qrng = sh.g.qrng; rcS.g_skip = sh.g.useCached ? 1u : 0u;
+        rcS.g_u1 = sh.g.u1; rcS.g_u2 = sh.g.u2; rcS.remaining = e_nSteps - e_nDone; rcS.K = S.K;
+        spS.bBefore = 0; spS.dBefore = 0; spS.guess = 0; spS.active = 0; spS.u1 = 0.f; spS.u2 = 0.f; spS.go = 0; spS.ct = 0; spS.info = 0; spS.rng = 0; spS.pos = 0; spS.bin = 0; spS.r1 = 0; spS.c1 = 0;
+        if (trySpec && attempt) {
             const float dpAtLo = gm_death_prob((double)(uint64_t)nLo, S.domainLenD, S.alphaD, S.numBins), dpAtHi = gm_death_prob((double)(uint64_t)nHi, S.domainLenD, S.alphaD, S.numBins);
-            rcS.t = t; rcS.jm0 = jm0; rcS.ji0 = ji0; rcS.jm1 = jm1; rcS.ji1 = ji1; rcS.seed1 = 0ull; rcS.g_qrng = sh.g.qrng; rcS.g_skip = sh.g.useCached ? 1u : 0u;
-            rcS.g_u1 = sh.g.u1; rcS.g_u2 = sh.g.u2; rcS.remaining = e_nSteps - e_nDone; rcS.K = S.K;
             gen_spec_a1<WIN>(S, sh, rcS, nLo, nHi, dpAtLo, dpAtHi, spS);      // (the first of A1's two barriers inside)
         } else if (trySpec) cg_sync_lds();
-        if (trySpec) { for (uint32_t i = t; i < 512u; i += TPB) sh.dirty[i] = 0u; }
+        if (trySpec) { for (uint32_t i = t; i < 512u; i += cg_bdim()) sh.dirty[i] = 0u; }
         // the trip has landed: the attempt's seed and the table's window go to LDS; A1's second barrier
-        if (dpStaged) {
+        if (dpStaged && !spare) {
 #pragma unroll
             for (uint32_t k = 0; k < 4u; ++k) { const uint32_t i = t + k * TPB; if (i < dpCnt) sh.dpWin[i] = dpw[k]; }
         }
+        ChainItem it; chain_item_clear(it);
         if (trySpec) {
-            if (!helper && spS.guess != (uint32_t)GEN_T_NONE) sh.seed[t] = seedC;      // consumed after the type sort
+            if (attempt && spS.guess != (uint32_t)GEN_T_NONE) sh.seed[t] = seedC;      // consumed after the type sort
             cg_sync_lds();
-            if (!helper) gen_spec_slot<WIN>(S, sh, rcS, spS); else gen_spec_births<WIN>(S, sh, ht);
+            if (attempt) gen_spec_slot<WIN>(S, sh, rcS, spS);
         }
+        const bool drawAhead = trySpec && cg_uniform_u32(sh.specBad) == 0u;      // (a window with an attempt between the two thresholds: classified and drawn the usual way, behind the decisions)
         if (have0) chain_fetch_build(S, p0, mid0, it);
-        // (last of the work ahead: behind a branch the compiler waits for every load in flight, and here they have all landed)
-        ChainItem it1; chain_item_clear(it1);
-        if (e_prevQ > (uint32_t)WIN) { const uint32_t q1 = t + (unsigned)WIN; chain_fetch(S, hot.queueRd, q1 < hot.queueCap ? q1 : 0u, it1); }
-        GEN_PIN(it.type); GEN_PIN(it.bit2);
+        if (helper && ht < 16u) sh.freeTop[ht] = freeTopAhead;
         GEN_TS(32);
-        GEN_RT(2);
         const uint32_t tag = (uint32_t)sh.g.batchEpoch;      // the batch in the queue: the one this workgroup generated in the previous launch
         if (S.launchClock) clockEnd.slot = S.launchClock + 2u * (tag % GAPS_CLOCK_RING) + 1u;
 #if defined(COGAPS_EMUL)
         if (t == 0 && e_prevQ) cg_atomic_add_u64(&gs->prof[13], 1ull);      // test-only build: batches whose decisions arrived inside a chained launch
 #endif
-        uint32_t unitAcc = 0;
-        if (!helper) {
-            // one proposal: wait for its two granules (read past this workgroup's caches until both carry the batch's tag), note an erased atom
-            // in the erase cache, carry the decision out
-            auto take = [&](const uint32_t q, const bool haveIn, const ChainItem &it) {
+        if (attempt) {
+            // ---- the window drawn ahead: the domain's size taken as it is now (no atom erased: true of every second batch; otherwise the
+            // picks are checked against the size the flush leaves, gen_draw_valid)
+#if !defined(EXP_NO_AHEAD)
+            if (drawAhead) {
+                const uint32_t typeS = spS.info & 0xFFu;
+                gen_draw_a<WIN, true, true>(S, rcS, &spS, spS.go != 0u, typeS, spS.info >> 8, spS.rng, e_n, drawKeep);
+                gen_draw_b<WIN, true>(S, sh, rcS, typeS, drawKeep, [&]() {});
+            }
+#endif
+            GEN_PIN(drawKeep.flags); GEN_PIN(drawKeep.old1); GEN_PIN(drawKeep.old2);
+            GEN_TS(36);
+            GEN_RT(2);
+        } else {
+            // ---- the appliers: one proposal per lane and pass -- wait for its two granules (read past this workgroup's caches until both
+            // carry the batch's tag), note an erased atom in the erase cache, carry the decision out, note what changed
+            uint32_t unitAcc = 0;
+            for (uint32_t base = 0; base < e_prevQ; base += NA) {
+                const uint32_t q = base + al;
+                bool have = q < e_prevQ;
+                if (base) { chain_item_clear(it); if (have) chain_fetch(S, hot.queueRd, q, it); }      // (a queue longer than the applier lanes: the batch after a generator launch of two rounds)
                 const unsigned long long *gr = hot.grans + (size_t)q * CHAIN_GRAN_STRIDE;
                 unsigned long long g0 = 0ull, g1 = 0ull; uint32_t spins = 0;
-                bool have = haveIn;
                 for (;;) {
                     if (have) { g0 = cg_load_l2_u64(&gr[0]); g1 = cg_load_l2_u64(&gr[1]); }
                     const bool ok = !have || ((uint32_t)(g0 >> 32) == tag && (uint32_t)(g1 >> 32) == tag);
                     if (cg_ballot(!ok) == 0ull) break;
-                    // bounded (platform.h: two seconds at least), never a hang.  A bound that is hit applies NOTHING: a granule without this batch's tag is an
-                    // older batch's decision -- the lane drops its proposal, the error word ends the update on the host (the session is then
-                    // marked unusable: its domain lacks decisions) and the workgroup leaves behind the barrier below without generating
+                    // bounded (platform.h: two seconds at least), never a hang.  A bound that is hit applies NOTHING: a granule without this batch's
+                    // tag is an older batch's decision -- the lane drops its proposal, the error word ends the update on the host (the session is
+                    // then marked unusable: its domain lacks decisions) and the workgroup leaves behind the barrier below without generating
                     if (cg_poll_expired(++spins)) { if (!ok) have = false; if ((t & 63u) == 0u) { gs->error = GAPS_ERR_SPIN; sh.spinFail = 1u; } break; }
                     cg_poll_pause();
                 }
                 GEN_TS(33);
-                GEN_RT(3);
+                if (base == 0u) GEN_RT_AT(3, WIN);
                 const uint32_t code = have ? ((uint32_t)g0 & 0xFFu) : CHAIN_NONE;
                 if (have) unitAcc += ((uint32_t)g0 >> 8) & 0xFFFFu;
                 // erase cache (ConcurrentAtomicDomain.cpp:62-69): one slot per erased atom, in any order -- the flush sorts by position.
                 // (Before the stores: what the barrier below waits for is LDS traffic only.)
-                const bool er = have && code == CHAIN_ERASE;
-                // bitmap words whose bits or bins' heads this decision (or the flush, for an erased atom) changes: the births looked up ahead check them
-                if (er) gen_mark_dirty(sh.dirty, (uint32_t)(it.eraseEntry >> 32));
-                if (have && code == CHAIN_APPLY && it.type == 'M') { gen_mark_dirty(sh.dirty, it.mb1); gen_mark_dirty(sh.dirty, it.mb2); }
+                const bool er = have && code == CHAIN_ERASE, ap = have && code == CHAIN_APPLY;
+                // bitmap words whose bits or bins' heads this decision (or the flush, for an erased atom) changes: the births drawn ahead check them
+                if (er) gen_mark_dirty(sh.dirty, it.cell1);
+                if (ap && it.type == 'M') { gen_mark_dirty(sh.dirty, it.mb1); gen_mark_dirty(sh.dirty, it.mb2); }
+                // atom records whose fields change: the atom's own (mass / position) and the neighbours that cache copies of them; an erased
+                // atom's neighbours are relinked by the flush.  Matrix cells that are rewritten.
+                if (er || ap) {
+                    gen_note_add<GEN_DIRTY_ATOMS>(sh.dAtom, it.h1);
+                    if (it.hL != CG_NONE) gen_note_add<GEN_DIRTY_ATOMS>(sh.dAtom, it.hL);
+                    if ((er || it.type == 'M') && it.hR != CG_NONE) gen_note_add<GEN_DIRTY_ATOMS>(sh.dAtom, it.hR);
+                    if (ap && it.type == 'E') { gen_note_add<GEN_DIRTY_ATOMS>(sh.dAtom, it.h2); if (it.l2 != CG_NONE) gen_note_add<GEN_DIRTY_ATOMS>(sh.dAtom, it.l2); }
+                    if (er) gen_note_add<GEN_DIRTY_ATOMS>(sh.dAtom, ~it.idx);      // (the vector slot the flush refills from the tail)
+                    if (ap || it.type == 'D') gen_note_add<GEN_DIRTY_CELLS>(sh.dCell, it.cell1);
+                    if (ap && (it.type == 'M' || it.type == 'E')) gen_note_add<GEN_DIRTY_CELLS>(sh.dCell, it.cell2);
+                }
                 const unsigned long long em = cg_ballot(er);
                 if (em) {
                     const uint32_t cntE = (uint32_t)cg_popc64(em);
@@ -1327,45 +1467,32 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
                     }
                 }
                 if (have) chain_apply(it, code, gm_u2f((uint32_t)g1));
-            };
-            // a batch of several rounds may have queued more than a window (rare): those proposals first, so that the usual case -- and the
-            // last stores before the barrier -- is straight-line code (a loop's exit made the compiler wait for every store's acknowledgement)
-            if (e_prevQ > 2u * (uint32_t)WIN) {
-                for (uint32_t base = 2u * (uint32_t)WIN; base < e_prevQ; base += (uint32_t)WIN) {
-                    const uint32_t q = base + t;
-                    const bool have = q < e_prevQ;
-                    ChainItem itX; chain_item_clear(itX);
-                    if (have) chain_fetch(S, hot.queueRd, q, itX);
-                    take(q, have, itX);
-                }
             }
-            // (the second window's worth of a long queue -- the batch after a generator launch of two rounds -- was fetched ahead like the first)
-            if (e_prevQ > (uint32_t)WIN) take((uint32_t)WIN + t, have1, it1);
-            take(t, have0, it);
             const uint32_t waveUnits = cg_wave_sum_u32(unitAcc);
             if ((t & 63u) == 0u && waveUnits) cg_atomic_add_u32(&sh.unitSum, waveUnits);
         }
         GEN_TS(34);
-        cg_sync();      // the decisions are in the domain (stores issued by this workgroup are seen by its later loads), the erase cache and the unit sum are complete
+        cg_sync();      // the decisions are in the domain (stores issued by this workgroup are seen by its later loads), the erase cache, the notes and the unit sum are complete
         GEN_TS(35);
         GEN_RT(4);
         if (cg_uniform_u32(sh.spinFail) != 0u) return;      // a decision never arrived (GAPS_ERR_SPIN is set): every wave leaves, nothing is generated
+        if (spare) { { const bool ts_ok = e_prevQ >= 140u && e_nSteps - e_nDone >= 512u; (void)ts_ok; GEN_TS_DUMP_WAVE(); } return; }      // (the waves beyond the helper wave only applied)
         e_m = cg_uniform_u32(sh.eraseN);
         if (e_m > eraseCap) e_m = eraseCap;
         if (helper) specE = (ht < (unsigned)FLUSH_MAX && ht < e_m) ? sh.eraseTmp[ht] : 0ull;
-        specDone = trySpec && cg_uniform_u32(sh.specBad) == 0u;
+        specDone = drawAhead;
 #if defined(GEN_TIMELINE)
         if (t == 0u) sh.rtInfo = (unsigned long long)e_prevQ | ((unsigned long long)e_m << 16) | ((unsigned long long)(specDone ? 1u : 0u) << 32);
 #endif
 #if defined(COGAPS_EMUL)
-        if (t == 0 && !updateDone) cg_atomic_add_u64(&gs->prof[specDone ? 12 : 11], 1ull);      // test-only build: windows classified ahead of the decisions / the usual way
+        if (t == 0 && !updateDone) cg_atomic_add_u64(&gs->prof[specDone ? 12 : 11], 1ull);      // test-only build: windows classified and drawn ahead of the decisions / the usual way
 #endif
         if (specDone) specKeep = spS;
     }
     if (updateDone) {
         // a launch past the end of the update: the last erase cache is flushed (by the helper wave alone) and the progress words reported
         if (!CHAIN) cg_sync_lds();              // (the unit sum is complete)
-        if (!helper) return;
+        if (!helper) return;                    // (attempt lanes; the chained launch's spare waves left behind the join)
         GenFlushRegs fr;
         gen_flush_fetch<WIN>(S, fr, ht, e_m, e_n, specE, e_fc);
         if (ht == 0) { sh.flushM = 0; sh.flushBase = e_fc; sh.nLow = 0; }
@@ -1401,7 +1528,25 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
     GenRoundCtx rc; rc.t = t; rc.jm0 = jm0; rc.ji0 = ji0; rc.jm1 = jm1; rc.ji1 = ji1; rc.seed1 = seed1; rc.batchEpoch = batchEpoch; rc.g_qrng = g_qrng; rc.n0 = n0; rc.updBase = updBase;
     rc.remaining = remaining; rc.K = K; rc.g_skip = g_skip; rc.e_prevQ = e_prevQ; rc.dp0 = dp0; rc.g_u1 = g_u1; rc.g_u2 = g_u2; rc.gs = gs; rc.tabHi = tabHi; rc.tabLo = tabLo;
     rc.queueOut = CHAIN ? hot.queueWr : S.queue; rc.dpBase = dpBase;
-    if (CHAIN && specDone) { if (gen_round<WIN, true, true>(S, sh, rc, 1u, &specKeep)) return; }
+    if (CHAIN && specDone) {
+        // which lanes drew what they would draw now (gen_draw_valid).  If every lane of the window did, the round goes straight into its
+        // conflict phases and the helper wave's flush runs beside them (gen_helper); otherwise the join with the flush first
+        const bool valid = gen_draw_valid<WIN>(S, sh, specKeep, drawKeep, n0, e_m, K);
+        if (cg_ballot(!valid) != 0ull && (t & 63u) == 0u) sh.anyRedo = 1u;
+        GEN_PIN(drawKeep.flags);
+        GEN_TS(37);
+#if defined(GEN_TIMELINE)
+        { const unsigned long long bad_ = cg_ballot(!valid); if ((t & 63u) == 0u && bad_) cg_atomic_add_u64(&sh.rt[6], (unsigned long long)cg_popc64(bad_)); }
+#endif
+        cg_sync_lds();
+        const bool anyRedo = cg_uniform_u32(sh.anyRedo) != 0u;
+        if (anyRedo) cg_sync();
+        GEN_TS(38);
+#if defined(GEN_TIMELINE)
+        if (t == 0u) { sh.rt[7] = __builtin_amdgcn_s_memrealtime(); sh.rtInfo |= ((sh.rt[6] & 0xFFull) << 40) | (((sh.rt[7] - sh.rt[4]) & 0xFFFFull) << 48); }
+#endif
+        if (gen_round<WIN, true, true, true>(S, sh, rc, 1u, &specKeep, &drawKeep, valid)) return;
+    }
     else if (gen_round<WIN, true>(S, sh, rc, 1u)) return;
     for (uint32_t roundNo = 2; ; ++roundNo) {
         // ------------------------------------------------------------------ set-up of the next round of this batch (the helper wave has published

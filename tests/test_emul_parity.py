@@ -48,37 +48,42 @@ def test_batches_of_several_rounds_use_the_lds_table_then_the_stamp_tables(emul_
         assert n_lds > 100, (n_lds, n_hbm)
 
 
-@pytest.mark.parametrize("variant", ["chained", "chained_fallback", "two_launches", "few_compute_units"])
+@pytest.mark.parametrize("variant", ["chained", "chained_fallback", "chained_redraw", "two_launches", "few_compute_units"])
 def test_chained_launch_against_the_oracle(emul_lib, monkeypatch, variant):
-    """csrc/chain_kernel.h: one launch evaluates batch n and generates batch n + 1 -- the generator workgroup applies the decisions it
-    receives as tagged granules, classifies its window and looks its births up ahead of them.  1200 x 300: both samplers take the chained
-    form at the 64-attempt window (workgroups of 128 / 512 threads), the domains are large enough for the look-ups made ahead to survive
-    and small enough for some to be invalidated by an accepted move or an erased atom in the same bitmap word.  Stepwise against the
-    oracle (every proposal of every batch, the state after every update), then the test-only build's counters: every path was taken.
+    """csrc/chain_kernel.h: one launch evaluates batch n and generates batch n + 1 -- the generator workgroup's applier waves carry out the
+    decisions they receive as tagged granules while its attempt waves classify AND DRAW the next window ahead of them; behind the join
+    every lane whose reads the decisions or the flush touched draws again (gen_draw_valid, gen_round<.., AHEAD>).  1200 x 300: both
+    samplers take the chained form at the 64-attempt window (workgroups of 128 / 512 threads: one to seven applier waves), the domains
+    are small enough for a good share of the lanes to be invalidated.  Stepwise against the oracle (every proposal of every batch, the
+    state after every update), then the test-only build's counters: every path was taken.
     Workgroups with several proposals evaluate them in pairs, one per half (eval_chain_pair).
     `chained_fallback`: a build variant that declares every third window's classification unusable (the path a window takes when an
-    attempt falls between the two birth / death thresholds -- too rare to meet otherwise); `two_launches`: COGAPS_NO_CHAIN=1; `few_compute_units`: a device with
-    fewer compute units than the chained launch has workgroups keeps two launches per batch."""
+    attempt falls between the two birth / death thresholds -- too rare to meet otherwise): such a window is classified and drawn behind
+    the decisions; `chained_redraw`: a variant that declares every fifth lane's draw invalid, whatever it read; `two_launches`:
+    COGAPS_NO_CHAIN=1; `few_compute_units`: a device with fewer compute units than the chained launch has workgroups keeps two launches per batch."""
     from cogaps_amd import _capi
     if variant == "two_launches": monkeypatch.setenv("COGAPS_NO_CHAIN", "1")
     if variant == "few_compute_units": monkeypatch.setenv("COGAPS_TEST_COMPUTE_UNITS", "4")      # (a partitioned GPU: fewer compute units than the chained launch has workgroups)
-    lib = emul_lib(64, extra="-DGEN_SPEC_BAD_EVERY=3", tag="_specbad") if variant == "chained_fallback" else emul_lib(64)
+    lib = (emul_lib(64, extra="-DGEN_SPEC_BAD_EVERY=3", tag="_specbad") if variant == "chained_fallback" else
+           emul_lib(64, extra="-DGEN_AHEAD_BAD_EVERY=5", tag="_aheadbad") if variant == "chained_redraw" else emul_lib(64))
     data = pu.synthetic(1200, 300, seed=7)
     pu.run_stepwise(lib, data, 24, nPatterns=3, seed=123, total_iter=40, check_every=4)
     S = _capi.Session(data, lib=lib, nPatterns=3, seed=123, nIterations=40)
     S.run_iterations(1, 0, 24)
     tot = np.zeros(16, dtype=np.int64)
     for w in "AP":
-        assert S.chained(w) == (variant in ("chained", "chained_fallback"))
+        assert S.chained(w) == (variant in ("chained", "chained_fallback", "chained_redraw"))
         tot += np.array(S.debug_prof(w), dtype=np.int64)
     S.close()
-    ahead, marked, none, usual, spec, chain_batches, pairs = (int(tot[i]) for i in (10, 9, 8, 11, 12, 13, 7))
+    held, redrawn, usual, spec, chain_batches, pairs = (int(tot[i]) for i in (8, 9, 11, 12, 13, 7))
     if variant in ("two_launches", "few_compute_units"):
-        assert chain_batches == 0 and spec == 0 and ahead == 0 and pairs == 0
+        assert chain_batches == 0 and spec == 0 and held == 0 and redrawn == 0 and pairs == 0
     else:
-        assert chain_batches > 300 and spec > 200 and usual > 20 and ahead > 300 and marked > 3 and none > 3, (chain_batches, spec, usual, ahead, marked, none)
+        assert chain_batches > 300 and spec > 200 and usual > 20 and held > 3000 and redrawn > 30, (chain_batches, spec, usual, held, redrawn)
         if variant == "chained_fallback": assert usual > spec // 3
+        if variant == "chained_redraw": assert redrawn > held // 5
         assert pairs > 300, pairs        # (seven evaluation workgroups per launch in this build: most proposals are evaluated two at a time, eval_chain_pair)
+    print(variant, dict(chain_batches=chain_batches, ahead=spec, usual=usual, lanes_held=held, lanes_redrawn=redrawn, pairs=pairs))
 
 
 def test_tiny_domain_hazards(emul_lib):

@@ -14,14 +14,14 @@ names = {0: 'entry', 1: 'entry loads+sync (B0)', 2: 'helper: round vars set, flu
          7: 'A1 exact decide', 8: 'A1 count3 #2+perm (C2)', 9: 'A1 sync (C3)', 10: 'A2 stage1 rng/addr', 25: 'A2 join with the flush', 11: 'A2 stage2 (vec/bits0 used)', 12: 'A2 stage3 (atoms/binHead used)',
          13: 'A2 neighbour loads issued', 14: 'A2 finish', 15: 'B1 registrations', 16: 'B1 sync', 17: 'B2 lookups', 18: 'B2 logic', 19: 'B2 sync (Bp)', 20: 'C masks sync (Bc1)', 21: 'C commit issued',
          22: 'attempt wave ends', 26: 'entry: loads issued', 27: 'entry: conflict table preset', 28: 'entry: kernel arguments in', 29: 'entry: first trip landed, scalars in LDS', 23: 'helper: bookkeeping done', 24: 'helper: write-back issued',
-         36: 'A2 birth block done', 30: 'chain: before the fetch', 31: 'chain: record + atoms fetched', 32: 'chain: seeds / table window issued', 33: 'chain: granules in (poll done)', 34: 'chain: decisions applied (stores issued)', 35: 'chain: stores acknowledged + barrier'}
-WAVES = 5
+         36: 'A2 birth block done', 30: 'chain: before the fetch', 31: 'chain: record + atoms fetched', 32: 'chain: seeds / table window issued', 33: 'chain: granules in (poll done)', 34: 'chain: decisions applied (stores issued)', 35: 'chain: stores acknowledged + barrier', 36: 'chain: window drawn ahead', 37: 'chain: draws validated', 38: 'chain: joined with the flush'}
+WAVES = 8
 buf = (ctypes.c_uint64 * (WAVES * 64))()
 PL.cogaps_debug_timeline.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert PL.cogaps_debug_timeline(buf, WAVES * 64) == 0
 a = np.array(buf).reshape(WAVES, 64)
 seq = {w: [(int(x) & 0xFF, int(x) >> 8) for x in a[w] if x] for w in range(WAVES)}
-print('cycles since the wave\'s own first mark (+ since its previous mark); waves 0-3: attempt lanes, wave 4: the helper wave')
+print('cycles since the wave\'s own first mark (+ since its previous mark); waves 0-3: attempt lanes, wave 4: the helper wave, waves 5-7: further applier waves of a chained launch')
 print('%-46s' % 'mark' + ''.join('      wave%d        ' % w for w in range(WAVES)))
 order = []
 for w in range(WAVES):
