@@ -161,15 +161,17 @@ CG_DEVICE void gen_helper(const SamplerDev &S, GenShared<WIN> &sh, GenScalars *g
         if (first && specDone) {
             // Chained launch, the window drawn ahead of the decisions (gen_body): the attempt lanes have validated their draws when they
             // arrive at the first barrier.  No lane draws again (every second launch): the domain is not read before the commit, and the
-            // flush runs BESIDE the conflict phases -- sort, list surgery and index replay before the registration barrier (the commit
-            // reads their LDS results), the write-back before the look-up barrier, acknowledged (cg_sync waits for this wave's stores).
+            // flush runs BESIDE the conflict phases -- it is complete, its stores acknowledged (cg_sync waits for this wave's), at the
+            // look-up barrier, behind which the attempt lanes read its LDS results for the commit.
             // Some lane draws again: it reads the domain as the flush leaves it -- the whole flush, then the join, as in the other forms.
-            gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 0);
             cg_sync_lds();
             const bool anyRedo = cg_uniform_u32(sh.anyRedo) != 0u;
+            gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 0);
             gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 1); gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 2);
-            if (anyRedo) { gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 3); GEN_TS(3); cg_sync(); cg_sync_lds(); cg_sync_lds(); }
-            else { cg_sync_lds(); gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 3); GEN_TS(3); cg_sync(); }
+            if (!anyRedo) cg_sync_lds();      // (the registration barrier, which the attempt lanes reach about now)
+            gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 3); GEN_TS(3);
+            cg_sync();                        // (no lane draws again: the look-up barrier; otherwise the join)
+            if (anyRedo) { cg_sync_lds(); cg_sync_lds(); }
         } else {
             if (first) { gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 0); if (ht < 16u) sh.freeTop[ht] = fr.freeTop; }
             cg_sync_lds();
@@ -387,21 +389,26 @@ CG_DEVICE void gen_mark_dirty(uint32_t *dirty, uint32_t bin)
 // for; an exact hash set's compare-and-swap chains cost the applying waves 3 k cycles per launch), the lanes that drew the next window
 // ahead read their keys' bits behind the join.  A key that was never noted reads as noted with probability ~2e-5 (two of ~600 set bits
 // among 131072): the lane then draws again, which is always correct.
+// (a key's two bit numbers are computed where the key is known -- ahead of the decisions, on both sides --, so that behind the wait only
+// the LDS operations themselves remain)
+struct GenNotePos { uint32_t a, b; };
 template <int WORDS>
-CG_DEVICE void gen_note_add(uint32_t *bits, uint32_t key)
+CG_DEVICE GenNotePos gen_note_pos(uint32_t key)
 {
     constexpr uint32_t LOG2 = WORDS == 4096 ? 17u : 16u;
-    static_assert(WORDS == 4096 || WORDS == 2048, "bit positions are the hashes' top 17 / 16 bits");
-    const uint32_t a = (key * 2654435761u) >> (32u - LOG2), b = (key * 0x85EBCA6Bu + 0x27D4EB2Fu) >> (32u - LOG2);
-    cg_atomic_or_u32(&bits[a >> 5], 1u << (a & 31u));
-    cg_atomic_or_u32(&bits[b >> 5], 1u << (b & 31u));
+    static_assert(WORDS == 4096 || WORDS == 2048, "bit numbers are 17 / 16 bits of the hash");
+    const uint32_t h = key * 2654435761u;
+    GenNotePos p; p.a = h >> (32u - LOG2); p.b = (h ^ (h >> 11)) & ((1u << LOG2) - 1u);
+    return p;
 }
-template <int WORDS>
-CG_DEVICE uint32_t gen_note_has(const uint32_t *bits, uint32_t key)
+CG_DEVICE void gen_note_set(uint32_t *bits, const GenNotePos p)
 {
-    constexpr uint32_t LOG2 = WORDS == 4096 ? 17u : 16u;
-    const uint32_t a = (key * 2654435761u) >> (32u - LOG2), b = (key * 0x85EBCA6Bu + 0x27D4EB2Fu) >> (32u - LOG2);
-    return (bits[a >> 5] >> (a & 31u)) & (bits[b >> 5] >> (b & 31u)) & 1u;
+    cg_atomic_or_u32(&bits[p.a >> 5], 1u << (p.a & 31u));
+    cg_atomic_or_u32(&bits[p.b >> 5], 1u << (p.b & 31u));
+}
+CG_DEVICE uint32_t gen_note_get(const uint32_t *bits, const GenNotePos p)
+{
+    return (bits[p.a >> 5] >> (p.a & 31u)) & (bits[p.b >> 5] >> (p.b & 31u)) & 1u;
 }
 
 // ---- the populate-phase draws of one attempt (ProposalQueue.cpp:162-283: birth / death / move / exchange up to the conflict rules) ------
@@ -601,12 +608,24 @@ CG_DEVICE void gen_draw_b(const SamplerDev &S, GenShared<WIN> &sh, const GenRoun
     d.headBin = headBin; d.v2 = v2;      // (v3, xPick, redo: set where they arise)
 }
 
-// Did the lane, drawing ahead of the decisions, read only what they and the flush left alone?  nR: the domain's size behind the flush
-// (the draw assumed that nothing is erased), m: atoms erased.  A pick is uniform32(0, size - 1) (Random.cpp:79-96): x / iPart with
-// iPart = UINT32_MAX / size, x below size * iPart -- the same index from both sizes unless iPart or the rejection differs, which is
-// recomputed here from the 32 bits the pick was made from.  All reads are independent: one LDS trip.
+// Did the lane, drawing ahead of the decisions, read only what they and the flush left alone?  gen_draw_check, ahead of the decisions:
+// where the lane's keys sit in the note bit sets -- the matrix cells (a birth: its bin; a pick: its atom's bin and, for a move /
+// exchange, the other site's), the atom record(s), the pick's slot in the unsorted vector.  gen_draw_valid, behind them: the bits, the
+// bitmap words a birth read, and the pick itself from the size the flush leaves (nR; m atoms erased).  A pick is uniform32(0, size - 1)
+// (Random.cpp:79-96): x / iPart with iPart = UINT32_MAX / size, x below size * iPart -- the same index from both sizes unless iPart or
+// the rejection differs; iPart for the smaller size is the old one or the next (checked by multiplication, no division behind the wait).
+struct GenCheck { GenNotePos atomA, atomB, slot, cellA, cellB; uint32_t iPartS; };
+CG_DEVICE GenCheck gen_draw_check(const GenSpec &sp, const GenDraw &d, const uint32_t nRs, const uint32_t K)
+{
+    const bool isB = (sp.info & 0xFFu) == 'B';
+    GenCheck c;
+    c.cellA = gen_note_pos<GEN_DIRTY_CELLS>(isB ? d.bin : d.r1 * K + d.c1); c.cellB = gen_note_pos<GEN_DIRTY_CELLS>(d.r2 * K + d.c2);
+    c.atomA = gen_note_pos<GEN_DIRTY_ATOMS>(isB ? d.v2 : d.h1); c.atomB = gen_note_pos<GEN_DIRTY_ATOMS>(d.v3); c.slot = gen_note_pos<GEN_DIRTY_ATOMS>(~d.i1);
+    c.iPartS = 0xFFFFFFFFu / (nRs + (sp.info >> 8));
+    return c;
+}
 template <int WIN>
-CG_DEVICE bool gen_draw_valid(const SamplerDev &S, GenShared<WIN> &sh, const GenSpec &sp, const GenDraw &d, const uint32_t nR, const uint32_t m, const uint32_t K)
+CG_DEVICE bool gen_draw_valid(const SamplerDev &S, GenShared<WIN> &sh, const GenSpec &sp, const GenDraw &d, const GenCheck &ck, const uint32_t nR, const uint32_t m)
 {
     const uint32_t type = sp.info & 0xFFu, bBefore = sp.info >> 8;
     uint32_t bad = d.redo ? 1u : 0u;
@@ -614,12 +633,9 @@ CG_DEVICE bool gen_draw_valid(const SamplerDev &S, GenShared<WIN> &sh, const Gen
     if (((sp.ct + (uint32_t)sh.g.batchEpoch) % (uint32_t)GEN_AHEAD_BAD_EVERY) == 0u) bad = 1u;      // test-only variant: lanes drawn again, regularly
 #endif
     const bool isB = type == 'B';
-    // the matrix cells (a birth: its bin; a pick: its atom's bin and, for a move / exchange, the other site's), the atom record(s)
-    const uint32_t cellA = isB ? d.bin : d.r1 * K + d.c1, cellB = d.r2 * K + d.c2;
-    const uint32_t atomA = isB ? d.v2 : d.h1, atomB = d.v3;
     const bool reads = isB || d.pick;       // (a lane without an attempt, or whose pick fell on an atom born in this window, read nothing)
-    const uint32_t nA = gen_note_has<GEN_DIRTY_ATOMS>(sh.dAtom, atomA), nB = gen_note_has<GEN_DIRTY_ATOMS>(sh.dAtom, atomB), nS = gen_note_has<GEN_DIRTY_ATOMS>(sh.dAtom, ~d.i1);
-    const uint32_t cA = gen_note_has<GEN_DIRTY_CELLS>(sh.dCell, cellA), cB = gen_note_has<GEN_DIRTY_CELLS>(sh.dCell, cellB);
+    const uint32_t nA = gen_note_get(sh.dAtom, ck.atomA), nB = gen_note_get(sh.dAtom, ck.atomB), nS = gen_note_get(sh.dAtom, ck.slot);
+    const uint32_t cA = gen_note_get(sh.dCell, ck.cellA), cB = gen_note_get(sh.dCell, ck.cellB);
     if (reads) bad |= nA | cA;
     if (isB && d.v3 != CG_NONE) bad |= nB;
     if (d.pick && (type == 'M' || type == 'E')) bad |= cB;
@@ -637,8 +653,12 @@ CG_DEVICE bool gen_draw_valid(const SamplerDev &S, GenShared<WIN> &sh, const Gen
         bad |= dd ? 1u : 0u;
     } else if (m != 0u && type != 0u) {
         // the pick again, from the size the flush leaves; its slot must not be one the flush refills from the vector's tail
-        const uint32_t nT = nR + bBefore, iPart = 0xFFFFFFFFu / nT;
-        const uint32_t same = (uint32_t)(d.xPick < nT * iPart) & (uint32_t)(d.xPick / iPart == d.i1) & (uint32_t)(!(d.pick && d.i1 >= nR));
+        const uint32_t nT = nR + bBefore;
+        uint32_t q = ck.iPartS, rem = 0xFFFFFFFFu - q * nT;             // (q * nT <= q * (the larger size) <= UINT32_MAX)
+        const uint32_t up = (uint32_t)(rem >= nT);
+        q += up; rem -= up ? nT : 0u;
+        const uint32_t lo = d.i1 * q;                                   // (i1 < nT: no overflow)
+        const uint32_t same = (uint32_t)(rem < nT) & (uint32_t)(d.xPick < 0xFFFFFFFFu - rem) & (uint32_t)(d.xPick >= lo) & (uint32_t)(d.xPick - lo < q) & (uint32_t)(!(d.pick && d.i1 >= nR));
         bad |= (same ^ 1u) | (d.pick ? nS : 0u);
     }
     const bool ok = !(d.go != 0u && bad != 0u);
@@ -1321,6 +1341,8 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
     GenSpec specKeep; specKeep.bBefore = 0; specKeep.dBefore = 0; specKeep.guess = 0; specKeep.active = 0; specKeep.u1 = 0.f; specKeep.u2 = 0.f; specKeep.go = 0; specKeep.ct = 0; specKeep.info = 0;
     specKeep.rng = 0; specKeep.pos = 0; specKeep.bin = 0; specKeep.r1 = 0; specKeep.c1 = 0;
     GenDraw drawKeep; gen_draw_clear(drawKeep);      // chained launch: the lane's attempt of the next window, drawn ahead of the decisions
+    GenCheck checkKeep; checkKeep.atomA.a = checkKeep.atomA.b = checkKeep.atomB.a = checkKeep.atomB.b = checkKeep.slot.a = checkKeep.slot.b = 0u;
+    checkKeep.cellA.a = checkKeep.cellA.b = checkKeep.cellB.a = checkKeep.cellB.b = 0u; checkKeep.iPartS = 1u;
     if (!CHAIN) {
         GEN_TS_ZERO(7u, 13u);
 #if defined(GEN_TIMELINE)
@@ -1409,6 +1431,7 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
                 gen_draw_b<WIN, true>(S, sh, rcS, typeS, drawKeep, [&]() {});
             }
 #endif
+            if (drawAhead) checkKeep = gen_draw_check(spS, drawKeep, e_n, rcS.K);
             GEN_PIN(drawKeep.flags); GEN_PIN(drawKeep.old1); GEN_PIN(drawKeep.old2);
             GEN_TS(36);
             GEN_RT(2);
@@ -1420,6 +1443,10 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
                 const uint32_t q = base + al;
                 bool have = q < e_prevQ;
                 if (base) { chain_item_clear(it); if (have) chain_fetch(S, hot.queueRd, q, it); }      // (a queue longer than the applier lanes: the batch after a generator launch of two rounds)
+                // where the notes of this proposal go, whatever is decided (the hashes ahead of the wait)
+                const GenNotePos nH1 = gen_note_pos<GEN_DIRTY_ATOMS>(it.h1), nHL = gen_note_pos<GEN_DIRTY_ATOMS>(it.hL), nHR = gen_note_pos<GEN_DIRTY_ATOMS>(it.hR),
+                                 nH2 = gen_note_pos<GEN_DIRTY_ATOMS>(it.h2), nL2 = gen_note_pos<GEN_DIRTY_ATOMS>(it.l2), nIdx = gen_note_pos<GEN_DIRTY_ATOMS>(~it.idx),
+                                 nC1 = gen_note_pos<GEN_DIRTY_CELLS>(it.cell1), nC2 = gen_note_pos<GEN_DIRTY_CELLS>(it.cell2);
                 const unsigned long long *gr = hot.grans + (size_t)q * CHAIN_GRAN_STRIDE;
                 unsigned long long g0 = 0ull, g1 = 0ull; uint32_t spins = 0;
                 for (;;) {
@@ -1445,13 +1472,13 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
                 // atom records whose fields change: the atom's own (mass / position) and the neighbours that cache copies of them; an erased
                 // atom's neighbours are relinked by the flush.  Matrix cells that are rewritten.
                 if (er || ap) {
-                    gen_note_add<GEN_DIRTY_ATOMS>(sh.dAtom, it.h1);
-                    if (it.hL != CG_NONE) gen_note_add<GEN_DIRTY_ATOMS>(sh.dAtom, it.hL);
-                    if ((er || it.type == 'M') && it.hR != CG_NONE) gen_note_add<GEN_DIRTY_ATOMS>(sh.dAtom, it.hR);
-                    if (ap && it.type == 'E') { gen_note_add<GEN_DIRTY_ATOMS>(sh.dAtom, it.h2); if (it.l2 != CG_NONE) gen_note_add<GEN_DIRTY_ATOMS>(sh.dAtom, it.l2); }
-                    if (er) gen_note_add<GEN_DIRTY_ATOMS>(sh.dAtom, ~it.idx);      // (the vector slot the flush refills from the tail)
-                    if (ap || it.type == 'D') gen_note_add<GEN_DIRTY_CELLS>(sh.dCell, it.cell1);
-                    if (ap && (it.type == 'M' || it.type == 'E')) gen_note_add<GEN_DIRTY_CELLS>(sh.dCell, it.cell2);
+                    gen_note_set(sh.dAtom, nH1);
+                    if (it.hL != CG_NONE) gen_note_set(sh.dAtom, nHL);
+                    if ((er || it.type == 'M') && it.hR != CG_NONE) gen_note_set(sh.dAtom, nHR);
+                    if (ap && it.type == 'E') { gen_note_set(sh.dAtom, nH2); if (it.l2 != CG_NONE) gen_note_set(sh.dAtom, nL2); }
+                    if (er) gen_note_set(sh.dAtom, nIdx);      // (the vector slot the flush refills from the tail)
+                    if (ap || it.type == 'D') gen_note_set(sh.dCell, nC1);
+                    if (ap && (it.type == 'M' || it.type == 'E')) gen_note_set(sh.dCell, nC2);
                 }
                 const unsigned long long em = cg_ballot(er);
                 if (em) {
@@ -1472,11 +1499,20 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
             if ((t & 63u) == 0u && waveUnits) cg_atomic_add_u32(&sh.unitSum, waveUnits);
         }
         GEN_TS(34);
-        cg_sync();      // the decisions are in the domain (stores issued by this workgroup are seen by its later loads), the erase cache, the notes and the unit sum are complete
+        // The join: the decisions are issued to the domain, the erase cache, the notes and the unit sum are complete.  The window drawn
+        // ahead: nobody reads the domain before the lanes have validated their draws, so the join waits for LDS traffic only and the
+        // appliers' stores are acknowledged further down -- the spare waves stay for two more barriers (the validation's; then the join
+        // of the lanes that draw again, or the registration barrier -- cg_sync: this wave's stores are acknowledged before either).
+        // The usual way: the attempt lanes read the domain next, behind stores that are acknowledged here.
+        if (drawAhead) cg_sync_lds(); else cg_sync();
         GEN_TS(35);
         GEN_RT(4);
         if (cg_uniform_u32(sh.spinFail) != 0u) return;      // a decision never arrived (GAPS_ERR_SPIN is set): every wave leaves, nothing is generated
-        if (spare) { { const bool ts_ok = e_prevQ >= 140u && e_nSteps - e_nDone >= 512u; (void)ts_ok; GEN_TS_DUMP_WAVE(); } return; }      // (the waves beyond the helper wave only applied)
+        if (spare) {                                        // (the waves beyond the helper wave only applied)
+            if (drawAhead && !updateDone) { cg_sync_lds(); cg_sync(); }
+            { const bool ts_ok = e_prevQ >= 140u && e_nSteps - e_nDone >= 512u; (void)ts_ok; GEN_TS_DUMP_WAVE(); }
+            return;
+        }
         e_m = cg_uniform_u32(sh.eraseN);
         if (e_m > eraseCap) e_m = eraseCap;
         if (helper) specE = (ht < (unsigned)FLUSH_MAX && ht < e_m) ? sh.eraseTmp[ht] : 0ull;
@@ -1515,14 +1551,19 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
     // first guess, which needs only the entry of the count itself (computed here: the load would be on the critical path).
     // (The chained launch staged the table's window in LDS while it waited for the decisions: no trip, no division.)
     const bool fromWin = CHAIN && dpStaged;
-    const float tabHi = fromWin ? sh.dpWin[n0 + t - dpBase] : S.deathProb[n0 + t], tabLo = (n0 >= t) ? (fromWin ? sh.dpWin[n0 - t - dpBase] : S.deathProb[n0 - t]) : 0.f;
+    // (a window classified ahead reads the staged table where it needs it: none of the three values below is used there -- and the
+    // compiler would compute the division of the third whichever way the select goes)
+    float tabHi = 0.f, tabLo = 0.f, dp0 = 0.f;
+    if (!(CHAIN && specDone)) {
+        tabHi = fromWin ? sh.dpWin[n0 + t - dpBase] : S.deathProb[n0 + t]; tabLo = (n0 >= t) ? (fromWin ? sh.dpWin[n0 - t - dpBase] : S.deathProb[n0 - t]) : 0.f;
+        dp0 = fromWin ? sh.dpWin[n0 - dpBase] : gm_death_prob((double)(uint64_t)n0, S.domainLenD, S.alphaD, S.numBins);
+    }
     const uint64_t batchEpoch = sh.g.batchEpoch + 1;
     const uint32_t updBase = e_nDone;           // attempts consumed by earlier batches of this update
     const uint32_t remaining = e_nSteps - e_nDone;
     const uint32_t K = S.K;
     // round 1 takes its scalars from the LDS copy of GenScalars (complete since the first barrier); the helper wave writes the round
     // variables' LDS copies, which later phases and rounds read
-    const float dp0 = fromWin ? sh.dpWin[n0 - dpBase] : gm_death_prob((double)(uint64_t)n0, S.domainLenD, S.alphaD, S.numBins);
     const uint64_t g_qrng = sh.g.qrng; const uint32_t g_skip = sh.g.useCached ? 1u : 0u; const float g_u1 = sh.g.u1, g_u2 = sh.g.u2;
 
     GenRoundCtx rc; rc.t = t; rc.jm0 = jm0; rc.ji0 = ji0; rc.jm1 = jm1; rc.ji1 = ji1; rc.seed1 = seed1; rc.batchEpoch = batchEpoch; rc.g_qrng = g_qrng; rc.n0 = n0; rc.updBase = updBase;
@@ -1531,7 +1572,7 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
     if (CHAIN && specDone) {
         // which lanes drew what they would draw now (gen_draw_valid).  If every lane of the window did, the round goes straight into its
         // conflict phases and the helper wave's flush runs beside them (gen_helper); otherwise the join with the flush first
-        const bool valid = gen_draw_valid<WIN>(S, sh, specKeep, drawKeep, n0, e_m, K);
+        const bool valid = gen_draw_valid<WIN>(S, sh, specKeep, drawKeep, checkKeep, n0, e_m);
         if (cg_ballot(!valid) != 0ull && (t & 63u) == 0u) sh.anyRedo = 1u;
         GEN_PIN(drawKeep.flags);
         GEN_TS(37);
