@@ -426,7 +426,7 @@ def main():
         fusedA = args.sparse or S.dims("A")[1] <= 4096
         fusedP = args.sparse or S.dims("P")[1] <= 4096
         chained = {w: S.chained(w) for w in "AP"}      # one launch per batch (csrc/chain_kernel.h): its time is the "evaluation" time, there is no generator launch
-        CHAIN_NAME = "chain_kernel (one launch: workgroups 0..n-2 evaluate batch n as eval_kernel<EVAL_FUSED> does, the last workgroup generates batch n+1)"
+        CHAIN_NAME = "chain_kernel (one launch: workgroups 0..n-2 evaluate batch n -- fused, or in slices with a deciding workgroup per proposal --, the last workgroup generates batch n+1)"
         ev_name = lambda fused: "eval_sparse_kernel" if args.sparse else ("eval_kernel<EVAL_FUSED>" if fused else "eval_kernel<EVAL_DECIDE> (split evaluation, one launch; its A*P updates run beside the next generator launch)")
 
         def kernel_line(name, sampler, ms, launches, nbytes, sampled):

@@ -32,10 +32,14 @@
 // dev: one chained launch on the chip-wide 100 MHz clock -- per workgroup {entry, decision published, end}; the generator workgroup's marks in g_chain_gen
 __device__ unsigned long long g_chain_rt[256 * 4];
 #endif
-template <int WIN>
+// SPLIT: the sampler's data vectors are evaluated in slices (more than 4096 elements: eval_kernel.h, EVAL_CHAIN_SPLIT) -- `slices` workgroups per
+// proposal, the grid's evaluation workgroups a multiple of it; every workgroup takes its items in increasing order, a deciding
+// workgroup waits only for items before its own and an update only for deciding workgroups: nothing waits in a circle.
+template <int WIN, bool SPLIT>
 CG_KERNEL void CG_LAUNCH_BOUNDS(CHAIN_MAX_THREADS) chain_kernel(const uint64_t *lcgMul, const uint64_t *lcgInc, GenScalars *gs, PropRec *queue, unsigned long long *grans, ChainSlot *slots,
-                                                                uint32_t queueCap, uint32_t parity, const SamplerDev CG_CONSTANT *sp)
+                                                                uint32_t queueCap, uint32_t parity, uint32_t slices, const SamplerDev CG_CONSTANT *sp)
 {
+    constexpr int PH = SPLIT ? EVAL_CHAIN_SPLIT : EVAL_CHAIN;
     if (cg_bid() + 1u == cg_gdim()) {
         GenHot hot; hot.lcgMul = lcgMul; hot.lcgInc = lcgInc; hot.gs = gs; hot.eraseList = nullptr; hot.queueUnits = nullptr; hot.eraseCap = 0; hot.queueCap = queueCap;
         hot.queueRd = queue + (size_t)parity * queueCap; hot.queueWr = queue + (size_t)(1u - parity) * queueCap; hot.grans = grans; hot.slotWr = &slots[1u - parity];
@@ -47,11 +51,21 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(CHAIN_MAX_THREADS) chain_kernel(const uint64_t *
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
     const unsigned long long clk0 = (cg_bid() == 0u && cg_tid() == 0u) ? cg_realtime() : 0ull;
-    const EvalFirst first = eval_first<EVAL_CHAIN>(hot, 1u, cg_bid());
-    const SamplerDev &S = eval_record<EVAL_CHAIN>(sp);
+    const EvalFirst first = eval_first<PH>(hot, slices, cg_bid());
+    const SamplerDev &S = eval_record<PH>(sp);
     if (cg_bid() == 0u && cg_tid() == 0u && S.launchClock) S.launchClock[2u * (first.tag % GAPS_CLOCK_RING)] = clk0;      // (launch clock: gaps_state.h)
-    eval_body<EVAL_CHAIN, true>(S, 1u, cg_bid(), cg_gdim() - 1u, hot, first);
+    eval_body<PH, true>(S, slices, cg_bid(), cg_gdim() - 1u, hot, first);
 #if defined(GEN_TIMELINE)
     if (cg_tid() == 0u && first.qlen >= 140u && gs->nSteps - gs->nDone >= 512u && cg_bid() < 255u) { g_chain_rt[cg_bid() * 4u] = rt0; g_chain_rt[cg_bid() * 4u + 2u] = __builtin_amdgcn_s_memrealtime(); g_chain_rt[cg_bid() * 4u + 3u] = first.qlen; }
 #endif
 }
+
+#if defined(COGAPS_EMUL)
+// test-only emulator (workgroups run one after the other): the split form's A*P updates as a launch of their own behind the chained one
+CG_KERNEL void chain_updates_kernel(PropRec *queue, unsigned long long *grans, ChainSlot *slots, uint32_t queueCap, uint32_t parity, const SamplerDev CG_CONSTANT *sp)
+{
+    EvalHot hot; hot.queue = queue + (size_t)parity * queueCap; hot.gs = nullptr; hot.queueCap = queueCap; hot.slot = &slots[parity]; hot.grans = grans;
+    const ChainSlot cs = *hot.slot;
+    eval_chain_updates(*(const SamplerDev *)sp, hot, cs.tag, cs.qlen, cg_bid(), cg_gdim());
+}
+#endif

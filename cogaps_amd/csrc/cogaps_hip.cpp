@@ -162,7 +162,8 @@ extern "C" uint32_t cogaps_sparse_width(uint32_t N)
 // exist in development builds only (-DCOGAPS_DEV, -DGEN_PROFILE): the product library does not look at them.  What the product library
 // does read from the environment, on purpose, is documented in include/cogaps_hip.h: COGAPS_NO_GRAPH (every launch as a plain call --
 // counter collection hangs on replayed graphs), COGAPS_NO_CHAIN (two launches per batch: the A/B and the equality test of the chained launch) and
-// COGAPS_FORCE_CHAIN (tests: the chained launch on a device with fewer compute units than the launch has workgroups).
+// COGAPS_FORCE_CHAIN (tests: the chained launch on a device with fewer compute units than the launch has workgroups), COGAPS_CHAIN_SPLIT (the
+// split evaluation inside the chained launch: measured, not the default).
 static const char *dev_env(const char *name)
 {
 #if defined(COGAPS_DEV) || defined(GEN_PROFILE) || defined(COGAPS_EMUL)
@@ -193,6 +194,7 @@ struct HostSampler {
     // chained launch (chain_kernel.h): one launch per batch; consecutive launches alternate the parity they carry as a kernel argument, so
     // a captured run of launches exists once per starting parity
     bool chain = false; uint32_t chainParity = 0;
+    unsigned long long *chainGrans = nullptr;      // [queueCap][CHAIN_GRAN_STRIDE] the decisions' granules (the split form's per-slice totals keep SamplerDev::grans)
     rt_graph chainGraph[2]; bool chainGraphValid[2] = {false, false};
     size_t traceCap = 0;
     char name = 'A';
@@ -229,6 +231,11 @@ struct cogaps_session {
     bool timing = false; bool evInit = false;
     bool noGraph = getenv("COGAPS_NO_GRAPH") != nullptr;     // diagnostics: every launch as a plain call (counter collection tools)
     bool noChain = getenv("COGAPS_NO_CHAIN") != nullptr;     // A/B and tests: two launches per batch (gen_kernel, eval_kernel<EVAL_FUSED>) where the chained launch would serve
+    // The split evaluation inside the chained launch (EVAL_CHAIN_SPLIT) is built, tested on the hardware and NOT the default: measured on the
+    // headline chain it loses 6 % (profiles/r05_ab_chained_split_evaluation_not_kept.txt -- the launch's workgroups carry the generator's 142 KB
+    // of LDS, so one evaluation workgroup fits a compute unit and each takes 3-4 slices one after the other, where the two-launch form has
+    // two per unit and all slices resident).  COGAPS_CHAIN_SPLIT=1 takes it (the A/B, the equality test).
+    bool noChainSplit = getenv("COGAPS_CHAIN_SPLIT") == nullptr;
     bool forceChain = getenv("COGAPS_FORCE_CHAIN") != nullptr;      // tests: the chained launch also where the device shows fewer compute units than the launch has workgroups (they then run in turns, the generator last)
     unsigned computeUnits = 0;      // of the session's device: the chained launch wants all its workgroups resident at once, one per compute unit
     std::vector<rt_event_pair> evPool; std::vector<int> evKind; std::vector<HostSampler *> evOwner; std::vector<uint64_t> evOrd; size_t evUsed = 0;
@@ -256,7 +263,7 @@ static void free_sampler(HostSampler &h)
     rt_free(d.seqScratch); rt_free((void *)d.deathProb); rt_free(d.launchClock);
     rt_free((void *)d.D); rt_free((void *)d.S2); rt_free(d.AP); rt_free(d.mat); rt_free(d.colPos);
     rt_free(d.atoms); rt_free(d.vec); rt_free(d.freeHandles); rt_free(d.binHead);
-    rt_free(d.bits0); rt_free(d.bits1); rt_free(d.bits2); rt_free(d.eraseList); rt_free(d.queue); rt_free(d.queueUnits); rt_free(d.chainSlots); rt_free(d.partials); rt_free(d.grans); rt_free(d.dec);
+    rt_free(d.bits0); rt_free(d.bits1); rt_free(d.bits2); rt_free(d.eraseList); rt_free(d.queue); rt_free(d.queueUnits); rt_free(d.chainSlots); rt_free(h.chainGrans); rt_free(d.partials); rt_free(d.grans); rt_free(d.dec);
     rt_free(d.rowStamp); rt_free(d.atomStamp); rt_free(d.gapStamp); rt_free(d.inlineStamp); rt_free(d.atomDest);
     rt_free(d.gs); rt_free(d.trace); rt_free(d.traceBatchNproc); rt_free(d.traceBatchQlen);
     rt_free(h.Sraw); rt_free(h.seeds); rt_free_host(h.hSeeds); rt_free(h.partial); rt_free(h.dRecord);
@@ -362,7 +369,7 @@ static void build_sampler(cogaps_session *s, HostSampler &h, char name, const fl
     d.nWords0 = (uint32_t)((nBins + 63) / 64); d.nWords1 = (d.nWords0 + 63) / 64; d.nWords2 = (d.nWords1 + 63) / 64;
     d.bits0 = dalloc<unsigned long long>(d.nWords0); d.bits1 = dalloc<unsigned long long>(d.nWords1); d.bits2 = dalloc<unsigned long long>(d.nWords2);
     d.queueCap = d.M + 8; d.eraseCap = d.queueCap;
-    d.eraseList = dalloc<unsigned long long>(d.eraseCap); d.queue = dalloc<PropRec>((size_t)2 * d.queueCap); d.chainSlots = dalloc<ChainSlot>(2); d.launchClock = dalloc<unsigned long long>(2u * GAPS_CLOCK_RING); d.queueUnits = dalloc<uint32_t>(d.queueCap); d.partials = dalloc<float>((size_t)d.queueCap * 64); d.grans = dalloc<unsigned long long>((size_t)d.queueCap * 64); d.dec = dalloc<DecRec>(d.queueCap);
+    d.eraseList = dalloc<unsigned long long>(d.eraseCap); d.queue = dalloc<PropRec>((size_t)2 * d.queueCap); d.chainSlots = dalloc<ChainSlot>(2); d.launchClock = dalloc<unsigned long long>(2u * GAPS_CLOCK_RING); h.chainGrans = dalloc<unsigned long long>((size_t)d.queueCap * CHAIN_GRAN_STRIDE); d.queueUnits = dalloc<uint32_t>(d.queueCap); d.partials = dalloc<float>((size_t)d.queueCap * 64); d.grans = dalloc<unsigned long long>((size_t)d.queueCap * 64); d.dec = dalloc<DecRec>(d.queueCap);
     d.rowStamp = dalloc<unsigned long long>(d.M);
     d.atomStamp = dalloc<unsigned long long>(d.atomCap); d.gapStamp = dalloc<unsigned long long>((size_t)d.atomCap + 1);
     d.inlineStamp = dalloc<unsigned long long>(d.atomCap); d.atomDest = dalloc<uint64_t>(d.atomCap);
@@ -486,14 +493,33 @@ static uint32_t apply_grid()
 // The chained launch serves the one-chain fused evaluation (dense model, product arithmetic) whose workgroups are at least as large as
 // the generator's and small enough for the generator's register budget (chain_kernel.h); everything else keeps two launches per batch.
 static bool chain_eligible(const cogaps_session *s, const HostSampler &h);
+// launch geometry of the split evaluation (data vectors of more than 4096 elements): `slices` workgroups of `bs` threads per proposal
+// (512 threads fill the machine a little better than 1024; at most 16 slices fit the partials record)
+static void split_geometry(const HostSampler &h, uint32_t &bs, uint32_t &slices)
+{
+    bs = std::max<uint32_t>(512u, h.d.redW / 16u);
+    slices = std::min<uint32_t>(h.d.redW / bs, ((h.d.Npad >> 2) + bs - 1u) / bs);
+}
 static void launch_chain(cogaps_session *s, HostSampler &h)
 {
     const int slot = timing_slot(s, h, 1, h.evalLaunches);
     const SamplerDev CG_CONSTANT *rec = (const SamplerDev CG_CONSTANT *)h.dRecord;
-    const uint32_t grid = std::min<uint32_t>(h.d.queueCap, CHAIN_EVAL_GRID) + 1u;
     const uint32_t parity = h.chainParity; h.chainParity ^= 1u;
-    if (h.genWin == (uint32_t)GEN_WIN) LAUNCH_MAYBE_TIMED(slot, chain_kernel<GEN_WIN>, grid, h.d.redW, h.d.lcgMul, h.d.lcgInc, h.d.gs, h.d.queue, h.d.grans, h.d.chainSlots, h.d.queueCap, parity, rec);
-    else LAUNCH_MAYBE_TIMED(slot, chain_kernel<GEN_WIN_HALF>, grid, h.d.redW, h.d.lcgMul, h.d.lcgInc, h.d.gs, h.d.queue, h.d.grans, h.d.chainSlots, h.d.queueCap, parity, rec);
+    if (h.d.redW > 1024u) {
+        // split evaluation: the evaluation workgroups are a multiple of the slices per proposal (chain_kernel.h)
+        uint32_t bs, slices; split_geometry(h, bs, slices);
+        const uint32_t groups = std::max<uint32_t>(1u, std::min<uint32_t>(h.d.queueCap, CHAIN_EVAL_GRID / slices));
+        const uint32_t grid = groups * slices + 1u;
+        if (h.genWin == (uint32_t)GEN_WIN) LAUNCH_MAYBE_TIMED(slot, (chain_kernel<GEN_WIN, true>), grid, bs, h.d.lcgMul, h.d.lcgInc, h.d.gs, h.d.queue, h.chainGrans, h.d.chainSlots, h.d.queueCap, parity, slices, rec);
+        else LAUNCH_MAYBE_TIMED(slot, (chain_kernel<GEN_WIN_HALF, true>), grid, bs, h.d.lcgMul, h.d.lcgInc, h.d.gs, h.d.queue, h.chainGrans, h.d.chainSlots, h.d.queueCap, parity, slices, rec);
+#if defined(COGAPS_EMUL)
+        RT_LAUNCH(chain_updates_kernel, 5, bs, s->stream, h.d.queue, h.chainGrans, h.d.chainSlots, h.d.queueCap, parity, rec);      // (test-only emulator: the updates behind the launch)
+#endif
+    } else {
+        const uint32_t grid = std::min<uint32_t>(h.d.queueCap, CHAIN_EVAL_GRID) + 1u;
+        if (h.genWin == (uint32_t)GEN_WIN) LAUNCH_MAYBE_TIMED(slot, (chain_kernel<GEN_WIN, false>), grid, h.d.redW, h.d.lcgMul, h.d.lcgInc, h.d.gs, h.d.queue, h.chainGrans, h.d.chainSlots, h.d.queueCap, parity, 1u, rec);
+        else LAUNCH_MAYBE_TIMED(slot, (chain_kernel<GEN_WIN_HALF, false>), grid, h.d.redW, h.d.lcgMul, h.d.lcgInc, h.d.gs, h.d.queue, h.chainGrans, h.d.chainSlots, h.d.queueCap, parity, 1u, rec);
+    }
     h.evalLaunches++;      // (one launch per batch: counted with the evaluation launches, as its time is)
 }
 static void launch_gen(cogaps_session *s, HostSampler &h)
@@ -532,8 +558,7 @@ static void launch_eval(cogaps_session *s, HostSampler &h)
     } else {
         // long data vectors: `slices` workgroups of `bs` threads per proposal, alpha kernel then apply kernel
         // (512 threads fill the machine a little better than 1024; at most 16 slices fit the partials record)
-        const uint32_t bs = std::max<uint32_t>(512u, h.d.redW / 16u);
-        const uint32_t slices = std::min<uint32_t>(h.d.redW / bs, ((h.d.Npad >> 2) + bs - 1u) / bs);
+        uint32_t bs, slices; split_geometry(h, bs, slices);
         const uint32_t perWave = std::max<uint32_t>(1u, (512u * (1024u / bs)) / slices);   // two resident 1024-thread workgroups per compute unit
         const uint32_t grid = std::min<uint32_t>(h.d.queueCap, perWave) * slices;
         if (split_one_launch(h)) {
@@ -559,7 +584,13 @@ static bool chain_eligible(const cogaps_session *s, const HostSampler &h)
 {
     // (a device with fewer compute units than the launch has workgroups -- a partitioned GPU -- would run them in turns, the generator
     // workgroup last: correct, and slower than two launches)
-    return !s->noChain && !h.d.seq && !h.d.sparse && h.d.redW <= (uint32_t)CHAIN_MAX_THREADS && h.d.redW >= h.genWin + 64u
+    if (s->noChain || h.d.seq || h.d.sparse) return false;
+    uint32_t block = h.d.redW;
+    if (h.d.redW > 1024u) {      // split evaluation (round 5): workgroups of 512 threads, at most as many slices per proposal as the launch has evaluation workgroups
+        uint32_t slices; split_geometry(h, block, slices);
+        if (!split_one_launch(h) || slices > 16u || s->noChainSplit) return false;
+    }
+    return block <= (uint32_t)CHAIN_MAX_THREADS && block >= h.genWin + 64u
            && (s->forceChain || s->computeUnits >= std::min<uint32_t>(h.d.queueCap, CHAIN_EVAL_GRID) + 1u);
 }
 // one batch step: the chained launch, or a generator launch and an evaluation launch

@@ -583,6 +583,9 @@ CG_DEVICE void eval_chain_pair(const SamplerDev &S, unsigned long long *grans, c
 #define EVAL_SEQ 3       // verification mode: one workgroup per proposal, sums in the reference's scalar order, session math mode
 #define EVAL_CHAIN 5     // the fused form inside the chained launch (chain_kernel.h): the decision goes to the next batch's generator workgroup of the SAME launch as
                          // two tagged granules and that workgroup applies it to the domain and the matrix; this workgroup only updates its A*P row(s)
+#define EVAL_CHAIN_SPLIT 6   // the split evaluation inside the chained launch (round 5): slices as EVAL_DECIDE, the deciding workgroup hands the decision to the launch's
+                             // generator workgroup as EVAL_CHAIN does, and every evaluation workgroup, done with its slices, takes a share of the A*P updates the
+                             // decisions owe (eval_chain_updates) -- beside the generator's round, complete at the launch's end
 #define EVAL_DECIDE 4    // split evaluation in ONE launch (one-chain form): the slices' workgroups hand their totals to the proposal's last slice
                          // workgroup, which decides and records what the A*P cache owes (DecRec); eval_apply_items carries that out beside the
                          // NEXT generator launch (gen_apply_kernel), off the generate -> decide -> generate chain
@@ -606,7 +609,7 @@ CG_DEVICE EvalFirst eval_first(const EvalHot hot, uint32_t slices, uint32_t vbid
 {
     const uint32_t qFirst = (PHASE == EVAL_FUSED || PHASE == EVAL_SEQ || PHASE == EVAL_CHAIN) ? vbid : vbid / slices;
     EvalFirst f; f.p = hot.queue[qFirst < hot.queueCap ? qFirst : 0u]; f.T = hot.gs->annealTemp;
-    if (PHASE == EVAL_CHAIN) { const ChainSlot cs = *hot.slot; f.qlen = cs.qlen; f.tag = cs.tag; }      // (this launch's parity: nothing in this launch writes it)
+    if (PHASE == EVAL_CHAIN || PHASE == EVAL_CHAIN_SPLIT) { const ChainSlot cs = *hot.slot; f.qlen = cs.qlen; f.tag = cs.tag; }      // (this launch's parity: nothing in this launch writes it)
     else { f.qlen = hot.gs->qlen; f.tag = (PHASE == EVAL_DECIDE) ? (uint32_t)hot.gs->batchEpoch : 0u; }
     return f;
 }
@@ -623,6 +626,46 @@ CG_DEVICE const SamplerDev &eval_record(const SamplerDev CG_CONSTANT *sp)
     sp = cg_const_warm_end(sp, lines);
     return *(const SamplerDev *)sp;
 }
+// ---- chained launch, split evaluation: the A*P updates the batch's decisions owe ------------------------------------------------------
+// Every evaluation workgroup, done with its slices, takes items (proposal, share of its row(s)): it reads the proposal's decision where
+// the generator workgroup reads it -- the two tagged granules its deciding workgroup published (waiting for them if need be: a deciding
+// workgroup never waits for an update, so the wait ends) -- and derives what the A*P cache is owed from the queue record exactly as the
+// decision did (AsynchronousGibbsSampler.h:127-219 with safelyChangeMatrix's clamp, DenseNormalModel.cpp:110-123); then
+// AP += delta * other, element by element, eval_apply_items' operations in its order.  The launch's end completes them: the next
+// launch's evaluation reads the rows.
+CG_DEVICE void eval_chain_updates(const SamplerDev &S, const EvalHot hot, const uint32_t tag, const uint32_t qlen, const uint32_t wg, const uint32_t nwg)
+{
+    const uint32_t TPB = cg_bdim(), nq = S.Npad >> 2;
+    uint32_t parts = (nq + 4u * TPB - 1u) / (4u * TPB);
+    parts = parts < 1u ? 1u : (parts > 64u ? 64u : parts);
+    for (uint32_t item = wg; item < qlen * parts; item += nwg) {
+        const uint32_t q = item / parts, part = item - q * parts;
+        const PropRec p = hot.queue[q < hot.queueCap ? q : 0u];
+        const unsigned long long *gr = hot.grans + (size_t)q * CHAIN_GRAN_STRIDE;
+        unsigned long long g0 = 0ull, g1 = 0ull; uint32_t spins = 0; bool have = true;
+        for (;;) {
+            g0 = cg_load_l2_u64(&gr[0]); g1 = cg_load_l2_u64(&gr[1]);
+            const bool ok = (uint32_t)(g0 >> 32) == tag && (uint32_t)(g1 >> 32) == tag;
+            if (cg_ballot(!ok) == 0ull) break;
+            if (cg_poll_expired(++spins)) { if (cg_tid() == 0u) S.gs->error = GAPS_ERR_SPIN; have = false; break; }      // (bounded; nothing is applied from a stale granule)
+            cg_poll_pause();
+        }
+        if (!have) return;
+        const uint32_t code = (uint32_t)g0 & 0xFFu; const float val = gm_u2f((uint32_t)g1);
+        const float m1 = p.m1, m2 = p.m2, old1 = p.old1, old2 = p.old2;
+        if (code == CHAIN_APPLY) {
+            if (p.type == 'B') eval_update_ap(S, p.r1, p.c1, val, part * TPB, TPB * parts);
+            else if (p.type == 'D') { const float nv = gm_max(old1 + (val - m1), 0.f); eval_update_ap(S, p.r1, p.c1, nv - old1, part * TPB, TPB * parts); }
+            else if (p.type == 'M') { const float nv1 = gm_max(old1 + (-m1), 0.f); eval_update_ap2(S, p.r1, p.c1, nv1 - old1, p.r2, p.c2, m1, part * TPB, TPB * parts); }
+            else if (p.type == 'E') {
+                const float n1 = m1 + val, n2 = m2 - val;
+                const float nv1 = gm_max(old1 + (n1 - m1), 0.f), nv2 = gm_max(old2 + (n2 - m2), 0.f);
+                eval_update_ap2(S, p.r1, p.c1, nv1 - old1, p.r2, p.c2, nv2 - old2, part * TPB, TPB * parts);
+            }
+        } else if (code == CHAIN_ERASE && p.type == 'D') { const float nv = gm_max(old1 + (-1.f * m1), 0.f); eval_update_ap(S, p.r1, p.c1, nv - old1, part * TPB, TPB * parts); }
+    }
+}
+
 // SINGLE: a one-chain launch (the fused form then asks for the chunk it will rewrite before the scalar step, see EvalPre)
 template <int PHASE, bool SINGLE>
 CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vbid, const uint32_t vgdim, const EvalHot hot, const EvalFirst &first)
@@ -630,8 +673,9 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
 #if defined(GEN_TIMELINE)
     unsigned long long ets[11]; uint32_t ets_n = 0;
 #endif
-    constexpr bool CHAIN = PHASE == EVAL_CHAIN;
-    constexpr bool FUSEDF = PHASE == EVAL_FUSED || CHAIN;      // the fused form: one workgroup reduces, decides and updates
+    constexpr bool CHAINP = PHASE == EVAL_CHAIN_SPLIT;
+    constexpr bool CHAIN = PHASE == EVAL_CHAIN || CHAINP;       // the decision goes to the launch's generator workgroup; nothing but A*P rows is written here
+    constexpr bool FUSEDF = PHASE == EVAL_FUSED || PHASE == EVAL_CHAIN;      // the fused form: one workgroup reduces, decides and updates
     const uint32_t qFirst = (FUSEDF || PHASE == EVAL_SEQ) ? vbid : vbid / slices;
     PropRec pNext = first.p;
     const uint32_t qlen = first.qlen;
@@ -655,7 +699,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
     const uint32_t slice = WHOLE ? 0u : vbid % slices;
     const uint32_t qStep = WHOLE ? vgdim : vgdim / slices;
     const uint32_t chunk0 = slice * BS, stride = WHOLE ? BS : S.redW;
-    constexpr bool DECIDE = PHASE == EVAL_DECIDE;
+    constexpr bool DECIDE = PHASE == EVAL_DECIDE || CHAINP;
     const bool decider = DECIDE && slice + 1u == slices;      // the proposal's last slice: it is dispatched last, so its siblings are on the machine when it waits for their totals
     const bool writer = !CHAIN && (DECIDE ? decider : slice == 0u) && t == 0u;          // the one thread that stores the proposal's scalar results (chained launch: nobody here)
     // chained launch: thread 0 hands the decision to the generator workgroup of this launch the moment it is made, before the broadcast
@@ -670,12 +714,12 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
         cg_store_agent_u64(&gr_[1], ((unsigned long long)first.tag << 32) | (unsigned long long)gm_f2u(VAL)); } } while (0)
     // (the deciding workgroup's other waves have nothing to do with the decision: no broadcast)
 #define EVAL_BCAST(F0, I0) do { if (multiWave && !DECIDE) { if (t == 0) { decf = (F0); deci = (I0); } cg_sync(); (F0) = decf; (I0) = deci; } } while (0)
-    if (DECIDE && vbid == 0u && t == 0u) S.gs->applyCount = qlen;      // what the next generator launch's update workgroups will find in S.dec (0: this launch found no queue)
+    if (PHASE == EVAL_DECIDE && vbid == 0u && t == 0u) S.gs->applyCount = qlen;      // what the next generator launch's update workgroups will find in S.dec (0: this launch found no queue)
     for (uint32_t q = qFirst; ; q += qStep) {
         // one trip: the record (slot q always exists: q < queueCap), the queue length, the annealing temperature
         const PropRec p = pNext;
         if (q >= qlen) break;
-        if (CHAIN && q + qStep < qlen && (S.Npad >> 2) <= BS && BS >= 128u) {
+        if (PHASE == EVAL_CHAIN && q + qStep < qlen && (S.Npad >> 2) <= BS && BS >= 128u) {
             // a queue longer than the launch has evaluation workgroups: this workgroup's next two proposals side by side (eval_chain_pair)
             const uint32_t qB = q + qStep;
             const PropRec pB = hot.queue[qB < hot.queueCap ? qB : 0u];
@@ -918,6 +962,10 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
         { const uint32_t qn_ = q + qStep; pNext = hot.queue[qn_ < hot.queueCap ? qn_ : 0u]; }
         cg_sync();   // the LDS scratch is reused by the next proposal
     }
+#if !defined(COGAPS_EMUL)
+    // (the test-only emulator runs workgroups one after the other: there the updates are a launch of their own behind this one, chain_updates_kernel)
+    if (CHAINP) eval_chain_updates(S, hot, first.tag, qlen, vbid, vgdim);
+#endif
 }
 
 // the split kernels are built for two resident 1024-thread workgroups per compute unit (<= 64 VGPRs)

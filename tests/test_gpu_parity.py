@@ -252,6 +252,34 @@ def test_chained_equals_two_launches_on_the_gpu(hip_lib, monkeypatch):
     assert chained == plain
 
 
+def test_chained_split_evaluation_equals_two_launches_on_the_gpu(hip_lib, monkeypatch):
+    """The same for the split evaluation inside the chained launch (EVAL_CHAIN_SPLIT: data vectors of more than 4096 elements -- slices,
+    a deciding workgroup per proposal, the A*P updates taken up by the evaluation workgroups behind their slices): 9000 x 1500, K = 12 --
+    the P sampler's vectors have 9000 elements (5 slices of 512 threads), the A sampler's 1500 (fused) -- taken with COGAPS_CHAIN_SPLIT=1 (it is
+    not the default: measured slower, profiles/r05_ab_chained_split_evaluation_not_kept.txt) against the default (gen_apply_kernel +
+    eval_kernel<EVAL_DECIDE>) and against COGAPS_NO_CHAIN=1, bit for bit."""
+    from cogaps_amd import _capi
+    def run():
+        S = _capi.Session(pu.synthetic(9000, 1500, rank=4, seed=5), lib=hip_lib, nPatterns=12, nIterations=30, seed=17)
+        for it in range(8):
+            S.set_annealing(min(1.0, 2.0 * it / 30))
+            nA, nP = S.draw_steps()
+            S.iterate(nA, nP)
+        st = _chain_state(S), S.chained("A"), S.chained("P")
+        S.close()
+        return st
+    monkeypatch.setenv("COGAPS_CHAIN_SPLIT", "1")
+    a = run()
+    assert (a[1], a[2]) == (1, 1), "the split evaluation did not chain"
+    monkeypatch.delenv("COGAPS_CHAIN_SPLIT")
+    b = run()
+    assert (b[1], b[2]) == (1, 0)
+    monkeypatch.setenv("COGAPS_NO_CHAIN", "1")
+    c = run()
+    assert (c[1], c[2]) == (0, 0)
+    assert a[0] == b[0] == c[0]
+
+
 def test_chained_launch_with_half_the_compute_units(hip_lib):
     """`Correct and slower, never a hang` as a hardware fact.  The same chain in processes whose queues may use 120 of the 256 compute
     units (HSA_CU_MASK): (1) as the library decides; (2) with COGAPS_FORCE_CHAIN=1 the chained launch whatever the runtime reports --
