@@ -342,7 +342,7 @@ static void build_sampler(cogaps_session *s, HostSampler &h, char name, const fl
     else {
         // SparseMatrix (flag words + packed values per vector) and the HybridMatrix copies; D / Sraw stay for meanChiSq
         d.sparse = 1; d.beta = 100.f; d.unitBytes = 1u;
-        d.Mw = d.M / 64u + 1u; d.Kpad = (d.K + 3u) & ~3u;
+        d.Mw = d.M / 64u + 1u; d.Kpad = (d.K + 3u) & ~3u; d.spW = cogaps_sparse_width(d.N);
         ptr[d.M] = (uint32_t)vals.size();
         unsigned long long *dfl = dalloc<unsigned long long>(fl.size()); uint32_t *dpre = dalloc<uint32_t>(pre.size()), *dptr = dalloc<uint32_t>(ptr.size()); float *dv = dalloc<float>(vals.size() + 1);
         rt_h2d(dfl, fl.data(), fl.size() * 8, s->stream); rt_h2d(dpre, pre.data(), pre.size() * 4, s->stream); rt_h2d(dptr, ptr.data(), ptr.size() * 4, s->stream);
@@ -505,7 +505,17 @@ static void launch_chain(cogaps_session *s, HostSampler &h)
     const int slot = timing_slot(s, h, 1, h.evalLaunches);
     const SamplerDev CG_CONSTANT *rec = (const SamplerDev CG_CONSTANT *)h.dRecord;
     const uint32_t parity = h.chainParity; h.chainParity ^= 1u;
-    if (h.d.redW > 1024u) {
+    if (h.d.sparse) {
+        // sparse model (sparse_kernels.h, chain_sparse_kernel): the launch has 512 threads per workgroup whatever the model's width
+        // (255 evaluation workgroups + the generator = the chip's 256 compute units: a batch of the 256-attempt window then fits one pass --
+        // the sparse evaluation has no pairs, a second pass costs a whole evaluation; the dense launch keeps 240, profiles/r04_ab_chained_launch_not_kept.txt)
+        const uint32_t grid = std::min<uint32_t>(h.d.queueCap, s->computeUnits >= 256u ? 255u : CHAIN_EVAL_GRID) + 1u;
+        const bool wide = h.d.Wn > cogaps_sparse_width(h.d.N), big = h.genWin == (uint32_t)GEN_WIN;
+        if (big && wide) LAUNCH_MAYBE_TIMED(slot, (chain_sparse_kernel<GEN_WIN, true>), grid, CHAIN_MAX_THREADS, h.d.lcgMul, h.d.lcgInc, h.d.gs, h.d.queue, h.chainGrans, h.d.chainSlots, h.d.queueCap, parity, rec);
+        else if (big) LAUNCH_MAYBE_TIMED(slot, (chain_sparse_kernel<GEN_WIN, false>), grid, CHAIN_MAX_THREADS, h.d.lcgMul, h.d.lcgInc, h.d.gs, h.d.queue, h.chainGrans, h.d.chainSlots, h.d.queueCap, parity, rec);
+        else if (wide) LAUNCH_MAYBE_TIMED(slot, (chain_sparse_kernel<GEN_WIN_HALF, true>), grid, CHAIN_MAX_THREADS, h.d.lcgMul, h.d.lcgInc, h.d.gs, h.d.queue, h.chainGrans, h.d.chainSlots, h.d.queueCap, parity, rec);
+        else LAUNCH_MAYBE_TIMED(slot, (chain_sparse_kernel<GEN_WIN_HALF, false>), grid, CHAIN_MAX_THREADS, h.d.lcgMul, h.d.lcgInc, h.d.gs, h.d.queue, h.chainGrans, h.d.chainSlots, h.d.queueCap, parity, rec);
+    } else if (h.d.redW > 1024u) {
         // split evaluation: the evaluation workgroups are a multiple of the slices per proposal (chain_kernel.h)
         uint32_t bs, slices; split_geometry(h, bs, slices);
         const uint32_t groups = std::max<uint32_t>(1u, std::min<uint32_t>(h.d.queueCap, CHAIN_EVAL_GRID / slices));
@@ -584,7 +594,9 @@ static bool chain_eligible(const cogaps_session *s, const HostSampler &h)
 {
     // (a device with fewer compute units than the launch has workgroups -- a partitioned GPU -- would run them in turns, the generator
     // workgroup last: correct, and slower than two launches)
-    if (s->noChain || h.d.seq || h.d.sparse) return false;
+    if (s->noChain || h.d.seq) return false;
+    if (h.d.sparse)      // sparse model (round 5): a launch of 512-thread workgroups, the evaluation keeps the model's width inside it
+        return CHAIN_MAX_THREADS >= h.genWin + 64u && (s->forceChain || s->computeUnits >= std::min<uint32_t>(h.d.queueCap, CHAIN_EVAL_GRID) + 1u);
     uint32_t block = h.d.redW;
     if (h.d.redW > 1024u) {      // split evaluation (round 5): workgroups of 512 threads, at most as many slices per proposal as the launch has evaluation workgroups
         uint32_t slices; split_geometry(h, block, slices);

@@ -63,11 +63,13 @@ __device__ unsigned long long g_eval_timeline[2 * 16 * 2 * 12];     // [narrow |
 // lane-order sum of the NC components whose per-wave, per-slot partials sit in lds[wave][NC][V] (after a
 // barrier): wave 0 folds them, lane i < NC*V over the waves (bits 6.. of the virtual lane index), then the
 // thread-slot bits across lanes.  Totals are returned in wave 0.
+// (nwaves: the workgroup's waves that took part -- all of them unless the caller says otherwise: an evaluation workgroup inside a chained
+// launch of the sparse model has the launch's size and the model's width)
 template <int NC, int V>
-CG_DEVICE void eval_vfinish(const float *lds, float (&tot)[NC])
+CG_DEVICE void eval_vfinish(const float *lds, float (&tot)[NC], const uint32_t nwaves = 0u)
 {
     constexpr int NV = NC * V;
-    const uint32_t t = cg_tid(), nw = cg_fresh_u32(cg_bdim() >> 6);
+    const uint32_t t = cg_tid(), nw = cg_fresh_u32(nwaves ? nwaves : (cg_bdim() >> 6));
     if (t < 64u) {
         const uint32_t i = t < (uint32_t)NV ? t : 0u;
         // all sixteen slots are read at once (one wait instead of one per wave) and the ones past the last wave masked afterwards:

@@ -157,6 +157,7 @@ struct SamplerDev {
     uint32_t sparse;       // 1: useSparseOptimization
     uint32_t Wn, Mw, oMw;  // flag words per data vector (N/64+1), per column of this matrix (M/64+1) and of the other one
     uint32_t Kpad, oKpad;  // row stride of the row copies
+    uint32_t spW;          // cogaps_sparse_width(N): threads = virtual lanes of an evaluation workgroup (the launch's block size, except inside a chained launch, which has the generator's)
     const unsigned long long *dflags; const uint32_t *dprefix, *dptr; const float *dvals;
     float *rows;           // [M][Kpad] HybridMatrix row copy (mMatrix(r,c))
     unsigned long long *mflags;        // [K][Mw] flags of the column copy `mat`

@@ -1153,6 +1153,8 @@ struct ChainItem {
     // what the decision touches, by name (the notes for the window drawn ahead): the neighbours, the partner and its left neighbour, the
     // two matrix cells (bins), the atom's slot in the unsorted vector
     uint32_t hL, hR, h2, l2, cell1, cell2, idx;
+    // sparse model (HybridMatrix: row copy, column copy with its epsilon rule and flag word, flagged count -- sp_change_matrix / sp_safely_change_matrix)
+    uint32_t sparse; float *rows1, *rows2; unsigned long long *fl1, *fl2; unsigned long long fbit1, fbit2; float colv1, colv2; uint32_t flg1, flg2;
 };
 CG_DEVICE void chain_item_clear(ChainItem &it)
 {
@@ -1162,9 +1164,11 @@ CG_DEVICE void chain_item_clear(ChainItem &it)
     it.pos1 = nullptr; it.rposL = nullptr; it.lposR = nullptr; it.head1 = nullptr; it.head2 = nullptr; it.head1Val = CG_NONE; it.h1 = 0;
     it.b0clr = nullptr; it.b0set = nullptr; it.b1set = nullptr; it.b2set = nullptr; it.bit1 = 0; it.bit2 = 0; it.bit1w = 0; it.bit2w = 0;
     it.hL = CG_NONE; it.hR = CG_NONE; it.h2 = CG_NONE; it.l2 = CG_NONE; it.cell1 = 0; it.cell2 = 0; it.idx = 0;
+    it.sparse = 0; it.rows1 = nullptr; it.rows2 = nullptr; it.fl1 = nullptr; it.fl2 = nullptr; it.fbit1 = 0ull; it.fbit2 = 0ull; it.colv1 = 0.f; it.colv2 = 0.f; it.flg1 = 0; it.flg2 = 0;
 }
 // what the second trip brings: the atom's record, the partner's left link, a move's old bin head and upper bitmap words
-struct ChainMid { AtomRec a; uint32_t l2, head1, b1, b2; unsigned long long x1, x2; };
+struct ChainMid { AtomRec a; uint32_t l2, head1, b1, b2; unsigned long long x1, x2;
+                  float colv1, colv2; unsigned long long fw1, fw2; };      // sparse model: the column copy's entries and their flag words (sp_cell_load)
 CG_DEVICE ChainMid chain_fetch_mid(const SamplerDev &S, const PropRec &p)
 {
     // every lane issues every load (a lane without a proposal, or of another type, reads harmless words: handle 0, bin 0): loads inside
@@ -1177,6 +1181,11 @@ CG_DEVICE ChainMid chain_fetch_mid(const SamplerDev &S, const PropRec &p)
     m.l2 = S.atoms[hE].left;
     m.head1 = S.binHead[m.b1];
     m.x1 = S.bits1[w1]; m.x2 = S.bits2[w2];
+    m.colv1 = 0.f; m.colv2 = 0.f; m.fw1 = 0ull; m.fw2 = 0ull;
+    if (S.sparse) {      // (wave-uniform) the HybridMatrix column copy and its flags: rows are proposal-exclusive for the whole batch, so what is read here is what the decision finds
+        m.colv1 = S.mat[(size_t)p.c1 * S.Mpad + p.r1]; m.fw1 = S.mflags[(size_t)p.c1 * S.Mw + (p.r1 >> 6)];
+        m.colv2 = S.mat[(size_t)p.c2 * S.Mpad + p.r2]; m.fw2 = S.mflags[(size_t)p.c2 * S.Mw + (p.r2 >> 6)];
+    }
     return m;
 }
 CG_DEVICE void chain_fetch_build(const SamplerDev &S, const PropRec &p, const ChainMid &m, ChainItem &it);
@@ -1197,6 +1206,15 @@ CG_DEVICE void chain_fetch_build(const SamplerDev &S, const PropRec &p, const Ch
     it.mat1 = &S.mat[(size_t)p.c1 * S.Mpad + p.r1]; it.col1 = &S.colPos[p.c1];
     const bool two = p.type == 'M' || p.type == 'E';
     if (two) { it.mat2 = &S.mat[(size_t)p.c2 * S.Mpad + p.r2]; it.col2 = &S.colPos[p.c2]; }
+    if (S.sparse) {
+        it.sparse = 1u;
+        it.rows1 = &S.rows[(size_t)p.r1 * S.Kpad + p.c1]; it.fl1 = &S.mflags[(size_t)p.c1 * S.Mw + (p.r1 >> 6)]; it.fbit1 = 1ull << (p.r1 & 63u);
+        it.colv1 = m.colv1; it.flg1 = (uint32_t)((m.fw1 >> (p.r1 & 63u)) & 1ull);
+        if (two) {
+            it.rows2 = &S.rows[(size_t)p.r2 * S.Kpad + p.c2]; it.fl2 = &S.mflags[(size_t)p.c2 * S.Mw + (p.r2 >> 6)]; it.fbit2 = 1ull << (p.r2 & 63u);
+            it.colv2 = m.colv2; it.flg2 = (uint32_t)((m.fw2 >> (p.r2 & 63u)) & 1ull);
+        }
+    }
     if (p.type == 'E') { const uint32_t l2 = m.l2; it.mass2 = &S.atoms[p.h2].mass; it.rm2 = l2 != CG_NONE ? &S.atoms[l2].rmass : nullptr; }
     if (p.type == 'M') {
         const uint32_t b1 = m.b1, b2 = m.b2;
@@ -1222,6 +1240,19 @@ CG_DEVICE void chain_store_matrix(float *cell, uint32_t *col, float oldv, float 
     const bool was = oldv > 0.f, is = newv > 0.f;
     if (was != is) { if (is) cg_atomic_add_u32(col, 1u); else cg_atomic_sub_u32(col, 1u); }
 }
+// sparse model: row copy = rowNew; column copy = colNew, or 0 with the flag cleared when colNew < epsilon (sp_store_col)
+CG_DEVICE void chain_store_hybrid(float *rowCell, float *colCell, unsigned long long *flagWord, unsigned long long bit, uint32_t *colCount, float rowNew, float colNew, bool wasFlagged)
+{
+    *rowCell = rowNew;
+    const bool zero = colNew < GAPS_EPSILON;
+    if (zero) {
+        if (wasFlagged) { (void)cg_atomic_and_u64(flagWord, ~bit); (void)cg_atomic_sub_u32(colCount, 1u); }
+        *colCell = 0.f;
+    } else {
+        if (!wasFlagged) { (void)cg_atomic_or_u64(flagWord, bit); (void)cg_atomic_add_u32(colCount, 1u); }
+        *colCell = colNew;
+    }
+}
 // Carries the decision out (the stores of eval_kernel.h's writer thread: atom_set_mass, eval_store_matrix, eval_domain_move); returns
 // whether the atom goes to the erase cache.  AsynchronousGibbsSampler.h:127-144 birth, :148-180 death / rebirth, :184-196 move, :201-219 exchange.
 CG_DEVICE bool chain_apply(const ChainItem &it, uint32_t code, float val)
@@ -1241,8 +1272,16 @@ CG_DEVICE bool chain_apply(const ChainItem &it, uint32_t code, float val)
     const bool doMass1 = app && tM == 0u, doMass2 = app && tE != 0u;
     if (doMass1) { *it.mass1 = n1; if (it.rm1) *it.rm1 = n1; }
     if (doMass2) { *it.mass2 = n2; if (it.rm2) *it.rm2 = n2; }
-    if (doMat1) chain_store_matrix(it.mat1, it.col1, it.old1, nv1);
-    if (doMat2) chain_store_matrix(it.mat2, it.col2, it.old2, nv2);
+    if (it.sparse) {
+        // the HybridMatrix entries (sparse_kernels.h: sp_change_matrix for a birth and a move's destination, sp_safely_change_matrix elsewhere):
+        // the row copy takes the new value; the column copy the new value -- for changeMatrix its OWN old value plus the change -- or zero
+        // below epsilon, with its flag and the column's flagged count (HybridVector.cpp:55-86)
+        if (doMat1) { const float colNew = tB ? it.colv1 + d1 : nv1; chain_store_hybrid(it.rows1, it.mat1, it.fl1, it.fbit1, it.col1, nv1, colNew, it.flg1 != 0u); }
+        if (doMat2) { const float colNew = tM ? it.colv2 + it.m1 : nv2; chain_store_hybrid(it.rows2, it.mat2, it.fl2, it.fbit2, it.col2, nv2, colNew, it.flg2 != 0u); }
+    } else {
+        if (doMat1) chain_store_matrix(it.mat1, it.col1, it.old1, nv1);
+        if (doMat2) chain_store_matrix(it.mat2, it.col2, it.old2, nv2);
+    }
     if (app && tM != 0u) {
         *it.pos1 = it.pos; if (it.rposL) *it.rposL = it.pos; if (it.lposR) *it.lposR = it.pos;
         if (it.head1) *it.head1 = it.head1Val;
@@ -1267,9 +1306,8 @@ struct GenClockEnd {
     CG_DEVICE ~GenClockEnd() { if (slot && (t & 63u) == 0u) cg_atomic_max_u64(slot, cg_realtime()); }
 };
 template <int WIN, bool ASYNC, bool CHAIN = false>
-CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
+CG_DEVICE void gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot hot, GenShared<WIN> &sh)
 {
-    CG_SHARED GenShared<WIN> sh;
     GenClockEnd clockEnd(cg_tid());
     constexpr unsigned TPB = (unsigned)WIN + 64u;       // attempt lanes + the helper wave
     const unsigned t = cg_tid();
@@ -1462,7 +1500,7 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
                 GEN_TS(33);
                 if (base == 0u) GEN_RT_AT(3, WIN);
                 const uint32_t code = have ? ((uint32_t)g0 & 0xFFu) : CHAIN_NONE;
-                if (have) unitAcc += ((uint32_t)g0 >> 8) & 0xFFFFu;
+                if (have) unitAcc += ((uint32_t)g0 >> 8) << (it.sparse ? 5u : 0u);      // (dense: units of 4N bytes; sparse: bytes / 32, GenScalars::evalBytes counts bytes there)
                 // erase cache (ConcurrentAtomicDomain.cpp:62-69): one slot per erased atom, in any order -- the flush sorts by position.
                 // (Before the stores: what the barrier below waits for is LDS traffic only.)
                 const bool er = have && code == CHAIN_ERASE, ap = have && code == CHAIN_APPLY;
@@ -1603,6 +1641,14 @@ CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
     }
 }
 
+// (the generator's LDS as the kernel's own static block; the chained launch of the sparse model places it in a block it shares with the
+// evaluation workgroups' -- a launch's workgroups all carry the kernel's static LDS, whichever role they play: chain_kernel.h)
+template <int WIN, bool ASYNC, bool CHAIN = false>
+CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
+{
+    CG_SHARED GenShared<WIN> sh;
+    gen_body_sh<WIN, ASYNC, CHAIN>(sp, hot, sh);
+}
 // WIN attempt lanes + the helper wave.  The launch's first loads need only the leading scalar arguments (preloaded into SGPRs); the
 // sampler's record is read from device memory through `sp`
 template <int WIN>

@@ -180,7 +180,7 @@ CG_DEVICE SpPre sp_preload(const SamplerDev &S, uint32_t row, uint32_t col, uint
 template <int MODE, int CAP>
 CG_DEVICE void sp_partial_rounds(const SamplerDev &S, uint32_t row, uint32_t col, uint32_t col2, float ch, const float *arow, SpBal<CAP> &bal, const SpPre &pre0, float &ps, float &pm, uint32_t &visited)
 {
-    const uint32_t BS = cg_bdim(), t = cg_tid();
+    const uint32_t BS = S.spW, t = cg_tid();
     const unsigned long long *fD = S.dflags + (size_t)row * S.Wn;
     const unsigned long long *fV = S.oflags + (size_t)col * S.oMw, *fV2 = S.oflags + (size_t)col2 * S.oMw;
     const uint32_t *pre = S.dprefix + (size_t)row * S.Wn;
@@ -265,7 +265,7 @@ CG_DEVICE void sp_partial_rounds(const SamplerDev &S, uint32_t row, uint32_t col
 template <int MODE, int CAP>
 CG_DEVICE void sp_partial_merged(const SamplerDev &S, uint32_t row, uint32_t col, uint32_t col2, float ch, const float *arow, SpBal<CAP> &bal, const SpPre &pre0, float &ps, float &pm, uint32_t &visited)
 {
-    const uint32_t BS = cg_bdim(), t = cg_tid();
+    const uint32_t BS = S.spW, t = cg_tid();
     if (S.Wn <= BS || S.Wn > (uint32_t)SP_MERGE_ROUNDS * BS) { sp_partial_rounds<MODE, CAP>(S, row, col, col2, ch, arow, bal, pre0, ps, pm, visited); return; }      // (one round: nothing to merge)
     const unsigned long long *fD = S.dflags + (size_t)row * S.Wn;
     const unsigned long long *fV = S.oflags + (size_t)col * S.oMw, *fV2 = S.oflags + (size_t)col2 * S.oMw;
@@ -348,7 +348,7 @@ template <int CAP>
 CG_DEVICE void sp_partial_pair(const SamplerDev &S, uint32_t rowA, uint32_t colA, const float *arowA, const SpPre &preA, uint32_t rowB, uint32_t colB, const float *arowB, const SpPre &preB,
                                SpBal<CAP> &bal, float (&x)[4], uint32_t &visited)
 {
-    const uint32_t BS = cg_bdim(), t = cg_tid();
+    const uint32_t BS = S.spW, t = cg_tid();
     const float *dataA = S.dvals + S.dptr[rowA], *dataB = S.dvals + S.dptr[rowB];
     const float *VA = S.other + (size_t)colA * S.Npad, *VB = S.other + (size_t)colB * S.Npad;
     if (t == 0) bal.n = 0u;
@@ -402,7 +402,7 @@ template <int CAP>
 CG_DEVICE void sp_list_rounds(const SamplerDev &S, uint32_t row, uint32_t col, const SpPre &pre0, SpBal<CAP> &bal, uint32_t tag,
                               uint32_t (&cnt)[SP_MERGE_ROUNDS], uint32_t (&base)[SP_MERGE_ROUNDS], uint32_t &mine)
 {
-    const uint32_t BS = cg_bdim(), t = cg_tid();
+    const uint32_t BS = S.spW, t = cg_tid();
     const unsigned long long *fD = S.dflags + (size_t)row * S.Wn, *fV = S.oflags + (size_t)col * S.oMw;
     const uint32_t *pre = S.dprefix + (size_t)row * S.Wn;
     unsigned long long dfl[SP_MERGE_ROUNDS], common[SP_MERGE_ROUNDS]; uint32_t dbase[SP_MERGE_ROUNDS];
@@ -445,7 +445,7 @@ template <int CAP>
 CG_DEVICE void sp_partial_merged_pair(const SamplerDev &S, uint32_t rowA, uint32_t colA, const float *arowA, const SpPre &preA, uint32_t rowB, uint32_t colB, const float *arowB, const SpPre &preB,
                                       SpBal<CAP> &bal, float (&x)[4], uint32_t &visited)
 {
-    const uint32_t BS = cg_bdim(), t = cg_tid();
+    const uint32_t BS = S.spW, t = cg_tid();
     if (S.Wn <= BS || S.Wn > (uint32_t)SP_MERGE_ROUNDS * BS || S.N >= 0x80000000u) {
         sp_partial_merged<SP_MODE_ONE, CAP>(S, rowA, colA, 0u, 0.f, arowA, bal, preA, x[0], x[1], visited);
         sp_partial_merged<SP_MODE_ONE, CAP>(S, rowB, colB, 0u, 0.f, arowB, bal, preB, x[2], x[3], visited);
@@ -505,7 +505,7 @@ template <int MODE>
 CG_DEVICE void sp_alpha_seq(const SamplerDev &S, uint32_t row, uint32_t col, uint32_t col2, float ch, const float *arow, float s0, float m0,
                             uint32_t *wcnt, float *bc, float &sOut, float &mOut, uint32_t &visited)
 {
-    const uint32_t BS = cg_bdim(), t = cg_tid(), K = S.K;
+    const uint32_t BS = S.spW, t = cg_tid(), K = S.K;
     const unsigned long long *fD = S.dflags + (size_t)row * S.Wn;
     const unsigned long long *fV = S.oflags + (size_t)col * S.oMw, *fV2 = S.oflags + (size_t)col2 * S.oMw;
     const uint32_t *pre = S.dprefix + (size_t)row * S.Wn;
@@ -588,22 +588,34 @@ CG_DEVICE void sp_safely_change_matrix(const SamplerDev &S, uint32_t row, uint32
 
 // One workgroup of W = cogaps_sparse_width(N) threads per queued proposal (AsynchronousGibbsSampler.h:127-219 over the
 // sparse model).
+// the workgroup's LDS (one struct: the chained launch places it where its generator workgroup has the generator's, chain_kernel.h)
 template <bool SEQ, bool WIDE>
-CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const uint32_t vgdim, const EvalHot hot, const EvalFirst &first)
+struct SpShared {
+    float lds[16 * 4];
+    float arowA[SP_KMAX], arowB[SP_KMAX];
+    float z2A[SP_KMAX], z2B[SP_KMAX];        // the Z2 columns of c1 / c2 (table terms)
+    float decf; uint32_t deci;
+    uint32_t nzShared;           // common non-zeros visited by this workgroup (roofline bookkeeping)
+    uint32_t seqCnt[SEQ ? SP_SEQ_WORDS + 1 : 1]; float seqBc[2];     // verification mode (sp_alpha_seq)
+    SpBal<(WIDE ? SP_BAL_CAP_WIDE : SP_BAL_CAP)> bal;                   // lane-balanced term list (sp_partial_balanced); unused in verification mode
+};
+// CHAIN: inside the chained launch (chain_kernel.h, round 5) -- the decision goes to the launch's generator workgroup as two tagged granules
+// ({code, bytes of algorithmic traffic / 32}, {value}: gaps_state.h, CHAIN_*), which carries it out on the atomic domain and the
+// HybridMatrix; nothing is written here.
+template <bool SEQ, bool WIDE, bool CHAIN>
+CG_DEVICE void eval_sparse_body_sh(const SamplerDev &S, const uint32_t vbid, const uint32_t vgdim, const EvalHot hot, const EvalFirst &first, SpShared<SEQ, WIDE> &sm)
 {
     // (eval_kernel.h: the first record's trip starts from preloaded kernel arguments, the sampler's record comes in under it)
     PropRec pNext = first.p;
     const uint32_t qlen = first.qlen;
     const float T = first.T;
-    CG_SHARED float lds[16 * 4];
-    CG_SHARED float arowA[SP_KMAX], arowB[SP_KMAX];
-    CG_SHARED float z2A[SP_KMAX], z2B[SP_KMAX];        // the Z2 columns of c1 / c2 (table terms)
-    CG_SHARED float decf; CG_SHARED uint32_t deci;
-    CG_SHARED uint32_t nzShared;           // common non-zeros visited by this workgroup (roofline bookkeeping)
-    CG_SHARED uint32_t seqCnt[SEQ ? SP_SEQ_WORDS + 1 : 1]; CG_SHARED float seqBc[2];     // verification mode (sp_alpha_seq)
-    CG_SHARED SpBal<(WIDE ? SP_BAL_CAP_WIDE : SP_BAL_CAP)> bal;                   // lane-balanced term list (sp_partial_balanced); unused in verification mode
+    float (&lds)[16 * 4] = sm.lds;
+    float (&arowA)[SP_KMAX] = sm.arowA; float (&arowB)[SP_KMAX] = sm.arowB; float (&z2A)[SP_KMAX] = sm.z2A; float (&z2B)[SP_KMAX] = sm.z2B;
+    float &decf = sm.decf; uint32_t &deci = sm.deci; uint32_t &nzShared = sm.nzShared;
+    uint32_t (&seqCnt)[SEQ ? SP_SEQ_WORDS + 1 : 1] = sm.seqCnt; float (&seqBc)[2] = sm.seqBc;
+    SpBal<(WIDE ? SP_BAL_CAP_WIDE : SP_BAL_CAP)> &bal = sm.bal;
     const uint32_t mm = SEQ ? S.mathMode : GM_MATH_PORTABLE;
-    const uint32_t t = cg_tid(), BS = cg_bdim(), K = S.K;
+    const uint32_t t = cg_tid(), BS = S.spW, K = S.K;      // (threads beyond the model's width never get here)
     const float lambda = S.lambda, beta = S.beta;
     const bool multiWave = BS > 64u;
     const bool scalarLane = !multiWave || t < 64u;
@@ -616,7 +628,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
         if (q >= qlen) break;
         EVAL_TS(1);
         uint64_t rng = p.rng;
-        const EvalAtoms ea = eval_atoms_load(S, p, t == 0u);
+        const EvalAtoms ea = eval_atoms_load(S, p, !CHAIN && t == 0u);      // (chained launch: the generator workgroup fetches what it rewrites)
         const bool two = (p.type == 'M' || p.type == 'E');
         const float m1 = p.m1, m2 = p.m2, old1 = p.old1, old2 = p.old2;     // old1/old2: the ROW copy (mMatrix(r,c))
         const bool gibbs1 = (p.gibbs & 1u) != 0u, gibbs2 = (p.gibbs & 2u) != 0u;
@@ -628,7 +640,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
         // Everything the record addresses goes out in ONE memory trip: the cells the decision will rewrite (writer), the table terms'
         // Z1 entries, the first round of flag words, and below the matrix rows / Z2 columns for LDS.
         SpCell cell1, cell2; cell1.colv = 0.f; cell1.flagged = false; cell2 = cell1;
-        if (t == 0u) { cell1 = sp_cell_load(S, p.r1, p.c1); if (two) cell2 = sp_cell_load(S, p.r2, p.c2); }
+        if (!CHAIN && t == 0u) { cell1 = sp_cell_load(S, p.r1, p.c1); if (two) cell2 = sp_cell_load(S, p.r2, p.c2); }
         const float z1a = need ? S.Z1[p.c1] : 0.f, z1b = (need && two) ? S.Z1[p.c2] : 0.f;
         SpPre preA, preB; preA.dfl = preA.fv = 0ull; preA.dbase = 0u; preB = preA;
         if (!SEQ && need) { preA = sp_preload(S, p.r1, p.c1, p.c2, two && !diff); if (diff) preB = sp_preload(S, p.r2, p.c2, 0u, false); }
@@ -686,7 +698,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
             if (multiWave) {
                 if ((t & 63u) == 0) { for (int c = 0; c < 4; ++c) lds[(t >> 6) * 4 + c] = x[c]; }
                 cg_sync();
-                eval_vfinish<4, 1>(lds, tot);
+                eval_vfinish<4, 1>(lds, tot, BS >> 6);
             }
             EVAL_TS(4);
             if (scalarLane) {
@@ -711,13 +723,23 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
         }
         EVAL_PIN(s); EVAL_TS(5);
         s = s * T; smu = smu * T;
-        const bool writer = t == 0u;
-#define SP_BCAST(F0, I0) do { if (multiWave) { if (t == 0) { decf = (F0); deci = (I0); } cg_sync(); (F0) = decf; (I0) = deci; } } while (0)
+        const bool writer = !CHAIN && t == 0u;
+        // roofline bookkeeping in bytes (sparse): per alpha call the flag words of the data vector and of the
+        // column(s), this matrix row and a Z2 column; per common non-zero the data value, the column entry and a row of
+        // the other matrix.  (Every path above has passed a barrier since the lanes added their counts, or is one wave.)
+        uint32_t bytes = 0;
+        if (t == 0u && need) bytes = (diff ? 2u : 1u) * (16u * S.Wn + 8u * K) + ((two && !diff) ? 8u * S.Wn : 0u) + nzShared * (8u + 4u * K);
+        // chained launch: thread 0 hands the decision to the launch's generator workgroup the moment it is made (eval_kernel.h, EVAL_PUBLISH)
+#define SP_PUBLISH(CODE, VAL) do { if (CHAIN && t == 0u) { unsigned long long *gr_ = hot.grans + (size_t)q * CHAIN_GRAN_STRIDE; \
+        cg_store_agent_u64(&gr_[0], ((unsigned long long)first.tag << 32) | (unsigned long long)((CODE) | (((bytes + 16u) >> 5) << 8))); \
+        cg_store_agent_u64(&gr_[1], ((unsigned long long)first.tag << 32) | (unsigned long long)gm_f2u(VAL)); } } while (0)
+#define SP_BCAST(F0, I0) do { if (multiWave && !CHAIN) { if (t == 0) { decf = (F0); deci = (I0); } cg_sync(); (F0) = decf; (I0) = deci; } } while (0)
         if (p.type == 'B') {
             float bv = 0.f; uint32_t bhas = 0;
             if (scalarLane) {
                 if (gibbs1) { OptF g = gm_gibbs_mass(s, smu, 0.f, S.maxGibbsMass, rng, S.luts, true, lambda); bv = g.v; bhas = g.has ? 1u : 0u; }
                 else { bv = pcg_exponential(rng, lambda, mm); bhas = 1u; }
+                if (bhas != 0u && bv >= GAPS_EPSILON) SP_PUBLISH(CHAIN_APPLY, bv); else SP_PUBLISH(CHAIN_ERASE, 0.f);
             }
             SP_BCAST(bv, bhas);
             if (bhas != 0u && bv >= GAPS_EPSILON) {
@@ -729,6 +751,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
                 if (gibbs1) { OptF g = gm_gibbs_mass(s, smu, 0.f, S.maxGibbsMass, rng, S.luts, true, lambda); if (g.has) rebirth = g.v; }
                 const float deltaLL = rebirth * (smu - s * rebirth / 2.f);
                 acc = (gm_logf_m(pcg_uniform(rng), mm) < deltaLL) ? 1u : 0u;
+                if (acc != 0u) { if (rebirth != m1) SP_PUBLISH(CHAIN_APPLY, rebirth); else SP_PUBLISH(CHAIN_NONE, 0.f); } else SP_PUBLISH(CHAIN_ERASE, 0.f);
             }
             SP_BCAST(rebirth, acc);
             if (writer) {
@@ -737,7 +760,8 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
             }
         } else if (p.type == 'M') {
             uint32_t acc = 0; float unused = 0.f;
-            if (scalarLane) { const float deltaLL = -1.f * m1 * (smu + s * m1 / 2.f); acc = (gm_logf_m(pcg_uniform(rng), mm) < deltaLL) ? 1u : 0u; }
+            if (scalarLane) { const float deltaLL = -1.f * m1 * (smu + s * m1 / 2.f); acc = (gm_logf_m(pcg_uniform(rng), mm) < deltaLL) ? 1u : 0u;
+                              if (acc) SP_PUBLISH(CHAIN_APPLY, 0.f); else SP_PUBLISH(CHAIN_NONE, 0.f); }
             SP_BCAST(unused, acc);
             if (acc && writer) {
                 eval_domain_move(S, p, ea.a1);
@@ -746,7 +770,8 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
             }
         } else if (need) {
             float gv = 0.f; uint32_t gh = 0;
-            if (scalarLane) { OptF g0 = gm_gibbs_mass(s, smu, -m1, m2, rng, S.luts, false, 0.f); gv = g0.v; gh = g0.has ? 1u : 0u; }
+            if (scalarLane) { OptF g0 = gm_gibbs_mass(s, smu, -m1, m2, rng, S.luts, false, 0.f); gv = g0.v; gh = g0.has ? 1u : 0u;
+                              if (gh != 0u && m1 + gv > GAPS_EPSILON && m2 - gv > GAPS_EPSILON) SP_PUBLISH(CHAIN_APPLY, gv); else SP_PUBLISH(CHAIN_NONE, 0.f); }
             SP_BCAST(gv, gh);
             const float n1 = m1 + gv, n2 = m2 - gv;
             if (gh != 0u && n1 > GAPS_EPSILON && n2 > GAPS_EPSILON && writer) {
@@ -755,6 +780,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
                 atom_set_mass(S, p.h1, ea.a1.left, n1); atom_set_mass(S, p.h2, ea.left2, n2);
             }
         }
+        else SP_PUBLISH(CHAIN_NONE, 0.f);      // an exchange that cannot use Gibbs: nothing happens, the generator still waits for its word
         EVAL_TS(6);
 #if defined(GEN_TIMELINE)
         if (cg_bid() < 16u && (t & 63u) == 0u && ((t >> 6) == 0u || (t >> 6) == ((BS - 1u) >> 6)) && qlen >= 20u) {
@@ -763,18 +789,17 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
             for (uint32_t i_ = 0; i_ < 11u; ++i_) o_[1 + i_] = i_ < ets_n ? ets[i_] : 0ull;
         }
 #endif
-        if (writer) {
-            // roofline bookkeeping in bytes (sparse): per alpha call the flag words of the data vector and of the
-            // column(s), this matrix row and a Z2 column; per common non-zero the data value, the column entry and a row of
-            // the other matrix.  (Every path above has passed a barrier since the lanes added their counts, or is one wave.)
-            uint32_t bytes = 0;
-            if (need) bytes = (diff ? 2u : 1u) * (16u * S.Wn + 8u * K) + ((two && !diff) ? 8u * S.Wn : 0u) + nzShared * (8u + 4u * K);
-            S.queueUnits[q] = bytes;
-        }
+        if (writer) S.queueUnits[q] = bytes;
         if (q + vgdim >= qlen) break;
         { const uint32_t qn_ = q + vgdim; pNext = hot.queue[qn_ < hot.queueCap ? qn_ : 0u]; }
         cg_sync();
     }
+}
+template <bool SEQ, bool WIDE>
+CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const uint32_t vgdim, const EvalHot hot, const EvalFirst &first)
+{
+    CG_SHARED SpShared<SEQ, WIDE> sm;
+    eval_sparse_body_sh<SEQ, WIDE, false>(S, vbid, vgdim, hot, first, sm);
 }
 CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_kernel(const PropRec *hotQueue, const GenScalars *hotGs, uint32_t hotCap, const SamplerDev CG_CONSTANT *sp)
 {
@@ -990,4 +1015,33 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(256) chisq_sparse_seq_kernel(SamplerDev S, float
         acc = seq_sum(acc, nnz, lds, [&](uint64_t e) { return S.seqScratch[e]; });
     }
     if (t == 0) out[0] = acc;
+}
+
+// ---- the chained launch of the sparse model (round 5; chain_kernel.h for the scheme) ----------------------------------------------------------
+// Workgroups 0 .. n-2 evaluate batch b as eval_sparse_kernel[_wide] does and hand each decision to the LAST workgroup, the generator of
+// batch b + 1, which carries it out on the atomic domain and the HybridMatrix (gen_populate.h: chain_apply, chain_store_hybrid).  The
+// sparse evaluation is long (15-27 us per batch at BASELINE configs[4]'s shard shape against ~8 us of generator work that does not
+// depend on the decisions), so the generator's prologue, classification and draws disappear behind it.  One static LDS block serves
+// both roles -- a launch's workgroups all carry the kernel's static LDS, and the two roles' blocks side by side (142 + 49 / 90 KB) exceed
+// a compute unit's 160 KB.  The launch has the generator's workgroup size (512 threads: window + helper wave + applier waves); an
+// evaluation workgroup keeps the model's width (S.spW threads = virtual lanes: the parity contract), its further waves leave at once.
+template <int WIN, bool WIDE>
+CG_KERNEL void CG_LAUNCH_BOUNDS(CHAIN_MAX_THREADS) chain_sparse_kernel(const uint64_t *lcgMul, const uint64_t *lcgInc, GenScalars *gs, PropRec *queue, unsigned long long *grans, ChainSlot *slots,
+                                                                       uint32_t queueCap, uint32_t parity, const SamplerDev CG_CONSTANT *sp)
+{
+    constexpr size_t POOL = sizeof(GenShared<WIN>) > sizeof(SpShared<false, WIDE>) ? sizeof(GenShared<WIN>) : sizeof(SpShared<false, WIDE>);
+    CG_SHARED alignas(16) unsigned char pool[POOL];
+    if (cg_bid() + 1u == cg_gdim()) {
+        GenHot hot; hot.lcgMul = lcgMul; hot.lcgInc = lcgInc; hot.gs = gs; hot.eraseList = nullptr; hot.queueUnits = nullptr; hot.eraseCap = 0; hot.queueCap = queueCap;
+        hot.queueRd = queue + (size_t)parity * queueCap; hot.queueWr = queue + (size_t)(1u - parity) * queueCap; hot.grans = grans; hot.slotWr = &slots[1u - parity];
+        gen_body_sh<WIN, true, true>(sp, hot, *reinterpret_cast<GenShared<WIN> *>(pool));
+        return;
+    }
+    EvalHot hot; hot.queue = queue + (size_t)parity * queueCap; hot.gs = gs; hot.queueCap = queueCap; hot.slot = &slots[parity]; hot.grans = grans;
+    const unsigned long long clk0 = (cg_bid() == 0u && cg_tid() == 0u) ? cg_realtime() : 0ull;
+    const EvalFirst first = eval_first<EVAL_CHAIN>(hot, 1u, cg_bid());
+    const SamplerDev &S = eval_record<EVAL_CHAIN>(sp);
+    if (cg_bid() == 0u && cg_tid() == 0u && S.launchClock) S.launchClock[2u * (first.tag % GAPS_CLOCK_RING)] = clk0;      // (launch clock: gaps_state.h)
+    if (cg_tid() >= S.spW) return;
+    eval_sparse_body_sh<false, WIDE, true>(S, cg_bid(), cg_gdim() - 1u, hot, first, *reinterpret_cast<SpShared<false, WIDE> *>(pool));
 }

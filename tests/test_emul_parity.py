@@ -109,6 +109,22 @@ def test_split_evaluation(emul_lib, genes, iters):
     pu.run_stepwise(emul_lib(256), data, iters, trace=False, nPatterns=3, seed=7, total_iter=10)
 
 
+@pytest.mark.parametrize("genes,iters", [(6000, 6), (20000, 4)])
+def test_split_evaluation_inside_the_chained_launch(emul_lib, monkeypatch, genes, iters):
+    """COGAPS_CHAIN_SPLIT=1: the split evaluation as part of the chained launch (EVAL_CHAIN_SPLIT -- slices, a deciding workgroup per proposal
+    that hands the decision to the launch's generator workgroup, the A*P updates from the decisions' granules; 3 and 10 slices per
+    proposal) stepwise against the oracle.  Not the product's default (measured slower on the MI355X), kept under test."""
+    from cogaps_amd import _capi
+    monkeypatch.setenv("COGAPS_CHAIN_SPLIT", "1")
+    lib = emul_lib(256)
+    data = pu.synthetic(genes, 8, seed=genes)
+    pu.run_stepwise(lib, data, iters, trace=True, nPatterns=3, seed=7, total_iter=10)
+    S = _capi.Session(data, lib=lib, nPatterns=3, seed=7, nIterations=10)
+    S.run_iterations(1, 0, 2)
+    assert S.chained("P") == 1 and S.chained("A") == 0
+    S.close()
+
+
 def test_two_launch_split_evaluation_still_matches(emul_lib):
     """COGAPS_SPLIT_TWO_LAUNCHES=1 (the A/B switch of round 4) brings back the alpha + apply launches for one chain: the same bits as the
     one-launch form, i.e. as the oracle (the variable is read once per process: a child process runs the comparison)"""

@@ -5,8 +5,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cogaps_amd import _capi
 from bench import synthetic_dense
 PL = _capi.bind(ctypes.CDLL(os.path.join(os.path.dirname(_capi.LIB_PATH), 'libcogaps_hip_PROFILE_DEV.so')))
-data = synthetic_dense(20000, 2000)
-S = _capi.Session(data, lib=PL, nPatterns=50, nIterations=100, seed=42)
+SPARSE = '--sparse' in sys.argv
+if SPARSE:      # BASELINE configs[4]'s shard shape, as bench.py --sparse --genes 50000 --samples 12500 makes it
+    sys.argv.remove('--sparse')
+    data = synthetic_dense(50000, 12500)
+    data = (data * (np.random.Generator(np.random.MT19937(777)).random(data.shape) >= 0.95)).astype(np.float32)
+    S = _capi.Session(data, lib=PL, nPatterns=50, nIterations=100, seed=42, sparseOptimization=True)
+else:
+    data = synthetic_dense(20000, 2000)
+    S = _capi.Session(data, lib=PL, nPatterns=50, nIterations=100, seed=42)
 S.run_iterations(1, 0, int(sys.argv[1]) if len(sys.argv) > 1 else 60)
 N = 65536
 buf = (ctypes.c_uint64 * (N * 8))(); n = ctypes.c_uint32()
