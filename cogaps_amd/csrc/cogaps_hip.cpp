@@ -5,6 +5,7 @@
 // the atomic domains and the proposal queues resident in HBM.  The host only draws the per-iteration
 // Poisson step counts (GapsRunner.cpp:294-295), streams the Xoroshiro seed sequence the proposal
 // generator consumes (math/Random.cpp:221-248) and enqueues kernels.
+#include <atomic>
 #include "../../include/cogaps_hip.h"
 #include "rt.h"
 #include "gaps_state.h"
@@ -490,6 +491,12 @@ static uint32_t apply_grid()
 #endif
     return g < 1u ? 1u : g;
 }
+// Updates in flight in this process (sessions stepped from several host threads: shards in flight, bench --chains-mode threads).  A chained
+// launch wants every workgroup of its launch resident at once -- one per compute unit: its kernel's LDS -- so two chains' chained launches
+// take turns on the chip and the hand-over inside each waits for the other's workgroups to leave (correct, and slower than two launches
+// per batch each).  The chained form is therefore taken only by an update that runs alone; the count is looked at when an update begins.
+static std::atomic<int> &g_updatesRunning() { static std::atomic<int> n{0}; return n; }
+struct UpdateInFlight { UpdateInFlight() { g_updatesRunning().fetch_add(1); } ~UpdateInFlight() { g_updatesRunning().fetch_sub(1); } };
 // The chained launch serves the one-chain fused evaluation (dense model, product arithmetic) whose workgroups are at least as large as
 // the generator's and small enough for the generator's register budget (chain_kernel.h); everything else keeps two launches per batch.
 static bool chain_eligible(const cogaps_session *s, const HostSampler &h);
@@ -595,6 +602,7 @@ static bool chain_eligible(const cogaps_session *s, const HostSampler &h)
     // (a device with fewer compute units than the launch has workgroups -- a partitioned GPU -- would run them in turns, the generator
     // workgroup last: correct, and slower than two launches)
     if (s->noChain || h.d.seq) return false;
+    if (g_updatesRunning().load() > 1 && !s->forceChain) return false;      // (another session's update is in flight on this process's GPU: see g_updatesRunning)
     if (h.d.sparse)      // sparse model (round 5): a launch of 512-thread workgroups, the evaluation keeps the model's width inside it
         return CHAIN_MAX_THREADS >= h.genWin + 64u && (s->forceChain || s->computeUnits >= std::min<uint32_t>(h.d.queueCap, CHAIN_EVAL_GRID) + 1u);
     uint32_t block = h.d.redW;
@@ -678,6 +686,7 @@ static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool t
 {
     SamplerDev &d = h.d;
     if (s->poisoned) return fail("this session was ended by a device error in an earlier update; its chain cannot be continued");
+    UpdateInFlight inFlight;
     read_gs(s, h);
     GenScalars g = *s->hGs;
     grow_atoms(s, h, g.nAtoms + nSteps + 1024u);
@@ -874,6 +883,7 @@ cogaps_session *cogaps_session_create(const float *data, uint32_t nrow, uint32_t
         s = new cogaps_session(); s->computeUnits = rt_compute_units();
         s->p = p;
         s->p.device = rt_get_device();            // (-1 resolved: later calls from other host threads select the same GPU)
+        g_updatesRunning();                       // (the counter exists before any session steps)
         s->startTime = now_s();
         if (p.printMessages) { printf("Loading Data..."); fflush(stdout); }                  // GapsRunner.cpp:399
         if (p.subsetData && p.dataIndicesSubset) s->subset.assign(p.dataIndicesSubset, p.dataIndicesSubset + p.nSubset);

@@ -1378,6 +1378,7 @@ CG_DEVICE void gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot hot, G
     uint64_t seedC = 0ull; bool dpStaged = false, trySpec = false, specDone = false; uint32_t dpBase = 0;
     GenSpec specKeep; specKeep.bBefore = 0; specKeep.dBefore = 0; specKeep.guess = 0; specKeep.active = 0; specKeep.u1 = 0.f; specKeep.u2 = 0.f; specKeep.go = 0; specKeep.ct = 0; specKeep.info = 0;
     specKeep.rng = 0; specKeep.pos = 0; specKeep.bin = 0; specKeep.r1 = 0; specKeep.c1 = 0;
+    uint64_t epoch0 = 0;
     GenDraw drawKeep; gen_draw_clear(drawKeep);      // chained launch: the lane's attempt of the next window, drawn ahead of the decisions
     GenCheck checkKeep; checkKeep.atomA.a = checkKeep.atomA.b = checkKeep.atomB.a = checkKeep.atomB.b = checkKeep.slot.a = checkKeep.slot.b = 0u;
     checkKeep.cellA.a = checkKeep.cellA.b = checkKeep.cellB.a = checkKeep.cellB.b = 0u; checkKeep.iPartS = 1u;
@@ -1454,7 +1455,8 @@ CG_DEVICE void gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot hot, G
         if (have0) chain_fetch_build(S, p0, mid0, it);
         if (helper && ht < 16u) sh.freeTop[ht] = freeTopAhead;
         GEN_TS(32);
-        const uint32_t tag = (uint32_t)sh.g.batchEpoch;      // the batch in the queue: the one this workgroup generated in the previous launch
+        epoch0 = sh.g.batchEpoch;
+        const uint32_t tag = (uint32_t)epoch0;      // the batch in the queue: the one this workgroup generated in the previous launch
         if (S.launchClock) clockEnd.slot = S.launchClock + 2u * (tag % GAPS_CLOCK_RING) + 1u;
 #if defined(COGAPS_EMUL)
         if (t == 0 && e_prevQ) cg_atomic_add_u64(&gs->prof[13], 1ull);      // test-only build: batches whose decisions arrived inside a chained launch
@@ -1545,13 +1547,14 @@ CG_DEVICE void gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot hot, G
         if (drawAhead) cg_sync_lds(); else cg_sync();
         GEN_TS(35);
         GEN_RT(4);
-        if (cg_uniform_u32(sh.spinFail) != 0u) return;      // a decision never arrived (GAPS_ERR_SPIN is set): every wave leaves, nothing is generated
+        const uint32_t sfRaw = sh.spinFail, emRaw = sh.eraseN;      // (both words in one LDS trip)
+        if (cg_uniform_u32(sfRaw) != 0u) return;      // a decision never arrived (GAPS_ERR_SPIN is set): every wave leaves, nothing is generated
         if (spare) {                                        // (the waves beyond the helper wave only applied)
             if (drawAhead && !updateDone) { cg_sync_lds(); cg_sync(); }
             { const bool ts_ok = e_prevQ >= 140u && e_nSteps - e_nDone >= 512u; (void)ts_ok; GEN_TS_DUMP_WAVE(); }
             return;
         }
-        e_m = cg_uniform_u32(sh.eraseN);
+        e_m = cg_uniform_u32(emRaw);
         if (e_m > eraseCap) e_m = eraseCap;
         if (helper) specE = (ht < (unsigned)FLUSH_MAX && ht < e_m) ? sh.eraseTmp[ht] : 0ull;
         specDone = drawAhead;
@@ -1596,13 +1599,15 @@ CG_DEVICE void gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot hot, G
         tabHi = fromWin ? sh.dpWin[n0 + t - dpBase] : S.deathProb[n0 + t]; tabLo = (n0 >= t) ? (fromWin ? sh.dpWin[n0 - t - dpBase] : S.deathProb[n0 - t]) : 0.f;
         dp0 = fromWin ? sh.dpWin[n0 - dpBase] : gm_death_prob((double)(uint64_t)n0, S.domainLenD, S.alphaD, S.numBins);
     }
-    const uint64_t batchEpoch = sh.g.batchEpoch + 1;
+    const uint64_t batchEpoch = (CHAIN ? epoch0 : sh.g.batchEpoch) + 1;
     const uint32_t updBase = e_nDone;           // attempts consumed by earlier batches of this update
     const uint32_t remaining = e_nSteps - e_nDone;
     const uint32_t K = S.K;
     // round 1 takes its scalars from the LDS copy of GenScalars (complete since the first barrier); the helper wave writes the round
     // variables' LDS copies, which later phases and rounds read
-    const uint64_t g_qrng = sh.g.qrng; const uint32_t g_skip = sh.g.useCached ? 1u : 0u; const float g_u1 = sh.g.u1, g_u2 = sh.g.u2;
+    // (a window drawn ahead has consumed these already: nothing of them is read behind the decisions)
+    uint64_t g_qrng = 0; uint32_t g_skip = 0; float g_u1 = 0.f, g_u2 = 0.f;
+    if (!(CHAIN && specDone)) { g_qrng = sh.g.qrng; g_skip = sh.g.useCached ? 1u : 0u; g_u1 = sh.g.u1; g_u2 = sh.g.u2; }
 
     GenRoundCtx rc; rc.t = t; rc.jm0 = jm0; rc.ji0 = ji0; rc.jm1 = jm1; rc.ji1 = ji1; rc.seed1 = seed1; rc.batchEpoch = batchEpoch; rc.g_qrng = g_qrng; rc.n0 = n0; rc.updBase = updBase;
     rc.remaining = remaining; rc.K = K; rc.g_skip = g_skip; rc.e_prevQ = e_prevQ; rc.dp0 = dp0; rc.g_u1 = g_u1; rc.g_u2 = g_u2; rc.gs = gs; rc.tabHi = tabHi; rc.tabLo = tabLo;

@@ -29,5 +29,5 @@ if [ -n "$PROF" ]; then
   python tools/prof_summary.py /tmp/prof > $O/rocprofv3_kernel_trace_summary.txt 2>&1; head -8 $O/rocprofv3_kernel_trace_summary.txt
   cp $(find /tmp/prof -name '*kernel_stats.csv' | head -1) $O/rocprofv3_kernel_stats.csv 2>/dev/null
   python tools/prof_dist.py /tmp/prof > $O/rocprofv3_kernel_duration_percentiles.txt 2>&1; cat $O/rocprofv3_kernel_duration_percentiles.txt
-  [ -n "$PROF_WINDOW" ] && python tools/prof_dist.py /tmp/prof --last-steps $PROF_WINDOW > $O/rocprofv3_kernel_duration_percentiles_timed_window.txt 2>&1
+  python tools/prof_dist.py /tmp/prof --bench-json $O/bench_under_rocprofv3.json > $O/rocprofv3_kernel_duration_percentiles_timed_window.txt 2>&1; cat $O/rocprofv3_kernel_duration_percentiles_timed_window.txt
 fi
