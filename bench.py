@@ -41,7 +41,7 @@ def synthetic_dense(n_genes, n_samples, rank=10, seed=12345):
     return np.ascontiguousarray(d, dtype=np.float32)
 
 
-def cpu_baseline(data, params, budget_s, state, first_step, n_steps):
+def cpu_baseline(data, params, budget_s, state, first_step, n_steps, threads_only=None):
     """The oracle (oracle/gaps_oracle.c: OpenMP over the queue exactly like the reference's `#pragma omp parallel for`,
     sequential fp32 reductions + libm = the reference's scalar build) timed on this host ON THE ITERATIONS THE GPU IS TIMED ON: the
     port's session takes over the chain state the GPU had at the start of its timed window (atoms and factor matrices, copied out
@@ -61,6 +61,8 @@ def cpu_baseline(data, params, budget_s, state, first_step, n_steps):
     plan = [(t, 0.94 * budget_s / len(small)) for t in small]
     if ncpu not in small:
         plan.append((ncpu, 0.06 * budget_s))
+    if threads_only is not None:      # (N > 1: one leg per rank, all ranks at once)
+        plan = [(int(threads_only), 0.4 * budget_s)]
     n_iter = params["nIterations"]
     best, by_threads = None, []
     for threads, share in plan:
@@ -375,7 +377,7 @@ def main():
     run_steps(burn, W)
     # the chain state at the start of the timed window, for the CPU baseline's like-for-like sample (copied out before the timed region)
     cpu_state = None
-    if rank == 0 and not args.no_cpu:
+    if (rank == 0 or world > 1) and not args.no_cpu:      # (N > 1: every rank times the port on ITS shard, all at once: below)
         cpu_state = {"atomsA": S.atoms("A"), "A": S.rows("A"), "atomsP": S.atoms("P"), "P": S.rows("P")}
     perf0 = {w: S.perf(w) for w in "AP"}
     S.set_timing(True)
@@ -410,6 +412,20 @@ def main():
         dist.all_gather(per_rank, torch.tensor([dt], dtype=torch.float64, device=comm_dev))
         rank_seconds = sorted(float(x.item()) for x in per_rank)
 
+    # N > 1: the CPU comparator of a GWCoGAPS / scCoGAPS job is nSets port runs, one per subset.  They are MEASURED side by
+    # side, not extrapolated from one shard: every rank runs the port on its own shard's timed window at the same time (one leg,
+    # min(16, host threads / ranks) OpenMP threads each, started behind a barrier), and the job's figure is the sum of the ranks' rates
+    side_by_side = None
+    if world > 1 and not args.no_cpu:
+        thr = max(1, min(16, (os.cpu_count() or 1) // world))
+        dist.barrier()
+        mine = cpu_baseline(data, params, args.cpu_seconds, cpu_state, burn + W, K, threads_only=thr)
+        leg = mine["by_threads"][0] if mine.get("by_threads") else {"value": 0.0, "iterations": 0}
+        t = torch.tensor([float(leg["value"] or 0.0), float(leg["iterations"])], dtype=torch.float64, device=comm_dev)
+        ssum = t.clone(); dist.all_reduce(ssum, op=dist.ReduceOp.SUM)
+        smin = t.clone(); dist.all_reduce(smin, op=dist.ReduceOp.MIN)
+        side_by_side = {"value": float(ssum[0].item()), "threads_per_shard": thr, "iterations_covered_by_the_slowest_rank": int(smin[1].item()),
+                        "slowest_shard_value": float(smin[0].item()), "rank0": mine}
     if rank == 0:
         # HIP start/stop events ride on the dispatch packets of a sample of the launches (hipExtLaunchKernelGGL on the kernels'
         # own stream): begin-to-end time of the dispatch, the quantity rocprofv3 --kernel-trace reports.  The library scales the
@@ -493,7 +509,7 @@ def main():
                 traffic_stale = traffic_measured_on != lib_hash
                 traffic_kernels = {k: v["hbm_bytes_per_launch"] for k, v in pk.items()}
                 tb = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in pk.values())
-                nb = sum(v["launches"] for k, v in pk.items() if k.startswith("gen_kernel") or k.startswith("chain_kernel"))      # one generator (or chained) launch per batch
+                nb = sum(v["launches"] for k, v in pk.items() if k.startswith("gen_kernel") or k.startswith("chain_") or k.startswith("void chain_"))      # one generator (or chained) launch per batch
                 if nb and not traffic_stale:
                     traffic = tb / nb
                 if nb:
@@ -535,16 +551,18 @@ def main():
                          "kernels": kernels},
         }
         if not args.no_cpu:
-            cb = cpu_baseline(data, params, args.cpu_seconds, cpu_state, burn + W, K)
+            if world > 1:
+                # measured above, all shards at once (round 4 multiplied rank 0's figure by nSets)
+                cb = dict(side_by_side["rank0"])
+                cb["value_rank0_shard"] = cb.get("value")
+                cb["value"] = side_by_side["value"] if side_by_side["iterations_covered_by_the_slowest_rank"] > 0 else None
+                cb["cores"] = side_by_side["threads_per_shard"] * world
+                cb["side_by_side"] = {k: v for k, v in side_by_side.items() if k != "rank0"}
+                cb["sample"] = ("SUM over the %d shards' port runs made side by side on this host (%d OpenMP threads each, every rank its own shard's timed window, "
+                                "started together): rank 0's: " % (world, side_by_side["threads_per_shard"])) + str(cb.get("sample"))
+            else:
+                cb = cpu_baseline(data, params, args.cpu_seconds, cpu_state, burn + W, K)
             if cb["value"] is not None:
-                if world > 1:
-                    # the CPU comparator of a GWCoGAPS / scCoGAPS job is nSets port runs, one per subset.  Rank 0's
-                    # shard was timed (same window, same start state); the job's figure is that rate x nSets -- the subsets are of one
-                    # shape, the host runs them side by side (`cores` threads each of its `host_cpus`) -- labelled as the extrapolation it is
-                    cb["value_one_shard"] = cb["value"]
-                    cb["value"] = cb["value"] * world
-                    cb["sample"] = ("rank 0's shard x nSets = %d (BASELINE.md 3.5: one port run per subset with its dataIndicesSubset, side by side on the host; "
-                                    "one shard measured, the others are of the same shape): " % world) + cb["sample"]
                 # like for like only when the port ran the WHOLE timed window (the driver's --steps 20 does; the 190-step default lets
                 # the port cover the window's first part, where the chain is still growing and the port is slower per proposal)
                 covered = max(b["iterations"] for b in cb["by_threads"] if b["threads"] == cb["cores"]) / float(K)

@@ -16,8 +16,12 @@
  * concurrently from different host threads, on the same GPU or on different ones (each owns one non-blocking
  * stream and the library creates no other; no legacy-stream operation is issued; graph capture is thread-local).
  * Up to four sessions per process and GPU run truly side by side (HIP's four hardware queues per process).  The library keeps no global
- * mutable state besides the per-thread last error.  Environment: COGAPS_NO_GRAPH (any value) sends every
- * kernel as a plain launch instead of replaying captured graphs -- for counter-collection tools only.
+ * mutable state besides the per-thread last error and a count of the updates in flight (a chained launch, which wants the whole chip, is
+ * taken only by an update that runs alone).  Environment, all optional, none changes a result: COGAPS_NO_GRAPH (any value) sends every
+ * kernel as a plain launch instead of replaying captured graphs -- for counter-collection tools only; COGAPS_NO_CHAIN: two launches per
+ * batch instead of the chained launch (A/B runs, equality tests); COGAPS_FORCE_CHAIN: the chained launch also where the device shows fewer
+ * compute units than the launch has workgroups or another update is in flight (tests); COGAPS_CHAIN_SPLIT: the split evaluation (data
+ * vectors of more than 4096 elements) inside the chained launch -- built and tested, measured slower, not the default.
  */
 #ifndef COGAPS_HIP_H
 #define COGAPS_HIP_H

@@ -252,6 +252,31 @@ def test_chained_equals_two_launches_on_the_gpu(hip_lib, monkeypatch):
     assert chained == plain
 
 
+def test_launch_clock_of_chained_launches(hip_lib):
+    """cogaps_session_launch_clock: the chip-wide clock read inside EVERY chained launch since set_timing(1) (replayed graphs included) --
+    as many launches as the sampler generated batches in the window (one launch per batch; the update's first launch evaluates nothing
+    and is not counted), plausible durations, ordered percentiles; nothing for a sampler that does not chain."""
+    from cogaps_amd import _capi
+    c = _CHAIN_AB
+    S = _capi.Session(pu.synthetic(c["genes"], c["samples"], rank=5, seed=3), lib=hip_lib, nPatterns=c["nPatterns"], nIterations=c["nIterations"], seed=c["seed"])
+    for it in range(6):
+        nA, nP = S.draw_steps(); S.iterate(nA, nP)
+    S.set_timing(True)
+    b0 = S.perf("A")["batches"]
+    for it in range(6):
+        nA, nP = S.draw_steps(); S.iterate(nA, nP)
+    batches = S.perf("A")["batches"] - b0
+    a, p = S.launch_clock("A"), S.launch_clock("P")
+    S.close()
+    assert S_chained_ok(a, batches), (a, batches)
+    assert p["launches"] == 0 and p["mean_us"] == 0.0
+
+
+def S_chained_ok(a, batches):
+    return (0.9 * batches <= a["launches"] <= batches and 3.0 < a["mean_us"] < 200.0
+            and 0 < a["p10_us"] <= a["p50_us"] <= a["p75_us"] <= a["p90_us"] <= a["p99_us"] < 2000.0)
+
+
 def test_chained_split_evaluation_equals_two_launches_on_the_gpu(hip_lib, monkeypatch):
     """The same for the split evaluation inside the chained launch (EVAL_CHAIN_SPLIT: data vectors of more than 4096 elements -- slices,
     a deciding workgroup per proposal, the A*P updates taken up by the evaluation workgroups behind their slices): 9000 x 1500, K = 12 --
@@ -560,10 +585,13 @@ def test_bench_multi_rank_path_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 12 and d["warmup"] == 4 and d["scaling"] == "weak" and d["unit"] == "proposals/s"
     assert d["value"] > 0 and d["roofline"]["traffic"] is None          # (not the shape the counters were collected on)
-    # the N > 1 line carries the CPU comparator of BASELINE.md 3.5 (rank 0's shard through the port on the same window, x nSets, labelled), the
-    # spread of the ranks' timed regions and the library build the line was measured with
+    # the N > 1 line carries the CPU comparator of BASELINE.md 3.5 -- one port run per subset, MEASURED side by side on the host (every rank its own
+    # shard's window, all at once; round 5: no longer rank 0's figure times nSets) --, the spread of the ranks' timed regions and the library build
     cb = d["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["value"] == 2 * cb["value_one_shard"] and "x nSets = 2" in cb["sample"] and cb["ten_x_line"] == 10 * cb["value"]
+    sbs = cb["side_by_side"]
+    assert cb["kind"] == "port" and cb["value"] == sbs["value"] > 0 and sbs["threads_per_shard"] >= 1 and cb["cores"] == 2 * sbs["threads_per_shard"]
+    assert 0 < sbs["slowest_shard_value"] <= cb["value"] and cb["value"] < 2.5 * max(cb["value_rank0_shard"], sbs["slowest_shard_value"])
+    assert "side by side" in cb["sample"] and cb["ten_x_line"] == 10 * cb["value"]
     rs = d["config"]["rank_seconds"]
     assert 0 < rs["min"] <= rs["median"] <= rs["max"] and abs(rs["max"] * 1e3 / 12 - d["ms_per_step"]) < 1e-6 * d["ms_per_step"] + 1e-9
     assert len(d["roofline"]["lib_source_hash"]) == 16
