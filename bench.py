@@ -565,7 +565,7 @@ def main():
             if cb["value"] is not None:
                 # like for like only when the port ran the WHOLE timed window (the driver's --steps 20 does; the 190-step default lets
                 # the port cover the window's first part, where the chain is still growing and the port is slower per proposal)
-                covered = max(b["iterations"] for b in cb["by_threads"] if b["threads"] == cb["cores"]) / float(K)
+                covered = (side_by_side["iterations_covered_by_the_slowest_rank"] if world > 1 else max(b["iterations"] for b in cb["by_threads"] if b["threads"] == cb["cores"])) / float(K)
                 cb["window_covered"] = covered
                 cb["gpu_over_cpu_same_window" if covered >= 1.0 else "gpu_over_cpu_partial_window"] = out["value"] / cb["value"]
                 # north_star's target is 10x the CPU path: where that line lies on this host and how far the GPU figure is from it
