@@ -1,21 +1,28 @@
-// chain_kernel.h -- the chained launch: ONE launch per batch for a sampler whose evaluation is the fused form.
+// chain_kernel.h -- the chained launch: ONE launch per batch.
 //
 // AsynchronousGibbsSampler::update (AsynchronousGibbsSampler.h:88-122) alternates populate and the evaluation of the queue; as two
-// launches per batch (gen_kernel, eval_kernel<EVAL_FUSED>) every batch pays two kernel boundaries and the generator's prologue --
-// kernel arguments, the sampler's record, the PCG jump coefficients, 80 KB of conflict table to empty, the seeds and the
-// death-probability rows of its window -- between the last decision and the first attempt of the next batch.  Here workgroups
-// 0 .. gridDim-2 evaluate batch n exactly as eval_kernel<EVAL_FUSED> does, and the LAST workgroup is the generator of batch n + 1: it
-// runs its prologue and fetches everything the decisions will rewrite while the evaluation workgroups work, receives each decision as a
-// pair of tagged 8-byte granules (one write-through store each, polled past its caches: MI355X guide, handoff-1to1), carries the
-// decisions out on the atomic domain and the factor matrix itself (gen_populate.h, chain_apply) and goes straight into the
-// classification.  The evaluation workgroups write nothing but the granules and their A*P rows; the A*P updates run beside the
-// generator, off the decide -> generate chain.
+// launches per batch (gen_kernel, eval_kernel) every batch pays two kernel boundaries and, between the last decision and the first
+// attempt of the next batch, everything the generator does that never needed the decisions.  Here workgroups 0 .. gridDim-2 evaluate
+// batch n exactly as the stand-alone evaluation kernels do, and the LAST workgroup is the generator of batch n + 1 (gen_populate.h,
+// gen_body<.., CHAIN>).  It has the evaluation's workgroup size and splits by wave:
+//   * attempt waves: prologue, classification of the next window with both ends' birth / death thresholds, and -- round 5 -- the window's
+//     DRAWS (picks, records, matrix entries, a birth's gap: a round's three dependent memory trips) against the domain as this
+//     workgroup's own commit left it;
+//   * applier waves (the helper wave and the waves beyond it): fetch what each decision will rewrite, receive the decision as a pair of
+//     tagged 8-byte granules (one write-through store each by the evaluation workgroup, polled past the caches: MI355X guide,
+//     handoff-1to1), carry it out on the atomic domain and the factor matrix, and note which atom records, matrix cells, vector slots
+//     and bitmap words change;
+//   * behind the join a lane that read none of these has drawn what it would draw now; the others draw again (gen_draw_valid,
+//     gen_round<.., AHEAD>) -- the same code against the current domain: bit-identical to the serial procedure.
+// The evaluation workgroups write nothing but the granules and their A*P rows; the A*P updates run beside the generator.
 //
 // What an evaluation workgroup reads when it starts -- its queue record, the queue length, the batch tag -- exists in two copies, one
 // per launch PARITY (a kernel argument: consecutive launches alternate): a launch of parity p evaluates copy p and its generator writes
 // copy 1 - p, so nothing in a launch reads what the same launch writes, however late a workgroup starts.  The generator workgroup is
-// the last one so that every evaluation workgroup has been dispatched when it begins to wait (and so that the test-only emulator, which
-// runs workgroups in index order, never spins); the grid is kept at one workgroup per compute unit or less, all resident at once.
+// the last one so that every evaluation workgroup has been dispatched when it begins to wait (the dispatcher starts workgroups in index
+// order: observed, not promised -- a generator that waited for a workgroup not yet started would give up after two seconds with
+// GAPS_ERR_SPIN, applying nothing; and the test-only emulator, which runs workgroups in index order, never spins); the grid is kept at
+// one workgroup per compute unit or less, all resident at once, and the host takes the chained form only for an update that runs alone.
 // Bit-identical to the two-launch form: the same reductions, decisions and stores, and the erase cache's order does not matter (the
 // flush sorts it by position, ConcurrentAtomicDomain.cpp:71-79).
 #pragma once

@@ -1583,6 +1583,7 @@ extern "C" int cogaps_debug_chain_timeline(unsigned long long *wgs, unsigned lon
     if (hipMemcpyFromSymbol(wgs, HIP_SYMBOL(g_chain_rt), sizeof(unsigned long long) * 1024) != hipSuccess) return 1;
     return (int)hipMemcpyFromSymbol(gen, HIP_SYMBOL(g_chain_gen), sizeof(unsigned long long) * 8);
 }
+extern "C" int cogaps_debug_ahead_why(unsigned long long *out8) { return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_ahead_why), sizeof(unsigned long long) * 8); }
 extern "C" int cogaps_debug_chain_log(unsigned long long *out, unsigned int *n)
 {
     if (hipMemcpyFromSymbol(n, HIP_SYMBOL(g_chain_log_n), sizeof(unsigned int)) != hipSuccess) return 1;

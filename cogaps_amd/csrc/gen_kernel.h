@@ -33,6 +33,7 @@ __device__ unsigned long long g_timeline[8 * 64];      // (up to eight waves: th
 #define GEN_TS_RESUME(k) ts_n = (k)
 #define GEN_TS_ZERO(a, b) do { if ((t & 63u) == 0u) for (uint32_t i_ = (a); i_ < (b); ++i_) sh.ts[(t & ~63u) + i_] = 0ull; } while (0)
 #define GEN_PIN(x) asm volatile("" : "+v"(x) :: "memory")      // the value is computed before the next timestamp
+__device__ unsigned long long g_ahead_why[8];      // dev: why lanes of a window drawn ahead draw again (gen_draw_valid)
 __device__ unsigned long long g_chain_gen[8];      // the chained launch's generator workgroup on the chip-wide 100 MHz clock (chain_kernel.h)
 #define GEN_RT(i) do { if (t == 0u) sh.rt[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define GEN_RT_AT(i, lane) do { if (t == (unsigned)(lane)) sh.rt[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -70,7 +71,6 @@ __device__ unsigned long long g_chain_log[GEN_LOG_N * 8]; __device__ unsigned in
 #define GEN_F_BINEMPTY 128u // birth's bin had no atom
 #define GEN_F_WORDZERO 256u // ... and its whole level-0 bitmap word was empty (hints must be set)
 
-#define GEN_SPEC_INVALID 0xFFFFFFFEu   // gen_spec_births: no look-up was made for this slot
 #define GEN_STAMP_COMMITTED 0xFFFFFFull
 // buckets of the LDS conflict table (round 1 of a batch), 4 slots each: 1024 for a window of 256 attempts (at most 768 registrations:
 // 19 % of the slots), half of that for the 128-lane window -- the table is emptied at every launch (80 KB / 40 KB of LDS stores).
@@ -132,10 +132,9 @@ struct GenShared {
     // of the death-probability table this launch can need (staged while the evaluation workgroups of the same launch still run)
     unsigned long long eraseTmp[FLUSH_MAX]; uint32_t eraseN, specBad, spinFail;
     float dpWin[4 * WIN];
-    // ... and the births of the window classified ahead (gen_spec_births, by the helper wave while the attempt lanes wait for the decisions):
-    // the bitmap words and the successor bin's head each birth will need, per sorted slot; `dirty`: one bit per level-0 bitmap word
-    // (mod 16384) that the decisions being applied or the flush change -- a birth whose words are marked looks them up again
-    unsigned long long bw0[WIN], bw0n[WIN]; uint32_t bv2[WIN], bhb[WIN]; uint32_t bslot[64]; uint32_t dirty[512];
+    // `dirty`: one bit per level-0 bitmap word (mod 16384) that the decisions being applied or the flush change -- a birth drawn ahead whose
+    // words are marked draws again
+    uint32_t dirty[512];
     // ... and (round 5) the whole window DRAWN ahead: what the decisions being applied change, noted by the lanes that apply them --
     // atom records (handles), matrix cells (bins), the vector slots the flush refills (gen_populate.h, gen_draw_valid)
     alignas(16) uint32_t dAtom[GEN_DIRTY_ATOMS]; uint32_t dCell[GEN_DIRTY_CELLS]; uint32_t anyRedo;      // (bit sets, two hash positions per key; anyRedo: some lane of the window draws again)

@@ -311,7 +311,6 @@ CG_DEVICE void gen_spec_a1(const SamplerDev &S, GenShared<WIN> &sh, const GenRou
         sh.info[t] = guess | (eX[0] << 8);
     }
     if (t == 0) { sh.nWork = T0 + T1 + T2; sh.nBD = T0; }
-    sh.bv2[t] = GEN_SPEC_INVALID;
     // (the caller parks the attempt's seed in sh.seed[t] once the trip that brings it has landed, then closes with the second barrier)
 }
 // ... second half (lane = sorted slot): the attempt's generator state, a birth's position
@@ -328,55 +327,13 @@ CG_DEVICE void gen_spec_slot(const SamplerDev &S, GenShared<WIN> &sh, const GenR
     if (go && (sp.info & 0xFFu) == 'B') {
         uint64_t x = pcg_u64(sp.rng);
         while (x >= S.limitL) x = pcg_u64(sp.rng);
-        sp.pos = (S.iPartL == 1ull ? x : x / S.iPartL) + 1ull;
+        sp.pos = (S.iPartL == 1ull ? x : gm_udiv64(x, S.iPartL)) + 1ull;      // (exact; the compiler's 64-bit division is a ~130-instruction routine the whole wave waits for)
         sp.bin = gen_bin_of(S, sp.pos); sp.r1 = gen_div_k(S, sp.bin); sp.c1 = sp.bin - sp.r1 * c.K;
     }
 }
 
-// The births of the window classified ahead, looked up ahead -- by the helper wave, which has nothing to do until the decisions are
-// applied.  A birth is the one attempt type with three dependent memory trips in front of its conflict registration (bitmap word ->
-// successor bin's head -> that atom's record; a pick has two) and its wave held every other wave at the registration barrier for the
-// length of a trip or two.  The first two trips only read the bitmap and the bin heads, which change where an accepted move or an
-// erased atom touches a bin: the lanes that apply the decisions mark those bitmap words in sh.dirty, and a birth whose two words are
-// unmarked takes the words and the head found here and goes straight to the record (gen_round, stage 1).
-template <int WIN>
-CG_DEVICE void gen_spec_births(const SamplerDev &S, GenShared<WIN> &sh, const unsigned ht)
-{
-    // the births' sorted slots, compacted (births and deaths share the slots [0, nBD) in attempt order)
-    const uint32_t nBD = sh.nBD;
-    uint32_t nb = 0;
-    for (uint32_t base = 0; base < nBD; base += 64u) {
-        const uint32_t j = base + ht;
-        const bool isB = j < nBD && (sh.info[sh.perm[j]] & 0xFFu) == 'B';
-        const unsigned long long m = cg_ballot(isB);
-        const uint32_t k = nb + (uint32_t)cg_popc64(m & ((1ull << ht) - 1ull));
-        if (isB && k < 64u) sh.bslot[k] = j;
-        nb += (uint32_t)cg_popc64(m);
-    }
-    cg_wave_sync();
-    if (nb > 64u) nb = 64u;
-    if (ht < nb) {
-        const uint32_t slot = sh.bslot[ht], ct = sh.perm[slot];
-        uint64_t rng = pcg_from_seed(sh.seed[ct]);
-        uint64_t x = pcg_u64(rng);
-        while (x >= S.limitL) x = pcg_u64(rng);
-        const uint64_t pos = (S.iPartL == 1ull ? x : x / S.iPartL) + 1ull;
-        const uint32_t bin = gen_bin_of(S, pos), wd = bin >> 6, bit = bin & 63u;
-        const unsigned long long w0 = S.bits0[wd], w0n = (wd + 1u < S.nWords0) ? S.bits0[wd + 1u] : 0ull;
-        uint32_t headBin = bin; bool ok = true;
-        if (!((w0 >> bit) & 1ull)) {
-            const unsigned long long m = (bit == 63u) ? 0ull : (w0 & ~((2ull << bit) - 1ull));
-            if (m) headBin = (bin & ~63u) + (uint32_t)cg_ctz64(m); else if (w0n) headBin = (bin & ~63u) + 64u + (uint32_t)cg_ctz64(w0n);
-            else {
-                // an empty stretch of the domain: the search through the bitmap's upper levels (half a dozen dependent trips: every wave of the
-                // launch waited for the one birth that needed it) is made here, ahead, as well; the birth checks every word up to the successor's
-                headBin = bm_next_bin(S, bin);
-                ok = headBin != CG_NONE;      // (past the last atom: the usual way)
-            }
-        }
-        if (ok) { const uint32_t v2 = S.binHead[headBin]; sh.bw0[slot] = w0; sh.bw0n[slot] = w0n; sh.bhb[slot] = headBin; sh.bv2[slot] = v2; }
-    }
-}
+// one bit per level-0 bitmap word (mod 16384) that a decision being applied, or the flush of an atom it erases, changes: a birth drawn
+// ahead of the decisions checks the words it read (gen_draw_valid)
 CG_DEVICE void gen_mark_dirty(uint32_t *dirty, uint32_t bin)
 {
     const uint32_t w = (bin >> 6) & 16383u;
@@ -449,7 +406,7 @@ CG_DEVICE void gen_draw_a(const SamplerDev &S, const GenRoundCtx &c, const GenSp
             // uniform64(1, L) (Random.cpp:105-123) with the constant range's iPart precomputed
             uint64_t x = pcg_u64(d.rng);
             while (x >= S.limitL) x = pcg_u64(d.rng);
-            d.pos = (S.iPartL == 1ull ? x : x / S.iPartL) + 1ull;
+            d.pos = (S.iPartL == 1ull ? x : gm_udiv64(x, S.iPartL)) + 1ull;
             d.bin = gen_bin_of(S, d.pos); d.r1 = gen_div_k(S, d.bin); d.c1 = d.bin - d.r1 * c.K;
         }
         d.i1 = nT;
@@ -662,6 +619,21 @@ CG_DEVICE bool gen_draw_valid(const SamplerDev &S, GenShared<WIN> &sh, const Gen
         bad |= (same ^ 1u) | (d.pick ? nS : 0u);
     }
     const bool ok = !(d.go != 0u && bad != 0u);
+#if defined(GEN_TIMELINE)
+    // dev: why lanes draw again -- [0] lanes with an attempt, [1] drew again, [2] the pick moved (iPart / rejection / beyond the size), [3] its slot refilled,
+    // [4] a noted atom record, [5] a noted matrix cell, [6] a birth's bitmap words, [7] one of the long ways (redo flag)
+    if (d.go) {
+        const uint32_t moved = (!isB && m != 0u && type != 0u) ? (uint32_t)(((bad & 1u) != 0u) && !(d.redo) && !((reads ? (nA | cA) : 0u) & 1u)) : 0u;
+        cg_atomic_add_u64(&g_ahead_why[0], 1ull);
+        if (!ok) cg_atomic_add_u64(&g_ahead_why[1], 1ull);
+        if (moved) cg_atomic_add_u64(&g_ahead_why[2], 1ull);
+        if (d.pick && m != 0u && nS) cg_atomic_add_u64(&g_ahead_why[3], 1ull);
+        if (reads && (nA | ((isB && d.v3 != CG_NONE) ? nB : 0u))) cg_atomic_add_u64(&g_ahead_why[4], 1ull);
+        if (reads && (cA | ((d.pick && (type == 'M' || type == 'E')) ? cB : 0u))) cg_atomic_add_u64(&g_ahead_why[5], 1ull);
+        if (isB && !ok && !d.redo && !(nA | cA)) cg_atomic_add_u64(&g_ahead_why[6], 1ull);
+        if (d.redo) cg_atomic_add_u64(&g_ahead_why[7], 1ull);
+    }
+#endif
 #if defined(COGAPS_EMUL)
     if (d.go) cg_atomic_add_u64(&S.gs->prof[ok ? 8 : 9], 1ull);      // test-only build: lanes whose draw ahead held / that drew again
 #endif

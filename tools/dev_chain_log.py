@@ -46,3 +46,12 @@ for lo, hi in ((100, 200), (200, 240), (240, 256), (256, 2000)):
 print('lanes that drew again per launch: mean %.2f; launches with none %.3f; with erased atoms %.3f' % (bad.mean(), (bad == 0).mean(), (em > 0).mean()))
 for nm, sel in (('no lane drew again, nothing erased', (bad == 0) & (em == 0) & one), ('no lane drew again, atoms erased', (bad == 0) & (em > 0) & one), ('some lane drew again', (bad > 0) & one)):
     if sel.sum() > 5: print('  one round, %-36s %5d launches: whole %.2f  round %.2f  validate + join %.2f us' % (nm, sel.sum(), tot[sel].mean(), t[sel, 4].mean(), vj[sel].mean()))
+
+why = (ctypes.c_uint64 * 8)()
+PL.cogaps_debug_ahead_why.argtypes = [ctypes.c_void_p]
+if PL.cogaps_debug_ahead_why(why) == 0:
+    w = [int(x) for x in why]
+    if w[0]:
+        print('lanes drawn ahead (whole run): %d; drew again %.4f; by cause (a lane may have several): pick moved with the domain\'s size %.4f, slot refilled by the flush %.5f, '
+              'noted atom record %.4f, noted matrix cell %.4f, a birth\'s bitmap words %.4f, a long way (walk / full search / front()) %.4f'
+              % (w[0], w[1] / w[0], w[2] / w[0], w[3] / w[0], w[4] / w[0], w[5] / w[0], w[6] / w[0], w[7] / w[0]))
