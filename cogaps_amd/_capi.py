@@ -76,7 +76,7 @@ EXPORTS = [
     "cogaps_session_chisq", "cogaps_session_get_matrix", "cogaps_session_get_ap",
     "cogaps_session_get_atoms", "cogaps_session_dims", "cogaps_session_avg_queue",
     "cogaps_session_finish", "cogaps_session_set_timing", "cogaps_session_perf",
-    "cogaps_session_perf_sampler", "cogaps_session_chained", "cogaps_session_launch_clock", "cogaps_session_get_rows", "cogaps_sparse_width", "cogaps_reduction_width", "cogaps_session_debug_prof", "cogaps_session_debug_replay",
+    "cogaps_session_perf_sampler", "cogaps_session_chained", "cogaps_session_launch_clock", "cogaps_session_launch_period", "cogaps_session_get_rows", "cogaps_sparse_width", "cogaps_reduction_width", "cogaps_session_debug_prof", "cogaps_session_debug_replay",
     "cogaps_run_from_file", "cogaps_read_matrix_file", "cogaps_read_matrix_file_subset", "cogaps_matrix_free", "cogaps_file_info", "cogaps_debug_math", "cogaps_current_device", "cogaps_device_memory",
     "cogaps_session_debug_check_domain", "cogaps_batch_create", "cogaps_batch_destroy", "cogaps_batch_run_iterations", "cogaps_batch_set_timing", "cogaps_batch_perf",
 ]
@@ -143,6 +143,8 @@ def bind(L):
     L.cogaps_session_perf.argtypes = [vp, C.POINTER(CogapsPerfC)]
     L.cogaps_session_perf_sampler.argtypes = [vp, C.c_char, C.POINTER(CogapsPerfC)]
     L.cogaps_session_chained.argtypes = [vp, C.c_char, C.POINTER(C.c_int)]
+    if hasattr(L, "cogaps_session_launch_period"):
+        L.cogaps_session_launch_period.argtypes = [vp, C.c_char, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     if hasattr(L, "cogaps_session_launch_clock"):      # (an A/B build of an older source tree may lack it: launch_clock() then reports no launches)
         L.cogaps_session_launch_clock.argtypes = [vp, C.c_char, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.cogaps_session_debug_prof.argtypes = [vp, C.c_char, C.POINTER(C.c_uint64)]
@@ -399,6 +401,15 @@ class Session:
 
     def set_timing(self, on):
         self._ck(self.L.cogaps_session_set_timing(self.h, int(on)))
+
+    def launch_period(self, which):
+        """the same launches by their period (entry to the next launch's entry: dispatcher start-up and end-of-kernel write-back included)"""
+        m, n = C.c_double(0), C.c_uint64(0)
+        pc = (C.c_double * 5)()
+        if not hasattr(self.L, "cogaps_session_launch_period"):
+            return {"mean_us": 0.0, "p10_us": 0.0, "p50_us": 0.0, "p75_us": 0.0, "p90_us": 0.0, "p99_us": 0.0, "launches": 0}
+        self._ck(self.L.cogaps_session_launch_period(self.h, which.encode(), C.byref(m), pc, C.byref(n)))
+        return {"mean_us": m.value, "p10_us": pc[0], "p50_us": pc[1], "p75_us": pc[2], "p90_us": pc[3], "p99_us": pc[4], "launches": int(n.value)}
 
     def launch_clock(self, which):
         """durations of the sampler's chained launches since set_timing(1), every launch (device clock): mean, percentiles, count"""

@@ -208,6 +208,9 @@ struct HostSampler {
     uint64_t plainRotor = 0;     // which graph replay of a chunk runs as plain, event-carrying launches while timing is on
     // launch clock of the chained launches (gaps_state.h): durations in 0.1 us bins since timing was switched on, their sum and count
     std::vector<unsigned long long> clockHost; uint64_t clockSeen = 0; std::vector<uint64_t> clockHist; double clockSumUs = 0; uint64_t clockN = 0;
+    // ... and the launch-to-launch PERIOD (entry of one launch's first workgroup to the next launch's): the launch with everything the
+    // dispatcher does around it -- what rocprofv3's dispatch duration plus the idle gap adds up to
+    std::vector<uint64_t> periodHist; double periodSumUs = 0; uint64_t periodN = 0;
 };
 
 struct cogaps_session {
@@ -666,6 +669,7 @@ static void clock_collect(cogaps_session *s, HostSampler &h, uint64_t epoch, boo
     h.clockHost.resize(2u * GAPS_CLOCK_RING);
     rt_d2h(h.clockHost.data(), h.d.launchClock, sizeof(unsigned long long) * 2u * GAPS_CLOCK_RING, s->stream); rt_sync(s->stream);
     if (h.clockHist.empty()) h.clockHist.assign(2048, 0);
+    if (h.periodHist.empty()) h.periodHist.assign(2048, 0);
     const uint64_t from = upTo - h.clockSeen > GAPS_CLOCK_RING ? upTo - GAPS_CLOCK_RING : h.clockSeen;
     for (uint64_t e = from + 1u; e <= upTo; ++e) {
         const unsigned long long b = h.clockHost[2u * (uint32_t)(e % GAPS_CLOCK_RING)], en = h.clockHost[2u * (uint32_t)(e % GAPS_CLOCK_RING) + 1u];
@@ -673,6 +677,16 @@ static void clock_collect(cogaps_session *s, HostSampler &h, uint64_t epoch, boo
         const double us = 0.01 * (double)(en - b);
         h.clockSumUs += us; h.clockN++;
         h.clockHist[std::min<size_t>(h.clockHist.size() - 1u, (size_t)(us * 10.0))]++;
+        // the period to the next launch (the batch behind this one is evaluated by the very next launch on the stream; a chunk's last launch is
+        // followed by the host's progress read-back: periods beyond 100 us are such seams and left out)
+        if (e + 1u <= upTo) {
+            const unsigned long long nb = h.clockHost[2u * (uint32_t)((e + 1u) % GAPS_CLOCK_RING)];
+            if (nb > b && nb - b < 10000ull) {
+                const double pu = 0.01 * (double)(nb - b);
+                h.periodSumUs += pu; h.periodN++;
+                h.periodHist[std::min<size_t>(h.periodHist.size() - 1u, (size_t)(pu * 10.0))]++;
+            }
+        }
     }
     h.clockSeen = upTo;
 }
@@ -1607,6 +1621,7 @@ int cogaps_session_set_timing(cogaps_session *s, int on)
             h->batchesAtTimingOn = h->batches;
             h->evalMs = h->genMs = h->evalNoopMs = h->genNoopMs = 0; h->evalTimed = h->genTimed = h->evalNoopTimed = h->genNoopTimed = 0;
             h->clockHist.assign(2048, 0); h->clockSumUs = 0; h->clockN = 0;
+            h->periodHist.assign(2048, 0); h->periodSumUs = 0; h->periodN = 0;
         }
         s->syncMs = 0; s->syncTimed = 0; s->syncBytes = 0;
     }
@@ -1655,6 +1670,21 @@ int cogaps_session_launch_clock(cogaps_session *s, char which, double *meanUs, d
         if (!h.clockN) continue;
         const uint64_t want = (uint64_t)(q[k] * (double)h.clockN); uint64_t acc = 0;
         for (size_t b = 0; b < h.clockHist.size(); ++b) { acc += h.clockHist[b]; if (acc > want) { percentilesUs[k] = 0.1 * ((double)b + 0.5); break; } }
+    }
+    SESSION_END
+}
+int cogaps_session_launch_period(cogaps_session *s, char which, double *meanUs, double *percentilesUs, uint64_t *launches)
+{
+    SESSION_TRY
+    if (!meanUs || !percentilesUs || !launches) return fail("null argument");
+    HostSampler &h = pick(s, which);
+    *launches = h.periodN; *meanUs = h.periodN ? h.periodSumUs / (double)h.periodN : 0.0;
+    static const double q[5] = {0.10, 0.50, 0.75, 0.90, 0.99};
+    for (int k = 0; k < 5; ++k) {
+        percentilesUs[k] = 0.0;
+        if (!h.periodN) continue;
+        const uint64_t want = (uint64_t)(q[k] * (double)h.periodN); uint64_t acc = 0;
+        for (size_t b = 0; b < h.periodHist.size(); ++b) { acc += h.periodHist[b]; if (acc > want) { percentilesUs[k] = 0.1 * ((double)b + 0.5); break; } }
     }
     SESSION_END
 }

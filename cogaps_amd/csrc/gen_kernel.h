@@ -97,6 +97,7 @@ __device__ unsigned long long g_chain_log[GEN_LOG_N * 8]; __device__ unsigned in
 
 #define GEN_DIRTY_ATOMS 4096      // 32-bit words of the note bit sets (a batch's decisions touch ~3 atom records and ~1.5 cells each: ~600 of 131072 bits)
 #define GEN_DIRTY_CELLS 2048
+#define GEN_DIRTY_ERASE 256       // (8192 bits for at most 3 x FLUSH_MAX keys)
 struct GenTabVal { uint32_t used, gap, inl, pad; };
 struct GenTabKeys { uint32_t k[4]; };
 
@@ -137,7 +138,9 @@ struct GenShared {
     uint32_t dirty[512];
     // ... and (round 5) the whole window DRAWN ahead: what the decisions being applied change, noted by the lanes that apply them --
     // atom records (handles), matrix cells (bins), the vector slots the flush refills (gen_populate.h, gen_draw_valid)
-    alignas(16) uint32_t dAtom[GEN_DIRTY_ATOMS]; uint32_t dCell[GEN_DIRTY_CELLS]; uint32_t anyRedo;      // (bit sets, two hash positions per key; anyRedo: some lane of the window draws again)
+    // (bit sets, two hash positions per key; dErase: the atom records the FLUSH will rewrite -- an erased atom and its two neighbours;
+    // anyRedo: 0 no lane of the window draws again, 1 some do and none of them reads what the flush changes, 2 some wait for the flush)
+    alignas(16) uint32_t dAtom[GEN_DIRTY_ATOMS]; uint32_t dCell[GEN_DIRTY_CELLS]; uint32_t dErase[GEN_DIRTY_ERASE]; uint32_t anyRedo;
 };
 
 // bin index = pos / binLength, exact: double-precision reciprocal estimate (off by at most one), then a

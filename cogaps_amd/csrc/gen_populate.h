@@ -165,13 +165,15 @@ CG_DEVICE void gen_helper(const SamplerDev &S, GenShared<WIN> &sh, GenScalars *g
             // look-up barrier, behind which the attempt lanes read its LDS results for the commit.
             // Some lane draws again: it reads the domain as the flush leaves it -- the whole flush, then the join, as in the other forms.
             cg_sync_lds();
-            const bool anyRedo = cg_uniform_u32(sh.anyRedo) != 0u;
+            const uint32_t redoLevel = cg_uniform_u32(sh.anyRedo);
+            const bool beside = redoLevel != 2u;      // the flush runs beside the attempt lanes' phases (nobody waits for it before the look-up barrier)
+            if (redoLevel == 1u) cg_sync();           // (lanes draw again, keeping their picks: this wave's own applied decisions are acknowledged first)
             gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 0);
             gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 1); gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 2);
-            if (!anyRedo) cg_sync_lds();      // (the registration barrier, which the attempt lanes reach about now)
+            if (beside) cg_sync_lds();        // (the registration barrier, which the attempt lanes reach about now)
             gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 3); GEN_TS(3);
-            cg_sync();                        // (no lane draws again: the look-up barrier; otherwise the join)
-            if (anyRedo) { cg_sync_lds(); cg_sync_lds(); }
+            cg_sync();                        // (beside: the look-up barrier; otherwise the join)
+            if (!beside) { cg_sync_lds(); cg_sync_lds(); }
         } else {
             if (first) { gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 0); if (ht < 16u) sh.freeTop[ht] = fr.freeTop; }
             cg_sync_lds();
@@ -352,8 +354,8 @@ struct GenNotePos { uint32_t a, b; };
 template <int WORDS>
 CG_DEVICE GenNotePos gen_note_pos(uint32_t key)
 {
-    constexpr uint32_t LOG2 = WORDS == 4096 ? 17u : 16u;
-    static_assert(WORDS == 4096 || WORDS == 2048, "bit numbers are 17 / 16 bits of the hash");
+    constexpr uint32_t LOG2 = WORDS == 4096 ? 17u : (WORDS == 2048 ? 16u : 13u);
+    static_assert(WORDS == 4096 || WORDS == 2048 || WORDS == 256, "bit numbers are 17 / 16 / 13 bits of the hash");
     const uint32_t h = key * 2654435761u;
     GenNotePos p; p.a = h >> (32u - LOG2); p.b = (h ^ (h >> 11)) & ((1u << LOG2) - 1u);
     return p;
@@ -426,7 +428,7 @@ CG_DEVICE void gen_draw_a(const SamplerDev &S, const GenRoundCtx &c, const GenSp
 // positions and the right neighbour's mass -> matrix entries) and what follows from them.  underTrip(): the caller's work for the
 // first trip's shadow.  AHEAD: drawn before the previous batch's decisions are in -- the long ways are not taken, the lane is marked.
 template <int WIN, bool AHEAD, class F>
-CG_DEVICE void gen_draw_b(const SamplerDev &S, GenShared<WIN> &sh, const GenRoundCtx &c, const uint32_t type, GenDraw &d, F underTrip)
+CG_DEVICE void gen_draw_b(const SamplerDev &S, GenShared<WIN> &sh, const GenRoundCtx &c, const uint32_t type, GenDraw &d, F underTrip, const uint32_t keepH1 = CG_NONE)
 {
     const uint32_t K = c.K;
     const bool isB = d.isB, pick = d.pick;
@@ -445,7 +447,7 @@ CG_DEVICE void gen_draw_b(const SamplerDev &S, GenShared<WIN> &sh, const GenRoun
     uint32_t v2 = CG_NONE;
     AtomRec b3; b3.pos = 0; b3.lpos = 0; b3.rpos = 0; b3.left = CG_NONE; b3.right = CG_NONE; b3.mass = 0.f; b3.rmass = 0.f; b3.idx = 0;
     if (isB) { w0 = S.bits0[bin >> 6]; w0n = ((bin >> 6) + 1u < S.nWords0) ? S.bits0[(bin >> 6) + 1u] : 0ull; }
-    if (pick) v1 = S.vec[i1];
+    if (pick) v1 = keepH1 != CG_NONE ? keepH1 : S.vec[i1];      // (keepH1: a pick that stands -- gen_round, keepPick)
     underTrip();
     // stage 2 ---------------------------------------------------------------------------------
     bool slowB = false;
@@ -571,31 +573,39 @@ CG_DEVICE void gen_draw_b(const SamplerDev &S, GenShared<WIN> &sh, const GenRoun
 // bitmap words a birth read, and the pick itself from the size the flush leaves (nR; m atoms erased).  A pick is uniform32(0, size - 1)
 // (Random.cpp:79-96): x / iPart with iPart = UINT32_MAX / size, x below size * iPart -- the same index from both sizes unless iPart or
 // the rejection differs; iPart for the smaller size is the old one or the next (checked by multiplication, no division behind the wait).
-struct GenCheck { GenNotePos atomA, atomB, slot, cellA, cellB; uint32_t iPartS; };
+struct GenCheck { GenNotePos atomA, atomB, slot, cellA, cellB, eraseA; uint32_t iPartS; };
 CG_DEVICE GenCheck gen_draw_check(const GenSpec &sp, const GenDraw &d, const uint32_t nRs, const uint32_t K)
 {
     const bool isB = (sp.info & 0xFFu) == 'B';
     GenCheck c;
     c.cellA = gen_note_pos<GEN_DIRTY_CELLS>(isB ? d.bin : d.r1 * K + d.c1); c.cellB = gen_note_pos<GEN_DIRTY_CELLS>(d.r2 * K + d.c2);
     c.atomA = gen_note_pos<GEN_DIRTY_ATOMS>(isB ? d.v2 : d.h1); c.atomB = gen_note_pos<GEN_DIRTY_ATOMS>(d.v3); c.slot = gen_note_pos<GEN_DIRTY_ATOMS>(~d.i1);
+    c.eraseA = gen_note_pos<GEN_DIRTY_ERASE>(d.h1);
     c.iPartS = 0xFFFFFFFFu / (nRs + (sp.info >> 8));
     return c;
 }
+// Returns 0: the draw holds; 1: the lane draws again and reads nothing the flush changes -- a pick whose index and vector slot stand, whose
+// record or matrix cells the DECISIONS rewrote (it keeps its pick and need not wait for the flush); 2: it draws again behind the flush.
 template <int WIN>
-CG_DEVICE bool gen_draw_valid(const SamplerDev &S, GenShared<WIN> &sh, const GenSpec &sp, const GenDraw &d, const GenCheck &ck, const uint32_t nR, const uint32_t m)
+CG_DEVICE uint32_t gen_draw_valid(const SamplerDev &S, GenShared<WIN> &sh, const GenSpec &sp, const GenDraw &d, const GenCheck &ck, const uint32_t nR, const uint32_t m)
 {
     const uint32_t type = sp.info & 0xFFu, bBefore = sp.info >> 8;
-    uint32_t bad = d.redo ? 1u : 0u;
+    uint32_t bad = d.redo ? 1u : 0u, light = 0u;      // bad: behind the flush; light: the decisions' notes alone
 #if defined(GEN_AHEAD_BAD_EVERY)
-    if (((sp.ct + (uint32_t)sh.g.batchEpoch) % (uint32_t)GEN_AHEAD_BAD_EVERY) == 0u) bad = 1u;      // test-only variant: lanes drawn again, regularly
+    if (((sp.ct + (uint32_t)sh.g.batchEpoch) % (uint32_t)GEN_AHEAD_BAD_EVERY) == 0u) { if (sp.ct & 1u) bad = 1u; else light = 1u; }      // test-only variant: lanes drawn again, regularly, either way
 #endif
     const bool isB = type == 'B';
     const bool reads = isB || d.pick;       // (a lane without an attempt, or whose pick fell on an atom born in this window, read nothing)
     const uint32_t nA = gen_note_get(sh.dAtom, ck.atomA), nB = gen_note_get(sh.dAtom, ck.atomB), nS = gen_note_get(sh.dAtom, ck.slot);
     const uint32_t cA = gen_note_get(sh.dCell, ck.cellA), cB = gen_note_get(sh.dCell, ck.cellB);
-    if (reads) bad |= nA | cA;
-    if (isB && d.v3 != CG_NONE) bad |= nB;
-    if (d.pick && (type == 'M' || type == 'E')) bad |= cB;
+    // (a birth reads the bitmap, bin heads and may walk along its bin: it always waits for the flush; a pick reads its atom's record
+    // -- the flush rewrites the records of an erased atom's neighbours: dErase -- and matrix cells, which the flush never touches)
+    if (isB) { if (reads) bad |= nA | cA; if (d.v3 != CG_NONE) bad |= nB; }
+    else if (d.pick) {
+        const uint32_t nE = gen_note_get(sh.dErase, ck.eraseA);
+        light |= nA | cA | ((type == 'M' || type == 'E') ? cB : 0u);
+        bad |= nA & nE;
+    }
     if (isB) {
         // the bitmap words it read -- the bin's own, the next, and every further one up to the successor bin's
         const uint32_t wFirst = d.bin >> 6;
@@ -618,7 +628,8 @@ CG_DEVICE bool gen_draw_valid(const SamplerDev &S, GenShared<WIN> &sh, const Gen
         const uint32_t same = (uint32_t)(rem < nT) & (uint32_t)(d.xPick < 0xFFFFFFFFu - rem) & (uint32_t)(d.xPick >= lo) & (uint32_t)(d.xPick - lo < q) & (uint32_t)(!(d.pick && d.i1 >= nR));
         bad |= (same ^ 1u) | (d.pick ? nS : 0u);
     }
-    const bool ok = !(d.go != 0u && bad != 0u);
+    const bool ok = !(d.go != 0u && (bad | light) != 0u);
+    const uint32_t level = d.go == 0u ? 0u : (bad ? 2u : (light && d.pick ? 1u : (light ? 2u : 0u)));
 #if defined(GEN_TIMELINE)
     // dev: why lanes draw again -- [0] lanes with an attempt, [1] drew again, [2] the pick moved (iPart / rejection / beyond the size), [3] its slot refilled,
     // [4] a noted atom record, [5] a noted matrix cell, [6] a birth's bitmap words, [7] one of the long ways (redo flag)
@@ -635,13 +646,14 @@ CG_DEVICE bool gen_draw_valid(const SamplerDev &S, GenShared<WIN> &sh, const Gen
     }
 #endif
 #if defined(COGAPS_EMUL)
-    if (d.go) cg_atomic_add_u64(&S.gs->prof[ok ? 8 : 9], 1ull);      // test-only build: lanes whose draw ahead held / that drew again
+    if (d.go) cg_atomic_add_u64(&S.gs->prof[level == 0u ? 8 : (level == 1u ? 10 : 9)], 1ull);      // test-only build: lanes whose draw ahead held / that drew again behind the flush / keeping their pick
 #endif
-    return ok;
+    (void)ok;
+    return level;
 }
 
 template <int WIN, bool FIRST, bool SPEC = false, bool AHEAD = false>
-CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRoundCtx &c, const uint32_t roundNo, const GenSpec *spec = nullptr, const GenDraw *ahead = nullptr, const bool aheadValid = true)
+CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRoundCtx &c, const uint32_t roundNo, const GenSpec *spec = nullptr, const GenDraw *ahead = nullptr, const bool aheadValid = true, const bool keepPick = false)
 {
     static_assert(FIRST || !SPEC, "only a batch's first window is classified ahead of the decisions");
     static_assert(SPEC || !AHEAD, "only a window classified ahead is drawn ahead");
@@ -733,8 +745,10 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
 #if !defined(EXP_NO_REDO)
         const bool again = go && !aheadValid;
         if (cg_ballot(again) != 0ull) {      // (wave-uniform: the wave's other lanes walk through with nothing to draw, as lanes without an attempt do)
+            // (keepPick -- wave-uniform: the whole window draws again without waiting for the flush -- the index vector is not read again: the
+            // pick and its slot were validated, only the record and the matrix cells are read anew)
             GenDraw r; gen_draw_a<WIN, SPEC>(S, c, spec, again, type, bBefore, SPEC ? spec->rng : 0ull, nR, r);
-            gen_draw_b<WIN, false>(S, sh, c, type, r, [&]() {});
+            gen_draw_b<WIN, false>(S, sh, c, type, r, [&]() {}, keepPick ? ahead->h1 : CG_NONE);
             if (again) d = r;
         }
 #endif
@@ -1325,10 +1339,11 @@ CG_DEVICE void gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot hot, G
 #pragma unroll
         for (uint32_t k = 0; k < ROUNDS; ++k) { if (!spare && ((k + 1u) * TPB <= UNITS || t + k * TPB < UNITS)) tab[k * TPB] = none; }
         if (CHAIN) {      // ... and the notes of what the decisions change (atom records, matrix cells), by every lane of the launch's workgroup
-            static_assert(offsetof(GenShared<WIN>, dCell) == offsetof(GenShared<WIN>, dAtom) + 4u * (size_t)GEN_DIRTY_ATOMS, "the two note tables are contiguous");
+            static_assert(offsetof(GenShared<WIN>, dCell) == offsetof(GenShared<WIN>, dAtom) + 4u * (size_t)GEN_DIRTY_ATOMS
+                          && offsetof(GenShared<WIN>, dErase) == offsetof(GenShared<WIN>, dCell) + 4u * (size_t)GEN_DIRTY_CELLS, "the note tables are contiguous");
             GenTabKeys *dt = reinterpret_cast<GenTabKeys *>(&sh.dAtom[0]);
             GenTabKeys zero; zero.k[0] = zero.k[1] = zero.k[2] = zero.k[3] = 0u;
-            for (uint32_t i = t; i < (uint32_t)(GEN_DIRTY_ATOMS + GEN_DIRTY_CELLS) / 4u; i += cg_bdim()) dt[i] = zero;
+            for (uint32_t i = t; i < (uint32_t)(GEN_DIRTY_ATOMS + GEN_DIRTY_CELLS + GEN_DIRTY_ERASE) / 4u; i += cg_bdim()) dt[i] = zero;
         }
     }
     GEN_TS(27);
@@ -1488,7 +1503,12 @@ CG_DEVICE void gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot hot, G
                     if (it.hL != CG_NONE) gen_note_set(sh.dAtom, nHL);
                     if ((er || it.type == 'M') && it.hR != CG_NONE) gen_note_set(sh.dAtom, nHR);
                     if (ap && it.type == 'E') { gen_note_set(sh.dAtom, nH2); if (it.l2 != CG_NONE) gen_note_set(sh.dAtom, nL2); }
-                    if (er) gen_note_set(sh.dAtom, nIdx);      // (the vector slot the flush refills from the tail)
+                    if (er) {      // (the vector slot the flush refills from the tail; the records the flush rewrites: the erased atom's and its neighbours')
+                        gen_note_set(sh.dAtom, nIdx);
+                        gen_note_set(sh.dErase, gen_note_pos<GEN_DIRTY_ERASE>(it.h1));
+                        if (it.hL != CG_NONE) gen_note_set(sh.dErase, gen_note_pos<GEN_DIRTY_ERASE>(it.hL));
+                        if (it.hR != CG_NONE) gen_note_set(sh.dErase, gen_note_pos<GEN_DIRTY_ERASE>(it.hR));
+                    }
                     if (ap || it.type == 'D') gen_note_set(sh.dCell, nC1);
                     if (ap && (it.type == 'M' || it.type == 'E')) gen_note_set(sh.dCell, nC2);
                 }
@@ -1587,21 +1607,27 @@ CG_DEVICE void gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot hot, G
     if (CHAIN && specDone) {
         // which lanes drew what they would draw now (gen_draw_valid).  If every lane of the window did, the round goes straight into its
         // conflict phases and the helper wave's flush runs beside them (gen_helper); otherwise the join with the flush first
-        const bool valid = gen_draw_valid<WIN>(S, sh, specKeep, drawKeep, checkKeep, n0, e_m);
-        if (cg_ballot(!valid) != 0ull && (t & 63u) == 0u) sh.anyRedo = 1u;
+        const uint32_t again = gen_draw_valid<WIN>(S, sh, specKeep, drawKeep, checkKeep, n0, e_m);
+        const bool valid = again == 0u;
+        {   // the window's level: 2 if some lane waits for the flush, else 1 if some lane draws again at all
+            const uint32_t lv = cg_ballot(again == 2u) != 0ull ? 2u : (cg_ballot(again == 1u) != 0ull ? 1u : 0u);
+            if (lv != 0u && (t & 63u) == 0u) cg_atomic_max_u32(&sh.anyRedo, lv);
+        }
         GEN_PIN(drawKeep.flags);
         GEN_TS(37);
 #if defined(GEN_TIMELINE)
         { const unsigned long long bad_ = cg_ballot(!valid); if ((t & 63u) == 0u && bad_) cg_atomic_add_u64(&sh.rt[6], (unsigned long long)cg_popc64(bad_)); }
 #endif
         cg_sync_lds();
-        const bool anyRedo = cg_uniform_u32(sh.anyRedo) != 0u;
-        if (anyRedo) cg_sync();
+        // (level 1: the barrier only acknowledges the appliers' stores -- the lanes that draw again keep their picks and read records and
+        // matrix cells the flush leaves alone, which runs beside them as it does when no lane draws again; level 2: the join with the flush)
+        const uint32_t redoLevel = cg_uniform_u32(sh.anyRedo);
+        if (redoLevel != 0u) cg_sync();
         GEN_TS(38);
 #if defined(GEN_TIMELINE)
-        if (t == 0u) { sh.rt[7] = __builtin_amdgcn_s_memrealtime(); sh.rtInfo |= ((sh.rt[6] & 0xFFull) << 40) | (((sh.rt[7] - sh.rt[4]) & 0xFFFFull) << 48); }
+        if (t == 0u) { sh.rt[7] = __builtin_amdgcn_s_memrealtime(); sh.rtInfo |= ((sh.rt[6] & 0xFFull) << 40) | (((sh.rt[7] - sh.rt[4]) & 0xFFFFull) << 48) | ((unsigned long long)(redoLevel & 3u) << 36); }
 #endif
-        if (gen_round<WIN, true, true, true>(S, sh, rc, 1u, &specKeep, &drawKeep, valid)) return;
+        if (gen_round<WIN, true, true, true>(S, sh, rc, 1u, &specKeep, &drawKeep, valid, redoLevel == 1u)) return;
     }
     else if (gen_round<WIN, true>(S, sh, rc, 1u)) return;
     for (uint32_t roundNo = 2; ; ++roundNo) {

@@ -125,6 +125,7 @@ CG_DEVICE void cg_keep_f32(float x) { asm volatile("" :: "v"(x)); }
 CG_DEVICE uint32_t cg_atomic_add_u32(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 CG_DEVICE uint32_t cg_atomic_sub_u32(uint32_t *p, uint32_t v) { return atomicSub(p, v); }
 CG_DEVICE uint32_t cg_atomic_min_u32(uint32_t *p, uint32_t v) { return atomicMin(p, v); }
+CG_DEVICE uint32_t cg_atomic_max_u32(uint32_t *p, uint32_t v) { return atomicMax(p, v); }
 CG_DEVICE uint32_t cg_atomic_or_u32(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
 CG_DEVICE uint32_t cg_atomic_cas_u32(uint32_t *p, uint32_t cmp, uint32_t v) { return atomicCAS(p, cmp, v); }
 CG_DEVICE unsigned long long cg_atomic_add_u64(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }

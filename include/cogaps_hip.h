@@ -227,6 +227,10 @@ int cogaps_session_chained(cogaps_session *s, char which, int *chained);
  * workgroup, the last to finish: what rocprofv3 --kernel-trace reports as the dispatch's duration, minus the dispatcher's fill / drain).
  * meanUs; percentilesUs[5] = 10th, 50th, 75th, 90th, 99th (0.1 us bins); launches = how many were measured (0: the sampler does not chain). */
 int cogaps_session_launch_clock(cogaps_session *s, char which, double *meanUs, double *percentilesUs, uint64_t *launches);
+/* The same launches by their PERIOD: entry of a launch's first workgroup to the entry of the next launch's -- the launch with the dispatcher's
+ * start-up and the end-of-kernel write-back around it (what rocprofv3 reports as the dispatch's duration, plus the idle gap to the next
+ * dispatch); seams where the host read progress back (> 100 us) are left out.  The sum of the periods cannot exceed the wall time. */
+int cogaps_session_launch_period(cogaps_session *s, char which, double *meanUs, double *percentilesUs, uint64_t *launches);
 
 /* ------------------------------------------------------------------------------------------------
  * Batched multi-chain launches: the sessions of a batch -- the subsets of a GWCoGAPS / scCoGAPS job that share one GPU

@@ -51,6 +51,7 @@ inline float cg_sqrtf(float x) { return __builtin_sqrtf(x); }
 inline uint32_t cg_atomic_add_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 inline uint32_t cg_atomic_sub_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o - v; return o; }
 inline uint32_t cg_atomic_min_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
+inline uint32_t cg_atomic_max_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; if (v > o) *p = v; return o; }
 inline uint32_t cg_atomic_or_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
 inline uint32_t cg_atomic_cas_u32(uint32_t *p, uint32_t cmp, uint32_t v) { uint32_t o = *p; if (o == cmp) *p = v; return o; }
 inline unsigned long long cg_atomic_add_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }

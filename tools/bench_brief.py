@@ -12,7 +12,7 @@ s += "A %.2f + %.2f us  P %.2f + %.2f us  " % (k[0]["avg_launch_us"], k[2]["avg_
 for kk in k[:2]:
     if "launch_us_percentiles" in kk:
         p = kk["launch_us_percentiles"]
-        s += "[%s clock p50 %.1f p75 %.1f p90 %.1f p99 %.1f; events %.2f] " % (kk["sampler"], p["p50_us"], p["p75_us"], p["p90_us"], p["p99_us"], kk["avg_launch_us_hip_event_sample"])
+        s += "[%s inside %.2f p50 %.1f p75 %.1f p90 %.1f p99 %.1f; events %.2f] " % (kk["sampler"], kk.get("inside_launch_us", 0.0), p["p50_us"], p["p75_us"], p["p90_us"], p["p99_us"], kk["avg_launch_us_hip_event_sample"])
 s += "frac %s kt/wall %.3f" % (("%.4f" % d["roofline"]["frac"]) if d["roofline"]["frac"] else "None", d["roofline"].get("kernel_time_over_wall") or 0.0)
 cb = d.get("cpu_baseline")
 if cb and cb.get("value"):

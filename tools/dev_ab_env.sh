@@ -5,7 +5,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 CFG=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do CFG+=("$1"); shift; done; shift
 cp cogaps_amd/csrc/libcogaps_hip.so /tmp/keep.so
-for i in 1 2; do
+for i in $(seq 1 ${AB_ROUNDS:-2}); do
   for C in "${CFG[@]}"; do
     set -- $C; L=$1; shift
     cp $L cogaps_amd/csrc/libcogaps_hip.so

@@ -24,7 +24,7 @@ a = a[a[:, 0] > 0]
 t = (a[:, 1:6] - a[:, 0:5]) / 100.0            # phase lengths, us
 tot = (a[:, 5] - a[:, 0]) / 100.0
 prevq = a[:, 6] & 0xFFFF; em = (a[:, 6] >> 16) & 0xFFFF; spec = (a[:, 6] >> 32) & 1; rounds = a[:, 7]
-bad = (a[:, 6] >> 40) & 0xFF; vj = ((a[:, 6] >> 48) & 0xFFFF) / 100.0      # lanes that drew again; applied -> validated + joined with the flush, us
+level = (a[:, 6] >> 36) & 3; bad = (a[:, 6] >> 40) & 0xFF; vj = ((a[:, 6] >> 48) & 0xFFFF) / 100.0      # lanes that drew again; applied -> validated + joined with the flush, us
 names = ['entry -> first barrier', 'first barrier -> window drawn ahead (attempt lane 0)', 'drawn ahead -> granules in (helper lane 0; may be negative)', 'granules in -> applied + barrier', 'round(s) of the next batch']
 def line(name, v): print('  %-32s mean %6.2f  p10 %6.2f  p50 %6.2f  p75 %6.2f  p90 %6.2f  p99 %6.2f' % (name, v.mean(), *np.percentile(v, [10, 50, 75, 90, 99])))
 print('%d launches logged (queue >= 100); rounds: %s; classified ahead: %.3f' % (len(a), dict(zip(*np.unique(rounds, return_counts=True))), spec.mean()))
@@ -44,7 +44,8 @@ for lo, hi in ((100, 200), (200, 240), (240, 256), (256, 2000)):
     if sel.sum(): print('  queue in (%d, %d]: %5d launches, wait for the granules mean %.2f p50 %.2f p90 %.2f; apply mean %.2f' % (lo, hi, sel.sum(), w[sel].mean(), np.median(w[sel]), np.percentile(w[sel], 90), t[sel, 3].mean()))
 
 print('lanes that drew again per launch: mean %.2f; launches with none %.3f; with erased atoms %.3f' % (bad.mean(), (bad == 0).mean(), (em > 0).mean()))
-for nm, sel in (('no lane drew again, nothing erased', (bad == 0) & (em == 0) & one), ('no lane drew again, atoms erased', (bad == 0) & (em > 0) & one), ('some lane drew again', (bad > 0) & one)):
+for nm, sel in (('no lane drew again, nothing erased', (bad == 0) & (em == 0) & one), ('no lane drew again, atoms erased', (bad == 0) & (em > 0) & one), ('some lane drew again', (bad > 0) & one),
+                ('... keeping their picks (level 1)', (level == 1) & one), ('... behind the flush (level 2)', (level == 2) & one)):
     if sel.sum() > 5: print('  one round, %-36s %5d launches: whole %.2f  round %.2f  validate + join %.2f us' % (nm, sel.sum(), tot[sel].mean(), t[sel, 4].mean(), vj[sel].mean()))
 
 why = (ctypes.c_uint64 * 8)()
