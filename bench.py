@@ -232,7 +232,7 @@ def chains_main(args):
         # the groups' launches overlap and only the wall clock adds up anyway.  The per-launch samples stay listed as what they are.
         ach = (tot_bytes / 1e9) / dt
         # HBM bytes from the PMC counters (two separate rocprofv3 --pmc passes over this mode with 8 chains in one batch,
-        # tools/r3_pmc_pass.sh, committed under profiles/): per step of the batch, weighted by this run's A and P step counts
+        # tools/pmc_pass.sh, committed under profiles/): per step of the batch, weighted by this run's A and P step counts
         traffic, traffic_src = None, None
         if C == 8 and G == 1 and not args.sparse and (args.genes, args.samples, args.patterns) == (20000, 2000, 50):
             import glob
@@ -550,7 +550,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "path: generator + evaluation launches (one chained launch per batch where the fused evaluation serves) + sync, per batch (dominant by time: %s, sampler %s)" % (dominant["kernel"], dominant["sampler"]),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved is not None else None,
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_bytes_per_launch_by_kernel": (traffic_kernels if not traffic_stale else None),
-                         # the committed counter pass names the library build it measured; another build -> no figure, no ratio, re-run tools/r4_pmc_pass.sh
+                         # the committed counter pass names the library build it measured; another build -> no figure, no ratio, re-run tools/pmc_pass.sh
                          "traffic_stale": traffic_stale, "traffic_measured_on_lib": traffic_measured_on, "lib_source_hash": lib_hash,
                          "bytes_per_launch": b_alg / max(1, batches), "avg_launch_us": 1e3 * kernel_ms / max(1, batches), "launches": int(batches),
                          "kernel_time_over_wall": kernel_ms / (1e3 * dt), "timing_consistent": bool(consistent),
