@@ -426,13 +426,6 @@ class Session:
         self._ck(self.L.cogaps_session_chained(self.h, which.encode(), C.byref(v)))
         return bool(v.value)
 
-    def launch_form(self, which):
-        """the form the sampler's last update ran in: 0 a generator launch and an evaluation launch per batch, 1 the chained launch (one per
-        batch), 2 / 3 the persistent generator beside evaluation launches of their own (csrc/chain_kernel.h: on one stream batch by batch / on two)"""
-        v = C.c_int()
-        self._ck(self.L.cogaps_session_chained(self.h, which.encode(), C.byref(v)))
-        return int(v.value)
-
     def perf(self, which=None):
         p = CogapsPerfC()
         if which is None:

@@ -6,7 +6,6 @@
 // Poisson step counts (GapsRunner.cpp:294-295), streams the Xoroshiro seed sequence the proposal
 // generator consumes (math/Random.cpp:221-248) and enqueues kernels.
 #include <atomic>
-#include <mutex>
 #include "../../include/cogaps_hip.h"
 #include "rt.h"
 #include "gaps_state.h"
@@ -198,12 +197,6 @@ struct HostSampler {
     bool chain = false; uint32_t chainParity = 0;
     unsigned long long *chainGrans = nullptr;      // [queueCap][CHAIN_GRAN_STRIDE] the decisions' granules (the split form's per-slice totals keep SamplerDev::grans)
     rt_graph chainGraph[2]; bool chainGraphValid[2] = {false, false};
-    // persistent generator beside evaluation launches of their own (chain_kernel.h, chain_gen_kernel / chain_eval_kernel): 0 no, 1 one batch at
-    // a time on one stream (the test-only emulator, counter tools), 2 the generator for a whole chunk on the session's stream and the
-    // evaluation launches -- captured GRAPH_PAIRS at a time, once per starting parity -- on the session's second stream
-    int persist = 0; uint32_t evalParity = 0; uint32_t *chainCtl = nullptr; unsigned char *chainPub = nullptr;      // chainPub: [2][queueCap] published records (gaps_state.h, CHAIN_PUB_BYTES)
-    rt_graph evalGraph[2]; bool evalGraphValid[2] = {false, false};
-    rt_graph pgenGraph[2]; bool pgenGraphValid[2] = {false, false};      // (form 3: the generator one batch per launch, GRAPH_PAIRS launches captured)
     size_t traceCap = 0;
     char name = 'A';
     // perf accounting
@@ -247,9 +240,6 @@ struct cogaps_session {
     // of LDS, so one evaluation workgroup fits a compute unit and each takes 3-4 slices one after the other, where the two-launch form has
     // two per unit and all slices resident).  COGAPS_CHAIN_SPLIT=1 takes it (the A/B, the equality test).
     bool noChainSplit = getenv("COGAPS_CHAIN_SPLIT") == nullptr;
-    // COGAPS_PERSIST: 1 / seq (the two kernels batch by batch on one stream), 2 / on (concurrent; where the start-up probe saw two streams overlap)
-    int persistWanted = getenv("COGAPS_PERSIST") ? ((!strcmp(getenv("COGAPS_PERSIST"), "seq") || !strcmp(getenv("COGAPS_PERSIST"), "1")) ? 1 : ((!strcmp(getenv("COGAPS_PERSIST"), "0") || !strcmp(getenv("COGAPS_PERSIST"), "off")) ? 0 : (!strcmp(getenv("COGAPS_PERSIST"), "each") ? 3 : 2))) : 0;      // each: two streams, the generator one batch per launch
-    rt_stream_t evalStream = rt_stream_t(); bool evalStreamMade = false;
     bool forceChain = getenv("COGAPS_FORCE_CHAIN") != nullptr;      // tests: the chained launch also where the device shows fewer compute units than the launch has workgroups (they then run in turns, the generator last)
     unsigned computeUnits = 0;      // of the session's device: the chained launch wants all its workgroups resident at once, one per compute unit
     std::vector<rt_event_pair> evPool; std::vector<int> evKind; std::vector<HostSampler *> evOwner; std::vector<uint64_t> evOrd; size_t evUsed = 0;
@@ -277,7 +267,7 @@ static void free_sampler(HostSampler &h)
     rt_free(d.seqScratch); rt_free((void *)d.deathProb); rt_free(d.launchClock);
     rt_free((void *)d.D); rt_free((void *)d.S2); rt_free(d.AP); rt_free(d.mat); rt_free(d.colPos);
     rt_free(d.atoms); rt_free(d.vec); rt_free(d.freeHandles); rt_free(d.binHead);
-    rt_free(d.bits0); rt_free(d.bits1); rt_free(d.bits2); rt_free(d.eraseList); rt_free(d.queue); rt_free(d.queueUnits); rt_free(d.chainSlots); rt_free(h.chainGrans); rt_free(h.chainCtl); rt_free(h.chainPub); rt_free(d.partials); rt_free(d.grans); rt_free(d.dec);
+    rt_free(d.bits0); rt_free(d.bits1); rt_free(d.bits2); rt_free(d.eraseList); rt_free(d.queue); rt_free(d.queueUnits); rt_free(d.chainSlots); rt_free(h.chainGrans); rt_free(d.partials); rt_free(d.grans); rt_free(d.dec);
     rt_free(d.rowStamp); rt_free(d.atomStamp); rt_free(d.gapStamp); rt_free(d.inlineStamp); rt_free(d.atomDest);
     rt_free(d.gs); rt_free(d.trace); rt_free(d.traceBatchNproc); rt_free(d.traceBatchQlen);
     rt_free(h.Sraw); rt_free(h.seeds); rt_free_host(h.hSeeds); rt_free(h.partial); rt_free(h.dRecord);
@@ -383,7 +373,7 @@ static void build_sampler(cogaps_session *s, HostSampler &h, char name, const fl
     d.nWords0 = (uint32_t)((nBins + 63) / 64); d.nWords1 = (d.nWords0 + 63) / 64; d.nWords2 = (d.nWords1 + 63) / 64;
     d.bits0 = dalloc<unsigned long long>(d.nWords0); d.bits1 = dalloc<unsigned long long>(d.nWords1); d.bits2 = dalloc<unsigned long long>(d.nWords2);
     d.queueCap = d.M + 8; d.eraseCap = d.queueCap;
-    d.eraseList = dalloc<unsigned long long>(d.eraseCap); d.queue = dalloc<PropRec>((size_t)2 * d.queueCap); d.chainSlots = dalloc<ChainSlot>(4); h.chainCtl = dalloc<uint32_t>(2); h.chainPub = dalloc<unsigned char>((size_t)2 * d.queueCap * CHAIN_PUB_BYTES); rt_memset(h.chainPub, 0, (size_t)2 * d.queueCap * CHAIN_PUB_BYTES, s->stream); d.launchClock = dalloc<unsigned long long>(2u * GAPS_CLOCK_RING); h.chainGrans = dalloc<unsigned long long>((size_t)d.queueCap * CHAIN_GRAN_STRIDE); d.queueUnits = dalloc<uint32_t>(d.queueCap); d.partials = dalloc<float>((size_t)d.queueCap * 64); d.grans = dalloc<unsigned long long>((size_t)d.queueCap * 64); d.dec = dalloc<DecRec>(d.queueCap);
+    d.eraseList = dalloc<unsigned long long>(d.eraseCap); d.queue = dalloc<PropRec>((size_t)2 * d.queueCap); d.chainSlots = dalloc<ChainSlot>(2); d.launchClock = dalloc<unsigned long long>(2u * GAPS_CLOCK_RING); h.chainGrans = dalloc<unsigned long long>((size_t)d.queueCap * CHAIN_GRAN_STRIDE); d.queueUnits = dalloc<uint32_t>(d.queueCap); d.partials = dalloc<float>((size_t)d.queueCap * 64); d.grans = dalloc<unsigned long long>((size_t)d.queueCap * 64); d.dec = dalloc<DecRec>(d.queueCap);
     d.rowStamp = dalloc<unsigned long long>(d.M);
     d.atomStamp = dalloc<unsigned long long>(d.atomCap); d.gapStamp = dalloc<unsigned long long>((size_t)d.atomCap + 1);
     d.inlineStamp = dalloc<unsigned long long>(d.atomCap); d.atomDest = dalloc<uint64_t>(d.atomCap);
@@ -626,110 +616,6 @@ static bool chain_eligible(const cogaps_session *s, const HostSampler &h)
     return block <= (uint32_t)CHAIN_MAX_THREADS && block >= h.genWin + 64u
            && (s->forceChain || s->computeUnits >= std::min<uint32_t>(h.d.queueCap, CHAIN_EVAL_GRID) + 1u);
 }
-static void drop_graphs(HostSampler &h);
-// ---- persistent generator + evaluation launches of their own (chain_kernel.h) ----
-// Do kernels of two streams of this process run at the same time on this device?  One kernel waits (a bounded 20 ms) for a word that a
-// kernel on the other stream, enqueued behind it, sets.  A tool that serialises dispatches (counter collection) or a runtime that folds the
-// streams into one queue answers no, and the sampler keeps one launch per batch.  Asked once per process.
-CG_KERNEL void probe_wait_kernel(const unsigned long long *flag, uint32_t *seen)
-{
-#if !defined(COGAPS_EMUL)
-    const unsigned long long t0 = cg_realtime();
-    for (;;) {
-        if (cg_load_l2_u64(flag) != 0ull) { *seen = 1u; return; }
-        if (cg_realtime() - t0 > 2000000ull) { *seen = 0u; return; }
-        cg_poll_pause();
-    }
-#else
-    (void)flag; *seen = 0u;
-#endif
-}
-CG_KERNEL void probe_set_kernel(unsigned long long *flag) { cg_store_agent_u64(flag, 1ull); }
-static bool streams_overlap(cogaps_session *s)
-{
-    static std::mutex m; static int known = -1;
-    std::lock_guard<std::mutex> hold(m);
-    if (known >= 0) return known != 0;
-    unsigned long long *flag = dalloc<unsigned long long>(1); uint32_t *seen = dalloc<uint32_t>(1);
-    rt_memset(flag, 0, 8, s->stream); rt_memset(seen, 0, 4, s->stream); rt_sync(s->stream);
-    RT_LAUNCH(probe_wait_kernel, 1, 64, s->stream, (const unsigned long long *)flag, seen);
-    RT_LAUNCH(probe_set_kernel, 1, 64, s->evalStream, flag);
-    rt_sync(s->evalStream); rt_sync(s->stream);
-    uint32_t h = 0; rt_d2h(&h, seen, 4, s->stream); rt_sync(s->stream);
-    rt_free(flag); rt_free(seen);
-    known = h ? 1 : 0;
-    return known != 0;
-}
-// which form an update of this sampler takes: the fused evaluation's chained launch must be eligible (dense model, product arithmetic, data
-// vectors of at most 4096 elements, the update alone on the GPU)
-static int persist_mode(cogaps_session *s, const HostSampler &h)
-{
-    if (!s->persistWanted || !h.chain || h.d.sparse || h.d.redW > 1024u) return 0;
-#if defined(COGAPS_EMUL)
-    return 1;
-#else
-    if (s->persistWanted == 1) return 1;
-    if (!s->evalStreamMade) { s->evalStream = rt_stream_create(); s->evalStreamMade = true; }
-    return streams_overlap(s) ? s->persistWanted : 0;
-#endif
-}
-static void launch_pgen(cogaps_session *s, HostSampler &h, uint32_t nBatches)
-{
-    const SamplerDev CG_CONSTANT *rec = (const SamplerDev CG_CONSTANT *)h.dRecord;
-    const uint32_t parity = h.chainParity; h.chainParity ^= (nBatches & 1u);
-    if (h.genWin == (uint32_t)GEN_WIN) RT_LAUNCH(chain_gen_kernel<GEN_WIN>, 1, CHAIN_MAX_THREADS, s->stream, h.d.lcgMul, h.d.lcgInc, h.d.gs, h.d.queue, h.chainGrans, h.d.chainSlots, h.chainPub, h.d.queueCap, parity, nBatches, rec);
-    else RT_LAUNCH(chain_gen_kernel<GEN_WIN_HALF>, 1, CHAIN_MAX_THREADS, s->stream, h.d.lcgMul, h.d.lcgInc, h.d.gs, h.d.queue, h.chainGrans, h.d.chainSlots, h.chainPub, h.d.queueCap, parity, nBatches, rec);
-    h.genLaunches++;
-}
-static void launch_peval(cogaps_session *s, HostSampler &h, rt_stream_t st)
-{
-    const SamplerDev CG_CONSTANT *rec = (const SamplerDev CG_CONSTANT *)h.dRecord;
-    const uint32_t parity = h.evalParity; h.evalParity ^= 1u;
-    const uint32_t grid = std::min<uint32_t>(h.d.queueCap, CHAIN_EVAL_GRID);
-    RT_LAUNCH(chain_eval_kernel, grid, h.d.redW, st, h.d.gs, (const unsigned char *)h.chainPub, h.chainGrans, (const ChainSlot *)h.d.chainSlots, h.chainCtl, h.d.queueCap, parity, rec);
-    h.evalLaunches++;
-}
-static rt_graph &ensure_eval_graph(cogaps_session *s, HostSampler &h)
-{
-    if ((h.evalGraphValid[0] || h.evalGraphValid[1] || h.chainGraphValid[0] || h.chainGraphValid[1] || h.graphValid) && memcmp(&h.graphKey, &h.d, sizeof(SamplerDev)) != 0) drop_graphs(h);
-    const uint32_t k = h.evalParity;
-    if (!h.evalGraphValid[k]) {
-        const uint64_t e0 = h.evalLaunches;
-        rt_capture_begin(s->evalStream);
-        for (uint32_t b = 0; b < GRAPH_PAIRS; ++b) launch_peval(s, h, s->evalStream);
-        rt_capture_end(s->evalStream, h.evalGraph[k]);
-        h.evalLaunches = e0;
-        memcpy(&h.graphKey, &h.d, sizeof(SamplerDev)); h.evalGraphValid[k] = true;
-    }
-    return h.evalGraph[k];
-}
-// `n` batch steps of the persistent form
-static void launch_persist(cogaps_session *s, HostSampler &h, uint32_t n)
-{
-    if (h.persist == 1) { for (uint32_t b = 0; b < n; ++b) { launch_pgen(s, h, 1u); launch_peval(s, h, s->stream); } return; }
-    if ((h.evalGraphValid[0] || h.evalGraphValid[1] || h.pgenGraphValid[0] || h.pgenGraphValid[1] || h.chainGraphValid[0] || h.chainGraphValid[1] || h.graphValid) && memcmp(&h.graphKey, &h.d, sizeof(SamplerDev)) != 0) drop_graphs(h);
-    if (h.persist == 3) {      // (A/B: the generator leaves after every batch -- a launch per batch on the session's stream, the evaluation launches beside them)
-        uint32_t leftG = n;
-        if (rt_graphs_supported() && !s->noGraph)
-            for (; leftG >= GRAPH_PAIRS; leftG -= GRAPH_PAIRS) {
-                const uint32_t k = h.chainParity;
-                if (!h.pgenGraphValid[k]) {
-                    const uint64_t g0 = h.genLaunches;
-                    rt_capture_begin(s->stream);
-                    for (uint32_t b = 0; b < GRAPH_PAIRS; ++b) launch_pgen(s, h, 1u);
-                    rt_capture_end(s->stream, h.pgenGraph[k]);
-                    h.genLaunches = g0; memcpy(&h.graphKey, &h.d, sizeof(SamplerDev)); h.pgenGraphValid[k] = true;
-                }
-                rt_graph_launch(h.pgenGraph[k], s->stream);
-            }
-        for (uint32_t b = 0; b < leftG; ++b) launch_pgen(s, h, 1u);
-    } else
-    launch_pgen(s, h, n);      // (one launch: the generator stays for the chunk)
-    uint32_t left = n;
-    if (rt_graphs_supported() && !s->noGraph)
-        for (; left >= GRAPH_PAIRS; left -= GRAPH_PAIRS) { rt_graph_launch(ensure_eval_graph(s, h), s->evalStream); h.evalLaunches += GRAPH_PAIRS; }
-    for (uint32_t b = 0; b < left; ++b) launch_peval(s, h, s->evalStream);
-}
 // one batch step: the chained launch, or a generator launch and an evaluation launch
 static void launch_pair(cogaps_session *s, HostSampler &h)
 {
@@ -739,8 +625,6 @@ static void drop_graphs(HostSampler &h)
 {
     if (h.graphValid) { rt_graph_destroy(h.graph); h.graphValid = false; }
     for (int k = 0; k < 2; ++k) if (h.chainGraphValid[k]) { rt_graph_destroy(h.chainGraph[k]); h.chainGraphValid[k] = false; }
-    for (int k = 0; k < 2; ++k) if (h.evalGraphValid[k]) { rt_graph_destroy(h.evalGraph[k]); h.evalGraphValid[k] = false; }
-    for (int k = 0; k < 2; ++k) if (h.pgenGraphValid[k]) { rt_graph_destroy(h.pgenGraph[k]); h.pgenGraphValid[k] = false; }
 }
 // the captured run of GRAPH_PAIRS batch steps that starts at the sampler's current parity (an even number of launches: the parity after
 // a replay is the parity before it)
@@ -839,18 +723,12 @@ static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool t
     g.traceOn = trace ? 1u : 0u; g.traceCount = 0; g.traceCap = trace ? traceCap : 0; g.traceBatchCount = 0;
     *s->hGs = g;
     rt_h2d(d.gs, s->hGs, sizeof(GenScalars), s->stream);
-    const ChainSlot emptySlots[4] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};      // (the persistent form keeps its two slots 16 bytes apart)
+    const ChainSlot emptySlots[2] = {{0u, 0u}, {0u, 0u}};
     rt_h2d(d.chainSlots, emptySlots, sizeof(emptySlots), s->stream);      // (chained launch: both parities start from an empty queue)
     rt_sync(s->stream);
     if (nSteps == 0) return 0;
     sync_record(s, h);
     h.chain = chain_eligible(s, h);
-    h.persist = persist_mode(s, h);
-    if (h.persist) {      // the evaluation launches wait for the tag behind the one the queue holds; the first of them reads the copy the generator's first batch writes
-        const uint32_t ctl[2] = {(uint32_t)g.batchEpoch + 1u, 0u};
-        rt_h2d(h.chainCtl, ctl, sizeof(ctl), s->stream); rt_sync(s->stream);
-        h.evalParity = h.chainParity ^ 1u;
-    }
     h.updLaunches = 0;
     h.clockSeen = g.batchEpoch;      // (launch clock: the batches of this update carry the tags behind this one)
     // proposals per batch: the previous update of this sampler is the best predictor
@@ -865,8 +743,7 @@ static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool t
         if (chunk > 4096u) chunk = 4096u;
         firstChunk = false;
         uint32_t plain = chunk;
-        if (h.persist) { launch_persist(s, h, chunk); h.updLaunches += chunk; plain = 0; }
-        else if (rt_graphs_supported() && !s->noGraph && !trace && plain >= GRAPH_PAIRS) {
+        if (rt_graphs_supported() && !s->noGraph && !trace && plain >= GRAPH_PAIRS) {
             if (!h.chain) ensure_graph(s, h);
             // HIP events cannot ride on replayed launches.  While timing is on, one replay of every chunk -- its position moves
             // through the chunk from update to update -- is issued as plain launches that carry events, so that the sample covers
@@ -889,7 +766,6 @@ static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool t
         if (s->hGs->updateFlushed) break;
         if (s->hGs->nBatches > 0) avgq = std::max(1.f, (float)s->hGs->nDone / (float)s->hGs->nBatches);
     }
-    if (h.persist >= 2) rt_sync(s->evalStream);      // (the evaluation launches still enqueued leave at the end-of-update mark; the last batch's A*P rows are complete)
     h.nAtoms = s->hGs->nAtoms; h.avgQueue = s->hGs->avgQueue; h.batches += s->hGs->nBatches;
     if (s->hGs->nBatches >= 8u) h.stepsPerBatch = (float)nSteps / (float)s->hGs->nBatches;
     const uint32_t win = gen_window_for(h.genWin, h.stepsPerBatch);
@@ -1117,7 +993,6 @@ void cogaps_session_destroy(cogaps_session *s)
     rt_free(s->Asum); rt_free(s->Asq); rt_free(s->Psum); rt_free(s->Psq); rt_free(s->pump);
     rt_free_host(s->hGs);
     for (auto &e : s->evPool) rt_event_destroy(e);
-    if (s->evalStreamMade) rt_stream_destroy(s->evalStream);
     if (s->ownsStream) rt_stream_destroy(s->stream);
     delete s;
 }
@@ -1817,7 +1692,7 @@ int cogaps_session_chained(cogaps_session *s, char which, int *chained)
 {
     SESSION_TRY
     if (!chained) return fail("null argument");
-    *chained = pick(s, which).chain ? (pick(s, which).persist ? 1 + pick(s, which).persist : 1) : 0;      // 0 two launches per batch, 1 the chained launch, 2 / 3 the persistent generator (one stream / two)
+    *chained = pick(s, which).chain ? 1 : 0;
     SESSION_END
 }
 

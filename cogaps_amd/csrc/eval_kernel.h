@@ -602,38 +602,7 @@ CG_DEVICE void eval_chain_pair(const SamplerDev &S, unsigned long long *grans, c
 // hot: the three values a workgroup's first memory trip needs, passed as leading scalar kernel arguments so that the dispatcher preloads
 // them into SGPRs (-amdgpu-kernarg-preload-count): the queue record is requested at once, the lines of the sampler's record come in
 // under the same trip (eval_first / eval_record).
-struct EvalHot { const PropRec *queue; const GenScalars *gs; uint32_t queueCap; const ChainSlot *slot; unsigned long long *grans;      // slot, grans: chained launch only
-                 // pub: the queue is being published while this launch runs (persistent generator, chain_kernel.h): the records are read as
-                 // tagged granules past the caches (pubBase / pubBytes: this parity's copy; pubTag: the batch's tag)
-                 uint32_t pub; const void *pubBase; uint32_t pubBytes, pubTag; };
-// the seven granules of a published record -> the record (the trace word and the padding are not published)
-CG_DEVICE PropRec eval_rec_from_granules(const cg_u4 (&g)[7])
-{
-    uint32_t w[24];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) { w[3 * k] = g[k].x; w[3 * k + 1] = g[k].y; w[3 * k + 2] = g[k].z; }
-    w[20] = 0u; w[21] = 0u; w[22] = 0u; w[23] = 0u;
-    PropRec p; __builtin_memcpy(&p, w, sizeof(PropRec));
-    return p;
-}
-// A queue record.  pub (a constant wherever a kernel builds its EvalHot): the generator is writing it through while this launch runs -- every
-// lane reads the record's seven granules until all carry the batch's tag (bounded; a record that never arrives reads as no proposal).
-CG_DEVICE PropRec eval_qrec(const EvalHot &hot, const uint32_t q)
-{
-    const uint32_t qq = q < hot.queueCap ? q : 0u;
-    if (!hot.pub) return hot.queue[qq];
-    const cg_pub pb = cg_pub_open(hot.pubBase, hot.pubBytes);
-    cg_u4 g[7]; uint32_t spins = 0;
-    for (;;) {
-        bool ok = true;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) { g[k] = cg_pub_load(pb, qq * CHAIN_PUB_BYTES + 16u * (uint32_t)k); ok = ok && g[k].w == hot.pubTag; }
-        if (cg_ballot(!ok) == 0ull) break;
-        if (cg_poll_expired(++spins)) { PropRec none; __builtin_memset(&none, 0, sizeof(PropRec)); return none; }
-        cg_poll_pause();
-    }
-    return eval_rec_from_granules(g);
-}
+struct EvalHot { const PropRec *queue; const GenScalars *gs; uint32_t queueCap; const ChainSlot *slot; unsigned long long *grans; };      // slot, grans: chained launch only
 // The first memory trip of an evaluation workgroup: its first queue record, the queue length, the annealing temperature.  The
 // addresses need only `hot` and the workgroup index, so the one-chain kernels issue it before they have seen the sampler's record.
 struct EvalFirst { PropRec p; uint32_t qlen; float T; uint32_t tag; };      // tag: the batch's number (low word), what the in-launch hand-off marks its granules with
@@ -641,7 +610,7 @@ template <int PHASE>
 CG_DEVICE EvalFirst eval_first(const EvalHot hot, uint32_t slices, uint32_t vbid)
 {
     const uint32_t qFirst = (PHASE == EVAL_FUSED || PHASE == EVAL_SEQ || PHASE == EVAL_CHAIN) ? vbid : vbid / slices;
-    EvalFirst f; f.p = eval_qrec(hot, qFirst); f.T = hot.gs->annealTemp;
+    EvalFirst f; f.p = hot.queue[qFirst < hot.queueCap ? qFirst : 0u]; f.T = hot.gs->annealTemp;
     if (PHASE == EVAL_CHAIN || PHASE == EVAL_CHAIN_SPLIT) { const ChainSlot cs = *hot.slot; f.qlen = cs.qlen; f.tag = cs.tag; }      // (this launch's parity: nothing in this launch writes it)
     else { f.qlen = hot.gs->qlen; f.tag = (PHASE == EVAL_DECIDE) ? (uint32_t)hot.gs->batchEpoch : 0u; }
     return f;
@@ -673,7 +642,7 @@ CG_DEVICE void eval_chain_updates(const SamplerDev &S, const EvalHot hot, const 
     parts = parts < 1u ? 1u : (parts > 64u ? 64u : parts);
     for (uint32_t item = wg; item < qlen * parts; item += nwg) {
         const uint32_t q = item / parts, part = item - q * parts;
-        const PropRec p = eval_qrec(hot, q);
+        const PropRec p = hot.queue[q < hot.queueCap ? q : 0u];
         const unsigned long long *gr = hot.grans + (size_t)q * CHAIN_GRAN_STRIDE;
         unsigned long long g0 = 0ull, g1 = 0ull; uint32_t spins = 0; bool have = true;
         for (;;) {
@@ -755,9 +724,9 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
         if (PHASE == EVAL_CHAIN && q + qStep < qlen && (S.Npad >> 2) <= BS && BS >= 128u) {
             // a queue longer than the launch has evaluation workgroups: this workgroup's next two proposals side by side (eval_chain_pair)
             const uint32_t qB = q + qStep;
-            const PropRec pB = eval_qrec(hot, qB);
+            const PropRec pB = hot.queue[qB < hot.queueCap ? qB : 0u];
             const uint32_t qN = qB + qStep;
-            if (qN < qlen) pNext = eval_qrec(hot, qN);
+            if (qN < qlen) pNext = hot.queue[qN < hot.queueCap ? qN : 0u];
 #if defined(COGAPS_EMUL)
             if (t == 0u) cg_atomic_add_u64(&S.gs->prof[7], 1ull);      // test-only build: proposals evaluated in pairs
 #endif
@@ -887,10 +856,10 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
         if (PHASE == EVAL_FUSED) ea = eval_atoms_load(S, p, writer);
 #endif
         if (PHASE == EVAL_APPLY || (DECIDE && !eaLoaded)) ea = eval_atoms_load(S, p, writer);
-        if (PHASE == EVAL_ALPHA || (DECIDE && !decider)) { if (q + qStep >= qlen) break; { const uint32_t qn_ = q + qStep; pNext = eval_qrec(hot, qn_); } cg_sync(); continue; }
+        if (PHASE == EVAL_ALPHA || (DECIDE && !decider)) { if (q + qStep >= qlen) break; { const uint32_t qn_ = q + qStep; pNext = hot.queue[qn_ < hot.queueCap ? qn_ : 0u]; } cg_sync(); continue; }
         s = s * T; smu = smu * T;
 #if defined(GEN_PROFILE)
-        if (S.dbg & 8u) { if (q + qStep >= qlen) break; { const uint32_t qn_ = q + qStep; pNext = eval_qrec(hot, qn_); } cg_sync(); continue; }    // timing experiment: stop before the scalar step
+        if (S.dbg & 8u) { if (q + qStep >= qlen) break; { const uint32_t qn_ = q + qStep; pNext = hot.queue[qn_ < hot.queueCap ? qn_ : 0u]; } cg_sync(); continue; }    // timing experiment: stop before the scalar step
 #endif
         if (typeX == 'B') {
             // ---------------------------------------------------------------- birth (:127-144)
@@ -992,7 +961,7 @@ CG_DEVICE void eval_body(const SamplerDev &S, uint32_t slices, const uint32_t vb
             S.queueUnits[q] = units;
         }
         if (q + qStep >= qlen) break;   // last proposal of this workgroup
-        { const uint32_t qn_ = q + qStep; pNext = eval_qrec(hot, qn_); }
+        { const uint32_t qn_ = q + qStep; pNext = hot.queue[qn_ < hot.queueCap ? qn_ : 0u]; }
         cg_sync();   // the LDS scratch is reused by the next proposal
     }
 #if !defined(COGAPS_EMUL)
@@ -1008,7 +977,7 @@ template <int PHASE>
 #endif
 CG_KERNEL void CG_LAUNCH_BOUNDS2((PHASE == EVAL_SEQ ? EVAL_SEQ_BS : 1024), (PHASE == EVAL_FUSED || PHASE == EVAL_SEQ ? 4 : (PHASE == EVAL_APPLY || PHASE == EVAL_DECIDE ? EVAL_APPLY_WAVES : 8))) eval_kernel(const PropRec *hotQueue, const GenScalars *hotGs, uint32_t hotCap, uint32_t slices, const SamplerDev CG_CONSTANT *sp)
 {
-    EvalHot hot; hot.queue = hotQueue; hot.gs = hotGs; hot.queueCap = hotCap; hot.slot = nullptr; hot.grans = nullptr; hot.pub = 0u; hot.pubBase = nullptr; hot.pubBytes = 0u; hot.pubTag = 0u;
+    EvalHot hot; hot.queue = hotQueue; hot.gs = hotGs; hot.queueCap = hotCap; hot.slot = nullptr; hot.grans = nullptr;
     const EvalFirst first = eval_first<PHASE>(hot, slices, cg_bid());
     const SamplerDev &S = eval_record<PHASE>(sp);
     eval_body<PHASE, true>(S, slices, cg_bid(), cg_gdim(), hot, first);
@@ -1027,7 +996,7 @@ CG_KERNEL void CG_LAUNCH_BOUNDS2(1024, (PHASE == EVAL_FUSED ? EVAL_MULTI_FUSED_W
     const SamplerDev CG_CONSTANT *sp = arr + chain;
     cg_const_warm<sizeof(SamplerDev)>(sp);
     const SamplerDev &S = *(const SamplerDev *)sp;
-    EvalHot hot; hot.queue = S.queue; hot.gs = S.gs; hot.queueCap = S.queueCap; hot.slot = nullptr; hot.grans = nullptr; hot.pub = 0u; hot.pubBase = nullptr; hot.pubBytes = 0u; hot.pubTag = 0u;
+    EvalHot hot; hot.queue = S.queue; hot.gs = S.gs; hot.queueCap = S.queueCap; hot.slot = nullptr; hot.grans = nullptr;
     const uint32_t vbid = cg_bid() - chain * wgPerChain;
     eval_body<PHASE, false>(S, slices, vbid, wgPerChain, hot, eval_first<PHASE>(hot, slices, vbid));
 }

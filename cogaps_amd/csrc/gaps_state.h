@@ -57,8 +57,6 @@ struct alignas(16) DecRec { uint32_t n, r1, c1; float d1; uint32_t r2, c2; float
 // nothing an evaluation workgroup reads at its start can change while its launch runs.  tag: the batch's number (low word), what the
 // evaluation marks its decision granules with.
 struct alignas(8) ChainSlot { uint32_t qlen, tag; };
-#define CHAIN_PUB_BYTES 128u   // persistent generator: a queue record as published to the running evaluation launch -- seven 16-byte granules {three words of the record's first 80 bytes, batch tag} in one 128-byte line
-#define CHAIN_FIN 0xFFFFFFFFu  // ChainSlot::qlen of an update that is over (persistent generator: what the evaluation launches still enqueued leave on)
 // decision of one evaluated proposal, handed to the next batch's generator inside the launch as two {value, tag} granules
 // (grans[q * CHAIN_GRAN_STRIDE + 0] = code | units << 8, + 1 = one float): what the generator's lane applies to the atomic domain
 #define CHAIN_GRAN_STRIDE 2u  // 64-bit words per proposal in the granule array: the two granules side by side, four proposals per 64-byte line (a wave's poll
@@ -95,7 +93,7 @@ struct GenScalars {
     unsigned long long prof[16];    // GEN_PROFILE builds: cycles per generator phase
 };
 
-enum GapsError { GAPS_OK = 0, GAPS_ERR_ATOM_CAP = 1, GAPS_ERR_QUEUE_CAP = 2, GAPS_ERR_ERASE_CAP = 3, GAPS_ERR_SPIN = 4, GAPS_ERR_SPIN_EVAL = 5, GAPS_ERR_SPIN_FOLLOW = 6 };      // 5, 6: persistent form -- an evaluation launch that never saw its batch published, a passenger wave the helper wave never released
+enum GapsError { GAPS_OK = 0, GAPS_ERR_ATOM_CAP = 1, GAPS_ERR_QUEUE_CAP = 2, GAPS_ERR_ERASE_CAP = 3, GAPS_ERR_SPIN = 4 };
 
 #define GAPS_DEATH_PROB_PAD 1024u
 struct SamplerDev {

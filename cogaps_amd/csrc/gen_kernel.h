@@ -141,9 +141,6 @@ struct GenShared {
     // (bit sets, two hash positions per key; dErase: the atom records the FLUSH will rewrite -- an erased atom and its two neighbours;
     // anyRedo: 0 no lane of the window draws again, 1 some do and none of them reads what the flush changes, 2 some wait for the flush)
     alignas(16) uint32_t dAtom[GEN_DIRTY_ATOMS]; uint32_t dCell[GEN_DIRTY_CELLS]; uint32_t dErase[GEN_DIRTY_ERASE]; uint32_t anyRedo;
-    // persistent generator (chain_kernel.h, chain_gen_kernel): the waves that only apply decisions stay in the workgroup for the next batch,
-    // so behind the join they arrive at every barrier the helper wave announces (barSeq: one more per barrier) until it ends the batch (endGen = the batch's tag)
-    uint32_t barSeq, endGen;
 };
 
 // bin index = pos / binLength, exact: double-precision reciprocal estimate (off by at most one), then a

@@ -127,22 +127,10 @@ CG_DEVICE void gen_flush_part(const SamplerDev &S, GenShared<WIN> &sh, const Gen
 // bytes; 0 = the caller warmed them) come in under it instead of before it.
 struct GenHot { const uint64_t *lcgMul, *lcgInc; GenScalars *gs; const unsigned long long *eraseList; const uint32_t *queueUnits; uint32_t eraseCap, queueCap;
                 // chained launch only: the queue copy the previous batch sits in, the copy and slot this launch writes, the decision granules
-                const PropRec *queueRd; PropRec *queueWr; const unsigned long long *grans; ChainSlot *slotWr;
-                ChainSlot *slotRd; void *pubWr; uint32_t pubBytes; };      // persistent generator only: the other copy's slot (for the end-of-update mark), the published copy of the queue this batch writes
+                const PropRec *queueRd; PropRec *queueWr; const unsigned long long *grans; ChainSlot *slotWr; };
 
 // ---- the helper wave: flush, table presets, round bookkeeping, write-back.  Mirrors the attempt waves' barriers one for one. ----
-// PERSIST (chain_kernel.h, chain_gen_kernel: the generator workgroup stays for the next batch): the waves that only applied decisions
-// cannot leave behind the join -- a wave that has not ended counts at every barrier -- so this wave ANNOUNCES each barrier it is about
-// to enter (sh.barSeq + 1) and they arrive at one barrier per announcement (gen_follow) until it ends the batch (sh.endGen).  The
-// queue is published to evaluation workgroups that are ALREADY RUNNING (another launch, polling the slot): records written through,
-// every wave's stores drained, one barrier, then the slot -- write-through as well (MI355X guide: handoff-flag).
-template <int WIN, bool PERSIST>
-CG_DEVICE void gen_hsync(GenShared<WIN> &sh, const unsigned ht, const bool withStores)
-{
-    if (PERSIST) { if (ht == 0) cg_lds_poke_u32(&sh.barSeq, cg_lds_peek_u32(&sh.barSeq) + 1u); cg_wave_sync(); cg_follow_wake(); }
-    if (withStores) cg_sync(); else cg_sync_lds();
-}
-template <int WIN, bool PERSIST = false>
+template <int WIN>
 CG_DEVICE void gen_helper(const SamplerDev &S, GenShared<WIN> &sh, GenScalars *gs, const unsigned ht, const unsigned long long specE,
                           const uint32_t e_m, const uint32_t e_n, const uint32_t e_fc, const uint32_t e_prevQ, const uint32_t e_nDone, const uint32_t e_nSteps, ChainSlot *slotWr, const bool specDone = false)
 {
@@ -176,31 +164,31 @@ CG_DEVICE void gen_helper(const SamplerDev &S, GenShared<WIN> &sh, GenScalars *g
             // flush runs BESIDE the conflict phases -- it is complete, its stores acknowledged (cg_sync waits for this wave's), at the
             // look-up barrier, behind which the attempt lanes read its LDS results for the commit.
             // Some lane draws again: it reads the domain as the flush leaves it -- the whole flush, then the join, as in the other forms.
-            gen_hsync<WIN, PERSIST>(sh, ht, false);
+            cg_sync_lds();
             const uint32_t redoLevel = cg_uniform_u32(sh.anyRedo);
             const bool beside = redoLevel != 2u;      // the flush runs beside the attempt lanes' phases (nobody waits for it before the look-up barrier)
-            if (redoLevel == 1u) gen_hsync<WIN, PERSIST>(sh, ht, true);           // (lanes draw again, keeping their picks: this wave's own applied decisions are acknowledged first)
+            if (redoLevel == 1u) cg_sync();           // (lanes draw again, keeping their picks: this wave's own applied decisions are acknowledged first)
             gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 0);
             gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 1); gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 2);
-            if (beside) gen_hsync<WIN, PERSIST>(sh, ht, false);        // (the registration barrier, which the attempt lanes reach about now)
+            if (beside) cg_sync_lds();        // (the registration barrier, which the attempt lanes reach about now)
             gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 3); GEN_TS(3);
-            gen_hsync<WIN, PERSIST>(sh, ht, true);                        // (beside: the look-up barrier; otherwise the join)
-            if (!beside) { gen_hsync<WIN, PERSIST>(sh, ht, false); gen_hsync<WIN, PERSIST>(sh, ht, false); }
+            cg_sync();                        // (beside: the look-up barrier; otherwise the join)
+            if (!beside) { cg_sync_lds(); cg_sync_lds(); }
         } else {
             if (first) { gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 0); if (ht < 16u) sh.freeTop[ht] = fr.freeTop; }
-            gen_hsync<WIN, PERSIST>(sh, ht, false);
+            cg_sync_lds();
             if (first) { gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 1); gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 2); }
-            gen_hsync<WIN, PERSIST>(sh, ht, false);
-            if (first) { gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 3); GEN_TS(3); gen_hsync<WIN, PERSIST>(sh, ht, true); }      // the join: the flush's stores are acknowledged (vmcnt(0)) before any lane reads the domain
+            cg_sync_lds();
+            if (first) { gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, 3); GEN_TS(3); cg_sync(); }      // the join: the flush's stores are acknowledged (vmcnt(0)) before any lane reads the domain
             // ---- B1 / B2 barriers
-            if (ldsRound) gen_hsync<WIN, PERSIST>(sh, ht, false); else gen_hsync<WIN, PERSIST>(sh, ht, true);
-            if (ldsRound) gen_hsync<WIN, PERSIST>(sh, ht, false); else gen_hsync<WIN, PERSIST>(sh, ht, true);
+            if (ldsRound) cg_sync_lds(); else cg_sync();
+            if (ldsRound) cg_sync_lds(); else cg_sync();
         }
         // ---- C: masks complete behind this barrier; the attempt lanes commit, this wave keeps the books
         const uint32_t nR = sh.nR, minR = sh.minAtoms, skip = sh.skip, processed = sh.processed;
         const uint32_t left_ = remaining - processed;
         const uint32_t winN = left_ < (uint32_t)WIN ? left_ : (uint32_t)WIN;
-        gen_hsync<WIN, PERSIST>(sh, ht, false);
+        cg_sync_lds();
         GEN_TS(20);
         const uint32_t stopKey = sh.stopKey;
         const uint32_t stopT = (stopKey == 0xFFFFFFFFu) ? winN : (stopKey >> 1);
@@ -210,9 +198,6 @@ CG_DEVICE void gen_helper(const SamplerDev &S, GenShared<WIN> &sh, GenScalars *g
         if (ht == 0) {
             uint32_t totQ = 0, totB = 0, totD = 0;
             for (uint32_t w = 0; w < (uint32_t)(WIN / 64); ++w) { totQ += (uint32_t)cg_popc64(sh.mq[w]); totB += (uint32_t)cg_popc64(sh.mb[w]); totD += (uint32_t)cg_popc64(sh.md[w]); }
-            // persistent generator: the batch's length goes to the evaluation launch NOW -- its workgroups then wait for their records' own tags
-            // (the attempt lanes are storing them), not for a flag behind the last of them
-            if (PERSIST && endB) cg_store_agent_u64(reinterpret_cast<unsigned long long *>(slotWr), ((unsigned long long)(uint32_t)batchEpoch << 32) | (unsigned long long)(sh.qlen + totQ));
             if (totB) { const uint32_t fc = sh.g.freeCount; if (totB <= fc) sh.g.freeCount = fc - totB; else { sh.g.freeCount = 0; sh.g.handleHi += totB - fc; } sh.g.nAtoms = nR + totB; }
             sh.nR = nR + totB; sh.minAtoms = minR - totD;
             const uint32_t qlen = sh.qlen + totQ;
@@ -259,24 +244,16 @@ CG_DEVICE void gen_helper(const SamplerDev &S, GenShared<WIN> &sh, GenScalars *g
             for (uint32_t w = ht; w < GEN_GS_WORDS; w += 64u)
                 if (w != GEN_GS_ERROR_WORD && !(frontPending && w == frontWord)) reinterpret_cast<uint32_t *>(gs)[w] = reinterpret_cast<const uint32_t *>(&sh.g)[w];
             // chained launch: what the next launch's evaluation workgroups start from (the queue copy they read was filled by this launch's commit)
-            if (PERSIST) {
-                // the batch's closing barrier: this wave's write-back of the scalars (the next batch's first trip reads them) and the attempt
-                // waves' domain stores have landed; the passenger waves are released behind it
-                cg_drain_stores();
-                gen_hsync<WIN, PERSIST>(sh, ht, false);
-                if (ht == 0) cg_lds_poke_u32(&sh.endGen, (uint32_t)batchEpoch);
-                cg_wave_sync(); cg_follow_wake();
-            } else
             if (slotWr && ht == 0) { ChainSlot cs; cs.qlen = sh.g.qlen; cs.tag = (uint32_t)batchEpoch; *slotWr = cs; }
             GEN_TS(24);
             { const bool ts_ok = e_prevQ >= 140u && remaining >= 512u && GEN_TS_ROUND_OK(roundNo); (void)ts_ok; GEN_TS_DUMP_WAVE(); }
             return;
         }
         // ---- another round of this batch: its set-up once every lane is done with this round's masks
-        gen_hsync<WIN, PERSIST>(sh, ht, false);
+        cg_sync_lds();
         if (ht == 0) { sh.roundNo = roundNo + 1u; sh.stopKey = 0xFFFFFFFFu; sh.frontPending = 0; if (roundNo + 1u >= 4094u) gs->error = GAPS_ERR_SPIN; }
         if (ht < (unsigned)(WIN / 64)) { sh.mq[ht] = 0ull; sh.mb[ht] = 0ull; sh.md[ht] = 0ull; }
-        gen_hsync<WIN, PERSIST>(sh, ht, true);
+        cg_sync();
     }
 }
 
@@ -291,7 +268,6 @@ struct GenRoundCtx {
     float tabHi, tabLo;      // round 1: this lane's entries of the window's death-probability rows, on their way from SamplerDev::deathProb
     PropRec *queueOut;       // where the batch's queue records go (S.queue; the chained launch: the copy of the other parity)
     uint32_t dpBase;         // chained launch: first entry of the death-probability table's window in sh.dpWin
-    void *pubOut; uint32_t pubBytes;      // persistent generator: the published copy of the queue (granules, gaps_state.h CHAIN_PUB_BYTES)
 };
 // The chained launch classifies and sorts its first window BEFORE the previous batch's decisions are in (gen_spec_a1, while the
 // evaluation workgroups of the same launch run): what the lane keeps of that in registers.  First half: lane = attempt; second half:
@@ -676,9 +652,7 @@ CG_DEVICE uint32_t gen_draw_valid(const SamplerDev &S, GenShared<WIN> &sh, const
     return level;
 }
 
-// PUB (persistent generator): the queue records are written through for evaluation workgroups that are already running, and the batch's
-// last round ends with the barrier behind which the helper wave publishes the slot (gen_helper).
-template <int WIN, bool FIRST, bool SPEC = false, bool AHEAD = false, bool PUB = false>
+template <int WIN, bool FIRST, bool SPEC = false, bool AHEAD = false>
 CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRoundCtx &c, const uint32_t roundNo, const GenSpec *spec = nullptr, const GenDraw *ahead = nullptr, const bool aheadValid = true, const bool keepPick = false)
 {
     static_assert(FIRST || !SPEC, "only a batch's first window is classified ahead of the decisions");
@@ -1109,14 +1083,6 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
                 p.m1 = (type == 'B') ? 0.f : a.mass; p.m2 = (type == 'E') ? m2x : 0.f;
                 p.old1 = old1; p.old2 = two ? old2 : 0.f; p.curPos = (type == 'M') ? cpos : 0ull;
                 c.queueOut[slot] = p;
-                if (PUB) {      // ... and as granules for the evaluation launch that is already running (the first 80 bytes: `batch` and the padding are the traces')
-                    static_assert(offsetof(PropRec, batch) == 80u, "the record's live part is twenty words");
-                    uint32_t w[21]; __builtin_memcpy(w, &p, 80u); w[20] = 0u;
-                    const cg_pub pb = cg_pub_open(c.pubOut, c.pubBytes);
-                    const uint32_t tg = (uint32_t)batchEpoch;
-#pragma unroll
-                    for (int k = 0; k < 7; ++k) cg_pub_store(pb, slot * CHAIN_PUB_BYTES + 16u * (uint32_t)k, w[3 * k], w[3 * k + 1], w[3 * k + 2], tg);
-                }
                 if (c_traceOn) { const uint32_t ti = c_traceCount + slot; if (ti < c_traceCap) { p.batch = c_nBatches; S.trace[ti] = p; } }
             }
         }
@@ -1144,7 +1110,6 @@ CG_DEVICE bool gen_round(const SamplerDev &S, GenShared<WIN> &sh, const GenRound
     }
     GEN_TS(21);
     if (endB) { GEN_TS(22); GEN_RT(5); GEN_RT_DUMP(); { const bool ts_ok = c.e_prevQ >= 140u && c.remaining >= 512u && GEN_TS_ROUND_OK(roundNo); (void)ts_ok; GEN_TS_DUMP_WAVE(); } }
-    if (PUB && endB) { cg_drain_stores(); cg_sync_lds(); }      // (every record and every domain store of this wave has landed: the helper wave publishes the slot behind this barrier)
     return endB;
 }
 
@@ -1326,33 +1291,12 @@ struct GenClockEnd {
     CG_DEVICE GenClockEnd(unsigned t_) : slot(nullptr), t(t_) {}
     CG_DEVICE ~GenClockEnd() { if (slot && (t & 63u) == 0u) cg_atomic_max_u64(slot, cg_realtime()); }
 };
-// The passenger waves of the persistent generator behind the join (gen_helper's comment): one barrier per announcement, until the helper
-// wave has ended the batch.  (The helper cannot end the batch before its last announced barrier has released, which needs this wave:
-// when endGen shows the batch's tag every announcement has been answered.)  Bounded like every wait inside a launch.
-template <int WIN>
-CG_DEVICE void gen_follow(GenShared<WIN> &sh, uint32_t seq, const uint32_t gen, GenScalars *gs)
+template <int WIN, bool ASYNC, bool CHAIN = false>
+CG_DEVICE void gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot hot, GenShared<WIN> &sh)
 {
-    uint32_t spins = 0;
-    for (;;) {
-        if (cg_uniform_u32(cg_lds_peek_u32(&sh.barSeq)) != seq) { ++seq; cg_sync_lds(); spins = 0; continue; }
-        if (cg_uniform_u32(cg_lds_peek_u32(&sh.endGen)) == gen) return;
-        if (cg_poll_expired(++spins)) { gs->error = GAPS_ERR_SPIN_FOLLOW; return; }
-        cg_follow_pause();
-    }
-}
-// Returns whether the generator is done with the update (the last erase cache flushed, or an error): what ends the persistent form's loop
-// over batches (the same value in every wave); the one-batch launches ignore it.
-template <int WIN, bool ASYNC, bool CHAIN = false, bool PERSIST = false>
-CG_DEVICE uint32_t gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot hot, GenShared<WIN> &sh)
-{
-    static_assert(CHAIN || !PERSIST, "the persistent generator receives the decisions as the chained launch's does");
     GenClockEnd clockEnd(cg_tid());
-    const unsigned long long clockBegin = (PERSIST && cg_tid() == 0u) ? cg_realtime() : 0ull;
     constexpr unsigned TPB = (unsigned)WIN + 64u;       // attempt lanes + the helper wave
-    // (persistent generator: the lane number is taken as new in every batch -- what is derived from it inside the loop over batches was hoisted
-    // in front of it and held in registers for the whole launch: sixty spilled vector registers, thirty with this; what remains are the
-    // constants of rare paths, stored once per launch)
-    const unsigned t = PERSIST ? cg_opaque_u32(cg_tid()) : cg_tid();
+    const unsigned t = cg_tid();
     // wave-uniform roles: attempt lanes, the helper wave, and -- chained launch only, which has the evaluation's workgroup size -- the
     // waves beyond it, which with the helper wave apply the previous batch's decisions
     const bool attempt = t < (unsigned)WIN, helper = t >= (unsigned)WIN && t < TPB, spare = t >= TPB, applier = CHAIN && !attempt;
@@ -1501,8 +1445,6 @@ CG_DEVICE uint32_t gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot ho
         epoch0 = sh.g.batchEpoch;
         const uint32_t tag = (uint32_t)epoch0;      // the batch in the queue: the one this workgroup generated in the previous launch
         if (S.launchClock) clockEnd.slot = S.launchClock + 2u * (tag % GAPS_CLOCK_RING) + 1u;
-        if (PERSIST && t == 0u && S.launchClock) S.launchClock[2u * (tag % GAPS_CLOCK_RING)] = clockBegin;      // (the one-launch form: its first evaluation workgroup's entry)
-        const uint32_t seq0 = PERSIST ? cg_uniform_u32(cg_lds_peek_u32(&sh.barSeq)) : 0u;      // (nothing is announced before the join)
 #if defined(COGAPS_EMUL)
         if (t == 0 && e_prevQ) cg_atomic_add_u64(&gs->prof[13], 1ull);      // test-only build: batches whose decisions arrived inside a chained launch
 #endif
@@ -1598,12 +1540,11 @@ CG_DEVICE uint32_t gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot ho
         GEN_TS(35);
         GEN_RT(4);
         const uint32_t sfRaw = sh.spinFail, emRaw = sh.eraseN;      // (both words in one LDS trip)
-        if (cg_uniform_u32(sfRaw) != 0u) return 1u;      // a decision never arrived (GAPS_ERR_SPIN is set): every wave leaves, nothing is generated
+        if (cg_uniform_u32(sfRaw) != 0u) return;      // a decision never arrived (GAPS_ERR_SPIN is set): every wave leaves, nothing is generated
         if (spare) {                                        // (the waves beyond the helper wave only applied)
-            if (PERSIST) { if (!updateDone) gen_follow<WIN>(sh, seq0, tag + 1u, gs); }
-            else if (drawAhead && !updateDone) { cg_sync_lds(); cg_sync(); }
+            if (drawAhead && !updateDone) { cg_sync_lds(); cg_sync(); }
             { const bool ts_ok = e_prevQ >= 140u && e_nSteps - e_nDone >= 512u; (void)ts_ok; GEN_TS_DUMP_WAVE(); }
-            return updateDone ? 1u : 0u;
+            return;
         }
         e_m = cg_uniform_u32(emRaw);
         if (e_m > eraseCap) e_m = eraseCap;
@@ -1620,7 +1561,7 @@ CG_DEVICE uint32_t gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot ho
     if (updateDone) {
         // a launch past the end of the update: the last erase cache is flushed (by the helper wave alone) and the progress words reported
         if (!CHAIN) cg_sync_lds();              // (the unit sum is complete)
-        if (!helper) return 1u;                 // (attempt lanes; the chained launch's spare waves left behind the join)
+        if (!helper) return;                    // (attempt lanes; the chained launch's spare waves left behind the join)
         GenFlushRegs fr;
         gen_flush_fetch<WIN>(S, fr, ht, e_m, e_n, specE, e_fc);
         if (ht == 0) { sh.flushM = 0; sh.flushBase = e_fc; sh.nLow = 0; }
@@ -1628,15 +1569,10 @@ CG_DEVICE uint32_t gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot ho
         for (int part = 0; part < 4; ++part) { gen_flush_part<WIN>(S, sh, fr, ht, e_m, e_n, e_fc, part); cg_wave_sync(); }
         if (ht == 0) { gs->nAtoms = sh.g.nAtoms; gs->front = sh.g.front; gs->freeCount = sh.g.freeCount; gs->eraseCount = 0; gs->qlen = 0; gs->batchNproc = 0; gs->updateFlushed = 1;
                        gs->evalBytes = sh.g.evalBytes + (unsigned long long)sh.unitSum * S.unitBytes; gs->evalProps = sh.g.evalProps + e_prevQ;
-                       if (PERSIST) {      // (both copies: whichever the evaluation launches still enqueued look at)
-                           cg_drain_stores();
-                           const unsigned long long fin = ((unsigned long long)(uint32_t)sh.g.batchEpoch << 32) | (unsigned long long)CHAIN_FIN;
-                           cg_store_agent_u64(reinterpret_cast<unsigned long long *>(hot.slotWr), fin); cg_store_agent_u64(reinterpret_cast<unsigned long long *>(hot.slotRd), fin);
-                       } else
                        if (CHAIN) { ChainSlot cs; cs.qlen = 0; cs.tag = (uint32_t)sh.g.batchEpoch; *hot.slotWr = cs; } }
-        return 1u;
+        return;
     }
-    if (helper) { gen_helper<WIN, PERSIST>(S, sh, gs, ht, specE, e_m, e_n, e_fc, e_prevQ, e_nDone, e_nSteps, CHAIN ? hot.slotWr : nullptr, CHAIN && specDone); return 0u; }
+    if (helper) { gen_helper<WIN>(S, sh, gs, ht, specE, e_m, e_n, e_fc, e_prevQ, e_nDone, e_nSteps, CHAIN ? hot.slotWr : nullptr, CHAIN && specDone); return; }
 
     // ================================================================================ attempt lanes
     // second trip (addresses from the first): this round's seeds
@@ -1667,7 +1603,7 @@ CG_DEVICE uint32_t gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot ho
 
     GenRoundCtx rc; rc.t = t; rc.jm0 = jm0; rc.ji0 = ji0; rc.jm1 = jm1; rc.ji1 = ji1; rc.seed1 = seed1; rc.batchEpoch = batchEpoch; rc.g_qrng = g_qrng; rc.n0 = n0; rc.updBase = updBase;
     rc.remaining = remaining; rc.K = K; rc.g_skip = g_skip; rc.e_prevQ = e_prevQ; rc.dp0 = dp0; rc.g_u1 = g_u1; rc.g_u2 = g_u2; rc.gs = gs; rc.tabHi = tabHi; rc.tabLo = tabLo;
-    rc.queueOut = CHAIN ? hot.queueWr : S.queue; rc.dpBase = dpBase; rc.pubOut = PERSIST ? hot.pubWr : nullptr; rc.pubBytes = PERSIST ? hot.pubBytes : 0u;
+    rc.queueOut = CHAIN ? hot.queueWr : S.queue; rc.dpBase = dpBase;
     if (CHAIN && specDone) {
         // which lanes drew what they would draw now (gen_draw_valid).  If every lane of the window did, the round goes straight into its
         // conflict phases and the helper wave's flush runs beside them (gen_helper); otherwise the join with the flush first
@@ -1691,9 +1627,9 @@ CG_DEVICE uint32_t gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot ho
 #if defined(GEN_TIMELINE)
         if (t == 0u) { sh.rt[7] = __builtin_amdgcn_s_memrealtime(); sh.rtInfo |= ((sh.rt[6] & 0xFFull) << 40) | (((sh.rt[7] - sh.rt[4]) & 0xFFFFull) << 48) | ((unsigned long long)(redoLevel & 3u) << 36); }
 #endif
-        if (gen_round<WIN, true, true, true, PERSIST>(S, sh, rc, 1u, &specKeep, &drawKeep, valid, redoLevel == 1u)) return 0u;
+        if (gen_round<WIN, true, true, true>(S, sh, rc, 1u, &specKeep, &drawKeep, valid, redoLevel == 1u)) return;
     }
-    else if (gen_round<WIN, true, false, false, PERSIST>(S, sh, rc, 1u)) return 0u;
+    else if (gen_round<WIN, true>(S, sh, rc, 1u)) return;
     for (uint32_t roundNo = 2; ; ++roundNo) {
         // ------------------------------------------------------------------ set-up of the next round of this batch (the helper wave has published
         // sh.nR / sh.minAtoms and resets the masks and the stop key between the two barriers)
@@ -1704,7 +1640,7 @@ CG_DEVICE uint32_t gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot ho
             sh.dpLo[t] = (m0 >= t) ? gm_death_prob((double)(uint64_t)(m0 - t), S.domainLenD, S.alphaD, S.numBins) : 0.f;
         }
         cg_sync();
-        if (gen_round<WIN, false, false, false, PERSIST>(S, sh, rc, roundNo)) return 0u;
+        if (gen_round<WIN, false>(S, sh, rc, roundNo)) return;
     }
 }
 
@@ -1723,7 +1659,7 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(WIN + 64) gen_kernel(const uint64_t *lcgMul, con
                                                     uint32_t eraseCap, uint32_t queueCap, const SamplerDev CG_CONSTANT *sp)
 {
     GenHot hot; hot.lcgMul = lcgMul; hot.lcgInc = lcgInc; hot.gs = gs; hot.eraseList = eraseList; hot.queueUnits = queueUnits; hot.eraseCap = eraseCap; hot.queueCap = queueCap;
-    hot.queueRd = nullptr; hot.queueWr = nullptr; hot.grans = nullptr; hot.slotWr = nullptr; hot.slotRd = nullptr;
+    hot.queueRd = nullptr; hot.queueWr = nullptr; hot.grans = nullptr; hot.slotWr = nullptr;
     gen_body<WIN, true>(sp, hot);
 }
 // batched multi-chain launch (eval_kernel.h): one workgroup per chain
@@ -1734,6 +1670,6 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(WIN + 64) gen_kernel_multi(const SamplerDev CG_C
     cg_const_warm<sizeof(SamplerDev)>(sp);
     const SamplerDev &S = *(const SamplerDev *)sp;
     GenHot hot; hot.lcgMul = S.lcgMul; hot.lcgInc = S.lcgInc; hot.gs = S.gs; hot.eraseList = S.eraseList; hot.queueUnits = S.queueUnits; hot.eraseCap = S.eraseCap; hot.queueCap = S.queueCap;
-    hot.queueRd = nullptr; hot.queueWr = nullptr; hot.grans = nullptr; hot.slotWr = nullptr; hot.slotRd = nullptr;
+    hot.queueRd = nullptr; hot.queueWr = nullptr; hot.grans = nullptr; hot.slotWr = nullptr;
     gen_body<WIN, false>(sp, hot);
 }

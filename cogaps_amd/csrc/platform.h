@@ -144,31 +144,6 @@ CG_DEVICE unsigned long long cg_load_l2_u64(const unsigned long long *p) { retur
 // (MI355X_MICROARCH.md, persistent-kernel price list, handoff-1to1: ~0.8 us on an idle chip).
 CG_DEVICE void cg_store_agent_u64(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 CG_DEVICE void cg_poll_pause() { __builtin_amdgcn_s_sleep(1); }
-// A word in LDS that another wave of the workgroup writes while this one spins on it (the persistent generator's passenger waves,
-// gen_populate.h: gen_follow): read / written in place every time
-CG_DEVICE uint32_t cg_lds_peek_u32(const uint32_t *p) { return *(const volatile uint32_t *)p; }
-CG_DEVICE void cg_lds_poke_u32(uint32_t *p, uint32_t v) { *(volatile uint32_t *)p = v; }
-// Records published to workgroups of ANOTHER launch that is already running (persistent generator -> evaluation launches, chain_kernel.h):
-// 16-byte granules {three payload words, tag}, each written through to the device-coherent level by ONE store and read past the
-// reader's caches by one load (`sc1`, through a buffer descriptor: the compiler counts and schedules these as its own loads and stores).
-// The tag says the words are this batch's: no flag, no ordering between the granules of a record (MI355X guide: granules, R2).
-typedef uint32_t cg_u4 __attribute__((ext_vector_type(4)));
-struct cg_pub { __amdgpu_buffer_rsrc_t r; };
-CG_DEVICE cg_pub cg_pub_open(const void *base, uint32_t bytes) { cg_pub p; p.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000); return p; }      // (base: the same in every lane)
-CG_DEVICE void cg_pub_store(const cg_pub &p, uint32_t byteOff, uint32_t a, uint32_t b, uint32_t c, uint32_t tag) { cg_u4 v; v.x = a; v.y = b; v.z = c; v.w = tag; __builtin_amdgcn_raw_buffer_store_b128(v, p.r, byteOff, 0, 16); }
-CG_DEVICE cg_u4 cg_pub_load(const cg_pub &p, uint32_t byteOff) { return __builtin_amdgcn_raw_buffer_load_b128(p.r, byteOff, 0, 16); }
-// a value the compiler must take as new each time (the persistent generator's loop: nothing derived from the lane number is hoisted out of it and kept in a register across the whole batch)
-CG_DEVICE uint32_t cg_opaque_u32(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
-CG_DEVICE void cg_nap_long() { __builtin_amdgcn_s_sleep(127); }      // ~3.5 us (64 x 127 clocks)
-CG_DEVICE void cg_nap_short() { __builtin_amdgcn_s_sleep(8); }      // ~0.2 us
-// a wave that follows the helper wave's announcements sleeps half a microsecond per turn and is woken by the announcing wave (s_wakeup: every
-// sleeping wave of the workgroup; lost if the sleeper has not gone to sleep yet -- then the turn runs out): a wave that spun on the word
-// instead took issue slots and LDS turns from the attempt waves it shares its SIMDs with
-CG_DEVICE void cg_follow_pause() { __builtin_amdgcn_s_sleep(20); }
-CG_DEVICE void cg_follow_wake() { asm volatile("s_wakeup" ::: "memory"); }
-CG_DEVICE uint32_t cg_load_agent_u32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// this wave's stores have left the compute unit and, written through (cg_store_agent_u64), have reached the device-coherent level
-CG_DEVICE void cg_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 CG_DEVICE unsigned long long cg_realtime() { return __builtin_amdgcn_s_memrealtime(); }      // chip-wide constant 100 MHz clock
 // A poll inside a launch is bounded, generously: every turn is a load past the caches (>= 0.5 us while the word is not there) plus a
 // sleep, so 2^22 turns are at least two seconds -- a waiting workgroup may share the GPU with a foreign kernel, a debugger or a preempted

@@ -803,7 +803,7 @@ CG_DEVICE void eval_sparse_body(const SamplerDev &S, const uint32_t vbid, const 
 }
 CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_kernel(const PropRec *hotQueue, const GenScalars *hotGs, uint32_t hotCap, const SamplerDev CG_CONSTANT *sp)
 {
-    EvalHot hot; hot.queue = hotQueue; hot.gs = hotGs; hot.queueCap = hotCap; hot.slot = nullptr; hot.grans = nullptr; hot.pub = 0u; hot.pubBase = nullptr; hot.pubBytes = 0u; hot.pubTag = 0u;
+    EvalHot hot; hot.queue = hotQueue; hot.gs = hotGs; hot.queueCap = hotCap; hot.slot = nullptr; hot.grans = nullptr;
     const EvalFirst first = eval_first<EVAL_FUSED>(hot, 1u, cg_bid());
     const SamplerDev &S = eval_record<EVAL_FUSED>(sp);
     eval_sparse_body<false, false>(S, cg_bid(), cg_gdim(), hot, first);
@@ -811,7 +811,7 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_kernel(const PropRec *hotQueue,
 // data vectors of more than one round of flag words (more than 16384 elements): the rounds' common non-zeros listed together (sp_partial_merged)
 CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_kernel_wide(const PropRec *hotQueue, const GenScalars *hotGs, uint32_t hotCap, const SamplerDev CG_CONSTANT *sp)
 {
-    EvalHot hot; hot.queue = hotQueue; hot.gs = hotGs; hot.queueCap = hotCap; hot.slot = nullptr; hot.grans = nullptr; hot.pub = 0u; hot.pubBase = nullptr; hot.pubBytes = 0u; hot.pubTag = 0u;
+    EvalHot hot; hot.queue = hotQueue; hot.gs = hotGs; hot.queueCap = hotCap; hot.slot = nullptr; hot.grans = nullptr;
     const EvalFirst first = eval_first<EVAL_FUSED>(hot, 1u, cg_bid());
     const SamplerDev &S = eval_record<EVAL_FUSED>(sp);
     eval_sparse_body<false, true>(S, cg_bid(), cg_gdim(), hot, first);
@@ -822,14 +822,14 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_kernel_multi(const SamplerDev C
     const SamplerDev CG_CONSTANT *sp = arr + chain;
     cg_const_warm<sizeof(SamplerDev)>(sp);
     const SamplerDev &S = *(const SamplerDev *)sp;
-    EvalHot hot; hot.queue = S.queue; hot.gs = S.gs; hot.queueCap = S.queueCap; hot.slot = nullptr; hot.grans = nullptr; hot.pub = 0u; hot.pubBase = nullptr; hot.pubBytes = 0u; hot.pubTag = 0u;
+    EvalHot hot; hot.queue = S.queue; hot.gs = S.gs; hot.queueCap = S.queueCap; hot.slot = nullptr; hot.grans = nullptr;
     const uint32_t vbid = cg_bid() - chain * wgPerChain;
     eval_sparse_body<false, false>(S, vbid, wgPerChain, hot, eval_first<EVAL_FUSED>(hot, 1u, vbid));
 }
 CG_KERNEL void CG_LAUNCH_BOUNDS(256) eval_sparse_seq_kernel(SamplerDev S)
 {
     cg_kernarg_warm<sizeof(SamplerDev)>();
-    EvalHot hot; hot.queue = S.queue; hot.gs = S.gs; hot.queueCap = S.queueCap; hot.slot = nullptr; hot.grans = nullptr; hot.pub = 0u; hot.pubBase = nullptr; hot.pubBytes = 0u; hot.pubTag = 0u;
+    EvalHot hot; hot.queue = S.queue; hot.gs = S.gs; hot.queueCap = S.queueCap; hot.slot = nullptr; hot.grans = nullptr;
     eval_sparse_body<true, false>(S, cg_bid(), cg_gdim(), hot, eval_first<EVAL_FUSED>(hot, 1u, cg_bid()));
 }
 
@@ -1033,11 +1033,11 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(CHAIN_MAX_THREADS) chain_sparse_kernel(const uin
     CG_SHARED alignas(16) unsigned char pool[POOL];
     if (cg_bid() + 1u == cg_gdim()) {
         GenHot hot; hot.lcgMul = lcgMul; hot.lcgInc = lcgInc; hot.gs = gs; hot.eraseList = nullptr; hot.queueUnits = nullptr; hot.eraseCap = 0; hot.queueCap = queueCap;
-        hot.queueRd = queue + (size_t)parity * queueCap; hot.queueWr = queue + (size_t)(1u - parity) * queueCap; hot.grans = grans; hot.slotWr = &slots[1u - parity]; hot.slotRd = &slots[parity];
+        hot.queueRd = queue + (size_t)parity * queueCap; hot.queueWr = queue + (size_t)(1u - parity) * queueCap; hot.grans = grans; hot.slotWr = &slots[1u - parity];
         gen_body_sh<WIN, true, true>(sp, hot, *reinterpret_cast<GenShared<WIN> *>(pool));
         return;
     }
-    EvalHot hot; hot.queue = queue + (size_t)parity * queueCap; hot.gs = gs; hot.queueCap = queueCap; hot.slot = &slots[parity]; hot.grans = grans; hot.pub = 0u; hot.pubBase = nullptr; hot.pubBytes = 0u; hot.pubTag = 0u;
+    EvalHot hot; hot.queue = queue + (size_t)parity * queueCap; hot.gs = gs; hot.queueCap = queueCap; hot.slot = &slots[parity]; hot.grans = grans;
     const unsigned long long clk0 = (cg_bid() == 0u && cg_tid() == 0u) ? cg_realtime() : 0ull;
     const EvalFirst first = eval_first<EVAL_CHAIN>(hot, 1u, cg_bid());
     const SamplerDev &S = eval_record<EVAL_CHAIN>(sp);

@@ -64,7 +64,6 @@ static void yield_to_sched(State st)
 }
 
 void block_barrier() { yield_to_sched(WAIT_BLOCK); }
-void yield_ready() { yield_to_sched(READY); }
 void wave_barrier() { yield_to_sched(WAIT_WAVE); }
 
 float wave_exchange_f32(float v, int mask)

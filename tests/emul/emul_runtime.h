@@ -64,21 +64,6 @@ inline int cg_popc64(unsigned long long x) { return __builtin_popcountll(x); }
 inline unsigned long long cg_load_l2_u64(const unsigned long long *p) { return *p; }
 inline void cg_store_agent_u64(unsigned long long *p, unsigned long long v) { *p = v; }
 inline void cg_poll_pause() {}
-namespace cgemu { void yield_ready(); }
-inline uint32_t cg_lds_peek_u32(const uint32_t *p) { return *(const volatile uint32_t *)p; }
-inline void cg_lds_poke_u32(uint32_t *p, uint32_t v) { *(volatile uint32_t *)p = v; }
-inline void cg_follow_pause() { cgemu::yield_ready(); }      // (a fiber that spins on a word another fiber writes lets the others run)
-inline void cg_drain_stores() {}
-inline void cg_follow_wake() {}
-inline uint32_t cg_load_agent_u32(const uint32_t *p) { return *p; }
-inline void cg_nap_long() {}
-inline void cg_nap_short() {}
-inline uint32_t cg_opaque_u32(uint32_t x) { return x; }
-struct cg_u4 { uint32_t x, y, z, w; };
-struct cg_pub { char *base; };
-inline cg_pub cg_pub_open(const void *base, uint32_t) { cg_pub p; p.base = (char *)base; return p; }
-inline void cg_pub_store(const cg_pub &p, uint32_t byteOff, uint32_t a, uint32_t b, uint32_t c, uint32_t tag) { cg_u4 v; v.x = a; v.y = b; v.z = c; v.w = tag; memcpy(p.base + byteOff, &v, 16); }
-inline cg_u4 cg_pub_load(const cg_pub &p, uint32_t byteOff) { cg_u4 v; memcpy(&v, p.base + byteOff, 16); return v; }
 inline unsigned long long cg_realtime() { return 0ull; }
 inline bool cg_poll_expired(uint32_t spins) { return spins > (1u << 16); }      // (no clock here: the emulator's producers have always finished)
 inline float cg_shfl_xor_f32(float v, int mask) { return cgemu::wave_exchange_f32(v, mask); }

@@ -88,25 +88,6 @@ def test_chained_launch_against_the_oracle(emul_lib, monkeypatch, variant):
     print(variant, dict(chain_batches=chain_batches, ahead=spec, usual=usual, lanes_held=held, lanes_redrawn=redrawn, of_which_kept_their_pick=kept_pick, pairs=pairs))
 
 
-def test_generator_and_evaluation_as_launches_of_their_own(emul_lib, monkeypatch):
-    """COGAPS_PERSIST (csrc/chain_kernel.h, chain_gen_kernel / chain_eval_kernel): the generator workgroup in a launch of its own -- the
-    waves that only apply decisions stay behind the join and arrive at one barrier per announcement of the helper wave (gen_follow), the
-    queue goes out as tagged granules, the slot ahead of the records -- and the evaluation as a launch that waits for the slot and its
-    record.  On the emulator (launches run one after the other) batch by batch; stepwise against the oracle, both samplers."""
-    from cogaps_amd import _capi
-    monkeypatch.setenv("COGAPS_PERSIST", "seq")
-    lib = emul_lib(64)
-    data = pu.synthetic(1200, 300, seed=7)
-    pu.run_stepwise(lib, data, 16, nPatterns=3, seed=123, total_iter=40, check_every=4)
-    S = _capi.Session(data, lib=lib, nPatterns=3, seed=123, nIterations=40)
-    S.run_iterations(1, 0, 8)
-    assert S.launch_form("A") == 2 and S.launch_form("P") == 2
-    tot = np.zeros(16, dtype=np.int64)
-    for w in "AP": tot += np.array(S.debug_prof(w), dtype=np.int64)
-    S.close()
-    assert tot[13] > 50 and tot[12] > 20 and tot[8] > 100, tot.tolist()      # batches whose decisions the generator received, windows drawn ahead, lanes whose draw held
-
-
 def test_tiny_domain_hazards(emul_lib):
     """5 rows x 2 patterns: every window is full of row conflicts, same-bin moves and neighbour hazards"""
     data = pu.synthetic(5, 6, rank=2, seed=3)

@@ -252,31 +252,6 @@ def test_chained_equals_two_launches_on_the_gpu(hip_lib, monkeypatch):
     assert chained == plain
 
 
-def test_generator_and_evaluation_as_launches_of_their_own_equal_the_chained_launch_on_the_gpu(hip_lib, monkeypatch):
-    """csrc/chain_kernel.h, chain_gen_kernel / chain_eval_kernel (round 5; built, measured slower than the chained launch, not the default):
-    the generator workgroup in a launch of its own (the decisions' receiver of the chained launch, its passenger waves following the helper
-    wave's barrier announcements) and the evaluation as its own launch that WAITS for the batch's slot and reads its records as tagged
-    granules past the caches.  Here in the form that needs no two kernels to run at once (COGAPS_PERSIST=seq: batch by batch on one stream --
-    what the test-only emulator and the counter tools run): every hand-over of the two kernels on the hardware, bit-equal to the chained launch."""
-    from cogaps_amd import _capi
-    def run():
-        c = _CHAIN_AB
-        S = _capi.Session(pu.synthetic(c["genes"], c["samples"], rank=5, seed=3), lib=hip_lib, nPatterns=c["nPatterns"], nIterations=c["nIterations"], seed=c["seed"])
-        for it in range(c["iters"]):
-            S.set_annealing(min(1.0, 2.0 * it / c["nIterations"]))
-            nA, nP = S.draw_steps()
-            S.iterate(nA, nP)
-        st = _chain_state(S), S.launch_form("A")
-        S.close()
-        return st
-    chained, formA = run()
-    assert formA == 1
-    monkeypatch.setenv("COGAPS_PERSIST", "seq")
-    own, formB = run()
-    assert formB == 2, formB
-    assert own == chained
-
-
 def test_launch_clock_of_chained_launches(hip_lib):
     """cogaps_session_launch_clock: the chip-wide clock read inside EVERY chained launch since set_timing(1) (replayed graphs included) --
     as many launches as the sampler generated batches in the window (one launch per batch; the update's first launch evaluates nothing
