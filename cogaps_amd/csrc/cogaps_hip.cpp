@@ -497,9 +497,12 @@ static uint32_t apply_grid()
 // Updates in flight in this process (sessions stepped from several host threads: shards in flight, bench --chains-mode threads).  A chained
 // launch wants every workgroup of its launch resident at once -- one per compute unit: its kernel's LDS -- so two chains' chained launches
 // take turns on the chip and the hand-over inside each waits for the other's workgroups to leave (correct, and slower than two launches
-// per batch each).  The chained form is therefore taken only by an update that runs alone; the count is looked at when an update begins.
-static std::atomic<int> &g_updatesRunning() { static std::atomic<int> n{0}; return n; }
-struct UpdateInFlight { UpdateInFlight() { g_updatesRunning().fetch_add(1); } ~UpdateInFlight() { g_updatesRunning().fetch_sub(1); } };
+// per batch each).  The chained form is therefore taken only by an update that runs alone ON ITS GPU: one count per device ordinal (sessions
+// on different GPUs of one process do not switch each other's chained launch off), taken by the one-chain update and by the batched update
+// alike; the count is looked at when an update begins.
+static const int MAX_DEVICES = 64;
+static std::atomic<int> &g_updatesRunning(int device) { static std::atomic<int> n[MAX_DEVICES]; return n[device >= 0 && device < MAX_DEVICES ? device : 0]; }
+struct UpdateInFlight { int dev; explicit UpdateInFlight(int device) : dev(device) { g_updatesRunning(dev).fetch_add(1); } ~UpdateInFlight() { g_updatesRunning(dev).fetch_sub(1); } };
 // The chained launch serves the one-chain fused evaluation (dense model, product arithmetic) whose workgroups are at least as large as
 // the generator's and small enough for the generator's register budget (chain_kernel.h); everything else keeps two launches per batch.
 static bool chain_eligible(const cogaps_session *s, const HostSampler &h);
@@ -605,7 +608,7 @@ static bool chain_eligible(const cogaps_session *s, const HostSampler &h)
     // (a device with fewer compute units than the launch has workgroups -- a partitioned GPU -- would run them in turns, the generator
     // workgroup last: correct, and slower than two launches)
     if (s->noChain || h.d.seq) return false;
-    if (g_updatesRunning().load() > 1 && !s->forceChain) return false;      // (another session's update is in flight on this process's GPU: see g_updatesRunning)
+    if (g_updatesRunning(s->p.device).load() > 1 && !s->forceChain) return false;      // (another update -- a session's or a batch's -- is in flight on this session's GPU: see g_updatesRunning)
     if (h.d.sparse)      // sparse model (round 5): a launch of 512-thread workgroups, the evaluation keeps the model's width inside it
         return CHAIN_MAX_THREADS >= h.genWin + 64u && (s->forceChain || s->computeUnits >= std::min<uint32_t>(h.d.queueCap, CHAIN_EVAL_GRID) + 1u);
     uint32_t block = h.d.redW;
@@ -613,8 +616,12 @@ static bool chain_eligible(const cogaps_session *s, const HostSampler &h)
         uint32_t slices; split_geometry(h, block, slices);
         if (!split_one_launch(h) || slices > 16u || s->noChainSplit) return false;
     }
+    // (the split form's update items wait for deciding workgroups of HIGHER index -- eval_chain_updates --: every workgroup must be resident,
+    // so COGAPS_FORCE_CHAIN does not take it on a device with fewer compute units than the launch has workgroups; the fused form, whose
+    // evaluation workgroups never wait, runs in turns there)
+    const bool forced = s->forceChain && h.d.redW <= 1024u;
     return block <= (uint32_t)CHAIN_MAX_THREADS && block >= h.genWin + 64u
-           && (s->forceChain || s->computeUnits >= std::min<uint32_t>(h.d.queueCap, CHAIN_EVAL_GRID) + 1u);
+           && (forced || s->computeUnits >= std::min<uint32_t>(h.d.queueCap, CHAIN_EVAL_GRID) + 1u);
 }
 // one batch step: the chained launch, or a generator launch and an evaluation launch
 static void launch_pair(cogaps_session *s, HostSampler &h)
@@ -700,7 +707,7 @@ static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool t
 {
     SamplerDev &d = h.d;
     if (s->poisoned) return fail("this session was ended by a device error in an earlier update; its chain cannot be continued");
-    UpdateInFlight inFlight;
+    UpdateInFlight inFlight(s->p.device);
     read_gs(s, h);
     GenScalars g = *s->hGs;
     grow_atoms(s, h, g.nAtoms + nSteps + 1024u);
@@ -897,7 +904,7 @@ cogaps_session *cogaps_session_create(const float *data, uint32_t nrow, uint32_t
         s = new cogaps_session(); s->computeUnits = rt_compute_units();
         s->p = p;
         s->p.device = rt_get_device();            // (-1 resolved: later calls from other host threads select the same GPU)
-        g_updatesRunning();                       // (the counter exists before any session steps)
+        g_updatesRunning(s->p.device);            // (the counters exist before any session steps)
         s->startTime = now_s();
         if (p.printMessages) { printf("Loading Data..."); fflush(stdout); }                  // GapsRunner.cpp:399
         if (p.subsetData && p.dataIndicesSubset) s->subset.assign(p.dataIndicesSubset, p.dataIndicesSubset + p.nSubset);
@@ -1204,6 +1211,9 @@ static void multi_launch_pair(cogaps_batch *b, int w, const MultiGeom &g, int sl
 static int run_update_multi(cogaps_batch *b, int w, const std::vector<uint32_t> &nSteps)
 {
     const uint32_t C = (uint32_t)b->ss.size();
+    for (uint32_t c = 0; c < C; ++c)
+        if (b->ss[c]->poisoned) return fail("chain " + std::to_string(c) + " of this batch was ended by a device error in an earlier update; the batch cannot be continued");
+    UpdateInFlight inFlight(b->ss[0]->p.device);      // (a one-chain session stepped beside the batch on the same GPU keeps two launches per batch meanwhile)
     rt_alloc_scope allocOn(b->stream);
     for (uint32_t c = 0; c < C; ++c) rt_d2h(&b->hGs[c], bpick(b, c, w).d.gs, sizeof(GenScalars), b->stream);
     rt_sync(b->stream);
@@ -1363,6 +1373,8 @@ int cogaps_batch_run_iterations(cogaps_batch *b, int phase, uint32_t firstIter, 
         rt_set_device(b->ss[0]->p.device);
         rt_alloc_scope allocOn(b->stream);
         const uint32_t C = (uint32_t)b->ss.size();
+        for (uint32_t c = 0; c < C; ++c)
+            if (b->ss[c]->poisoned) return fail("chain " + std::to_string(c) + " of this batch was ended by a device error in an earlier update; the batch cannot be continued");
         const double t0 = now_s();
         for (cogaps_session *s : b->ss)
             if (s->p.printMessages && firstIter == 0 && n > 0) { printf(phase == 1 ? "-- Equilibration Phase --\n" : "-- Sampling Phase --\n"); fflush(stdout); }
@@ -1491,6 +1503,7 @@ int cogaps_session_finish(cogaps_session *s, cogaps_result *out)
 {
     SESSION_TRY
     memset(out, 0, sizeof(*out));
+    if (s->poisoned) return fail("this session was ended by a device error; it holds no result (the state getters still read the half-applied state, for diagnosis)");
     out->nGenes = s->nGenes; out->nSamples = s->nSamples; out->nPatterns = s->K;
     const uint32_t K = s->K;
     auto fetch = [&](float *dptr, size_t n) { std::vector<float> v(n); rt_d2h(v.data(), dptr, n * 4, s->stream); rt_sync(s->stream); return v; };

@@ -1031,5 +1031,5 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(WIN + 64) gen_apply_kernel(const uint64_t *lcgMu
         return;
     }
     GenHot hot; hot.lcgMul = lcgMul; hot.lcgInc = lcgInc; hot.gs = gs; hot.eraseList = eraseList; hot.queueUnits = queueUnits; hot.eraseCap = eraseCap; hot.queueCap = queueCap;
-    gen_body<WIN, true>(sp, hot);
+    gen_body<WIN, true, false, 0>(sp, hot);      // (the one-launch split evaluation is the dense model's)
 }

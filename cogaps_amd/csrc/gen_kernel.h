@@ -83,7 +83,9 @@ __device__ unsigned long long g_chain_log[GEN_LOG_N * 8]; __device__ unsigned in
 #ifndef GEN_LDS_ROUNDS_MAX
 #define GEN_LDS_ROUNDS_MAX 3       // (test variants of the emulator build lower it: 1 = every later round through the stamp tables, 2 = the hand-over after two LDS rounds)
 #endif
-#define GEN_LDS_ROUNDS ((10 * WIN) * 10 <= (4 * GEN_TAB_NB) * 7 ? GEN_LDS_ROUNDS_MAX : 1)
+// (a round registers at most three keys per attempt, a committed birth's atom now and then: ~3.1 keys per attempt; 256 attempts: 3 rounds, 320 / 384: 2)
+#define GEN_LDS_ROUNDS_FIT (((4 * GEN_TAB_NB) * 7 * 10) / (31 * WIN * 10))
+#define GEN_LDS_ROUNDS (GEN_LDS_ROUNDS_FIT >= GEN_LDS_ROUNDS_MAX ? GEN_LDS_ROUNDS_MAX : (GEN_LDS_ROUNDS_FIT < 1 ? 1 : GEN_LDS_ROUNDS_FIT))
 #define GEN_K_ROW 0u
 #define GEN_K_ATOM 1u
 #define GEN_K_GAP 2u

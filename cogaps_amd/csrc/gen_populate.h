@@ -268,6 +268,7 @@ struct GenRoundCtx {
     float tabHi, tabLo;      // round 1: this lane's entries of the window's death-probability rows, on their way from SamplerDev::deathProb
     PropRec *queueOut;       // where the batch's queue records go (S.queue; the chained launch: the copy of the other parity)
     uint32_t dpBase;         // chained launch: first entry of the death-probability table's window in sh.dpWin
+    uint32_t sparse;         // the model (SamplerDev::sparse) -- a compile-time constant where the kernel serves one model only (gen_body_sh<.., SP>)
 };
 // The chained launch classifies and sorts its first window BEFORE the previous batch's decisions are in (gen_spec_a1, while the
 // evaluation workgroups of the same launch run): what the lane keeps of that in registers.  First half: lane = attempt; second half:
@@ -489,7 +490,7 @@ CG_DEVICE void gen_draw_b(const SamplerDev &S, GenShared<WIN> &sh, const GenRoun
     uint64_t lposB = 0, rposB = 0; float rmassB = 0.f;        // birth: what the new atom's record caches of its neighbours
     if (isB && !slowB) b3 = S.atoms[v2];
     if (frontE) b3 = S.atoms[h2];
-    if (isB || pick) { old1 = S.sparse ? S.rows[(size_t)r1 * S.Kpad + c1] : S.mat[(size_t)c1 * S.Mpad + r1]; gib1 = S.otherColPos[c1]; }
+    if (isB || pick) { old1 = c.sparse ? S.rows[(size_t)r1 * S.Kpad + c1] : S.mat[(size_t)c1 * S.Mpad + r1]; gib1 = S.otherColPos[c1]; }
     if (pick && type == 'M') {
         if (hl != CG_NONE) { flags |= GEN_F_HASLEFT; lbpos = lp; } else lbpos = 0;
         if (hr != CG_NONE) { flags |= GEN_F_HASRIGHT; rbpos = rp; } else rbpos = S.rboundNone;
@@ -503,7 +504,7 @@ CG_DEVICE void gen_draw_b(const SamplerDev &S, GenShared<WIN> &sh, const GenRoun
         const uint32_t bin2 = gen_bin_of(S, rbpos);
         r2 = gen_div_k(S, bin2); c2 = bin2 - r2 * K;
     }
-    if (pick && (type == 'M' || (type == 'E' && !frontE))) { old2 = S.sparse ? S.rows[(size_t)r2 * S.Kpad + c2] : S.mat[(size_t)c2 * S.Mpad + r2]; gib2 = S.otherColPos[c2]; }
+    if (pick && (type == 'M' || (type == 'E' && !frontE))) { old2 = c.sparse ? S.rows[(size_t)r2 * S.Kpad + c2] : S.mat[(size_t)c2 * S.Mpad + r2]; gib2 = S.otherColPos[c2]; }
     // finish ----------------------------------------------------------------------------------
     if (isB) {
         if (!slowB) {
@@ -539,7 +540,7 @@ CG_DEVICE void gen_draw_b(const SamplerDev &S, GenShared<WIN> &sh, const GenRoun
             flags &= ~(GEN_F_BINEMPTY | GEN_F_WORDZERO | GEN_F_NEWHEAD);
             if (nh) flags |= GEN_F_NEWHEAD;
             if (S.binHead[bin] == CG_NONE) { flags |= GEN_F_BINEMPTY; if (S.bits0[bin >> 6] == 0ull) flags |= GEN_F_WORDZERO; }
-            old1 = S.sparse ? S.rows[(size_t)r1 * S.Kpad + c1] : S.mat[(size_t)c1 * S.Mpad + r1]; gib1 = S.otherColPos[c1];      // the retry may have moved the birth to another bin
+            old1 = c.sparse ? S.rows[(size_t)r1 * S.Kpad + c1] : S.mat[(size_t)c1 * S.Mpad + r1]; gib1 = S.otherColPos[c1];      // the retry may have moved the birth to another bin
             lposB = (hl != CG_NONE) ? S.atoms[hl].pos : 0ull;
             if (hr != CG_NONE) { rposB = S.atoms[hr].pos; rmassB = S.atoms[hr].mass; } else { rposB = 0ull; rmassB = 0.f; }
         }
@@ -548,7 +549,7 @@ CG_DEVICE void gen_draw_b(const SamplerDev &S, GenShared<WIN> &sh, const GenRoun
             rbpos = b3.pos; m2x = b3.mass;
             const uint32_t bin2 = gen_bin_of(S, rbpos);
             r2 = gen_div_k(S, bin2); c2 = bin2 - r2 * K;
-            old2 = S.sparse ? S.rows[(size_t)r2 * S.Kpad + c2] : S.mat[(size_t)c2 * S.Mpad + r2]; gib2 = S.otherColPos[c2];
+            old2 = c.sparse ? S.rows[(size_t)r2 * S.Kpad + c2] : S.mat[(size_t)c2 * S.Mpad + r2]; gib2 = S.otherColPos[c2];
         }
         if (r1 == r2 && c1 == c2 && !(AHEAD && d.redo)) {
             flags |= GEN_F_INLINE;
@@ -1155,7 +1156,7 @@ CG_DEVICE void chain_item_clear(ChainItem &it)
 // what the second trip brings: the atom's record, the partner's left link, a move's old bin head and upper bitmap words
 struct ChainMid { AtomRec a; uint32_t l2, head1, b1, b2; unsigned long long x1, x2;
                   float colv1, colv2; unsigned long long fw1, fw2; };      // sparse model: the column copy's entries and their flag words (sp_cell_load)
-CG_DEVICE ChainMid chain_fetch_mid(const SamplerDev &S, const PropRec &p)
+CG_DEVICE ChainMid chain_fetch_mid(const SamplerDev &S, const PropRec &p, const bool sparse)
 {
     // every lane issues every load (a lane without a proposal, or of another type, reads harmless words: handle 0, bin 0): loads inside
     // divergent branches made the compiler wait for the whole trip where the branches join, before the work meant to run under it
@@ -1168,20 +1169,20 @@ CG_DEVICE ChainMid chain_fetch_mid(const SamplerDev &S, const PropRec &p)
     m.head1 = S.binHead[m.b1];
     m.x1 = S.bits1[w1]; m.x2 = S.bits2[w2];
     m.colv1 = 0.f; m.colv2 = 0.f; m.fw1 = 0ull; m.fw2 = 0ull;
-    if (S.sparse) {      // (wave-uniform) the HybridMatrix column copy and its flags: rows are proposal-exclusive for the whole batch, so what is read here is what the decision finds
+    if (sparse) {      // (wave-uniform) the HybridMatrix column copy and its flags: rows are proposal-exclusive for the whole batch, so what is read here is what the decision finds
         m.colv1 = S.mat[(size_t)p.c1 * S.Mpad + p.r1]; m.fw1 = S.mflags[(size_t)p.c1 * S.Mw + (p.r1 >> 6)];
         m.colv2 = S.mat[(size_t)p.c2 * S.Mpad + p.r2]; m.fw2 = S.mflags[(size_t)p.c2 * S.Mw + (p.r2 >> 6)];
     }
     return m;
 }
-CG_DEVICE void chain_fetch_build(const SamplerDev &S, const PropRec &p, const ChainMid &m, ChainItem &it);
-CG_DEVICE void chain_fetch(const SamplerDev &S, const PropRec *queueRd, uint32_t q, ChainItem &it)
+CG_DEVICE void chain_fetch_build(const SamplerDev &S, const PropRec &p, const ChainMid &m, ChainItem &it, const bool sparse);
+CG_DEVICE void chain_fetch(const SamplerDev &S, const PropRec *queueRd, uint32_t q, ChainItem &it, const bool sparse)
 {
     const PropRec p = queueRd[q];
-    const ChainMid m = chain_fetch_mid(S, p);
-    chain_fetch_build(S, p, m, it);
+    const ChainMid m = chain_fetch_mid(S, p, sparse);
+    chain_fetch_build(S, p, m, it, sparse);
 }
-CG_DEVICE void chain_fetch_build(const SamplerDev &S, const PropRec &p, const ChainMid &m, ChainItem &it)
+CG_DEVICE void chain_fetch_build(const SamplerDev &S, const PropRec &p, const ChainMid &m, ChainItem &it, const bool sparse)
 {
     chain_item_clear(it);
     it.type = p.type; it.m1 = p.m1; it.m2 = p.m2; it.old1 = p.old1; it.old2 = p.old2; it.pos = p.pos; it.h1 = p.h1;
@@ -1192,7 +1193,7 @@ CG_DEVICE void chain_fetch_build(const SamplerDev &S, const PropRec &p, const Ch
     it.mat1 = &S.mat[(size_t)p.c1 * S.Mpad + p.r1]; it.col1 = &S.colPos[p.c1];
     const bool two = p.type == 'M' || p.type == 'E';
     if (two) { it.mat2 = &S.mat[(size_t)p.c2 * S.Mpad + p.r2]; it.col2 = &S.colPos[p.c2]; }
-    if (S.sparse) {
+    if (sparse) {
         it.sparse = 1u;
         it.rows1 = &S.rows[(size_t)p.r1 * S.Kpad + p.c1]; it.fl1 = &S.mflags[(size_t)p.c1 * S.Mw + (p.r1 >> 6)]; it.fbit1 = 1ull << (p.r1 & 63u);
         it.colv1 = m.colv1; it.flg1 = (uint32_t)((m.fw1 >> (p.r1 & 63u)) & 1ull);
@@ -1291,7 +1292,9 @@ struct GenClockEnd {
     CG_DEVICE GenClockEnd(unsigned t_) : slot(nullptr), t(t_) {}
     CG_DEVICE ~GenClockEnd() { if (slot && (t & 63u) == 0u) cg_atomic_max_u64(slot, cg_realtime()); }
 };
-template <int WIN, bool ASYNC, bool CHAIN = false>
+// SP: the model the kernel serves -- 0 dense, 1 sparse (the HybridMatrix branches and a decision's sparse fields fold away: -0.38 us per chained
+// launch of the dense model, profiles/r06_ab_model_as_a_template_parameter.txt), -1 either (read from the record)
+template <int WIN, bool ASYNC, bool CHAIN = false, int SP = -1>
 CG_DEVICE void gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot hot, GenShared<WIN> &sh)
 {
     GenClockEnd clockEnd(cg_tid());
@@ -1349,6 +1352,7 @@ CG_DEVICE void gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot hot, G
     GEN_TS(27);
     if (ASYNC) sp = cg_const_warm_end(sp, lines);
     const SamplerDev &S = *(const SamplerDev *)sp;
+    const bool isSparse = SP < 0 ? S.sparse != 0u : SP != 0;
     GEN_TS(28);
     if (t < GSW) reinterpret_cast<uint32_t *>(&sh.g)[t] = gword;
     if (t + TPB < GSW) reinterpret_cast<uint32_t *>(&sh.g)[t + TPB] = gword2;
@@ -1395,14 +1399,20 @@ CG_DEVICE void gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot hot, G
 #if defined(GEN_TIMELINE)
         if (t == 0u) { sh.rtOn = (e_prevQ >= 140u && e_nSteps - e_nDone >= 512u) ? 1u : 0u; sh.rt[6] = 0ull; sh.rt[7] = 0ull; sh.rtLog = (WIN == 256 && e_prevQ >= 100u && e_nSteps - e_nDone >= 512u) ? 1u : 0u; }
 #endif
+#if defined(GEN_TEST_APPLIER_LANES)
+        const uint32_t NA = (uint32_t)GEN_TEST_APPLIER_LANES, al = t - (uint32_t)WIN;      // test-only variant of the emulator build: few applier lanes, so that short queues take several passes
+        const bool applying = applier && al < NA;
+#else
         const uint32_t NA = cg_bdim() - (uint32_t)WIN, al = t - (uint32_t)WIN;      // applier lanes (al: this lane's number among them)
-        const bool have0 = applier && al < e_prevQ;
+        const bool applying = applier;
+#endif
+        const bool have0 = applying && al < e_prevQ;
         // second trip (the first brought the scalars and an applier's record): what the decision will rewrite; the seeds, the table's window
         ChainMid mid0; mid0.l2 = CG_NONE; mid0.head1 = CG_NONE; mid0.b1 = 0; mid0.b2 = 0; mid0.x1 = 0ull; mid0.x2 = 0ull;
         mid0.a.pos = 0; mid0.a.lpos = 0; mid0.a.rpos = 0; mid0.a.left = CG_NONE; mid0.a.right = CG_NONE; mid0.a.mass = 0.f; mid0.a.rmass = 0.f; mid0.a.idx = 0; mid0.a.pad0 = 0;
         // (the free-handle stack's top entries, which a committing birth pops: nothing the decisions change -- only the flush pushes)
         const uint32_t freeTopAhead = (helper && ht < 16u && ht < e_fc) ? S.freeHandles[e_fc - 1u - ht] : CG_NONE;
-        if (applier) mid0 = chain_fetch_mid(S, p0);      // (p0 of a lane without a proposal: a slot of the queue copy, whatever it holds -- handles and positions of an older batch: valid addresses)
+        if (applier) mid0 = chain_fetch_mid(S, p0, isSparse);      // (p0 of a lane without a proposal: a slot of the queue copy, whatever it holds -- handles and positions of an older batch: valid addresses)
         if (!updateDone && attempt) seedC = S.seeds[e_nDone + t < e_nSteps ? e_nDone + t : e_nSteps - 1u];
         const uint32_t span = e_prevQ + (uint32_t)(WIN - 1);
         dpBase = e_n > span ? e_n - span : 0u;
@@ -1420,7 +1430,7 @@ CG_DEVICE void gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot hot, G
         // ... and under it: the classification (the two thresholds computed -- the table's entries would arrive with the trip)
         GenRoundCtx rcS; GenSpec spS;
         rcS.t = t; rcS.jm0 = jm0; rcS.ji0 = ji0; rcS.jm1 = jm1; rcS.ji1 = ji1; rcS.seed1 = 0ull; rcS.g_qrng = sh.g.qrng; rcS.g_skip = sh.g.useCached ? 1u : 0u;
-        rcS.g_u1 = sh.g.u1; rcS.g_u2 = sh.g.u2; rcS.remaining = e_nSteps - e_nDone; rcS.K = S.K;
+        rcS.g_u1 = sh.g.u1; rcS.g_u2 = sh.g.u2; rcS.remaining = e_nSteps - e_nDone; rcS.K = S.K; rcS.sparse = isSparse ? 1u : 0u;
         spS.bBefore = 0; spS.dBefore = 0; spS.guess = 0; spS.active = 0; spS.u1 = 0.f; spS.u2 = 0.f; spS.go = 0; spS.ct = 0; spS.info = 0; spS.rng = 0; spS.pos = 0; spS.bin = 0; spS.r1 = 0; spS.c1 = 0;
         if (trySpec && attempt) {
             const float dpAtLo = gm_death_prob((double)(uint64_t)nLo, S.domainLenD, S.alphaD, S.numBins), dpAtHi = gm_death_prob((double)(uint64_t)nHi, S.domainLenD, S.alphaD, S.numBins);
@@ -1439,7 +1449,7 @@ CG_DEVICE void gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot hot, G
             if (attempt) gen_spec_slot<WIN>(S, sh, rcS, spS);
         }
         const bool drawAhead = trySpec && cg_uniform_u32(sh.specBad) == 0u;      // (a window with an attempt between the two thresholds: classified and drawn the usual way, behind the decisions)
-        if (have0) chain_fetch_build(S, p0, mid0, it);
+        if (have0) chain_fetch_build(S, p0, mid0, it, isSparse);
         if (helper && ht < 16u) sh.freeTop[ht] = freeTopAhead;
         GEN_TS(32);
         epoch0 = sh.g.batchEpoch;
@@ -1468,8 +1478,8 @@ CG_DEVICE void gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot hot, G
             uint32_t unitAcc = 0;
             for (uint32_t base = 0; base < e_prevQ; base += NA) {
                 const uint32_t q = base + al;
-                bool have = q < e_prevQ;
-                if (base) { chain_item_clear(it); if (have) chain_fetch(S, hot.queueRd, q, it); }      // (a queue longer than the applier lanes: the batch after a generator launch of two rounds)
+                bool have = applying && q < e_prevQ;
+                if (base) { chain_item_clear(it); if (have) chain_fetch(S, hot.queueRd, q, it, isSparse); }      // (a queue longer than the applier lanes: the batch after a generator launch of two rounds)
                 // where the notes of this proposal go, whatever is decided (the hashes ahead of the wait)
                 const GenNotePos nH1 = gen_note_pos<GEN_DIRTY_ATOMS>(it.h1), nHL = gen_note_pos<GEN_DIRTY_ATOMS>(it.hL), nHR = gen_note_pos<GEN_DIRTY_ATOMS>(it.hR),
                                  nH2 = gen_note_pos<GEN_DIRTY_ATOMS>(it.h2), nL2 = gen_note_pos<GEN_DIRTY_ATOMS>(it.l2), nIdx = gen_note_pos<GEN_DIRTY_ATOMS>(~it.idx),
@@ -1526,6 +1536,9 @@ CG_DEVICE void gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot hot, G
                     }
                 }
                 if (have) chain_apply(it, code, gm_u2f((uint32_t)g1));
+#if defined(COGAPS_EMUL)
+                if (have && base) cg_atomic_add_u64(&gs->prof[6], 1ull);      // test-only build: decisions carried out in a pass beyond the first (a queue longer than the applier lanes)
+#endif
             }
             const uint32_t waveUnits = cg_wave_sum_u32(unitAcc);
             if ((t & 63u) == 0u && waveUnits) cg_atomic_add_u32(&sh.unitSum, waveUnits);
@@ -1603,7 +1616,7 @@ CG_DEVICE void gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot hot, G
 
     GenRoundCtx rc; rc.t = t; rc.jm0 = jm0; rc.ji0 = ji0; rc.jm1 = jm1; rc.ji1 = ji1; rc.seed1 = seed1; rc.batchEpoch = batchEpoch; rc.g_qrng = g_qrng; rc.n0 = n0; rc.updBase = updBase;
     rc.remaining = remaining; rc.K = K; rc.g_skip = g_skip; rc.e_prevQ = e_prevQ; rc.dp0 = dp0; rc.g_u1 = g_u1; rc.g_u2 = g_u2; rc.gs = gs; rc.tabHi = tabHi; rc.tabLo = tabLo;
-    rc.queueOut = CHAIN ? hot.queueWr : S.queue; rc.dpBase = dpBase;
+    rc.queueOut = CHAIN ? hot.queueWr : S.queue; rc.dpBase = dpBase; rc.sparse = isSparse ? 1u : 0u;
     if (CHAIN && specDone) {
         // which lanes drew what they would draw now (gen_draw_valid).  If every lane of the window did, the round goes straight into its
         // conflict phases and the helper wave's flush runs beside them (gen_helper); otherwise the join with the flush first
@@ -1646,11 +1659,11 @@ CG_DEVICE void gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot hot, G
 
 // (the generator's LDS as the kernel's own static block; the chained launch of the sparse model places it in a block it shares with the
 // evaluation workgroups' -- a launch's workgroups all carry the kernel's static LDS, whichever role they play: chain_kernel.h)
-template <int WIN, bool ASYNC, bool CHAIN = false>
+template <int WIN, bool ASYNC, bool CHAIN = false, int SP = -1>
 CG_DEVICE void gen_body(const SamplerDev CG_CONSTANT *sp, const GenHot hot)
 {
     CG_SHARED GenShared<WIN> sh;
-    gen_body_sh<WIN, ASYNC, CHAIN>(sp, hot, sh);
+    gen_body_sh<WIN, ASYNC, CHAIN, SP>(sp, hot, sh);
 }
 // WIN attempt lanes + the helper wave.  The launch's first loads need only the leading scalar arguments (preloaded into SGPRs); the
 // sampler's record is read from device memory through `sp`

@@ -1034,7 +1034,7 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(CHAIN_MAX_THREADS) chain_sparse_kernel(const uin
     if (cg_bid() + 1u == cg_gdim()) {
         GenHot hot; hot.lcgMul = lcgMul; hot.lcgInc = lcgInc; hot.gs = gs; hot.eraseList = nullptr; hot.queueUnits = nullptr; hot.eraseCap = 0; hot.queueCap = queueCap;
         hot.queueRd = queue + (size_t)parity * queueCap; hot.queueWr = queue + (size_t)(1u - parity) * queueCap; hot.grans = grans; hot.slotWr = &slots[1u - parity];
-        gen_body_sh<WIN, true, true>(sp, hot, *reinterpret_cast<GenShared<WIN> *>(pool));
+        gen_body_sh<WIN, true, true, 1>(sp, hot, *reinterpret_cast<GenShared<WIN> *>(pool));
         return;
     }
     EvalHot hot; hot.queue = queue + (size_t)parity * queueCap; hot.gs = gs; hot.queueCap = queueCap; hot.slot = &slots[parity]; hot.grans = grans;

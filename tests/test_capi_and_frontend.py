@@ -301,14 +301,3 @@ def test_bench_refuses_to_report_fewer_gpus_than_asked_for():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--no-cpu"], cwd=ROOT, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
                          capture_output=True, text=True, timeout=600)
     assert out.returncode != 0 and "WORLD_SIZE=2" in out.stderr and not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-
-
-def test_the_persistent_generator_experiment_still_applies_to_the_tree(tmp_path):
-    """tools/persist_experiment/persist_experiment.patch (round 5: the generator and the evaluation as launches of their own -- built, measured
-    slower, kept out of the shipped tree) is a record someone is meant to pick up: it must apply to the sources as they are."""
-    import shutil, subprocess
-    if shutil.which("patch") is None: pytest.skip("no patch(1) here")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run(["patch", "--dry-run", "-p1", "-s", "-i", os.path.join(root, "tools", "persist_experiment", "persist_experiment.patch")],
-                         cwd=root, capture_output=True, text=True)
-    assert out.returncode == 0, out.stdout + out.stderr

@@ -48,7 +48,7 @@ def test_batches_of_several_rounds_use_the_lds_table_then_the_stamp_tables(emul_
         assert n_lds > 100, (n_lds, n_hbm)
 
 
-@pytest.mark.parametrize("variant", ["chained", "chained_fallback", "chained_redraw", "two_launches", "few_compute_units"])
+@pytest.mark.parametrize("variant", ["chained", "chained_fallback", "chained_redraw", "chained_few_appliers", "two_launches", "few_compute_units"])
 def test_chained_launch_against_the_oracle(emul_lib, monkeypatch, variant):
     """csrc/chain_kernel.h: one launch evaluates batch n and generates batch n + 1 -- the generator workgroup's applier waves carry out the
     decisions they receive as tagged granules while its attempt waves classify AND DRAW the next window ahead of them; behind the join
@@ -57,6 +57,9 @@ def test_chained_launch_against_the_oracle(emul_lib, monkeypatch, variant):
     are small enough for a good share of the lanes to be invalidated.  Stepwise against the oracle (every proposal of every batch, the
     state after every update), then the test-only build's counters: every path was taken.
     Workgroups with several proposals evaluate them in pairs, one per half (eval_chain_pair).
+    `chained_few_appliers`: a variant whose generator workgroup has five applier lanes -- the queue takes several passes over them, each
+    pass fetching its records behind the previous one's wait (what a queue longer than the applier lanes takes on the hardware: the
+    batch behind a generator launch of two rounds);
     `chained_fallback`: a build variant that declares every third window's classification unusable (the path a window takes when an
     attempt falls between the two birth / death thresholds -- too rare to meet otherwise): such a window is classified and drawn behind
     the decisions; `chained_redraw`: a variant that declares every fifth lane's draw invalid, whatever it read; `two_launches`:
@@ -65,27 +68,29 @@ def test_chained_launch_against_the_oracle(emul_lib, monkeypatch, variant):
     if variant == "two_launches": monkeypatch.setenv("COGAPS_NO_CHAIN", "1")
     if variant == "few_compute_units": monkeypatch.setenv("COGAPS_TEST_COMPUTE_UNITS", "4")      # (a partitioned GPU: fewer compute units than the chained launch has workgroups)
     lib = (emul_lib(64, extra="-DGEN_SPEC_BAD_EVERY=3", tag="_specbad") if variant == "chained_fallback" else
-           emul_lib(64, extra="-DGEN_AHEAD_BAD_EVERY=5", tag="_aheadbad") if variant == "chained_redraw" else emul_lib(64))
+           emul_lib(64, extra="-DGEN_AHEAD_BAD_EVERY=5", tag="_aheadbad") if variant == "chained_redraw" else
+           emul_lib(64, extra="-DGEN_TEST_APPLIER_LANES=5", tag="_appl5") if variant == "chained_few_appliers" else emul_lib(64))
     data = pu.synthetic(1200, 300, seed=7)
     pu.run_stepwise(lib, data, 24, nPatterns=3, seed=123, total_iter=40, check_every=4)
     S = _capi.Session(data, lib=lib, nPatterns=3, seed=123, nIterations=40)
     S.run_iterations(1, 0, 24)
     tot = np.zeros(16, dtype=np.int64)
     for w in "AP":
-        assert S.chained(w) == (variant in ("chained", "chained_fallback", "chained_redraw"))
+        assert S.chained(w) == (variant in ("chained", "chained_fallback", "chained_redraw", "chained_few_appliers"))
         tot += np.array(S.debug_prof(w), dtype=np.int64)
     S.close()
-    held, redrawn, usual, spec, chain_batches, pairs, kept_pick = (int(tot[i]) for i in (8, 9, 11, 12, 13, 7, 10))
+    held, redrawn, usual, spec, chain_batches, pairs, kept_pick, seconds = (int(tot[i]) for i in (8, 9, 11, 12, 13, 7, 10, 6))
     redrawn += kept_pick      # (lanes that drew again: behind the flush, or -- a pick whose record or cells the decisions alone rewrote -- keeping their pick)
     if variant in ("two_launches", "few_compute_units"):
-        assert chain_batches == 0 and spec == 0 and held == 0 and redrawn == 0 and pairs == 0
+        assert chain_batches == 0 and spec == 0 and held == 0 and redrawn == 0 and pairs == 0 and seconds == 0
     else:
         assert chain_batches > 300 and spec > 200 and usual > 20 and held > 3000 and redrawn > 30, (chain_batches, spec, usual, held, redrawn)
         if variant == "chained_fallback": assert usual > spec // 3
         if variant == "chained_redraw": assert redrawn > held // 5 and kept_pick > 300
         assert kept_pick > 5, kept_pick
         assert pairs > 300, pairs        # (seven evaluation workgroups per launch in this build: most proposals are evaluated two at a time, eval_chain_pair)
-    print(variant, dict(chain_batches=chain_batches, ahead=spec, usual=usual, lanes_held=held, lanes_redrawn=redrawn, of_which_kept_their_pick=kept_pick, pairs=pairs))
+        if variant == "chained_few_appliers": assert seconds > 500, seconds      # (decisions carried out in a pass beyond the first)
+    print(variant, dict(chain_batches=chain_batches, ahead=spec, usual=usual, lanes_held=held, lanes_redrawn=redrawn, of_which_kept_their_pick=kept_pick, pairs=pairs, in_later_passes=seconds))
 
 
 def test_tiny_domain_hazards(emul_lib):

@@ -4,7 +4,7 @@ import sys, os, ctypes, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cogaps_amd import _capi
 from bench import synthetic_dense
-PL = _capi.bind(ctypes.CDLL(os.path.join(os.path.dirname(_capi.LIB_PATH), 'libcogaps_hip_PROFILE_DEV.so')))
+PL = _capi.bind(ctypes.CDLL(os.environ.get('COGAPS_PROFILE_LIB', os.path.join(os.path.dirname(_capi.LIB_PATH), 'libcogaps_hip_PROFILE_DEV.so'))))      # (COGAPS_PROFILE_LIB: another profile build, for A/B phase logs)
 SPARSE = '--sparse' in sys.argv
 if SPARSE:      # BASELINE configs[4]'s shard shape, as bench.py --sparse --genes 50000 --samples 12500 makes it
     sys.argv.remove('--sparse')
