@@ -51,16 +51,17 @@ def cpu_baseline(data, params, budget_s, state, first_step, n_steps, threads_onl
     two compare where both can run (configs[2] whole, build container: the same speed within +-25 % at 8 threads, the port 1.4x faster on one;
     printed with the line as cpu_baseline.port_over_reference_build).  A batch holds only ~50-160 proposals, so
     threads beyond a handful only add fork/join cost: 8, 16, 24 and 32 threads share most of the budget (round 5: the best thread count is
-    searched for, not assumed -- a 10x claim is against the best of them), the nproc-thread run SURVEY.md
-    section 8d asks for gets the rest and is cut into slices of an iteration so that it ends with its share (it never sets
-    `value`); `value` is the best whole-iteration rate, every thread count's rate is listed in `by_threads`."""
+    searched for, not assumed -- a 10x claim is against the best of them); the ONE-thread figure BASELINE.md section 3 quotes gets the
+    rest and is cut into slices of an iteration so that it ends with its share (it never sets `value`).  (Round 6: the nproc-thread leg
+    is gone -- 256 threads on ~150 proposals per batch measured fork/join, 800 proposals/s, and cost six seconds of every run.)
+    `value` is the best whole-iteration rate, every thread count's rate is listed in `by_threads`."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
     ncpu = os.cpu_count() or 1
     small = sorted({min(ncpu, c) for c in (8, 16, 24, 32)})
-    plan = [(t, 0.94 * budget_s / len(small)) for t in small]
-    if ncpu not in small:
-        plan.append((ncpu, 0.06 * budget_s))
+    plan = [(t, 0.88 * budget_s / len(small)) for t in small]
+    if 1 not in small:
+        plan.append((1, 0.12 * budget_s))
     if threads_only is not None:      # (N > 1: one leg per rank, all ranks at once)
         plan = [(int(threads_only), 0.4 * budget_s)]
     n_iter = params["nIterations"]
@@ -69,10 +70,9 @@ def cpu_baseline(data, params, budget_s, state, first_step, n_steps, threads_onl
         O = po.Session(data, omp=True, maxThreads=threads, math_mode=po.MATH_LIBM, redW_A=1, redW_P=1, redG=1, **params)
         O.import_state(state["atomsA"], state["A"], state["atomsP"], state["P"])
         props, it, t0 = 0, 0, time.time()
-        # the nproc-thread leg is run in slices of an iteration (an A update of <= 2048 steps, a P update of its share, the
-        # iteration's own mix): at 256 threads one whole iteration of this chain takes six minutes of fork/join, and the leg's
-        # share of the budget is a few seconds -- the default run has to finish within minutes
-        sliced = threads == ncpu and ncpu not in small
+        # the one-thread leg is run in slices of an iteration (an A update of <= 2048 steps, a P update of its share, the
+        # iteration's own mix): its share of the budget is a few seconds, an iteration of the headline chain takes it several
+        sliced = threads == 1 and 1 not in small and threads_only is None
         while it < n_steps and time.time() - t0 < share:
             step = first_step + it
             O.set_annealing(min(1.0, 2.0 * step / n_iter) if step < n_iter else 1.0)
@@ -106,7 +106,7 @@ def cpu_baseline(data, params, budget_s, state, first_step, n_steps, threads_onl
         best = {"value": None, "unit": "proposals/s", "cores": None, "kind": "port", "host_cpus": ncpu,
                 "sample": "no whole iteration of the window fitted the time budget (%.0f s): see by_threads" % budget_s}
     best["by_threads"] = by_threads
-    best["nproc_threads_value"] = next((b["value"] for b in by_threads if b["threads"] == ncpu), None)
+    best["one_thread_value"] = next((b["value"] for b in by_threads if b["threads"] == 1), None)
     return best
 
 
@@ -200,6 +200,8 @@ def chains_main(args):
         phase(0, burn)
     phase(burn, W)
     upd = [0] * C
+    # every chain's state at the start of the timed window, for the CPU comparator's like-for-like legs (copied out before the timed region)
+    cpu_states = None if args.no_cpu else [{"atomsA": s.atoms("A"), "A": s.rows("A"), "atomsP": s.atoms("P"), "P": s.rows("P")} for s in S]
     perf0 = [{w: s.perf(w) for w in "AP"} for s in S]
     for b_ in BB:
         b_.set_timing(True)
@@ -219,9 +221,11 @@ def chains_main(args):
             # steps of the batch in the timed window = the batches of its slowest chain
             steps_w = max(p1[w]["batches"] - p0[w]["batches"] for p0, p1 in mine)
             ev_ms, gen_ms = bp["eval_us"] * steps_w / 1e3, bp["gen_us"] * steps_w / 1e3
-            ach = (nbytes / 1e9) / (ev_ms / 1e3) if ev_ms > 0 else 0.0
+            # (no per-launch `achieved` / `frac` here -- round 6: the algorithmic bytes are more than these launches move (the uncertainty row is
+            # recomputed, the other matrix's columns hit L2) and the sampled event time is shorter than the launch takes inside the replayed
+            # graph, so the quotient exceeded the HBM peak; the path figure over the wall time below is the one that means something)
             kern.append({"kernel": "batched evaluation launch, sampler %s, group %d (%d chains)" % (w, g, len(groups[g])), "steps": int(steps_w), "sampled_launches": bp["sampled"], "avg_launch_us": bp["eval_us"],
-                         "bytes_per_launch": nbytes / max(1, steps_w), "achieved": ach, "frac": ach / HBM_PEAK_GBS})
+                         "algorithmic_bytes_per_launch": nbytes / max(1, steps_w)})
             kern.append({"kernel": "batched generator launch, sampler %s, group %d" % (w, g), "steps": int(steps_w), "avg_launch_us": bp["gen_us"]})
             tot_ms += ev_ms + gen_ms
             tot_bytes += nbytes
@@ -246,7 +250,33 @@ def chains_main(args):
         roof = {"bound": "hbm", "kernel": "path: batched generator + evaluation launches, algorithmic bytes over the wall time of the timed region", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_step": tot_bytes / max(1, sum(k["steps"] for k in kern if k["kernel"].startswith("batched evaluation"))),
                 "sampled_kernel_time_over_wall": tot_ms / (1e3 * dt), "kernels": kern,
-                "note": "`kernels` lists HIP-event samples of plain (not graph-replayed) launches: they exclude the boundary write-back a replayed launch waits for, so their per-launch `frac` is an upper bound on what the launch reaches inside the graph"}
+                "note": "`kernels` lists HIP-event samples of plain (not graph-replayed) launches: they exclude the boundary write-back a replayed launch waits for; no per-launch fraction is derived from them"}
+    # CPU comparator (a job of nSets subsets on one host = nSets port runs): the C chains' port runs made SIDE BY SIDE,
+    # one host thread and one OpenMP team of min(16, host threads / C) threads per chain, each from its chain's state at the start of the
+    # timed window, over the window's iterations; the figure is the sum of their rates (as bench.py --gpus N measures it across ranks)
+    cb = None
+    if cpu_states is not None:
+        thr = max(1, min(16, (os.cpu_count() or 1) // C))
+        legs = [None] * C
+
+        def leg(c):
+            legs[c] = cpu_baseline(shard(c), params, args.cpu_seconds, cpu_states[c], burn + W, K, threads_only=thr)
+        th = [threading.Thread(target=leg, args=(c,)) for c in range(C)]
+        t_cpu = time.time()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        rows = [l["by_threads"][0] for l in legs]
+        covered = min(r["iterations"] for r in rows) / float(K)
+        total = sum(r["value"] for r in rows)
+        cb = {"value": total if covered > 0 else None, "unit": "proposals/s", "cores": thr * C, "kind": "port", "host_cpus": os.cpu_count(),
+              "sample": "SUM over the %d chains' port runs made side by side on this host (%d OpenMP threads each, every chain from its own state at the start of the timed window, "
+                        "started together, %.0f s): schedule steps %d-%d" % (C, thr, time.time() - t_cpu, burn + W + 1, burn + W + K),
+              "threads_per_chain": thr, "per_chain": [r["value"] for r in rows], "iterations_covered_by_the_slowest_chain": min(r["iterations"] for r in rows),
+              "window_covered": covered}
+        if cb["value"]:
+            cb["gpu_over_cpu_same_window" if covered >= 1.0 else "gpu_over_cpu_partial_window"] = (sum(upd) / dt) / cb["value"]
     print(json.dumps({"metric": METRIC + " [informational: %d chains on one GPU, %s]" % (C, "batched multi-chain launches" if batched else "one thread and stream per chain"),
                       "value": sum(upd) / dt, "unit": "proposals/s",
                       "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak",
@@ -254,7 +284,7 @@ def chains_main(args):
                       "config": {"workload": "%d independent synthetic %s %dx%d shards on one GPU, nPatterns=%d" % (C, "sparse (95 %% zeros)" if args.sparse else "dense", args.genes, args.samples, args.patterns),
                                  "chains_mode": args.chains_mode, "chain_groups": G, "per_chain": [u / dt for u in upd],
                                  "algorithmic_GBps_over_wall": (tot_bytes / 1e9) / dt if batched else None},
-                      "roofline": roof, "cpu_baseline": None}))
+                      "roofline": roof, "cpu_baseline": cb}))
     for b_ in BB:
         b_.close()
     for s in S:
@@ -287,7 +317,7 @@ def main():
     ap.add_argument("--genes", type=int, default=20000)
     ap.add_argument("--samples", type=int, default=2000)
     ap.add_argument("--patterns", type=int, default=50)
-    ap.add_argument("--cpu-seconds", type=float, default=64.0, help="time budget of the CPU baseline legs (the oracle port on rank 0's host; a leg ends when it has covered the timed window; for N > 1 rank 0's shard is timed and multiplied by nSets)")
+    ap.add_argument("--cpu-seconds", type=float, default=64.0, help="time budget of the CPU baseline legs (the oracle port on this host: 8 / 16 / 24 / 32 OpenMP threads and one, from the GPU chain's state at the start of its timed window; a leg ends when it has covered the window).  N > 1 ranks, or --chains C: every shard's port run is made side by side -- one leg per shard, all at once, min(16, host threads / shards) threads each, 0.4 of the budget -- and the figure is their sum")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--sparse", action="store_true",
                     help="not the headline: the SparseNormalModel on the same product with 95 %% of the entries zeroed (BASELINE configs[4] "

@@ -67,6 +67,45 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(CHAIN_MAX_THREADS) chain_kernel(const uint64_t *
 #endif
 }
 
+// ---- a hand-over that never arrived: the batch is completed, the update goes on (round 6) --------------------------------------------------
+// A generator lane that gave up waiting for a decision (GAPS_ERR_SPIN: the bounded poll of gen_body_sh) applied nothing of that proposal,
+// marked it (CHAIN_DROPPED_MARK in SamplerDev::queueUnits) and the workgroup left without generating; the launches enqueued behind it found
+// empty queues.  By the time the host reads the error word every evaluation workgroup of the failed launch has ended -- the fused evaluation
+// never waits for anything -- so every proposal's granules ARE there, and its A*P rows are updated.  This launch (one workgroup, behind the
+// stream's synchronisation) carries out the marked proposals' decisions exactly as the generator's lanes would have (chain_fetch /
+// chain_apply, erase cache entries appended), hands the traffic units to the two-launch generator's bookkeeping, and puts the scalars back:
+// the state is the one the two-launch form has behind the evaluation of this batch, and the host goes on from it with gen_kernel /
+// eval_kernel pairs.  A granule that is still missing (the split form's deciding workgroup gave up as well) leaves the error standing.
+CG_KERNEL void CG_LAUNCH_BOUNDS(256) chain_recover_kernel(GenScalars *gs, const PropRec *queueRd, const unsigned long long *grans, uint32_t nSteps, const SamplerDev CG_CONSTANT *sp)
+{
+    cg_const_warm<sizeof(SamplerDev)>(sp);
+    const SamplerDev &S = *(const SamplerDev *)sp;
+    CG_SHARED uint32_t missing;
+    const bool sparse = S.sparse != 0u;
+    const uint32_t qlen = gs->applyCount, tag = (uint32_t)gs->batchEpoch, mark = CHAIN_DROPPED_MARK(tag);
+    if (cg_tid() == 0u) { missing = 0u; gs->eraseCount = gs->savedErase; }
+    cg_sync();
+    for (uint32_t q = cg_tid(); q < qlen; q += cg_bdim()) {
+        const unsigned long long g0 = cg_load_l2_u64(&grans[(size_t)q * CHAIN_GRAN_STRIDE]), g1 = cg_load_l2_u64(&grans[(size_t)q * CHAIN_GRAN_STRIDE + 1u]);
+        if ((uint32_t)(g0 >> 32) != tag || (uint32_t)(g1 >> 32) != tag) { missing = 1u; continue; }
+        if (S.queueUnits[q] == mark) {
+            ChainItem it; chain_fetch(S, queueRd, q, it, sparse);
+            const uint32_t code = (uint32_t)g0 & 0xFFu;
+            if (code == CHAIN_ERASE) {
+                const uint32_t k = cg_atomic_add_u32(&gs->eraseCount, 1u);
+                if (k < S.eraseCap) S.eraseList[k] = it.eraseEntry; else missing = 1u;
+            }
+            chain_apply(it, code, gm_u2f((uint32_t)g1));
+#if defined(COGAPS_EMUL)
+            cg_atomic_add_u64(&gs->prof[5], 1ull);      // test-only build: decisions carried out by the recovery
+#endif
+        }
+        S.queueUnits[q] = ((uint32_t)g0 >> 8) << (sparse ? 5u : 0u);      // (the two-launch generator adds the slots up: units of 4N bytes; sparse model: bytes)
+    }
+    cg_sync();
+    if (cg_tid() == 0u && missing == 0u) { gs->qlen = qlen; gs->nSteps = nSteps; gs->applyCount = 0u; gs->savedErase = 0u; gs->updateFlushed = 0u; gs->error = GAPS_OK; }
+}
+
 #if defined(COGAPS_EMUL)
 // test-only emulator (workgroups run one after the other): the split form's A*P updates as a launch of their own behind the chained one
 CG_KERNEL void chain_updates_kernel(PropRec *queue, unsigned long long *grans, ChainSlot *slots, uint32_t queueCap, uint32_t parity, const SamplerDev CG_CONSTANT *sp)

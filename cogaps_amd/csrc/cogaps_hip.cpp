@@ -195,6 +195,8 @@ struct HostSampler {
     // chained launch (chain_kernel.h): one launch per batch; consecutive launches alternate the parity they carry as a kernel argument, so
     // a captured run of launches exists once per starting parity
     bool chain = false; uint32_t chainParity = 0;
+    uint32_t chainParityStart = 0;      // parity of the current update's first chained launch (which copy a given launch of the update evaluated)
+    bool chainOff = false; uint32_t chainRecoveries = 0;      // a hand-over inside a chained launch never arrived: the batch was completed by chain_recover, the sampler keeps two launches per batch from then on
     unsigned long long *chainGrans = nullptr;      // [queueCap][CHAIN_GRAN_STRIDE] the decisions' granules (the split form's per-slice totals keep SamplerDev::grans)
     rt_graph chainGraph[2]; bool chainGraphValid[2] = {false, false};
     size_t traceCap = 0;
@@ -607,7 +609,7 @@ static bool chain_eligible(const cogaps_session *s, const HostSampler &h)
 {
     // (a device with fewer compute units than the launch has workgroups -- a partitioned GPU -- would run them in turns, the generator
     // workgroup last: correct, and slower than two launches)
-    if (s->noChain || h.d.seq) return false;
+    if (s->noChain || h.d.seq || h.chainOff) return false;
     if (g_updatesRunning(s->p.device).load() > 1 && !s->forceChain) return false;      // (another update -- a session's or a batch's -- is in flight on this session's GPU: see g_updatesRunning)
     if (h.d.sparse)      // sparse model (round 5): a launch of 512-thread workgroups, the evaluation keeps the model's width inside it
         return CHAIN_MAX_THREADS >= h.genWin + 64u && (s->forceChain || s->computeUnits >= std::min<uint32_t>(h.d.queueCap, CHAIN_EVAL_GRID) + 1u);
@@ -698,6 +700,25 @@ static void clock_collect(cogaps_session *s, HostSampler &h, uint64_t epoch, boo
     h.clockSeen = upTo;
 }
 
+// A chained launch's generator gave up waiting for a decision (GAPS_ERR_SPIN; chain_kernel.h, chain_recover_kernel): the stream is idle
+// (the error word was read behind a synchronisation), the evaluation workgroups of the failed launch have all ended.  The batch is
+// completed on the device, the scalars are put back, and the sampler goes on with two launches per batch -- for the rest of the session:
+// what kept a workgroup from being scheduled for two seconds (a foreign kernel holding compute units, a debugger) may well still be there.
+// The split evaluation's chained form (not the default) is not recovered: its deciding workgroups wait as well.
+static bool chain_recover(cogaps_session *s, HostSampler &h, uint32_t nSteps)
+{
+    if (!h.chain || h.d.seq || (!h.d.sparse && h.d.redW > 1024u)) return false;
+    // launch k of the update (k = 0, 1, ...) has parity start ^ (k & 1), evaluates batch k and generates batch k + 1: the launch that gave up
+    // had generated nothing, so it is launch number nBatches and the batch it was carrying out lies in the queue copy of its parity
+    const uint32_t parityFail = (h.chainParityStart + s->hGs->nBatches) & 1u;
+    const SamplerDev CG_CONSTANT *rec = (const SamplerDev CG_CONSTANT *)h.dRecord;
+    RT_LAUNCH(chain_recover_kernel, 1, 256, s->stream, h.d.gs, (const PropRec *)(h.d.queue + (size_t)parityFail * h.d.queueCap), (const unsigned long long *)h.chainGrans, nSteps, rec);
+    read_gs(s, h);
+    if (s->hGs->error) return false;      // (a decision is still missing: the update cannot be completed)
+    h.chain = false; h.chainOff = true; h.chainRecoveries++;
+    return true;
+}
+
 // AsynchronousGibbsSampler::update (AsynchronousGibbsSampler.h:88-122): batches of generate + evaluate
 // until nSteps proposals have been processed.  The number of batches is data dependent, so (generate,
 // evaluate) pairs are enqueued in chunks and the generator's progress word is read back per chunk;
@@ -736,6 +757,7 @@ static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool t
     if (nSteps == 0) return 0;
     sync_record(s, h);
     h.chain = chain_eligible(s, h);
+    h.chainParityStart = h.chainParity;
     h.updLaunches = 0;
     h.clockSeen = g.batchEpoch;      // (launch clock: the batches of this update carry the tags behind this one)
     // proposals per batch: the previous update of this sampler is the best predictor
@@ -769,6 +791,7 @@ static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool t
         read_gs(s, h);
         timing_resolve(s, s->hGs->nBatches);
         if (h.chain) clock_collect(s, h, s->hGs->batchEpoch, s->hGs->updateFlushed != 0);
+        if (s->hGs->error == GAPS_ERR_SPIN && chain_recover(s, h, nSteps)) continue;      // (the batch completed, the update goes on with two launches per batch)
         if (s->hGs->error) { s->poisoned = true; return fail(std::string("device error code ") + std::to_string(s->hGs->error) + " in sampler " + h.name); }
         if (s->hGs->updateFlushed) break;
         if (s->hGs->nBatches > 0) avgq = std::max(1.f, (float)s->hGs->nDone / (float)s->hGs->nBatches);
@@ -1701,6 +1724,7 @@ int cogaps_session_launch_period(cogaps_session *s, char which, double *meanUs, 
     }
     SESSION_END
 }
+int cogaps_session_chain_recoveries(cogaps_session *s, char which, uint32_t *n) { *n = pick(s, which).chainRecoveries; return 0; }
 int cogaps_session_chained(cogaps_session *s, char which, int *chained)
 {
     SESSION_TRY

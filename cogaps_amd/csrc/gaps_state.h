@@ -64,6 +64,9 @@ struct alignas(8) ChainSlot { uint32_t qlen, tag; };
 #define CHAIN_NONE 0u        // nothing to change (rejected move / exchange, a death's rebirth with the old mass)
 #define CHAIN_APPLY 1u       // B: mass = value; D: rebirth mass = value; M: the move; E: delta = value
 #define CHAIN_ERASE 2u       // B: rejected, D: the atom dies -- the atom goes to the erase cache
+// what a generator lane leaves in SamplerDev::queueUnits[q] when it gave up waiting for proposal q's decision (GAPS_ERR_SPIN): the decision
+// was NOT carried out -- the host's recovery (chain_recover_kernel) carries it out once the launch has ended
+#define CHAIN_DROPPED_MARK(tag) (0xD0000000u | ((tag) & 0x0FFFFFFFu))
 
 // Mutable scalars of the proposal generator, one cache line region in HBM.
 struct GenScalars {
@@ -89,7 +92,8 @@ struct GenScalars {
     unsigned long long evalBytes;   // algorithmic HBM bytes of the evaluation kernel (roofline numerator)
     unsigned long long evalProps;   // proposals evaluated
     uint32_t applyCount;      // split evaluation: decision records (DecRec) the next generator launch's update workgroups have to carry out; written by every evaluation launch (0 when its queue was empty)
-    uint32_t pad;
+                              // (a chained launch whose hand-over never arrived parks the batch's queue length here: chain_recover_kernel)
+    uint32_t savedErase;      // ... and here the erase cache's fill at that moment (the entries are in SamplerDev::eraseList)
     unsigned long long prof[16];    // GEN_PROFILE builds: cycles per generator phase
 };
 

@@ -1493,9 +1493,19 @@ CG_DEVICE void gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot hot, G
                     // bounded (platform.h: two seconds at least), never a hang.  A bound that is hit applies NOTHING: a granule without this batch's
                     // tag is an older batch's decision -- the lane drops its proposal, the error word ends the update on the host (the session is
                     // then marked unusable: its domain lacks decisions) and the workgroup leaves behind the barrier below without generating
-                    if (cg_poll_expired(++spins)) { if (!ok) have = false; if ((t & 63u) == 0u) { gs->error = GAPS_ERR_SPIN; sh.spinFail = 1u; } break; }
+                    // (round 6: the dropped proposal is marked, the batch is completed by the host once the launch has ended -- chain_recover_kernel --
+                    // and the update goes on with two launches per batch)
+                    if (cg_poll_expired(++spins)) { if (!ok) { have = false; S.queueUnits[q] = CHAIN_DROPPED_MARK(tag); } if ((t & 63u) == 0u) { gs->error = GAPS_ERR_SPIN; sh.spinFail = 1u; } break; }
                     cg_poll_pause();
                 }
+#if defined(GEN_TEST_SPIN_FAIL_EPOCH)
+                // test-only variant of the emulator build (whose workgroups run one after the other: nothing ever waits): at one batch every third
+                // lane gives up as if its decision had not arrived -- the launch ends the way a lost hand-over ends it
+                if (cg_ballot(have && tag == (uint32_t)GEN_TEST_SPIN_FAIL_EPOCH && (q % 3u) == 1u) != 0ull) {
+                    if (have && (q % 3u) == 1u) { have = false; S.queueUnits[q] = CHAIN_DROPPED_MARK(tag); }
+                    if ((t & 63u) == 0u) { gs->error = GAPS_ERR_SPIN; sh.spinFail = 1u; }
+                }
+#endif
                 GEN_TS(33);
                 if (base == 0u) GEN_RT_AT(3, WIN);
                 const uint32_t code = have ? ((uint32_t)g0 & 0xFFu) : CHAIN_NONE;
@@ -1553,7 +1563,14 @@ CG_DEVICE void gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot hot, G
         GEN_TS(35);
         GEN_RT(4);
         const uint32_t sfRaw = sh.spinFail, emRaw = sh.eraseN;      // (both words in one LDS trip)
-        if (cg_uniform_u32(sfRaw) != 0u) return;      // a decision never arrived (GAPS_ERR_SPIN is set): every wave leaves, nothing is generated
+        // A decision never arrived (GAPS_ERR_SPIN is set): every wave leaves, nothing is generated.  What the host's recovery needs is parked
+        // (the batch's queue length, the erase cache's fill: its entries are in the list) and the launches already enqueued behind this one are
+        // made harmless: they find an empty queue in both copies (nothing is evaluated, nothing applied a second time) and an update that
+        // is over (nSteps = nDone: the generator only reports), until the host reads the error word.
+        if (cg_uniform_u32(sfRaw) != 0u) {
+            if (t == 0u) { gs->applyCount = e_prevQ; gs->savedErase = emRaw; gs->qlen = 0u; gs->nSteps = e_nDone; ChainSlot cs; cs.qlen = 0u; cs.tag = tag + 1u; *hot.slotWr = cs; }
+            return;
+        }
         if (spare) {                                        // (the waves beyond the helper wave only applied)
             if (drawAhead && !updateDone) { cg_sync_lds(); cg_sync(); }
             { const bool ts_ok = e_prevQ >= 140u && e_nSteps - e_nDone >= 512u; (void)ts_ok; GEN_TS_DUMP_WAVE(); }

@@ -120,6 +120,7 @@ CG_DEVICE uint32_t cg_fresh_u32(uint32_t x) { asm volatile("" : "+s"(x)); return
 CG_DEVICE void cg_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // keeps a loaded value (and so the load) alive without using it
 CG_DEVICE void cg_keep_f32(float x) { asm volatile("" :: "v"(x)); }
+CG_DEVICE void cg_keep_u32(uint32_t x) { asm volatile("" :: "v"(x)); }
 
 // global-memory atomics (device scope)
 CG_DEVICE uint32_t cg_atomic_add_u32(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }

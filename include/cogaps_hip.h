@@ -220,8 +220,14 @@ int cogaps_session_perf_sampler(cogaps_session *s, char which, cogaps_perf *out)
  * HSA_CU_MASK): the evaluation workgroups never wait for anything, so with fewer units the launch is still correct -- the workgroups run in
  * turns, the generator last -- but slower than two launches; COGAPS_FORCE_CHAIN=1 (tests) takes it there anyway.  The hand-over inside the
  * launch relies on the dispatcher starting workgroups in index order (observed, not promised by HIP): a generator that started before an
- * evaluation workgroup could be scheduled would wait for it, bounded by two seconds, and end the update with an error, never with a hang. */
+ * evaluation workgroup could be scheduled would wait for it, bounded by two seconds -- never a hang.  A wait that runs out applies nothing
+ * of the decision it waited for and makes the launches already enqueued behind it no-ops; the host then completes the batch from the
+ * decisions the evaluation workgroups have left by then (chain_recover_kernel), and the sampler goes on -- same chain, same bits -- with
+ * two launches per batch for the rest of the session.  cogaps_session_chain_recoveries counts such events (0 in every run so far).  Only if
+ * a decision is still missing then (the split evaluation's chained form, COGAPS_CHAIN_SPLIT: its deciding workgroups wait as well) does the
+ * update end with an error (GAPS_ERR_SPIN) and the session refuse further steps. */
 int cogaps_session_chained(cogaps_session *s, char which, int *chained);
+int cogaps_session_chain_recoveries(cogaps_session *s, char which, uint32_t *n);
 /* Durations of the sampler's chained launches since cogaps_session_set_timing(1), EVERY launch -- replayed graphs included, where HIP
  * events cannot ride --, from the chip-wide 100 MHz clock read inside the launch (entry of its first workgroup to the end of its generator
  * workgroup, the last to finish: what rocprofv3 --kernel-trace reports as the dispatch's duration, minus the dispatcher's fill / drain).

@@ -39,6 +39,7 @@ template <class T> inline const T *cg_const_warm_end(const T *p, cg_const_lines 
 #define CG_CONSTANT
 template <int BYTES, class T> inline void cg_const_warm(const T *) {}
 inline void cg_keep_f32(float) {}
+inline void cg_keep_u32(uint32_t) {}
 inline void cg_sched_fence() {}
 inline uint32_t cg_uniform_u32(uint32_t x) { return x; }
 inline uint32_t cg_fresh_u32(uint32_t x) { return x; }

@@ -93,6 +93,28 @@ def test_chained_launch_against_the_oracle(emul_lib, monkeypatch, variant):
     print(variant, dict(chain_batches=chain_batches, ahead=spec, usual=usual, lanes_held=held, lanes_redrawn=redrawn, of_which_kept_their_pick=kept_pick, pairs=pairs, in_later_passes=seconds))
 
 
+def test_a_lost_hand_over_is_completed_and_the_update_goes_on(emul_lib):
+    """A generator lane that gives up waiting for a decision inside a chained launch (GAPS_ERR_SPIN: the bounded poll) drops the proposal,
+    marks it, and the workgroup leaves without generating; the launches enqueued behind it are no-ops.  The host completes the batch from
+    the decisions the evaluation workgroups have left (chain_recover_kernel: the marked proposals carried out, the erase cache and the
+    scalars put back) and goes on with two launches per batch -- the same chain, bit for bit.  The emulator never waits (its workgroups run
+    one after the other), so a build variant makes every third lane give up at one batch of each sampler; the run is compared with the
+    oracle proposal by proposal, state by state, across the event."""
+    from cogaps_amd import _capi
+    lib = emul_lib(64, extra="-DGEN_TEST_SPIN_FAIL_EPOCH=57", tag="_spinfail")
+    data = pu.synthetic(1200, 300, seed=7)
+    pu.run_stepwise(lib, data, 24, nPatterns=3, seed=123, total_iter=40, check_every=4)
+    S = _capi.Session(data, lib=lib, nPatterns=3, seed=123, nIterations=40)
+    S.run_iterations(1, 0, 24)
+    carried = 0
+    for w in "AP":
+        assert S.chain_recoveries(w) == 1, (w, S.chain_recoveries(w))
+        assert not S.chained(w)            # two launches per batch from the event on
+        carried += S.debug_prof(w)[5]
+    S.close()
+    assert carried >= 2, carried           # decisions the recovery carried out
+
+
 def test_tiny_domain_hazards(emul_lib):
     """5 rows x 2 patterns: every window is full of row conflicts, same-bin moves and neighbour hazards"""
     data = pu.synthetic(5, 6, rank=2, seed=3)
