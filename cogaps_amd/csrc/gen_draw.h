@@ -231,6 +231,12 @@ CG_DEVICE void gen_draw_b(const SamplerDev &S, GenShared<WIN> &sh, const GenRoun
     // the scalars the evaluation starts from travel in the queue record (consumed at commit)
     float old1 = 0.f, old2 = 0.f; uint32_t gib1 = 0, gib2 = 0;
     uint64_t lposB = 0, rposB = 0; float rmassB = 0.f;        // birth: what the new atom's record caches of its neighbours
+    // (A window drawn AHEAD reads the domain while the applier waves of the same workgroup carry out the previous batch's decisions: a move
+    // that empties a bin stores the bin's head and clears its bitmap bit in two stores, and a birth of this window can read the bit still
+    // set and the head already gone.  Whatever such a lane read is noted and the lane draws again -- but its next load must not follow the
+    // missing handle: found by the soak beside a foreign kernel, round 6, where the decisions arrive before the window is drawn -- a
+    // memory fault of the round-5 build, profiles/r06_soak_beside_a_foreign_kernel.json)
+    if (AHEAD && isB && !slowB && v2 == CG_NONE) { d.redo = true; slowB = true; }
     if (isB && !slowB) b3 = S.atoms[v2];
     if (frontE) b3 = S.atoms[h2];
     if (isB || pick) { old1 = c.sparse ? S.rows[(size_t)r1 * S.Kpad + c1] : S.mat[(size_t)c1 * S.Mpad + r1]; gib1 = S.otherColPos[c1]; }

@@ -16,12 +16,19 @@
  * concurrently from different host threads, on the same GPU or on different ones (each owns one non-blocking
  * stream and the library creates no other; no legacy-stream operation is issued; graph capture is thread-local).
  * Up to four sessions per process and GPU run truly side by side (HIP's four hardware queues per process).  The library keeps no global
- * mutable state besides the per-thread last error and a count of the updates in flight (a chained launch, which wants the whole chip, is
- * taken only by an update that runs alone).  Environment, all optional, none changes a result: COGAPS_NO_GRAPH (any value) sends every
- * kernel as a plain launch instead of replaying captured graphs -- for counter-collection tools only; COGAPS_NO_CHAIN: two launches per
- * batch instead of the chained launch (A/B runs, equality tests); COGAPS_FORCE_CHAIN: the chained launch also where the device shows fewer
- * compute units than the launch has workgroups or another update is in flight (tests); COGAPS_CHAIN_SPLIT: the split evaluation (data
- * vectors of more than 4096 elements) inside the chained launch -- built and tested, measured slower, not the default.
+ * mutable state besides the per-thread last error and, per device, a count of the updates in flight on it (a chained launch, which wants
+ * the whole chip, is taken only by an update -- a session's or a batch's -- that runs alone on its GPU).
+ * Environment, all optional, none changes a result; each is read when a session is created and has its test (tests/test_gpu_parity.py):
+ *   COGAPS_NO_GRAPH (any value)  every kernel as a plain launch instead of replaying captured graphs -- for counter-collection tools
+ *                                (tools/pmc_pass.sh); the whole -m gpu suite passes with it
+ *   COGAPS_NO_CHAIN              two launches per batch instead of the chained launch: A/B runs, test_chained_equals_two_launches_on_the_gpu
+ *   COGAPS_FORCE_CHAIN           the fused evaluation's chained launch also where the device shows fewer compute units than the launch has
+ *                                workgroups, or another update is in flight: test_chained_launch_with_half_the_compute_units.  (Not the split
+ *                                evaluation's: its update items wait for deciding workgroups of higher index, every workgroup must be resident.)
+ *   COGAPS_CHAIN_SPLIT           the split evaluation (data vectors of more than 4096 elements) inside the chained launch -- built, measured
+ *                                6 % slower on the headline chain (profiles/r05_ab_chained_split_evaluation_not_kept.txt), not the default:
+ *                                test_chained_split_evaluation_equals_two_launches_on_the_gpu
+ * Development builds (-DCOGAPS_DEV, never shipped) read further switches that only change what is measured.
  */
 #ifndef COGAPS_HIP_H
 #define COGAPS_HIP_H

@@ -335,6 +335,29 @@ def test_chained_launch_with_half_the_compute_units(hip_lib):
         assert rec["state"] == ref
 
 
+def test_chained_launch_beside_a_foreign_kernel(hip_lib):
+    """The hand-over inside the chained launch while ANOTHER process keeps the GPU busy (tools/dev_soak.py: a 4 GiB tensor scaled in place,
+    back to back, on its own HIP context): the chained launch's workgroups -- 136 KB of LDS and a full register file each -- are scheduled
+    late, the generator's bounded wait must still hold.  The headline shape's first 36 iterations (~40 000 chained launches), first alone,
+    then disturbed: no hand-over runs out (cogaps_session_chain_recoveries == 0: nothing had to be completed by chain_recover_kernel), both
+    samplers stay in the chained form where they took it, and the disturbed run ends in the state of the quiet one, bit for bit.
+    (The million-launch run of the same tool is profiles/r06_soak_beside_a_foreign_kernel.json.)"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("dev_soak", os.path.join(root, "tools", "dev_soak.py"))
+    soak = importlib.util.module_from_spec(spec); spec.loader.exec_module(soak)
+    import bench
+    data = bench.synthetic_dense(20000, 2000)
+    params = dict(nPatterns=50, seed=42, outputFrequency=10)
+    quiet = soak.run(data, 100, 36, params)
+    disturbed = soak.run(data, 100, 36, params, foreign_seconds=max(30.0, 4.0 * quiet["seconds"]))
+    print("quiet %.1f s, beside the foreign kernels %.1f s (%s); A launch period p99 %.1f -> %.1f us" % (
+        quiet["seconds"], disturbed["seconds"], disturbed.get("foreign"), quiet["A"]["launch_period_us"]["p99_us"], disturbed["A"]["launch_period_us"]["p99_us"]))
+    assert quiet["A"]["chained"] and disturbed["A"]["chained"]
+    assert sum(r[w]["recoveries"] for r in (quiet, disturbed) for w in "AP") == 0
+    assert disturbed["state_digest"] == quiet["state_digest"] and disturbed["proposals"] == quiet["proposals"]
+
+
 def test_plain_c_client_equals_the_ctypes_path(hip_lib, gist):
     """the Rcpp-shaped C program (tests/c/rcpp_shim_test.c: allParams keys -> cogaps_params by the rules of src/Cogaps.cpp:64-139,
     then cogaps_run / cogaps_run_from_file, no Python in the process) prints the result cogaps_run gives through ctypes; a

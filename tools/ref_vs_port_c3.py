@@ -4,6 +4,9 @@ same thread counts, each timing the sampler alone (the reference's own start-to-
 print the same chain (atom histories, totalUpdates, meanChiSq, queue lengths): the comparison is of two programs computing the same thing.
 
     python tools/ref_vs_port_c3.py [--iterations 100] [--threads 8,1] [--one-thread-iterations 30] > profiles/r04_reference_vs_port_container.json
+    python tools/ref_vs_port_c3.py --sparse --genes 5000 --samples 1250 --iterations 40 --threads 8 > profiles/r06_reference_vs_port_sparse_container.json
+        (round 6: the SparseNormalModel path -- SparseNormalModel.cpp:152-292 under the same `omp parallel for` -- on SURVEY section 6's probe shape,
+         95 % of the entries zeroed as bench.py --sparse zeroes them)
 
 `bench.py` reads the committed record and prints `cpu_baseline.port_over_reference_build` from it, so that a reader can translate the
 GPU / port ratio measured on the GPU box (where only the port can run) into a GPU / reference-build ratio -- with the host named.
@@ -43,9 +46,12 @@ def main():
     ap.add_argument("--port-first", action="store_true", help="run the port before the reference build (the host is shared: a second pass in the other order shows how much of a difference is drift)")
     ap.add_argument("--genes", type=int, default=20000)
     ap.add_argument("--samples", type=int, default=2000)
+    ap.add_argument("--sparse", action="store_true", help="the SparseNormalModel: the same product with 95 %% of the entries zeroed (bench.py --sparse), sparseOptimization on in both programs")
     a = ap.parse_args()
     binary = rp.build()
     data = bench.synthetic_dense(a.genes, a.samples)
+    if a.sparse:
+        data *= (np.random.Generator(np.random.MT19937(777)).random(data.shape) >= 0.95)
     legs = []
     with tempfile.TemporaryDirectory() as tmp:
         path = os.path.join(tmp, "c3.csv")
@@ -56,12 +62,12 @@ def main():
             it = a.iterations if thr > 1 else min(a.iterations, a.one_thread_iterations)
             out_freq = max(1, it // 10)
             def run_ref():
-                r = rp.run(binary, path, nPatterns=50, nIterations=it, seed=42, outFreq=out_freq, threads=thr)
+                r = rp.run(binary, path, nPatterns=50, nIterations=it, seed=42, outFreq=out_freq, threads=thr, sparse=1 if a.sparse else 0)
                 sys.stderr.write("reference build, %d threads, %d + %d iterations: %.1f s\n" % (thr, it, it, r["samplerSeconds"]))
                 return r
 
             def run_port():
-                r = po.run(data, omp=thr > 1, nPatterns=50, nIterations=it, seed=42, outputFrequency=out_freq, maxThreads=thr)
+                r = po.run(data, omp=thr > 1, nPatterns=50, nIterations=it, seed=42, outputFrequency=out_freq, maxThreads=thr, sparseOptimization=bool(a.sparse))
                 sys.stderr.write("port, %d threads: %.1f s\n" % (thr, r["samplerSeconds"]))
                 return r
             if a.port_first:
@@ -77,8 +83,8 @@ def main():
                              port_over_reference_build=round(ref["samplerSeconds"] / o["samplerSeconds"], 4),
                              atomsA=ref["atomsA"].tolist(), meanChiSq=float(ref["meanChiSq"]), qA=float(ref["qA"]), qP=float(ref["qP"])))
     rec = dict(what="reference build (tools/refprobe: /root/reference/src + this repository's stand-in Boost headers, g++ -O2 -fopenmp, scalar SIMD path) vs the CPU port "
-                    "(oracle/gaps_oracle.c, sequential sums, libm, OpenMP over the queue) on BASELINE configs[2], sampler time only, same container",
-               workload="synthetic dense %dx%d fp32, nPatterns=50, seed=42, asynchronous sampler" % (a.genes, a.samples),
+                    "(oracle/gaps_oracle.c, sequential sums, libm, OpenMP over the queue) on %s, sampler time only, same container" % ("the sparse model (SURVEY section 6's probe shape)" if a.sparse else "BASELINE configs[2]"),
+               workload="synthetic %s %dx%d fp32, nPatterns=50, seed=42, asynchronous sampler" % ("sparse (95 % zeros, sparseOptimization)" if a.sparse else "dense", a.genes, a.samples),
                host=dict(cpu=cpu_model(), logical_cpus=os.cpu_count(), note="the build container, not the GPU box"),
                legs=legs)
     print(json.dumps(rec, indent=1))
