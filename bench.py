@@ -110,12 +110,13 @@ def cpu_baseline(data, params, budget_s, state, first_step, n_steps, threads_onl
     return best
 
 
-def reference_translation():
+def reference_translation(sparse=False):
     """How the port compares with the REFERENCE BUILD where both can run (the build container, tools/ref_vs_port_c3.py: configs[2] whole,
     sampler time only, same chain bit for bit).  Only this repository reaches the GPU box, so the bench's CPU figure is the port's; this
     record -- with its host named -- is what translates a GPU / port ratio into a GPU / reference-build ratio."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_reference_vs_port_container.json")))
+    # (the dense model: configs[2] whole; the sparse model -- round 6 -- SURVEY section 6's probe shape, 5000 x 1250 with 95 % zeros)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_reference_vs_port_sparse_container.json" if sparse else "r*_reference_vs_port_container.json")))
     if not files:
         return None
     rec = json.load(open(files[-1]))
@@ -610,7 +611,7 @@ def main():
                 cb["ten_x_line"] = 10.0 * cb["value"]
                 cb["gpu_over_ten_x_line"] = out["value"] / (10.0 * cb["value"])
             # the port timed here against the REFERENCE BUILD where both can run (build container, committed record)
-            cb["port_over_reference_build"] = reference_translation()
+            cb["port_over_reference_build"] = reference_translation(args.sparse)
             out["cpu_baseline"] = cb
         else:
             out["cpu_baseline"] = None

@@ -682,7 +682,7 @@ static void dom_cache_erase(go_domain *d, uint32_t h)
         d->erase[d->n_erase++] = h;
     }
 }
-static go_domain *g_sort_dom;
+static __thread go_domain *g_sort_dom;      /* (per host thread: several sessions may be stepped from several threads at once -- bench.py --chains) */
 static int cmp_erase(const void *a, const void *b)
 {
     uint64_t pa = g_sort_dom->pool[*(const uint32_t *)a].pos, pb = g_sort_dom->pool[*(const uint32_t *)b].pos;
