@@ -52,7 +52,7 @@ def cpu_baseline(data, params, budget_s, state, first_step, n_steps, threads_onl
     printed with the line as cpu_baseline.port_over_reference_build).  A batch holds only ~50-160 proposals, so
     threads beyond a handful only add fork/join cost: 8, 16, 24 and 32 threads share most of the budget (round 5: the best thread count is
     searched for, not assumed -- a 10x claim is against the best of them); the ONE-thread figure BASELINE.md section 3 quotes gets the
-    rest and is cut into slices of an iteration so that it ends with its share (it never sets `value`).  (Round 6: the nproc-thread leg
+    rest -- whole iterations as far as its share reaches, at least one (it never sets `value`).  (Round 6: the nproc-thread leg
     is gone -- 256 threads on ~150 proposals per batch measured fork/join, 800 proposals/s, and cost six seconds of every run.)
     `value` is the best whole-iteration rate, every thread count's rate is listed in `by_threads`."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -70,9 +70,10 @@ def cpu_baseline(data, params, budget_s, state, first_step, n_steps, threads_onl
         O = po.Session(data, omp=True, maxThreads=threads, math_mode=po.MATH_LIBM, redW_A=1, redW_P=1, redG=1, **params)
         O.import_state(state["atomsA"], state["A"], state["atomsP"], state["P"])
         props, it, t0 = 0, 0, time.time()
-        # the one-thread leg is run in slices of an iteration (an A update of <= 2048 steps, a P update of its share, the
-        # iteration's own mix): its share of the budget is a few seconds, an iteration of the headline chain takes it several
-        sliced = threads == 1 and 1 not in small and threads_only is None
+        # (every leg runs whole iterations: the nproc-thread leg of rounds 3-5 was cut into slices of an iteration -- each slice pays the
+        # iteration's two A*P transposes, which is all a slice of one thread's work measures; the one-thread leg gets one or two whole
+        # iterations out of its share)
+        sliced = False
         while it < n_steps and time.time() - t0 < share:
             step = first_step + it
             O.set_annealing(min(1.0, 2.0 * step / n_iter) if step < n_iter else 1.0)
