@@ -3,7 +3,7 @@ import sys, os, ctypes, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cogaps_amd import _capi
 from bench import synthetic_dense
-PL = _capi.bind(ctypes.CDLL(os.path.join(os.path.dirname(_capi.LIB_PATH), 'libcogaps_hip_PROFILE_DEV.so')))
+PL = _capi.bind(ctypes.CDLL(os.environ.get('COGAPS_PROFILE_LIB', os.path.join(os.path.dirname(_capi.LIB_PATH), 'libcogaps_hip_PROFILE_DEV.so'))))
 SPARSE = "--sparse" in sys.argv
 if SPARSE: sys.argv.remove("--sparse")
 data = synthetic_dense(20000, 2000)
