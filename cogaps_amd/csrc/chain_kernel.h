@@ -67,6 +67,33 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(CHAIN_MAX_THREADS) chain_kernel(const uint64_t *
 #endif
 }
 
+// ---- the chained launch for a BATCH of chains (round 6; cogaps_batch_*, cogaps_hip.cpp: run_update_multi) ----------------------------------
+// The chains of a batch step in lock-step; until round 6 every step was a generator launch (one workgroup per chain) and an evaluation
+// launch.  Here one launch serves all chains: workgroups [c * wgPerChain, (c + 1) * wgPerChain) belong to chain c, the last of them is its
+// generator, the others evaluate its queue -- chain_kernel's two roles, each chain's scalars, queue copies, slots and granules taken from
+// its own record (the decisions' granules live in SamplerDev::grans, which the fused evaluation has no other use for).  Every workgroup
+// of the launch is resident at once (C * wgPerChain <= compute units: the host sees to it), so a chain's evaluation workgroups take
+// several proposals each -- in pairs, eval_chain_pair -- where the batched evaluation launch packs three workgroups per compute unit:
+// the launch pays off for few chains (profiles/r06_ab_chained_batch.txt).
+template <int WIN>
+CG_KERNEL void CG_LAUNCH_BOUNDS(CHAIN_MAX_THREADS) chain_kernel_multi(const SamplerDev CG_CONSTANT *arr, uint32_t parity, uint32_t wgPerChain)
+{
+    const uint32_t chain = cg_bid() / wgPerChain, vbid = cg_bid() - chain * wgPerChain;
+    const SamplerDev CG_CONSTANT *sp = arr + chain;
+    cg_const_warm<sizeof(SamplerDev)>(sp);
+    const SamplerDev &S = *(const SamplerDev *)sp;
+    PropRec *const queue = S.queue; const uint32_t queueCap = S.queueCap;
+    if (vbid + 1u == wgPerChain) {
+        GenHot hot; hot.lcgMul = S.lcgMul; hot.lcgInc = S.lcgInc; hot.gs = S.gs; hot.eraseList = nullptr; hot.queueUnits = nullptr; hot.eraseCap = 0; hot.queueCap = queueCap;
+        hot.queueRd = queue + (size_t)parity * queueCap; hot.queueWr = queue + (size_t)(1u - parity) * queueCap; hot.grans = S.grans; hot.slotWr = &S.chainSlots[1u - parity];
+        gen_body<WIN, false, true, 0>(sp, hot);
+        return;
+    }
+    EvalHot hot; hot.queue = queue + (size_t)parity * queueCap; hot.gs = S.gs; hot.queueCap = queueCap; hot.slot = &S.chainSlots[parity]; hot.grans = S.grans;
+    const EvalFirst first = eval_first<EVAL_CHAIN>(hot, 1u, vbid);
+    eval_body<EVAL_CHAIN, true>(S, 1u, vbid, wgPerChain - 1u, hot, first);
+}
+
 // ---- a hand-over that never arrived: the batch is completed, the update goes on (round 6) --------------------------------------------------
 // A generator lane that gave up waiting for a decision (GAPS_ERR_SPIN: the bounded poll of gen_body_sh) applied nothing of that proposal,
 // marked it (CHAIN_DROPPED_MARK in SamplerDev::queueUnits) and the workgroup left without generating; the launches enqueued behind it found

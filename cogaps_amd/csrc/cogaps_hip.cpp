@@ -1184,6 +1184,10 @@ struct cogaps_batch {
     SamplerDev *dev[2] = {nullptr, nullptr};            // [0] the A samplers' records, [1] the P samplers'
     std::vector<SamplerDev> host[2];                    // what the device arrays hold
     rt_graph graph[2]; bool graphValid[2] = {false, false};
+    // round 6: a side whose evaluation is the fused one steps as ONE chained launch for all chains (chain_kernel_multi) where every workgroup
+    // of it is resident at once; the captured run of launches exists per starting parity, as for the one-chain form
+    bool chain[2] = {false, false}; uint32_t chainParity[2] = {0, 0}; uint32_t chainWg[2] = {0, 0};
+    rt_graph chainGraph[2][2]; bool chainGraphValid[2][2] = {{false, false}, {false, false}};
     GenScalars *hGs = nullptr;                          // pinned, [C]
     bool sparse = false; char fixed = 'N';
     uint64_t launches[2] = {0, 0};
@@ -1213,11 +1217,33 @@ static MultiGeom multi_geom(cogaps_batch *b, int w)
     g.wgPerChain = std::min<uint32_t>(minCap, std::max<uint32_t>(4u, (2u * perWave) / C + 1u)) * g.slices;
     return g;
 }
+// The chained form for a batch (chain_kernel.h, chain_kernel_multi): the dense model's fused evaluation (workgroups as large as the generator's),
+// every workgroup of the launch resident at once -- compute units / chains per chain -- and no other update in flight on the GPU.  Taken
+// for up to FOUR chains (64 workgroups each on the MI355X): measured +9 % at two chains, +2 % at four, -7 % at eight, -20 % at sixteen
+// (profiles/r06_ab_chained_batch.txt) -- a chain's evaluation workgroups are alone on their compute units (the generator's LDS), where the
+// batched evaluation launch packs three per unit.  COGAPS_NO_CHAIN switches it off (A/B, equality tests).
+static uint32_t multi_chain_wg(cogaps_batch *b, int w, const MultiGeom &g)
+{
+    const cogaps_session *s0 = b->ss[0];
+    const uint32_t C = (uint32_t)b->ss.size();
+    if (s0->noChain || b->sparse || !g.fused || g.block > (uint32_t)CHAIN_MAX_THREADS || g.block < b->genWin[w] + 64u) return 0u;
+    if (g_updatesRunning(s0->p.device).load() > 1) return 0u;
+    for (cogaps_session *s : b->ss) if ((w == 0 ? s->A : s->P).d.seq) return 0u;
+    const uint32_t perChain = std::min<uint32_t>(s0->computeUnits / C, CHAIN_EVAL_GRID + 1u);
+    return perChain >= (CHAIN_EVAL_GRID >= 16u ? 64u : 3u) ? perChain : 0u;      // (the test-only emulator's launches have seven evaluation workgroups)
+}
 static void multi_launch_pair(cogaps_batch *b, int w, const MultiGeom &g, int slotGen, int slotEval, int slotEval2)
 {
     const uint32_t C = (uint32_t)b->ss.size();
     const SamplerDev CG_CONSTANT *arr = (const SamplerDev CG_CONSTANT *)b->dev[w];
 #define MLAUNCH(slot, KERNEL, grid, block, ...) do { if ((slot) >= 0) RT_LAUNCH_TIMED(KERNEL, grid, block, b->stream, b->ev[slot], __VA_ARGS__); else RT_LAUNCH(KERNEL, grid, block, b->stream, __VA_ARGS__); } while (0)
+    if (b->chain[w]) {
+        const uint32_t parity = b->chainParity[w]; b->chainParity[w] ^= 1u;
+        if (b->genWin[w] == (uint32_t)GEN_WIN) MLAUNCH(slotEval, chain_kernel_multi<GEN_WIN>, C * b->chainWg[w], g.block, arr, parity, b->chainWg[w]);
+        else MLAUNCH(slotEval, chain_kernel_multi<GEN_WIN_HALF>, C * b->chainWg[w], g.block, arr, parity, b->chainWg[w]);
+        b->launches[w]++;
+        return;
+    }
     if (b->genWin[w] == (uint32_t)GEN_WIN) MLAUNCH(slotGen, gen_kernel_multi<GEN_WIN>, C, GEN_WIN + 64, arr);
     else MLAUNCH(slotGen, gen_kernel_multi<GEN_WIN_HALF>, C, GEN_WIN_HALF + 64, arr);
     if (b->sparse) MLAUNCH(slotEval, eval_sparse_kernel_multi, C * g.wgPerChain, g.block, arr, g.wgPerChain);
@@ -1270,6 +1296,14 @@ static int run_update_multi(cogaps_batch *b, int w, const std::vector<uint32_t> 
     if (changed) rt_h2d(b->dev[w], b->host[w].data(), (size_t)C * sizeof(SamplerDev), b->stream);
     rt_sync(b->stream);
     const MultiGeom geo = multi_geom(b, w);
+    b->chainWg[w] = multi_chain_wg(b, w, geo);
+    b->chain[w] = b->chainWg[w] != 0u;
+    for (uint32_t c = 0; c < C; ++c) bpick(b, c, w).chain = b->chain[w];      // (cogaps_session_chained reports what runs)
+    if (b->chain[w]) {      // both parities of every chain start from an empty queue
+        const ChainSlot emptySlots[2] = {{0u, 0u}, {0u, 0u}};
+        for (uint32_t c = 0; c < C; ++c) rt_h2d(bpick(b, c, w).d.chainSlots, emptySlots, sizeof(emptySlots), b->stream);
+        rt_sync(b->stream);
+    }
     bool first = true, topped = false;
     for (;;) {
         // pairs to enqueue: what the slowest unfinished chain still needs (launches past the end of a chain's update are no-ops for it)
@@ -1282,7 +1316,20 @@ static int run_update_multi(cogaps_batch *b, int w, const std::vector<uint32_t> 
         first = false;
         uint32_t plain = chunk;
         const bool noGraph = b->ss[0]->noGraph;
-        if (rt_graphs_supported() && !noGraph && plain >= GRAPH_PAIRS) {
+        if (rt_graphs_supported() && !noGraph && plain >= GRAPH_PAIRS && b->chain[w]) {
+            // (an even number of launches per replay: the parity behind a replay is the parity before it)
+            for (; plain >= GRAPH_PAIRS; plain -= GRAPH_PAIRS) {
+                const uint32_t k = b->chainParity[w];
+                if (!b->chainGraphValid[w][k]) {
+                    const uint64_t l0 = b->launches[w];
+                    rt_capture_begin(b->stream);
+                    for (uint32_t i = 0; i < GRAPH_PAIRS; ++i) multi_launch_pair(b, w, geo, -1, -1, -1);
+                    rt_capture_end(b->stream, b->chainGraph[w][k]);
+                    b->launches[w] = l0; b->chainGraphValid[w][k] = true;
+                }
+                rt_graph_launch(b->chainGraph[w][k], b->stream); b->launches[w] += GRAPH_PAIRS; b->ord += GRAPH_PAIRS;
+            }
+        } else if (rt_graphs_supported() && !noGraph && plain >= GRAPH_PAIRS) {
             if (!b->graphValid[w]) {
                 const uint64_t l0 = b->launches[w];
                 rt_capture_begin(b->stream);
@@ -1295,8 +1342,11 @@ static int run_update_multi(cogaps_batch *b, int w, const std::vector<uint32_t> 
         for (uint32_t k = 0; k < plain; ++k) {
             int sg = -1, se = -1, se2 = -1;
             if (b->timing && (b->ord % 4u) == 0u && b->evUsed + 3 <= b->ev.size()) {
-                sg = (int)b->evUsed++; b->evKind[sg] = 0; se = (int)b->evUsed++; b->evKind[se] = 1;
-                if (!geo.fused) { se2 = (int)b->evUsed++; b->evKind[se2] = 2; }
+                if (b->chain[w]) { se = (int)b->evUsed++; b->evKind[se] = 1; }      // (one launch per step: timed as the evaluation launch, as the one-chain form's is)
+                else {
+                    sg = (int)b->evUsed++; b->evKind[sg] = 0; se = (int)b->evUsed++; b->evKind[se] = 1;
+                    if (!geo.fused) { se2 = (int)b->evUsed++; b->evKind[se2] = 2; }
+                }
             }
             multi_launch_pair(b, w, geo, sg, se, se2);
             b->ord++;
@@ -1328,7 +1378,11 @@ static int run_update_multi(cogaps_batch *b, int w, const std::vector<uint32_t> 
     }
     float spb = 0.f; for (uint32_t c = 0; c < C; ++c) spb = std::max(spb, bpick(b, c, w).stepsPerBatch);
     const uint32_t win = gen_window_for(b->genWin[w], spb);
-    if (win != b->genWin[w]) { b->genWin[w] = win; if (b->graphValid[w]) { rt_graph_destroy(b->graph[w]); b->graphValid[w] = false; } }
+    if (win != b->genWin[w]) {
+        b->genWin[w] = win;
+        if (b->graphValid[w]) { rt_graph_destroy(b->graph[w]); b->graphValid[w] = false; }
+        for (int k = 0; k < 2; ++k) if (b->chainGraphValid[w][k]) { rt_graph_destroy(b->chainGraph[w][k]); b->chainGraphValid[w][k] = false; }
+    }
     return 0;
 }
 
@@ -1382,7 +1436,7 @@ void cogaps_batch_destroy(cogaps_batch *b)
     if (!b) return;
     try { rt_sync(b->stream); } catch (...) { }
     for (cogaps_session *s : b->ss) { try { s->stream = rt_stream_create(); s->ownsStream = true; } catch (...) { } }      // the sessions outlive the batch
-    for (int w = 0; w < 2; ++w) { rt_graph_destroy(b->graph[w]); rt_free(b->dev[w]); }
+    for (int w = 0; w < 2; ++w) { rt_graph_destroy(b->graph[w]); rt_free(b->dev[w]); for (int k = 0; k < 2; ++k) if (b->chainGraphValid[w][k]) rt_graph_destroy(b->chainGraph[w][k]); }
     for (auto &e : b->ev) rt_event_destroy(e);
     rt_free_host(b->hGs);
     rt_stream_destroy(b->stream);

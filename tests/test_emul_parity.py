@@ -115,6 +115,36 @@ def test_a_lost_hand_over_is_completed_and_the_update_goes_on(emul_lib):
     assert carried >= 2, carried           # decisions the recovery carried out
 
 
+def test_a_batch_of_chains_in_one_chained_launch(emul_lib, monkeypatch):
+    """cogaps_batch_* with the chained launch for ALL chains of the batch (chain_kernel.h, chain_kernel_multi; round 6): workgroups
+    [c * wgPerChain, (c + 1) * wgPerChain) of one launch evaluate chain c's queue, the last of them generates its next batch.  Three
+    chains of 1200 x 300 (both samplers' evaluations are the fused one and as large as the generator's workgroup: both sides take the
+    form) stepped as one batch give, state for state, the three chains stepped one at a time; the counters say the chained form ran; with
+    COGAPS_NO_CHAIN the batch keeps a generator launch and an evaluation launch per step and gives the same states."""
+    from cogaps_amd import _capi
+    lib = emul_lib(64)
+    datas = [pu.synthetic(1200, 300, seed=7 + c) for c in range(3)]
+    kw = dict(nPatterns=3, nIterations=40)
+
+    def state(S):
+        return [(S.atoms(w)["pos"].copy(), S.atoms(w)["mass"].copy(), S.matrix(w).copy(), S.ap(w).copy()) for w in "AP"]
+    alone = []
+    for c, d in enumerate(datas):
+        S = _capi.Session(d, lib=lib, seed=100 + c, **kw); S.run_iterations(1, 0, 20); alone.append(state(S)); S.close()
+    for no_chain in (False, True):
+        if no_chain: monkeypatch.setenv("COGAPS_NO_CHAIN", "1")
+        ss = [_capi.Session(d, lib=lib, seed=100 + c, **kw) for c, d in enumerate(datas)]
+        B = _capi.Batch(ss)
+        B.run_iterations(1, 0, 20)
+        for c, S in enumerate(ss):
+            for w in "AP": assert S.chained(w) == (not no_chain), (c, w, no_chain)
+            for x, y in zip(state(S), alone[c]):
+                for u, v in zip(x, y): assert np.array_equal(u, v), (c, no_chain)
+            assert (sum(S.debug_prof(w)[13] for w in "AP") > 200) == (not no_chain)      # batches whose decisions arrived inside a chained launch
+        B.close()
+        for S in ss: S.close()
+
+
 def test_tiny_domain_hazards(emul_lib):
     """5 rows x 2 patterns: every window is full of row conflicts, same-bin moves and neighbour hazards"""
     data = pu.synthetic(5, 6, rank=2, seed=3)

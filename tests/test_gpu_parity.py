@@ -555,6 +555,33 @@ def test_batched_chains_equal_single_sessions(hip_lib, gist):
           whichMatrixFixed="P", fixedPatterns=fp)
 
 
+def test_a_batch_of_chains_in_one_chained_launch_on_the_gpu(hip_lib, monkeypatch):
+    """round 6, chain_kernel_multi: a batch of up to four chains whose evaluation is the fused one steps as ONE chained launch per lock-step
+    (chain c's workgroups evaluate its queue, the last of them generates its next batch).  Three chains of ~3000 x 1600 (A side: 512-thread
+    workgroups, the chained form; P side: 1024 threads, two launches) as one batch equal the three chains stepped alone, state for state;
+    cogaps_session_chained says which form ran; with COGAPS_NO_CHAIN the batch keeps two launches per step and gives the same states."""
+    from cogaps_amd import _capi
+    datas = [pu.synthetic(3000 + 8 * c, 1600, seed=11 + c) for c in range(3)]
+    kw = dict(nPatterns=6, nIterations=30)
+
+    def state(S):
+        return [(S.atoms(w)["pos"].copy(), S.atoms(w)["mass"].copy(), S.matrix(w).copy(), S.ap(w).copy()) for w in "AP"]
+    alone = []
+    for c, d in enumerate(datas):
+        S = _capi.Session(d, lib=hip_lib, seed=50 + c, **kw); S.run_iterations(1, 0, 30); S.run_iterations(2, 0, 10); alone.append(state(S)); S.close()
+    for no_chain in (False, True):
+        if no_chain: monkeypatch.setenv("COGAPS_NO_CHAIN", "1")
+        ss = [_capi.Session(d, lib=hip_lib, seed=50 + c, **kw) for c, d in enumerate(datas)]
+        B = _capi.Batch(ss)
+        B.run_iterations(1, 0, 30); B.run_iterations(2, 0, 10)
+        for c, S in enumerate(ss):
+            assert S.chained("A") == (not no_chain) and not S.chained("P"), (c, no_chain)
+            for x, y in zip(state(S), alone[c]):
+                for u, v in zip(x, y): assert np.array_equal(u, v), (c, no_chain)
+        B.close()
+        for S in ss: S.close()
+
+
 def test_batched_chains_grow_their_atom_tables(hip_lib, gist, monkeypatch):
     from cogaps_amd import _capi
     monkeypatch.setenv("COGAPS_INITIAL_ATOM_CAP", "64")
