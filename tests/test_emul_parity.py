@@ -113,6 +113,13 @@ def test_a_lost_hand_over_is_completed_and_the_update_goes_on(emul_lib):
         carried += S.debug_prof(w)[5]
     S.close()
     assert carried >= 2, carried           # decisions the recovery carried out
+    # ... and the sparse model's chained launch (chain_sparse_kernel: the decisions go to the HybridMatrix's two copies and its flags)
+    sp = pu.synthetic_counts(600, 200, zeros=0.9, seed=5)
+    pu.run_stepwise(lib, sp, 30, nPatterns=4, seed=11, total_iter=40, check_every=5, sparseOptimization=True)
+    S = _capi.Session(sp, lib=lib, nPatterns=4, seed=11, nIterations=40, sparseOptimization=True)
+    S.run_iterations(1, 0, 30)
+    assert sum(S.chain_recoveries(w) for w in "AP") >= 1 and sum(S.debug_prof(w)[5] for w in "AP") >= 1
+    S.close()
 
 
 def test_a_batch_of_chains_in_one_chained_launch(emul_lib, monkeypatch):
