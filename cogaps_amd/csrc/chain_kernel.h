@@ -18,11 +18,15 @@
 //
 // What an evaluation workgroup reads when it starts -- its queue record, the queue length, the batch tag -- exists in two copies, one
 // per launch PARITY (a kernel argument: consecutive launches alternate): a launch of parity p evaluates copy p and its generator writes
-// copy 1 - p, so nothing in a launch reads what the same launch writes, however late a workgroup starts.  The generator workgroup is
-// the last one so that every evaluation workgroup has been dispatched when it begins to wait (the dispatcher starts workgroups in index
-// order: observed, not promised -- a generator that waited for a workgroup not yet started would give up after two seconds with
-// GAPS_ERR_SPIN, applying nothing; and the test-only emulator, which runs workgroups in index order, never spins); the grid is kept at
-// one workgroup per compute unit or less, all resident at once, and the host takes the chained form only for an update that runs alone.
+// copy 1 - p, so nothing in a launch reads what the same launch writes, however late a workgroup starts.  Only the generator workgroup
+// ever waits, and only for evaluation workgroups, which never wait: in whatever order the dispatcher starts the workgroups, on however few
+// compute units, every one of them ends -- the launch cannot deadlock; the bounded poll (two seconds at least) is there for a workgroup the
+// GPU does not schedule at all, and what happens then is chain_recover_kernel's business (below).  Round 6: the fused form's generator is
+// the launch's FIRST workgroup (it enters ~0.25 us earlier than as the last of 241, and its window drawn ahead is what the join waits for:
+// +0.3 %, profiles/r06_ab_small_experiments.txt); the test-only emulator, which runs workgroups one after the other in index order, keeps it
+// last (a first workgroup there would wait for workgroups that have not run), as does the split form, whose update items are dealt out by
+// index.  The grid is kept at one workgroup per compute unit or less and the host takes the chained form only for an update that runs alone:
+// for speed, not for correctness.
 // Bit-identical to the two-launch form: the same reductions, decisions and stores, and the erase cache's order does not matter (the
 // flush sorts it by position, ConcurrentAtomicDomain.cpp:71-79).
 #pragma once
@@ -47,7 +51,12 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(CHAIN_MAX_THREADS) chain_kernel(const uint64_t *
                                                                 uint32_t queueCap, uint32_t parity, uint32_t slices, const SamplerDev CG_CONSTANT *sp)
 {
     constexpr int PH = SPLIT ? EVAL_CHAIN_SPLIT : EVAL_CHAIN;
-    if (cg_bid() + 1u == cg_gdim()) {
+#if defined(COGAPS_EMUL)
+    constexpr bool GEN_FIRST = false;
+#else
+    constexpr bool GEN_FIRST = !SPLIT;
+#endif
+    if (GEN_FIRST ? cg_bid() == 0u : cg_bid() + 1u == cg_gdim()) {
         GenHot hot; hot.lcgMul = lcgMul; hot.lcgInc = lcgInc; hot.gs = gs; hot.eraseList = nullptr; hot.queueUnits = nullptr; hot.eraseCap = 0; hot.queueCap = queueCap;
         hot.queueRd = queue + (size_t)parity * queueCap; hot.queueWr = queue + (size_t)(1u - parity) * queueCap; hot.grans = grans; hot.slotWr = &slots[1u - parity];
         gen_body<WIN, true, true, 0>(sp, hot);
@@ -57,11 +66,12 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(CHAIN_MAX_THREADS) chain_kernel(const uint64_t *
 #if defined(GEN_TIMELINE)
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    const unsigned long long clk0 = (cg_bid() == 0u && cg_tid() == 0u) ? cg_realtime() : 0ull;
-    const EvalFirst first = eval_first<PH>(hot, slices, cg_bid());
+    const uint32_t vb = GEN_FIRST ? cg_bid() - 1u : cg_bid();      // this workgroup's number among the evaluation workgroups
+    const unsigned long long clk0 = (vb == 0u && cg_tid() == 0u) ? cg_realtime() : 0ull;
+    const EvalFirst first = eval_first<PH>(hot, slices, vb);
     const SamplerDev &S = eval_record<PH>(sp);
-    if (cg_bid() == 0u && cg_tid() == 0u && S.launchClock) S.launchClock[2u * (first.tag % GAPS_CLOCK_RING)] = clk0;      // (launch clock: gaps_state.h)
-    eval_body<PH, true>(S, slices, cg_bid(), cg_gdim() - 1u, hot, first);
+    if (vb == 0u && cg_tid() == 0u && S.launchClock) S.launchClock[2u * (first.tag % GAPS_CLOCK_RING)] = clk0;      // (launch clock: gaps_state.h)
+    eval_body<PH, true>(S, slices, vb, cg_gdim() - 1u, hot, first);
 #if defined(GEN_TIMELINE)
     if (cg_tid() == 0u && first.qlen >= 140u && gs->nSteps - gs->nDone >= 512u && cg_bid() < 255u) { g_chain_rt[cg_bid() * 4u] = rt0; g_chain_rt[cg_bid() * 4u + 2u] = __builtin_amdgcn_s_memrealtime(); g_chain_rt[cg_bid() * 4u + 3u] = first.qlen; }
 #endif

@@ -225,9 +225,10 @@ int cogaps_session_perf_sampler(cogaps_session *s, char which, cogaps_perf *out)
  * the one-chain fused evaluation (AsynchronousGibbsSampler.h:88-122, same results); environment COGAPS_NO_CHAIN=1 switches it off.  It is taken
  * only where the device shows a compute unit per workgroup of the launch (241; hipDeviceAttributeMultiprocessorCount, which honours
  * HSA_CU_MASK): the evaluation workgroups never wait for anything, so with fewer units the launch is still correct -- the workgroups run in
- * turns, the generator last -- but slower than two launches; COGAPS_FORCE_CHAIN=1 (tests) takes it there anyway.  The hand-over inside the
- * launch relies on the dispatcher starting workgroups in index order (observed, not promised by HIP): a generator that started before an
- * evaluation workgroup could be scheduled would wait for it, bounded by two seconds -- never a hang.  A wait that runs out applies nothing
+ * turns beside the generator's -- but slower than two launches; COGAPS_FORCE_CHAIN=1 (tests) takes it there anyway.  The hand-over inside the
+ * launch assumes nothing about the order in which the dispatcher starts workgroups: only the generator workgroup waits, and only for
+ * evaluation workgroups, which never wait, so every workgroup ends; the wait is bounded all the same (two seconds at least, for a workgroup
+ * the GPU does not schedule at all) -- never a hang.  A wait that runs out applies nothing
  * of the decision it waited for and makes the launches already enqueued behind it no-ops; the host then completes the batch from the
  * decisions the evaluation workgroups have left by then (chain_recover_kernel), and the sampler goes on -- same chain, same bits -- with
  * two launches per batch for the rest of the session.  cogaps_session_chain_recoveries counts such events (0 in every run so far).  Only if

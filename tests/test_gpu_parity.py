@@ -311,8 +311,8 @@ def test_chained_split_evaluation_equals_two_launches_on_the_gpu(hip_lib, monkey
 def test_chained_launch_with_half_the_compute_units(hip_lib):
     """`Correct and slower, never a hang` as a hardware fact.  The same chain in processes whose queues may use 120 of the 256 compute
     units (HSA_CU_MASK): (1) as the library decides; (2) with COGAPS_FORCE_CHAIN=1 the chained launch whatever the runtime reports --
-    its 241 workgroups are then NOT all resident at once, the generator workgroup, the launch's last, starts when evaluation workgroups
-    have left.  Both must finish and equal the unmasked run bit for bit."""
+    its 241 workgroups are then NOT all resident at once: the generator workgroup (the launch's first since round 6) holds one unit and waits
+    while the evaluation workgroups, which never wait, run in turns on the others.  Both must finish and equal the unmasked run bit for bit."""
     import subprocess, sys, json
     ref, formA = _chain_ab_run(hip_lib)
     assert formA == 1
