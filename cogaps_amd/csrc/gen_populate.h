@@ -82,8 +82,10 @@ CG_DEVICE void gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot hot, G
         static_assert(offsetof(GenShared<WIN>, bval) == offsetof(GenShared<WIN>, bkey) + 16u * (size_t)GEN_TAB_NB, "keys and value words are contiguous");
         constexpr uint32_t UNITS = 5u * (uint32_t)GEN_TAB_NB, ROUNDS = (UNITS + TPB - 1u) / TPB;
         GenTabKeys *tab = reinterpret_cast<GenTabKeys *>(&sh.bkey[0]) + t;
+        // (round 6, chained launch: the table is needed behind the join only -- its 80 KB are emptied by the APPLIER waves while they wait for the
+        // decisions, see below, and the workgroup's first barrier, which the window drawn ahead starts from, comes ~0.4 us earlier)
 #pragma unroll
-        for (uint32_t k = 0; k < ROUNDS; ++k) { if (!spare && ((k + 1u) * TPB <= UNITS || t + k * TPB < UNITS)) tab[k * TPB] = none; }
+        for (uint32_t k = 0; k < ROUNDS; ++k) { if (!CHAIN && !spare && ((k + 1u) * TPB <= UNITS || t + k * TPB < UNITS)) tab[k * TPB] = none; }
         if (CHAIN) {      // ... and the notes of what the decisions change (atom records, matrix cells), by every lane of the launch's workgroup
             static_assert(offsetof(GenShared<WIN>, dCell) == offsetof(GenShared<WIN>, dAtom) + 4u * (size_t)GEN_DIRTY_ATOMS
                           && offsetof(GenShared<WIN>, dErase) == offsetof(GenShared<WIN>, dCell) + 4u * (size_t)GEN_DIRTY_CELLS, "the note tables are contiguous");
@@ -218,6 +220,15 @@ CG_DEVICE void gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot hot, G
         } else {
             // ---- the appliers: one proposal per lane and pass -- wait for its two granules (read past this workgroup's caches until both
             // carry the batch's tag), note an erased atom in the erase cache, carry the decision out, note what changed
+            {   // the conflict table of the round behind the join (keys and value words: one contiguous region), emptied here by the applier lanes:
+                // their fetches are out, the decisions some microseconds away; the join's barrier orders these stores before the registrations
+                GenTabKeys none; none.k[0] = none.k[1] = none.k[2] = none.k[3] = GEN_TAB_EMPTY;
+                constexpr uint32_t UNITS = 5u * (uint32_t)GEN_TAB_NB;
+                GenTabKeys *tab = reinterpret_cast<GenTabKeys *>(&sh.bkey[0]);
+                const uint32_t nAll = cg_bdim() - (uint32_t)WIN;
+#pragma unroll 4
+                for (uint32_t i = t - (uint32_t)WIN; i < UNITS; i += nAll) tab[i] = none;
+            }
             uint32_t unitAcc = 0;
             for (uint32_t base = 0; base < e_prevQ; base += NA) {
                 const uint32_t q = base + al;
