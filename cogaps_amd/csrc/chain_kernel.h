@@ -33,6 +33,7 @@
 #include "eval_kernel.h"
 
 #define CHAIN_MAX_THREADS 512        // 8 waves of up to 256 VGPRs: one workgroup per compute unit, whichever role it plays
+static_assert(CHAIN_MAX_THREADS == GEN_CHAIN_THREADS, "gen_kernel.h knows the chained launch's workgroup size");
 #if defined(COGAPS_EMUL)
 #define CHAIN_EVAL_GRID 7u           // (test-only emulator: a workgroup is a set of fibers; few of them keep the tests quick and make every workgroup evaluate several proposals)
 #else

@@ -524,7 +524,11 @@ static void launch_chain(cogaps_session *s, HostSampler &h)
         // sparse model (sparse_kernels.h, chain_sparse_kernel): the launch has 512 threads per workgroup whatever the model's width
         // (255 evaluation workgroups + the generator = the chip's 256 compute units: a batch of the 256-attempt window then fits one pass --
         // the sparse evaluation has no pairs, a second pass costs a whole evaluation; the dense launch keeps 240, profiles/r04_ab_chained_launch_not_kept.txt)
+#if defined(COGAPS_EMUL)
+        const uint32_t grid = std::min<uint32_t>(h.d.queueCap, CHAIN_EVAL_GRID) + 1u;      // (test-only emulator: few workgroups, so that both groups of an evaluation workgroup get proposals)
+#else
         const uint32_t grid = std::min<uint32_t>(h.d.queueCap, s->computeUnits >= 256u ? 255u : CHAIN_EVAL_GRID) + 1u;
+#endif
         const bool wide = h.d.Wn > cogaps_sparse_width(h.d.N), big = h.genWin == (uint32_t)GEN_WIN;
         if (big && wide) LAUNCH_MAYBE_TIMED(slot, (chain_sparse_kernel<GEN_WIN, true>), grid, CHAIN_MAX_THREADS, h.d.lcgMul, h.d.lcgInc, h.d.gs, h.d.queue, h.chainGrans, h.d.chainSlots, h.d.queueCap, parity, rec);
         else if (big) LAUNCH_MAYBE_TIMED(slot, (chain_sparse_kernel<GEN_WIN, false>), grid, CHAIN_MAX_THREADS, h.d.lcgMul, h.d.lcgInc, h.d.gs, h.d.queue, h.chainGrans, h.d.chainSlots, h.d.queueCap, parity, rec);

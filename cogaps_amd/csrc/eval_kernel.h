@@ -66,10 +66,10 @@ __device__ unsigned long long g_eval_timeline[2 * 16 * 2 * 12];     // [narrow |
 // (nwaves: the workgroup's waves that took part -- all of them unless the caller says otherwise: an evaluation workgroup inside a chained
 // launch of the sparse model has the launch's size and the model's width)
 template <int NC, int V>
-CG_DEVICE void eval_vfinish(const float *lds, float (&tot)[NC], const uint32_t nwaves = 0u)
+CG_DEVICE void eval_vfinish(const float *lds, float (&tot)[NC], const uint32_t nwaves = 0u, const uint32_t tid = 0xFFFFFFFFu)
 {
     constexpr int NV = NC * V;
-    const uint32_t t = cg_tid(), nw = cg_fresh_u32(nwaves ? nwaves : (cg_bdim() >> 6));
+    const uint32_t t = tid == 0xFFFFFFFFu ? cg_tid() : tid, nw = cg_fresh_u32(nwaves ? nwaves : (cg_bdim() >> 6));
     if (t < 64u) {
         const uint32_t i = t < (uint32_t)NV ? t : 0u;
         // all sixteen slots are read at once (one wait instead of one per wave) and the ones past the last wave masked afterwards:

@@ -96,6 +96,7 @@ __device__ unsigned long long g_chain_log[GEN_LOG_N * 8]; __device__ unsigned in
 #define FLUSH_MAX 64                 // erase caches up to this size are flushed in parallel
 #endif
 #define CG_KEEP 0xFFFFFFFEu          // "front unchanged" marker
+#define GEN_CHAIN_THREADS 512        // workgroup size of the chained launches the generator body is part of (chain_kernel.h: CHAIN_MAX_THREADS)
 
 #define GEN_DIRTY_ATOMS 4096      // 32-bit words of the note bit sets (a batch's decisions touch ~3 atom records and ~1.5 cells each: ~600 of 131072 bits)
 #define GEN_DIRTY_CELLS 2048

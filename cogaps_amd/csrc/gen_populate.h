@@ -152,6 +152,14 @@ CG_DEVICE void gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot hot, G
         const bool applying = applier;
 #endif
         const bool have0 = applying && al < e_prevQ;
+        // (sparse model, the full window: the attempt lanes take part in the hand-over -- below; the half window's launch has 384 applier lanes for
+        // queues of 128 per round, its attempt lanes would only pay for the pass: P side +0.5 us, profiles/r06_ab_sparse_chained_launch.txt)
+#if defined(GEN_TEST_APPLIER_LANES)
+        constexpr bool ATTEMPTS_APPLY = SP == 1;
+#else
+        constexpr bool ATTEMPTS_APPLY = SP == 1 && 2 * WIN >= GEN_CHAIN_THREADS;
+#endif
+        const uint32_t passLanes = ATTEMPTS_APPLY ? NA + (uint32_t)WIN : NA;      // proposals per pass of the hand-over
         // second trip (the first brought the scalars and an applier's record): what the decision will rewrite; the seeds, the table's window
         ChainMid mid0; mid0.l2 = CG_NONE; mid0.head1 = CG_NONE; mid0.b1 = 0; mid0.b2 = 0; mid0.x1 = 0ull; mid0.x2 = 0ull;
         mid0.a.pos = 0; mid0.a.lpos = 0; mid0.a.rpos = 0; mid0.a.left = CG_NONE; mid0.a.right = CG_NONE; mid0.a.mass = 0.f; mid0.a.rmass = 0.f; mid0.a.idx = 0; mid0.a.pad0 = 0;
@@ -217,6 +225,21 @@ CG_DEVICE void gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot hot, G
             GEN_PIN(drawKeep.flags); GEN_PIN(drawKeep.old1); GEN_PIN(drawKeep.old2);
             GEN_TS(36);
             GEN_RT(2);
+            // Sparse model (round 6): the window drawn ahead is done ~8 us before the sparse evaluation's decisions arrive -- the attempt lanes take
+            // the queue slots behind the applier lanes'.  A queue longer than the applier lanes (the batch behind a generator launch of two
+            // rounds: 39 % of the launches at BASELINE configs[4]'s shard shape) used to take a second pass -- three dependent trips, the wait, the
+            // stores -- behind the first one.
+            if constexpr (ATTEMPTS_APPLY) {
+#define HP_STRIDE passLanes
+#define HP_LANE (NA + t)
+#define HP_MINE true
+#define HP_FETCH(b) true
+#include "gen_handover_pass.h"
+#undef HP_STRIDE
+#undef HP_LANE
+#undef HP_MINE
+#undef HP_FETCH
+            }
         } else {
             // ---- the appliers: one proposal per lane and pass -- wait for its two granules (read past this workgroup's caches until both
             // carry the batch's tag), note an erased atom in the erase cache, carry the decision out, note what changed
@@ -229,83 +252,15 @@ CG_DEVICE void gen_body_sh(const SamplerDev CG_CONSTANT *sp, const GenHot hot, G
 #pragma unroll 4
                 for (uint32_t i = t - (uint32_t)WIN; i < UNITS; i += nAll) tab[i] = none;
             }
-            uint32_t unitAcc = 0;
-            for (uint32_t base = 0; base < e_prevQ; base += NA) {
-                const uint32_t q = base + al;
-                bool have = applying && q < e_prevQ;
-                if (base) { chain_item_clear(it); if (have) chain_fetch(S, hot.queueRd, q, it, isSparse); }      // (a queue longer than the applier lanes: the batch after a generator launch of two rounds)
-                // where the notes of this proposal go, whatever is decided (the hashes ahead of the wait)
-                const GenNotePos nH1 = gen_note_pos<GEN_DIRTY_ATOMS>(it.h1), nHL = gen_note_pos<GEN_DIRTY_ATOMS>(it.hL), nHR = gen_note_pos<GEN_DIRTY_ATOMS>(it.hR),
-                                 nH2 = gen_note_pos<GEN_DIRTY_ATOMS>(it.h2), nL2 = gen_note_pos<GEN_DIRTY_ATOMS>(it.l2), nIdx = gen_note_pos<GEN_DIRTY_ATOMS>(~it.idx),
-                                 nC1 = gen_note_pos<GEN_DIRTY_CELLS>(it.cell1), nC2 = gen_note_pos<GEN_DIRTY_CELLS>(it.cell2);
-                const unsigned long long *gr = hot.grans + (size_t)q * CHAIN_GRAN_STRIDE;
-                unsigned long long g0 = 0ull, g1 = 0ull; uint32_t spins = 0;
-                for (;;) {
-                    if (have) { g0 = cg_load_l2_u64(&gr[0]); g1 = cg_load_l2_u64(&gr[1]); }
-                    const bool ok = !have || ((uint32_t)(g0 >> 32) == tag && (uint32_t)(g1 >> 32) == tag);
-                    if (cg_ballot(!ok) == 0ull) break;
-                    // bounded (platform.h: two seconds at least), never a hang.  A bound that is hit applies NOTHING: a granule without this batch's
-                    // tag is an older batch's decision -- the lane drops its proposal, the error word ends the update on the host (the session is
-                    // then marked unusable: its domain lacks decisions) and the workgroup leaves behind the barrier below without generating
-                    // (round 6: the dropped proposal is marked, the batch is completed by the host once the launch has ended -- chain_recover_kernel --
-                    // and the update goes on with two launches per batch)
-                    if (cg_poll_expired(++spins)) { if (!ok) { have = false; S.queueUnits[q] = CHAIN_DROPPED_MARK(tag); } if ((t & 63u) == 0u) { gs->error = GAPS_ERR_SPIN; sh.spinFail = 1u; } break; }
-                    cg_poll_pause();
-                }
-#if defined(GEN_TEST_SPIN_FAIL_EPOCH)
-                // test-only variant of the emulator build (whose workgroups run one after the other: nothing ever waits): at one batch every third
-                // lane gives up as if its decision had not arrived -- the launch ends the way a lost hand-over ends it
-                if (cg_ballot(have && tag == (uint32_t)GEN_TEST_SPIN_FAIL_EPOCH && (q % 3u) == 1u) != 0ull) {
-                    if (have && (q % 3u) == 1u) { have = false; S.queueUnits[q] = CHAIN_DROPPED_MARK(tag); }
-                    if ((t & 63u) == 0u) { gs->error = GAPS_ERR_SPIN; sh.spinFail = 1u; }
-                }
-#endif
-                GEN_TS(33);
-                if (base == 0u) GEN_RT_AT(3, WIN);
-                const uint32_t code = have ? ((uint32_t)g0 & 0xFFu) : CHAIN_NONE;
-                if (have) unitAcc += ((uint32_t)g0 >> 8) << (it.sparse ? 5u : 0u);      // (dense: units of 4N bytes; sparse: bytes / 32, GenScalars::evalBytes counts bytes there)
-                // erase cache (ConcurrentAtomicDomain.cpp:62-69): one slot per erased atom, in any order -- the flush sorts by position.
-                // (Before the stores: what the barrier below waits for is LDS traffic only.)
-                const bool er = have && code == CHAIN_ERASE, ap = have && code == CHAIN_APPLY;
-                // bitmap words whose bits or bins' heads this decision (or the flush, for an erased atom) changes: the births drawn ahead check them
-                if (er) gen_mark_dirty(sh.dirty, it.cell1);
-                if (ap && it.type == 'M') { gen_mark_dirty(sh.dirty, it.mb1); gen_mark_dirty(sh.dirty, it.mb2); }
-                // atom records whose fields change: the atom's own (mass / position) and the neighbours that cache copies of them; an erased
-                // atom's neighbours are relinked by the flush.  Matrix cells that are rewritten.
-                if (er || ap) {
-                    gen_note_set(sh.dAtom, nH1);
-                    if (it.hL != CG_NONE) gen_note_set(sh.dAtom, nHL);
-                    if ((er || it.type == 'M') && it.hR != CG_NONE) gen_note_set(sh.dAtom, nHR);
-                    if (ap && it.type == 'E') { gen_note_set(sh.dAtom, nH2); if (it.l2 != CG_NONE) gen_note_set(sh.dAtom, nL2); }
-                    if (er) {      // (the vector slot the flush refills from the tail; the records the flush rewrites: the erased atom's and its neighbours')
-                        gen_note_set(sh.dAtom, nIdx);
-                        gen_note_set(sh.dErase, gen_note_pos<GEN_DIRTY_ERASE>(it.h1));
-                        if (it.hL != CG_NONE) gen_note_set(sh.dErase, gen_note_pos<GEN_DIRTY_ERASE>(it.hL));
-                        if (it.hR != CG_NONE) gen_note_set(sh.dErase, gen_note_pos<GEN_DIRTY_ERASE>(it.hR));
-                    }
-                    if (ap || it.type == 'D') gen_note_set(sh.dCell, nC1);
-                    if (ap && (it.type == 'M' || it.type == 'E')) gen_note_set(sh.dCell, nC2);
-                }
-                const unsigned long long em = cg_ballot(er);
-                if (em) {
-                    const uint32_t cntE = (uint32_t)cg_popc64(em);
-                    uint32_t b0 = 0;
-                    if ((t & 63u) == 0u) b0 = cg_atomic_add_u32(&sh.eraseN, cntE);
-                    b0 = cg_wave_bcast_u32(b0, 0);
-                    if (er) {
-                        const uint32_t k = b0 + (uint32_t)cg_popc64(em & ((1ull << (t & 63u)) - 1ull));
-                        const unsigned long long e = it.eraseEntry;
-                        if (k < (uint32_t)FLUSH_MAX) sh.eraseTmp[k] = e;
-                        if (k < eraseCap) eraseList[k] = e; else gs->error = GAPS_ERR_ERASE_CAP;
-                    }
-                }
-                if (have) chain_apply(it, code, gm_u2f((uint32_t)g1));
-#if defined(COGAPS_EMUL)
-                if (have && base) cg_atomic_add_u64(&gs->prof[6], 1ull);      // test-only build: decisions carried out in a pass beyond the first (a queue longer than the applier lanes)
-#endif
-            }
-            const uint32_t waveUnits = cg_wave_sum_u32(unitAcc);
-            if ((t & 63u) == 0u && waveUnits) cg_atomic_add_u32(&sh.unitSum, waveUnits);
+#define HP_STRIDE passLanes
+#define HP_LANE al
+#define HP_MINE applying
+#define HP_FETCH(b) (b)
+#include "gen_handover_pass.h"
+#undef HP_STRIDE
+#undef HP_LANE
+#undef HP_MINE
+#undef HP_FETCH
         }
         GEN_TS(34);
         // The join: the decisions are issued to the domain, the erase cache, the notes and the unit sum are complete.  The window drawn

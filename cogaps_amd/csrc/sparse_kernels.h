@@ -18,6 +18,12 @@
 #include "aux_kernels.h"
 
 #define SP_KMAX 512      // nPatterns limit of the sparse kernels (matrix rows staged in LDS)
+// An evaluation workgroup has the model's width (cogaps_sparse_width: 256 threads at most); inside the chained launch, whose workgroups have 512
+// threads, lanes 256.. are a second GROUP with a proposal and an LDS block of its own (chain_sparse_kernel).  sp_tid: the lane within its group.
+#define SP_GROUP_THREADS 256u
+#define SP_CHAIN_GROUPS(WIDE) ((WIDE) ? 1u : 2u)      // (the wide form's term list takes 80 KB: one group)
+CG_DEVICE uint32_t sp_tid() { return cg_tid() & (SP_GROUP_THREADS - 1u); }
+CG_DEVICE uint32_t sp_grp() { return cg_tid() / SP_GROUP_THREADS; }
 
 // gaps::dot, scalar build (VectorMath.h:41-134): up to 25 elements are added last-to-first, more first-to-last
 CG_DEVICE float sp_dot(const float *a, const float *b, uint32_t n)
@@ -166,7 +172,7 @@ struct SpPre { unsigned long long dfl, fv; uint32_t dbase; };
 CG_DEVICE SpPre sp_preload(const SamplerDev &S, uint32_t row, uint32_t col, uint32_t col2, bool same)
 {
     SpPre o; o.dfl = 0ull; o.fv = 0ull; o.dbase = 0u;
-    const uint32_t w = cg_tid();
+    const uint32_t w = sp_tid();
     if (w < S.Wn) {
         o.dfl = S.dflags[(size_t)row * S.Wn + w];
         o.fv = S.oflags[(size_t)col * S.oMw + w];
@@ -180,7 +186,7 @@ CG_DEVICE SpPre sp_preload(const SamplerDev &S, uint32_t row, uint32_t col, uint
 template <int MODE, int CAP>
 CG_DEVICE void sp_partial_rounds(const SamplerDev &S, uint32_t row, uint32_t col, uint32_t col2, float ch, const float *arow, SpBal<CAP> &bal, const SpPre &pre0, float &ps, float &pm, uint32_t &visited)
 {
-    const uint32_t BS = S.spW, t = cg_tid();
+    const uint32_t BS = S.spW, t = sp_tid();
     const unsigned long long *fD = S.dflags + (size_t)row * S.Wn;
     const unsigned long long *fV = S.oflags + (size_t)col * S.oMw, *fV2 = S.oflags + (size_t)col2 * S.oMw;
     const uint32_t *pre = S.dprefix + (size_t)row * S.Wn;
@@ -265,7 +271,7 @@ CG_DEVICE void sp_partial_rounds(const SamplerDev &S, uint32_t row, uint32_t col
 template <int MODE, int CAP>
 CG_DEVICE void sp_partial_merged(const SamplerDev &S, uint32_t row, uint32_t col, uint32_t col2, float ch, const float *arow, SpBal<CAP> &bal, const SpPre &pre0, float &ps, float &pm, uint32_t &visited)
 {
-    const uint32_t BS = S.spW, t = cg_tid();
+    const uint32_t BS = S.spW, t = sp_tid();
     if (S.Wn <= BS || S.Wn > (uint32_t)SP_MERGE_ROUNDS * BS) { sp_partial_rounds<MODE, CAP>(S, row, col, col2, ch, arow, bal, pre0, ps, pm, visited); return; }      // (one round: nothing to merge)
     const unsigned long long *fD = S.dflags + (size_t)row * S.Wn;
     const unsigned long long *fV = S.oflags + (size_t)col * S.oMw, *fV2 = S.oflags + (size_t)col2 * S.oMw;
@@ -348,7 +354,7 @@ template <int CAP>
 CG_DEVICE void sp_partial_pair(const SamplerDev &S, uint32_t rowA, uint32_t colA, const float *arowA, const SpPre &preA, uint32_t rowB, uint32_t colB, const float *arowB, const SpPre &preB,
                                SpBal<CAP> &bal, float (&x)[4], uint32_t &visited)
 {
-    const uint32_t BS = S.spW, t = cg_tid();
+    const uint32_t BS = S.spW, t = sp_tid();
     const float *dataA = S.dvals + S.dptr[rowA], *dataB = S.dvals + S.dptr[rowB];
     const float *VA = S.other + (size_t)colA * S.Npad, *VB = S.other + (size_t)colB * S.Npad;
     if (t == 0) bal.n = 0u;
@@ -402,7 +408,7 @@ template <int CAP>
 CG_DEVICE void sp_list_rounds(const SamplerDev &S, uint32_t row, uint32_t col, const SpPre &pre0, SpBal<CAP> &bal, uint32_t tag,
                               uint32_t (&cnt)[SP_MERGE_ROUNDS], uint32_t (&base)[SP_MERGE_ROUNDS], uint32_t &mine)
 {
-    const uint32_t BS = S.spW, t = cg_tid();
+    const uint32_t BS = S.spW, t = sp_tid();
     const unsigned long long *fD = S.dflags + (size_t)row * S.Wn, *fV = S.oflags + (size_t)col * S.oMw;
     const uint32_t *pre = S.dprefix + (size_t)row * S.Wn;
     unsigned long long dfl[SP_MERGE_ROUNDS], common[SP_MERGE_ROUNDS]; uint32_t dbase[SP_MERGE_ROUNDS];
@@ -445,7 +451,7 @@ template <int CAP>
 CG_DEVICE void sp_partial_merged_pair(const SamplerDev &S, uint32_t rowA, uint32_t colA, const float *arowA, const SpPre &preA, uint32_t rowB, uint32_t colB, const float *arowB, const SpPre &preB,
                                       SpBal<CAP> &bal, float (&x)[4], uint32_t &visited)
 {
-    const uint32_t BS = S.spW, t = cg_tid();
+    const uint32_t BS = S.spW, t = sp_tid();
     if (S.Wn <= BS || S.Wn > (uint32_t)SP_MERGE_ROUNDS * BS || S.N >= 0x80000000u) {
         sp_partial_merged<SP_MODE_ONE, CAP>(S, rowA, colA, 0u, 0.f, arowA, bal, preA, x[0], x[1], visited);
         sp_partial_merged<SP_MODE_ONE, CAP>(S, rowB, colB, 0u, 0.f, arowB, bal, preB, x[2], x[3], visited);
@@ -505,7 +511,7 @@ template <int MODE>
 CG_DEVICE void sp_alpha_seq(const SamplerDev &S, uint32_t row, uint32_t col, uint32_t col2, float ch, const float *arow, float s0, float m0,
                             uint32_t *wcnt, float *bc, float &sOut, float &mOut, uint32_t &visited)
 {
-    const uint32_t BS = S.spW, t = cg_tid(), K = S.K;
+    const uint32_t BS = S.spW, t = sp_tid(), K = S.K;
     const unsigned long long *fD = S.dflags + (size_t)row * S.Wn;
     const unsigned long long *fV = S.oflags + (size_t)col * S.oMw, *fV2 = S.oflags + (size_t)col2 * S.oMw;
     const uint32_t *pre = S.dprefix + (size_t)row * S.Wn;
@@ -615,7 +621,7 @@ CG_DEVICE void eval_sparse_body_sh(const SamplerDev &S, const uint32_t vbid, con
     uint32_t (&seqCnt)[SEQ ? SP_SEQ_WORDS + 1 : 1] = sm.seqCnt; float (&seqBc)[2] = sm.seqBc;
     SpBal<(WIDE ? SP_BAL_CAP_WIDE : SP_BAL_CAP)> &bal = sm.bal;
     const uint32_t mm = SEQ ? S.mathMode : GM_MATH_PORTABLE;
-    const uint32_t t = cg_tid(), BS = S.spW, K = S.K;      // (threads beyond the model's width never get here)
+    const uint32_t t = sp_tid(), BS = S.spW, K = S.K;      // (threads beyond the model's width never get here)
     const float lambda = S.lambda, beta = S.beta;
     const bool multiWave = BS > 64u;
     const bool scalarLane = !multiWave || t < 64u;
@@ -627,6 +633,9 @@ CG_DEVICE void eval_sparse_body_sh(const SamplerDev &S, const uint32_t vbid, con
         const PropRec p = pNext;
         if (q >= qlen) break;
         EVAL_TS(1);
+#if defined(COGAPS_EMUL)
+        if (CHAIN && t == 0u && sp_grp() != 0u) cg_atomic_add_u64(&S.gs->prof[4], 1ull);      // test-only build: proposals evaluated by a workgroup's second group
+#endif
         uint64_t rng = p.rng;
         const EvalAtoms ea = eval_atoms_load(S, p, !CHAIN && t == 0u);      // (chained launch: the generator workgroup fetches what it rewrites)
         const bool two = (p.type == 'M' || p.type == 'E');
@@ -698,7 +707,7 @@ CG_DEVICE void eval_sparse_body_sh(const SamplerDev &S, const uint32_t vbid, con
             if (multiWave) {
                 if ((t & 63u) == 0) { for (int c = 0; c < 4; ++c) lds[(t >> 6) * 4 + c] = x[c]; }
                 cg_sync();
-                eval_vfinish<4, 1>(lds, tot, BS >> 6);
+                eval_vfinish<4, 1>(lds, tot, BS >> 6, t);
             }
             EVAL_TS(4);
             if (scalarLane) {
@@ -1029,7 +1038,8 @@ template <int WIN, bool WIDE>
 CG_KERNEL void CG_LAUNCH_BOUNDS(CHAIN_MAX_THREADS) chain_sparse_kernel(const uint64_t *lcgMul, const uint64_t *lcgInc, GenScalars *gs, PropRec *queue, unsigned long long *grans, ChainSlot *slots,
                                                                        uint32_t queueCap, uint32_t parity, const SamplerDev CG_CONSTANT *sp)
 {
-    constexpr size_t POOL = sizeof(GenShared<WIN>) > sizeof(SpShared<false, WIDE>) ? sizeof(GenShared<WIN>) : sizeof(SpShared<false, WIDE>);
+    constexpr size_t GROUP_LDS = (sizeof(SpShared<false, WIDE>) + 15u) & ~(size_t)15u, EVAL_LDS = SP_CHAIN_GROUPS(WIDE) * GROUP_LDS;
+    constexpr size_t POOL = sizeof(GenShared<WIN>) > EVAL_LDS ? sizeof(GenShared<WIN>) : EVAL_LDS;
     CG_SHARED alignas(16) unsigned char pool[POOL];
     if (cg_bid() + 1u == cg_gdim()) {
         GenHot hot; hot.lcgMul = lcgMul; hot.lcgInc = lcgInc; hot.gs = gs; hot.eraseList = nullptr; hot.queueUnits = nullptr; hot.eraseCap = 0; hot.queueCap = queueCap;
@@ -1039,9 +1049,16 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(CHAIN_MAX_THREADS) chain_sparse_kernel(const uin
     }
     EvalHot hot; hot.queue = queue + (size_t)parity * queueCap; hot.gs = gs; hot.queueCap = queueCap; hot.slot = &slots[parity]; hot.grans = grans;
     const unsigned long long clk0 = (cg_bid() == 0u && cg_tid() == 0u) ? cg_realtime() : 0ull;
-    const EvalFirst first = eval_first<EVAL_CHAIN>(hot, 1u, cg_bid());
+    // (round 6) two proposals per evaluation workgroup: the launch's workgroups have 512 threads, the model's width is 256 at most -- the second
+    // four waves, which used to leave at once, take the proposal one grid further on (queue slot bid + n: a queue longer than the grid --
+    // 39 % of the A sampler's launches at BASELINE configs[4]'s shard shape -- no longer needs a second pass), with an LDS block of their own.
+    // The two groups share the workgroup's barrier: every wave has passed the same number of barriers, so a group's waves always meet at
+    // the group's own k-th barrier, whatever the other group's k-th one is; a group that is done ends and no longer counts.
+    const uint32_t grp = sp_grp(), nEval = cg_gdim() - 1u, vb = cg_bid() + grp * nEval;
+    if (grp >= SP_CHAIN_GROUPS(WIDE)) return;
+    const EvalFirst first = eval_first<EVAL_CHAIN>(hot, 1u, vb);
     const SamplerDev &S = eval_record<EVAL_CHAIN>(sp);
     if (cg_bid() == 0u && cg_tid() == 0u && S.launchClock) S.launchClock[2u * (first.tag % GAPS_CLOCK_RING)] = clk0;      // (launch clock: gaps_state.h)
-    if (cg_tid() >= S.spW) return;
-    eval_sparse_body_sh<false, WIDE, true>(S, cg_bid(), cg_gdim() - 1u, hot, first, *reinterpret_cast<SpShared<false, WIDE> *>(pool));
+    if (sp_tid() >= S.spW) return;
+    eval_sparse_body_sh<false, WIDE, true>(S, vb, nEval * SP_CHAIN_GROUPS(WIDE), hot, first, *reinterpret_cast<SpShared<false, WIDE> *>(pool + (size_t)grp * GROUP_LDS));
 }

@@ -122,6 +122,41 @@ def test_a_lost_hand_over_is_completed_and_the_update_goes_on(emul_lib):
     S.close()
 
 
+def test_sparse_chained_launch_two_proposals_per_evaluation_workgroup(emul_lib, monkeypatch):
+    """chain_sparse_kernel (sparse_kernels.h): the launch's workgroups have 512 threads, the sparse evaluation the model's width (256 at
+    most) -- lanes 256.. of an evaluation workgroup are a second group that takes the proposal one grid further on, with an LDS block of
+    its own; the two groups pass through the workgroup's barriers side by side, each in its own order of phases (proposals of different
+    types, one with a Gibbs mass and one without, vectors of one and of two words).  Stepwise against the oracle at model widths 64 and
+    256, then the test-only build's counter of proposals the second groups evaluated; with COGAPS_NO_CHAIN the counter stays at zero."""
+    from cogaps_amd import _capi
+    lib = emul_lib(64)
+    for data, kw, n in ((pu.synthetic_counts(600, 200, zeros=0.9, seed=5), dict(nPatterns=4, seed=11), 30),
+                        (pu.synthetic_counts(1500, 9000, zeros=0.95, seed=6), dict(nPatterns=3, seed=12), 12)):
+        pu.run_stepwise(lib, data, n, total_iter=40, check_every=5, sparseOptimization=True, **kw)
+        S = _capi.Session(data, lib=lib, nIterations=40, sparseOptimization=True, **kw)
+        S.run_iterations(1, 0, n)
+        second = {w: S.debug_prof(w)[4] for w in "AP"}
+        chained = {w: bool(S.chained(w)) for w in "AP"}
+        S.close()
+        assert all(chained.values()) and all(v > 20 for v in second.values()), (chained, second)
+    # the hand-over in the sparse model: the attempt lanes, done with the window drawn ahead, take the queue slots behind the applier lanes' (the
+    # variant with five applier lanes: slots 5 .. 68 go to the 64 attempt lanes, longer queues take further passes of 69)
+    lib5 = emul_lib(64, extra="-DGEN_TEST_APPLIER_LANES=5", tag="_appl5")
+    data = pu.synthetic_counts(600, 200, zeros=0.9, seed=5)
+    pu.run_stepwise(lib5, data, 30, total_iter=40, check_every=5, sparseOptimization=True, nPatterns=4, seed=11)
+    S = _capi.Session(data, lib=lib5, nIterations=40, sparseOptimization=True, nPatterns=4, seed=11)
+    S.run_iterations(1, 0, 30)
+    by_attempt_lanes = sum(S.debug_prof(w)[2] for w in "AP"); later = sum(S.debug_prof(w)[6] for w in "AP")
+    S.close()
+    assert by_attempt_lanes > 500, (by_attempt_lanes, later)
+    monkeypatch.setenv("COGAPS_NO_CHAIN", "1")
+    data = pu.synthetic_counts(600, 200, zeros=0.9, seed=5)
+    S = _capi.Session(data, lib=lib, nPatterns=4, seed=11, nIterations=40, sparseOptimization=True)
+    S.run_iterations(1, 0, 10)
+    assert sum(S.debug_prof(w)[4] for w in "AP") == 0
+    S.close()
+
+
 def test_a_batch_of_chains_in_one_chained_launch(emul_lib, monkeypatch):
     """cogaps_batch_* with the chained launch for ALL chains of the batch (chain_kernel.h, chain_kernel_multi; round 6): workgroups
     [c * wgPerChain, (c + 1) * wgPerChain) of one launch evaluate chain c's queue, the last of them generates its next batch.  Three
