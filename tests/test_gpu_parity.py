@@ -252,6 +252,47 @@ def test_chained_equals_two_launches_on_the_gpu(hip_lib, monkeypatch):
     assert chained == plain
 
 
+def test_sparse_chained_launch_with_long_queues_equals_two_launches_on_the_gpu(hip_lib, monkeypatch):
+    """The sparse model's chained launch (chain_sparse_kernel) where its round-6 paths are taken ON THE HARDWARE: queues longer than the 255
+    evaluation workgroups (the second group of four waves of a workgroup evaluates the proposal one grid further on, both groups passing
+    through the workgroup's barriers side by side) and longer than the generator workgroup's 256 applier lanes (its attempt lanes carry
+    out the slots behind theirs).  30000 x 3000, 95 % zeros, K = 30: stepped until the A sampler's batches average more than 256
+    proposals, then six iterations more; the same number of iterations with COGAPS_NO_CHAIN=1 (generator launch + eval_sparse_kernel,
+    one proposal per workgroup, the decisions written by the evaluation workgroups) must leave the same bits: atoms, links, both copies of
+    the HybridMatrix."""
+    import bench
+    from cogaps_amd import _capi
+    data = bench.synthetic_dense(30000, 3000)
+    data = (data * (np.random.Generator(np.random.MT19937(5)).random(data.shape) >= 0.95)).astype(np.float32)
+
+    def run(n_fixed=None):
+        S = _capi.Session(data, lib=hip_lib, nPatterns=30, nIterations=60, seed=23, sparseOptimization=True)
+        it = 0; long_since = None; mean_q = 0.0
+        while it < (n_fixed if n_fixed is not None else 60):
+            S.set_annealing(min(1.0, 2.0 * it / 60))
+            b0 = S.perf("A")
+            nA, nP = S.draw_steps(); S.iterate(nA, nP); it += 1
+            b1 = S.perf("A")
+            mean_q = (b1["proposalsQueued"] - b0["proposalsQueued"]) / max(1, b1["batches"] - b0["batches"])
+            if n_fixed is None and long_since is None and mean_q > 256.0: long_since = it
+            if n_fixed is None and long_since is not None and it >= long_since + 6: break
+        st = _chain_state(S) + [sha_rows(S)], (S.chained("A"), S.chained("P")), it, mean_q, long_since
+        S.close()
+        return st
+
+    def sha_rows(S):
+        import hashlib
+        return hashlib.sha256(np.ascontiguousarray(S.rows("A")).tobytes() + np.ascontiguousarray(S.rows("P")).tobytes()).hexdigest()
+
+    a, form_a, n, mean_q, long_since = run()
+    assert form_a == (1, 1), "the sparse model's chained launch did not run"
+    assert long_since is not None and mean_q > 256.0, "the A sampler's queues stayed short (mean %.1f after %d iterations): the paths under test were not taken" % (mean_q, n)
+    monkeypatch.setenv("COGAPS_NO_CHAIN", "1")
+    b, form_b, _, _, _ = run(n)
+    assert form_b == (0, 0)
+    assert a == b
+
+
 def test_launch_clock_of_chained_launches(hip_lib):
     """cogaps_session_launch_clock: the chip-wide clock read inside EVERY chained launch since set_timing(1) (replayed graphs included) --
     as many launches as the sampler generated batches in the window (one launch per batch; the update's first launch evaluates nothing
