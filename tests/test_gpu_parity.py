@@ -256,17 +256,17 @@ def test_sparse_chained_launch_with_long_queues_equals_two_launches_on_the_gpu(h
     """The sparse model's chained launch (chain_sparse_kernel) where its round-6 paths are taken ON THE HARDWARE: queues longer than the 255
     evaluation workgroups (the second group of four waves of a workgroup evaluates the proposal one grid further on, both groups passing
     through the workgroup's barriers side by side) and longer than the generator workgroup's 256 applier lanes (its attempt lanes carry
-    out the slots behind theirs).  30000 x 3000, 95 % zeros, K = 30: stepped until the A sampler's batches average more than 256
-    proposals, then six iterations more; the same number of iterations with COGAPS_NO_CHAIN=1 (generator launch + eval_sparse_kernel,
+    out the slots behind theirs).  80000 x 1200, 95 % zeros, K = 20 (a batch of the A sampler ends at the first repeated row: ~350 proposals
+    once the domain is populated): stepped until the A sampler's batches average more than 256 proposals, then six iterations more; the same number of iterations with COGAPS_NO_CHAIN=1 (generator launch + eval_sparse_kernel,
     one proposal per workgroup, the decisions written by the evaluation workgroups) must leave the same bits: atoms, links, both copies of
     the HybridMatrix."""
     import bench
     from cogaps_amd import _capi
-    data = bench.synthetic_dense(30000, 3000)
+    data = bench.synthetic_dense(80000, 1200)
     data = (data * (np.random.Generator(np.random.MT19937(5)).random(data.shape) >= 0.95)).astype(np.float32)
 
     def run(n_fixed=None):
-        S = _capi.Session(data, lib=hip_lib, nPatterns=30, nIterations=60, seed=23, sparseOptimization=True)
+        S = _capi.Session(data, lib=hip_lib, nPatterns=20, nIterations=60, seed=23, sparseOptimization=True)
         it = 0; long_since = None; mean_q = 0.0
         while it < (n_fixed if n_fixed is not None else 60):
             S.set_annealing(min(1.0, 2.0 * it / 60))
