@@ -76,7 +76,7 @@ EXPORTS = [
     "cogaps_session_chisq", "cogaps_session_get_matrix", "cogaps_session_get_ap",
     "cogaps_session_get_atoms", "cogaps_session_dims", "cogaps_session_avg_queue",
     "cogaps_session_finish", "cogaps_session_set_timing", "cogaps_session_perf",
-    "cogaps_session_perf_sampler", "cogaps_session_chained", "cogaps_session_chain_recoveries", "cogaps_session_launch_clock", "cogaps_session_launch_period", "cogaps_session_get_rows", "cogaps_sparse_width", "cogaps_reduction_width", "cogaps_session_debug_prof", "cogaps_session_debug_replay",
+    "cogaps_session_perf_sampler", "cogaps_session_chained", "cogaps_session_chain_recoveries", "cogaps_session_generator_window", "cogaps_session_launch_clock", "cogaps_session_launch_period", "cogaps_session_get_rows", "cogaps_sparse_width", "cogaps_reduction_width", "cogaps_session_debug_prof", "cogaps_session_debug_replay",
     "cogaps_run_from_file", "cogaps_read_matrix_file", "cogaps_read_matrix_file_subset", "cogaps_matrix_free", "cogaps_file_info", "cogaps_debug_math", "cogaps_current_device", "cogaps_device_memory",
     "cogaps_session_debug_check_domain", "cogaps_batch_create", "cogaps_batch_destroy", "cogaps_batch_run_iterations", "cogaps_batch_set_timing", "cogaps_batch_perf",
 ]
@@ -144,6 +144,7 @@ def bind(L):
     L.cogaps_session_perf_sampler.argtypes = [vp, C.c_char, C.POINTER(CogapsPerfC)]
     L.cogaps_session_chained.argtypes = [vp, C.c_char, C.POINTER(C.c_int)]
     L.cogaps_session_chain_recoveries.argtypes = [vp, C.c_char, C.POINTER(C.c_uint32)]
+    L.cogaps_session_generator_window.argtypes = [vp, C.c_char, C.POINTER(C.c_uint32)]
     if hasattr(L, "cogaps_session_launch_period"):
         L.cogaps_session_launch_period.argtypes = [vp, C.c_char, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     if hasattr(L, "cogaps_session_launch_clock"):      # (an A/B build of an older source tree may lack it: launch_clock() then reports no launches)
@@ -426,6 +427,12 @@ class Session:
         v = C.c_int()
         self._ck(self.L.cogaps_session_chained(self.h, which.encode(), C.byref(v)))
         return bool(v.value)
+
+    def generator_window(self, which):
+        """attempts per round of the sampler's generator launches as of its last update"""
+        v = C.c_uint32()
+        self._ck(self.L.cogaps_session_generator_window(self.h, which.encode(), C.byref(v)))
+        return v.value
 
     def chain_recoveries(self, which):
         """how often a hand-over inside a chained launch of this sampler never arrived and the batch was completed by the recovery (the sampler

@@ -32,8 +32,23 @@
 #ifndef GEN_WIN_HALF
 #define GEN_WIN_HALF (GEN_WIN / 2 >= 64 ? GEN_WIN / 2 : GEN_WIN)      // the narrower instantiation, for a sampler with short batches
 #endif
-static uint32_t gen_window_for(uint32_t current, float stepsPerBatch)
+// A third, WIDER window for the sparse model's chained launch (round 6): there the generator workgroup's window drawn ahead and its hand-over
+// disappear behind the evaluation, which is long, and a second round of the batch costs ~12 us -- with the widest window the launch's workgroup
+// holds (seven attempt waves + the helper wave: 448 attempts; the attempt lanes carry out the queue behind the helper wave's 64 slots) a batch of
+// ~250 proposals (BASELINE configs[4]'s shard shape: 34 % of the A sampler's launches took two rounds) nearly always ends in its first round:
+// A 33.9 -> 31.5 us per launch at 384 attempts, 30.9 at 448: 6.24 -> 6.55 -> 6.65 M proposals/s (profiles/r06_ab_sparse_chained_launch.txt).
+// The dense chain pays for every further attempt wave in every launch (profiles/r06_ab_windows_320_384.txt) and keeps two windows.  Only the
+// chained sparse launch is instantiated at this window: a sampler that steps by two launches per batch goes back to GEN_WIN first (the window
+// is free to change between batches: results do not depend on it).
+#ifndef GEN_WIN_WIDE
+#define GEN_WIN_WIDE (GEN_WIN == 256 ? GEN_CHAIN_THREADS - 64 : GEN_WIN)
+#endif
+static uint32_t gen_window_for(uint32_t current, float stepsPerBatch, bool wideOk = false)
 {
+    if (GEN_WIN_WIDE != GEN_WIN) {
+        if (current == (uint32_t)GEN_WIN_WIDE) return (wideOk && (stepsPerBatch <= 1.f || stepsPerBatch > 0.75f * (float)GEN_WIN)) ? current : (uint32_t)GEN_WIN;
+        if (wideOk && current == (uint32_t)GEN_WIN && stepsPerBatch > 0.9f * (float)GEN_WIN) return (uint32_t)GEN_WIN_WIDE;
+    }
     if (GEN_WIN_HALF == GEN_WIN || stepsPerBatch <= 1.f) return current;
     if (current == (uint32_t)GEN_WIN && stepsPerBatch < 0.85f * (float)GEN_WIN_HALF) return (uint32_t)GEN_WIN_HALF;
     if (current == (uint32_t)GEN_WIN_HALF && stepsPerBatch > 0.95f * (float)GEN_WIN_HALF) return (uint32_t)GEN_WIN;
@@ -242,6 +257,7 @@ struct cogaps_session {
     // of LDS, so one evaluation workgroup fits a compute unit and each takes 3-4 slices one after the other, where the two-launch form has
     // two per unit and all slices resident).  COGAPS_CHAIN_SPLIT=1 takes it (the A/B, the equality test).
     bool noChainSplit = getenv("COGAPS_CHAIN_SPLIT") == nullptr;
+    bool testWideWindow = getenv("COGAPS_TEST_WIDE_WINDOW") != nullptr;      // tests: the sparse model's chained launch at GEN_WIN_WIDE from the first update on (otherwise once batches exceed 0.9 * GEN_WIN)
     bool forceChain = getenv("COGAPS_FORCE_CHAIN") != nullptr;      // tests: the chained launch also where the device shows fewer compute units than the launch has workgroups (they then run in turns, the generator last)
     unsigned computeUnits = 0;      // of the session's device: the chained launch wants all its workgroups resident at once, one per compute unit
     std::vector<rt_event_pair> evPool; std::vector<int> evKind; std::vector<HostSampler *> evOwner; std::vector<uint64_t> evOrd; size_t evUsed = 0;
@@ -530,7 +546,11 @@ static void launch_chain(cogaps_session *s, HostSampler &h)
         const uint32_t grid = std::min<uint32_t>(h.d.queueCap, s->computeUnits >= 256u ? 255u : CHAIN_EVAL_GRID) + 1u;
 #endif
         const bool wide = h.d.Wn > cogaps_sparse_width(h.d.N), big = h.genWin == (uint32_t)GEN_WIN;
-        if (big && wide) LAUNCH_MAYBE_TIMED(slot, (chain_sparse_kernel<GEN_WIN, true>), grid, CHAIN_MAX_THREADS, h.d.lcgMul, h.d.lcgInc, h.d.gs, h.d.queue, h.chainGrans, h.d.chainSlots, h.d.queueCap, parity, rec);
+        if (GEN_WIN_WIDE != GEN_WIN && h.genWin == (uint32_t)GEN_WIN_WIDE) {
+            if (wide) LAUNCH_MAYBE_TIMED(slot, (chain_sparse_kernel<GEN_WIN_WIDE, true>), grid, CHAIN_MAX_THREADS, h.d.lcgMul, h.d.lcgInc, h.d.gs, h.d.queue, h.chainGrans, h.d.chainSlots, h.d.queueCap, parity, rec);
+            else LAUNCH_MAYBE_TIMED(slot, (chain_sparse_kernel<GEN_WIN_WIDE, false>), grid, CHAIN_MAX_THREADS, h.d.lcgMul, h.d.lcgInc, h.d.gs, h.d.queue, h.chainGrans, h.d.chainSlots, h.d.queueCap, parity, rec);
+        }
+        else if (big && wide) LAUNCH_MAYBE_TIMED(slot, (chain_sparse_kernel<GEN_WIN, true>), grid, CHAIN_MAX_THREADS, h.d.lcgMul, h.d.lcgInc, h.d.gs, h.d.queue, h.chainGrans, h.d.chainSlots, h.d.queueCap, parity, rec);
         else if (big) LAUNCH_MAYBE_TIMED(slot, (chain_sparse_kernel<GEN_WIN, false>), grid, CHAIN_MAX_THREADS, h.d.lcgMul, h.d.lcgInc, h.d.gs, h.d.queue, h.chainGrans, h.d.chainSlots, h.d.queueCap, parity, rec);
         else if (wide) LAUNCH_MAYBE_TIMED(slot, (chain_sparse_kernel<GEN_WIN_HALF, true>), grid, CHAIN_MAX_THREADS, h.d.lcgMul, h.d.lcgInc, h.d.gs, h.d.queue, h.chainGrans, h.d.chainSlots, h.d.queueCap, parity, rec);
         else LAUNCH_MAYBE_TIMED(slot, (chain_sparse_kernel<GEN_WIN_HALF, false>), grid, CHAIN_MAX_THREADS, h.d.lcgMul, h.d.lcgInc, h.d.gs, h.d.queue, h.chainGrans, h.d.chainSlots, h.d.queueCap, parity, rec);
@@ -720,6 +740,7 @@ static bool chain_recover(cogaps_session *s, HostSampler &h, uint32_t nSteps)
     read_gs(s, h);
     if (s->hGs->error) return false;      // (a decision is still missing: the update cannot be completed)
     h.chain = false; h.chainOff = true; h.chainRecoveries++;
+    if (h.genWin != gen_window_for(h.genWin, 0.f, false)) { h.genWin = gen_window_for(h.genWin, 0.f, false); drop_graphs(h); }      // (the wide window exists for the chained sparse launch only)
     return true;
 }
 
@@ -761,6 +782,12 @@ static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool t
     if (nSteps == 0) return 0;
     sync_record(s, h);
     h.chain = chain_eligible(s, h);
+    {   // the wide window: the chained sparse launch only (gen_window_for); tests take it from the first update on
+        const bool wideOk = h.chain && h.d.sparse != 0u;
+        uint32_t win = gen_window_for(h.genWin, 0.f, wideOk);
+        if (wideOk && s->testWideWindow) win = (uint32_t)GEN_WIN_WIDE;
+        if (win != h.genWin) { h.genWin = win; drop_graphs(h); }
+    }
     h.chainParityStart = h.chainParity;
     h.updLaunches = 0;
     h.clockSeen = g.batchEpoch;      // (launch clock: the batches of this update carry the tags behind this one)
@@ -802,7 +829,8 @@ static int run_update(cogaps_session *s, HostSampler &h, uint32_t nSteps, bool t
     }
     h.nAtoms = s->hGs->nAtoms; h.avgQueue = s->hGs->avgQueue; h.batches += s->hGs->nBatches;
     if (s->hGs->nBatches >= 8u) h.stepsPerBatch = (float)nSteps / (float)s->hGs->nBatches;
-    const uint32_t win = gen_window_for(h.genWin, h.stepsPerBatch);
+    uint32_t win = gen_window_for(h.genWin, h.stepsPerBatch, h.chain && h.d.sparse != 0u);
+    if (h.chain && h.d.sparse != 0u && s->testWideWindow) win = (uint32_t)GEN_WIN_WIDE;
     if (win != h.genWin) { h.genWin = win; drop_graphs(h); }      // (the captured launches carry the window)
     return 0;
 }
@@ -949,7 +977,7 @@ cogaps_session *cogaps_session_create(const float *data, uint32_t nrow, uint32_t
         std::vector<float> e, ei, qg; build_luts(e, ei, qg);
         s->dErf = dalloc<float>(e.size() + 8); s->dErfinv = dalloc<float>(ei.size() + 8); s->dQgamma = dalloc<float>(qg.size() + 8);      // (read as whole float4 chunks by the evaluation kernel's LDS staging)
         rt_h2d(s->dErf, e.data(), e.size() * 4, s->stream); rt_h2d(s->dErfinv, ei.data(), ei.size() * 4, s->stream); rt_h2d(s->dQgamma, qg.data(), qg.size() * 4, s->stream);
-        std::vector<uint64_t> lm(2 * GEN_WIN + 2), li(2 * GEN_WIN + 2);
+        std::vector<uint64_t> lm(2 * GEN_WIN_WIDE + 2), li(2 * GEN_WIN_WIDE + 2);      // (jumps of up to 2 * window steps; GEN_WIN_WIDE >= GEN_WIN)
         for (uint32_t k = 0; k < lm.size(); ++k) pcg_jump_coeffs(k, lm[k], li[k]);
         s->dLcgMul = dalloc<uint64_t>(lm.size()); s->dLcgInc = dalloc<uint64_t>(li.size());
         rt_h2d(s->dLcgMul, lm.data(), lm.size() * 8, s->stream); rt_h2d(s->dLcgInc, li.data(), li.size() * 8, s->stream);
@@ -1783,6 +1811,7 @@ int cogaps_session_launch_period(cogaps_session *s, char which, double *meanUs, 
     SESSION_END
 }
 int cogaps_session_chain_recoveries(cogaps_session *s, char which, uint32_t *n) { *n = pick(s, which).chainRecoveries; return 0; }
+int cogaps_session_generator_window(cogaps_session *s, char which, uint32_t *attempts) { *attempts = pick(s, which).genWin; return 0; }
 int cogaps_session_chained(cogaps_session *s, char which, int *chained)
 {
     SESSION_TRY

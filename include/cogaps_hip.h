@@ -28,6 +28,9 @@
  *   COGAPS_CHAIN_SPLIT           the split evaluation (data vectors of more than 4096 elements) inside the chained launch -- built, measured
  *                                6 % slower on the headline chain (profiles/r05_ab_chained_split_evaluation_not_kept.txt), not the default:
  *                                test_chained_split_evaluation_equals_two_launches_on_the_gpu
+ *   COGAPS_TEST_WIDE_WINDOW      the sparse model's chained launch with its widest generator window (448 attempts) from the first update on; the
+ *                                library takes it by itself once a sampler's batches exceed 230 proposals:
+ *                                test_sparse_chained_launch_with_long_queues_equals_two_launches_on_the_gpu
  * Development builds (-DCOGAPS_DEV, never shipped) read further switches that only change what is measured.
  */
 #ifndef COGAPS_HIP_H
@@ -236,6 +239,9 @@ int cogaps_session_perf_sampler(cogaps_session *s, char which, cogaps_perf *out)
  * update end with an error (GAPS_ERR_SPIN) and the session refuse further steps. */
 int cogaps_session_chained(cogaps_session *s, char which, int *chained);
 int cogaps_session_chain_recoveries(cogaps_session *s, char which, uint32_t *n);
+/* Attempts per round of the sampler's generator launches as of its last update (the library's instantiations: 128, 256, and 448 for the sparse
+ * model's chained launch once batches are long; no result depends on it). */
+int cogaps_session_generator_window(cogaps_session *s, char which, uint32_t *attempts);
 /* Durations of the sampler's chained launches since cogaps_session_set_timing(1), EVERY launch -- replayed graphs included, where HIP
  * events cannot ride --, from the chip-wide 100 MHz clock read inside the launch (entry of its first workgroup to the end of its generator
  * workgroup, the last to finish: what rocprofv3 --kernel-trace reports as the dispatch's duration, minus the dispatcher's fill / drain).

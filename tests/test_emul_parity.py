@@ -149,6 +149,17 @@ def test_sparse_chained_launch_two_proposals_per_evaluation_workgroup(emul_lib, 
     by_attempt_lanes = sum(S.debug_prof(w)[2] for w in "AP"); later = sum(S.debug_prof(w)[6] for w in "AP")
     S.close()
     assert by_attempt_lanes > 500, (by_attempt_lanes, later)
+    # the third, wider window of the sparse model's chained launch (448 attempts in the build with GEN_WIN = 256: seven attempt waves and the
+    # helper wave), taken from the first update on
+    monkeypatch.setenv("COGAPS_TEST_WIDE_WINDOW", "1")
+    lib256 = emul_lib(256)
+    data = pu.synthetic_counts(900, 260, zeros=0.9, seed=15)
+    pu.run_stepwise(lib256, data, 14, total_iter=30, check_every=2, sparseOptimization=True, nPatterns=4, seed=21)
+    S = _capi.Session(data, lib=lib256, nIterations=30, sparseOptimization=True, nPatterns=4, seed=21)
+    S.run_iterations(1, 0, 14)
+    assert all(S.chained(w) for w in "AP") and [S.generator_window(w) for w in "AP"] == [448, 448], [S.generator_window(w) for w in "AP"]
+    S.close()
+    monkeypatch.delenv("COGAPS_TEST_WIDE_WINDOW")
     monkeypatch.setenv("COGAPS_NO_CHAIN", "1")
     data = pu.synthetic_counts(600, 200, zeros=0.9, seed=5)
     S = _capi.Session(data, lib=lib, nPatterns=4, seed=11, nIterations=40, sparseOptimization=True)

@@ -256,7 +256,7 @@ def test_sparse_chained_launch_with_long_queues_equals_two_launches_on_the_gpu(h
     """The sparse model's chained launch (chain_sparse_kernel) where its round-6 paths are taken ON THE HARDWARE: queues longer than the 255
     evaluation workgroups (the second group of four waves of a workgroup evaluates the proposal one grid further on, both groups passing
     through the workgroup's barriers side by side) and longer than the generator workgroup's 256 applier lanes (its attempt lanes carry
-    out the slots behind theirs).  80000 x 1200, 95 % zeros, K = 20 (a batch of the A sampler ends at the first repeated row: ~350 proposals
+    out the slots behind theirs), and with the wide generator window such batches switch the sampler to (448 attempts).  80000 x 1200, 95 % zeros, K = 20 (a batch of the A sampler ends at the first repeated row: ~350 proposals
     once the domain is populated): stepped until the A sampler's batches average more than 256 proposals, then six iterations more; the same number of iterations with COGAPS_NO_CHAIN=1 (generator launch + eval_sparse_kernel,
     one proposal per workgroup, the decisions written by the evaluation workgroups) must leave the same bits: atoms, links, both copies of
     the HybridMatrix."""
@@ -276,7 +276,7 @@ def test_sparse_chained_launch_with_long_queues_equals_two_launches_on_the_gpu(h
             mean_q = (b1["proposalsQueued"] - b0["proposalsQueued"]) / max(1, b1["batches"] - b0["batches"])
             if n_fixed is None and long_since is None and mean_q > 256.0: long_since = it
             if n_fixed is None and long_since is not None and it >= long_since + 6: break
-        st = _chain_state(S) + [sha_rows(S)], (S.chained("A"), S.chained("P")), it, mean_q, long_since
+        st = _chain_state(S) + [sha_rows(S)], (S.chained("A"), S.chained("P")), it, mean_q, long_since, S.generator_window("A")
         S.close()
         return st
 
@@ -284,12 +284,13 @@ def test_sparse_chained_launch_with_long_queues_equals_two_launches_on_the_gpu(h
         import hashlib
         return hashlib.sha256(np.ascontiguousarray(S.rows("A")).tobytes() + np.ascontiguousarray(S.rows("P")).tobytes()).hexdigest()
 
-    a, form_a, n, mean_q, long_since = run()
+    a, form_a, n, mean_q, long_since, win_a = run()
     assert form_a == (1, 1), "the sparse model's chained launch did not run"
     assert long_since is not None and mean_q > 256.0, "the A sampler's queues stayed short (mean %.1f after %d iterations): the paths under test were not taken" % (mean_q, n)
     monkeypatch.setenv("COGAPS_NO_CHAIN", "1")
-    b, form_b, _, _, _ = run(n)
-    assert form_b == (0, 0)
+    assert win_a == 448, win_a      # (batches beyond 230 proposals: the chained sparse launch's wide window, seven attempt waves)
+    b, form_b, _, _, _, win_b = run(n)
+    assert form_b == (0, 0) and win_b == 256
     assert a == b
 
 
