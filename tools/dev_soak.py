@@ -61,16 +61,19 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--launches", type=int, default=1000000)
     ap.add_argument("--genes", type=int, default=20000); ap.add_argument("--samples", type=int, default=2000); ap.add_argument("--patterns", type=int, default=50)
+    ap.add_argument("--sparse", action="store_true", help="the sparse model (95 %% zeros): chain_sparse_kernel -- two proposals per evaluation workgroup, the attempt lanes in the hand-over, the 448-attempt window")
     a = ap.parse_args()
     import bench
     data = bench.synthetic_dense(a.genes, a.samples)
+    if a.sparse: data = (data * (np.random.Generator(np.random.MT19937(777)).random(data.shape) >= 0.95)).astype(np.float32)
     # ~2150 chained launches of the A sampler per iteration once the chain is populated (58 930 batches in 20 iterations, 73 % of them A's)
-    iters = max(8, int(a.launches / 2150.0) + 1)
+    iters = max(8, int(a.launches / (4900.0 if a.sparse else 2150.0)) + 1)
     n_iter = max(100, (iters + 1) // 2)
     params = dict(nPatterns=a.patterns, seed=42, outputFrequency=max(1, n_iter // 10))
+    if a.sparse: params["sparseOptimization"] = True
     quiet = run(data, n_iter, iters, params)
     disturbed = run(data, n_iter, iters, params, foreign_seconds=max(60.0, 6.0 * quiet["seconds"]))
-    rec = {"what": "headline chain, %d iterations (schedule of %d + %d), first alone, then beside a second process streaming over a 4 GiB tensor on the same GPU" % (iters, n_iter, n_iter),
+    rec = {"what": ("sparse model, %d x %d, " % (a.genes, a.samples) if a.sparse else "") + "headline chain, %d iterations (schedule of %d + %d), first alone, then beside a second process streaming over a 4 GiB tensor on the same GPU" % (iters, n_iter, n_iter),
            "quiet": quiet, "disturbed": disturbed,
            "same_final_state": quiet["state_digest"] == disturbed["state_digest"],
            "recoveries_total": sum(disturbed[w]["recoveries"] + quiet[w]["recoveries"] for w in "AP"),
