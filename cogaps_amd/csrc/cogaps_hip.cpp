@@ -538,8 +538,9 @@ static void launch_chain(cogaps_session *s, HostSampler &h)
     const uint32_t parity = h.chainParity; h.chainParity ^= 1u;
     if (h.d.sparse) {
         // sparse model (sparse_kernels.h, chain_sparse_kernel): the launch has 512 threads per workgroup whatever the model's width
-        // (255 evaluation workgroups + the generator = the chip's 256 compute units: a batch of the 256-attempt window then fits one pass --
-        // the sparse evaluation has no pairs, a second pass costs a whole evaluation; the dense launch keeps 240, profiles/r04_ab_chained_launch_not_kept.txt)
+        // (255 evaluation workgroups + the generator = the chip's 256 compute units; a workgroup evaluates two proposals side by side where the
+        // model's vectors take one round of flag words -- sparse_kernels.h, sp_grp -- so queues of up to 510 fit one pass; the dense launch keeps
+        // 240 workgroups, profiles/r04_ab_chained_launch_not_kept.txt)
 #if defined(COGAPS_EMUL)
         const uint32_t grid = std::min<uint32_t>(h.d.queueCap, CHAIN_EVAL_GRID) + 1u;      // (test-only emulator: few workgroups, so that both groups of an evaluation workgroup get proposals)
 #else

@@ -1026,14 +1026,15 @@ CG_KERNEL void CG_LAUNCH_BOUNDS(256) chisq_sparse_seq_kernel(SamplerDev S, float
     if (t == 0) out[0] = acc;
 }
 
-// ---- the chained launch of the sparse model (round 5; chain_kernel.h for the scheme) ----------------------------------------------------------
+// ---- the chained launch of the sparse model (rounds 5, 6; chain_kernel.h for the scheme) ---------------------------------------------------------
 // Workgroups 0 .. n-2 evaluate batch b as eval_sparse_kernel[_wide] does and hand each decision to the LAST workgroup, the generator of
 // batch b + 1, which carries it out on the atomic domain and the HybridMatrix (gen_populate.h: chain_apply, chain_store_hybrid).  The
 // sparse evaluation is long (15-27 us per batch at BASELINE configs[4]'s shard shape against ~8 us of generator work that does not
 // depend on the decisions), so the generator's prologue, classification and draws disappear behind it.  One static LDS block serves
 // both roles -- a launch's workgroups all carry the kernel's static LDS, and the two roles' blocks side by side (142 + 49 / 90 KB) exceed
 // a compute unit's 160 KB.  The launch has the generator's workgroup size (512 threads: window + helper wave + applier waves); an
-// evaluation workgroup keeps the model's width (S.spW threads = virtual lanes: the parity contract), its further waves leave at once.
+// evaluation keeps the model's width (S.spW threads = virtual lanes: the parity contract) -- a workgroup's first and second four waves are two
+// such evaluations side by side (one-round vectors; round 6, below), waves beyond the width leave at once.
 template <int WIN, bool WIDE>
 CG_KERNEL void CG_LAUNCH_BOUNDS(CHAIN_MAX_THREADS) chain_sparse_kernel(const uint64_t *lcgMul, const uint64_t *lcgInc, GenScalars *gs, PropRec *queue, unsigned long long *grans, ChainSlot *slots,
                                                                        uint32_t queueCap, uint32_t parity, const SamplerDev CG_CONSTANT *sp)
