@@ -294,6 +294,23 @@ def test_sparse_chained_launch_with_long_queues_equals_two_launches_on_the_gpu(h
     assert a == b
 
 
+@pytest.mark.parametrize("genes,samples,k,iters,zeros", [(3000, 700, 6, 24, 0.9), (900, 20000, 4, 8, 0.95)])
+def test_sparse_wide_generator_window_stepwise(hip_lib, monkeypatch, genes, samples, k, iters, zeros):
+    """chain_sparse_kernel<448, .> -- the sparse model's chained launch with seven attempt waves and the helper wave as its only applier wave, the
+    attempt lanes carrying out the queue behind its 64 slots -- taken from the first update on (COGAPS_TEST_WIDE_WINDOW) and compared with the
+    oracle proposal by proposal and state by state; both evaluation forms (one-round vectors with two groups per workgroup; the wide form:
+    20000-element vectors for the P sampler)."""
+    from cogaps_amd import _capi
+    monkeypatch.setenv("COGAPS_TEST_WIDE_WINDOW", "1")
+    data = pu.synthetic_counts(genes, samples, zeros=zeros, seed=genes % 97)
+    pu.run_stepwise(hip_lib, data, iters, trace=genes * samples < 50000, nPatterns=k, seed=19, total_iter=max(iters, 40), check_every=4, sparseOptimization=True)
+    S = _capi.Session(data, lib=hip_lib, nPatterns=k, nIterations=40, seed=19, sparseOptimization=True)
+    S.run_iterations(1, 0, 4)
+    wins = [S.generator_window(w) for w in "AP"], [S.chained(w) for w in "AP"]
+    S.close()
+    assert wins == ([448, 448], [1, 1]), wins
+
+
 def test_launch_clock_of_chained_launches(hip_lib):
     """cogaps_session_launch_clock: the chip-wide clock read inside EVERY chained launch since set_timing(1) (replayed graphs included) --
     as many launches as the sampler generated batches in the window (one launch per batch; the update's first launch evaluates nothing
